@@ -1,0 +1,194 @@
+/*
+ * wavlm_hip.h -- C ABI of libwavlm_hip.so: the MI355X (gfx950) kernels of the WavLM / UniSpeech
+ * pre-training hot path.
+ *
+ * The reference (microsoft/UniSpeech) has NO native interface on this path: every FLOP is a stock
+ * PyTorch op called from Python.  Each entry point below therefore cites the reference *Python*
+ * call site whose arithmetic it replaces (paths relative to the reference root).  A maintainer
+ * binds the library with ctypes (INTEGRATION.md shows the stub); unispeech_amd/_lib.py is that
+ * binding.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; no torch types; `stream` is a hipStream_t passed as void*
+ *   - returns 0 on success, <0 on error (-1 bad argument, -2 launch failure); never throws,
+ *     never allocates, never synchronises
+ *   - dtype codes: 0 = float32, 1 = bfloat16 (raw 16-bit)
+ *   - activations are channel-last: [B, T, C] row-major ("rows" = frames, contiguous channels)
+ */
+#ifndef WAVLM_HIP_H
+#define WAVLM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WAVLM_HIP_ABI_VERSION 1
+int wavlm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense contraction (MFMA for bf16, exact-f32 VALU tile for the parity mode).
+ *   C[zo,zi][m,n] = epi( alpha * sum_{kb<KB} sum_{k<K} A[zo,zi,kb](m,k) * B[zo,zi,kb](n,k) + bias[n] )
+ * A(m,k) lives at A + zo*sA_o + zi*sA_i + kb*sA_kb + (transA ? k*lda + m : m*lda + k); same for B.
+ * lda may be SMALLER than K (overlapping rows): that is how a strided Conv1d over a channel-last
+ * activation becomes a GEMM with no im2col.
+ * Replaces: F.linear (WavLM/WavLM.py:348, modules.py:540-563 q/k/v/out, WavLM.py:671-672 fc1/fc2),
+ * nn.Conv1d of the feature extractor (WavLM/WavLM.py:401,499-500), the grouped pos_conv
+ * (WavLM/WavLM.py:514-527), torch.bmm inside F.multi_head_attention_forward, the cosine-logit
+ * product (src/fairseq/models/wavlm/wavlm.py:431) and all their autograd backward contractions.
+ * epi: 0 none | 1 gelu (pre-activation stored to aux if aux != NULL) | 2 multiply by gelu'(aux)
+ * then: + res (if res != NULL), + old C (if accumulate).
+ * split_k > 1: the KB range is cut into split_k slabs written to `workspace` (f32) and summed by a
+ * second kernel (deterministic, no atomics).  workspace bytes >= wavlm_gemm_workspace_bytes().
+ * ------------------------------------------------------------------------------------------ */
+typedef struct wavlm_gemm_desc {
+  int32_t dtype;      /* element type of A and B */
+  int32_t c_dtype;    /* element type of C */
+  int32_t M, N, K, KB;
+  int32_t transA, transB;
+  int64_t lda, ldb, ldc;
+  int64_t sA_kb, sB_kb;
+  int32_t batch_o, batch_i;
+  int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+  const void* A;
+  const void* B;
+  void* C;
+  float alpha;
+  int32_t epi;
+  const void* bias; int32_t bias_dtype; int64_t sBias_o, sBias_i;
+  void* aux; int32_t aux_dtype; int64_t ld_aux, sAux_o, sAux_i;
+  const void* res; int32_t res_dtype; int64_t ld_res, sRes_o, sRes_i;
+  int32_t accumulate;
+  int32_t split_k;
+  void* workspace; uint64_t ws_bytes;
+} wavlm_gemm_desc;
+
+uint64_t wavlm_gemm_workspace_bytes(const wavlm_gemm_desc* d);
+int wavlm_gemm(const wavlm_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row kernels (one 64-lane wave per row, wave-shuffle reductions).
+ * ------------------------------------------------------------------------------------------ */
+
+/* y = dropout_out( act( LayerNorm( x + dropout_in(r) ) ) ).  r may be NULL.  s (optional) receives the
+ * pre-norm sum, mean/rstd (optional) the row statistics -- backward needs all three.  act: 0 none, 1 gelu.
+ * Replaces nn.LayerNorm / Fp32LayerNorm + the residual add + nn.Dropout around it
+ * (WavLM/WavLM.py:342, 582-584, 702-703, 726-729, 739-740; WavLM/modules.py:30-42). D % 8 == 0, D <= 2048. */
+int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* mean, float* rstd, const void* gamma,
+                        const void* beta, int64_t rows, int32_t D, float eps, int32_t dtype, int32_t param_dtype,
+                        int32_t act, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, void* stream);
+uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D);
+/* dx: gradient of x (and of the sum s); dr (optional): gradient of r (dx through the input-dropout mask);
+ * dgamma/dbeta in param dtype; dy is scaled by grad_scale first (GradMultiply, WavLM/modules.py:60-69). */
+int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd, const void* gamma,
+                        const void* beta, void* dx, void* dr, void* dgamma, void* dbeta, int64_t rows, int32_t D,
+                        int32_t dtype, int32_t param_dtype, int32_t act, float p_in, uint64_t seed_in, float p_out,
+                        uint64_t seed_out, float grad_scale, int32_t accumulate_params, void* workspace,
+                        uint64_t ws_bytes, void* stream);
+
+/* out[c] (+)= sum over rows of x[row, c]; a row counts iff (!include || include[row]) && (!exclude || !exclude[row]).
+ * Bias gradients of every nn.Linear / conv bias, and d(mask_emb) (src/fairseq/models/wavlm/wavlm.py:401). */
+uint64_t wavlm_colsum_workspace_bytes(int32_t N);
+int wavlm_colsum(const void* x, int64_t rows, int32_t N, int64_t ld, int32_t dtype, const uint8_t* include_mask,
+                 const uint8_t* exclude_mask, void* out, int32_t out_dtype, int32_t accumulate, void* workspace,
+                 uint64_t ws_bytes, void* stream);
+
+/* y[row] = zero[row] ? 0 : (sel[row] ? emb (0 if emb == NULL) : x[row]).  apply_mask's x[mask] = mask_emb and the
+ * encoder's x[padding_mask] = 0 in one pass (WavLM/WavLM.py:286, 574-575), and their backward. */
+int wavlm_select_rows(const void* x, void* y, const uint8_t* sel, const void* emb, const uint8_t* zero, int64_t rows,
+                      int32_t D, int32_t dtype, int32_t emb_dtype, void* stream);
+/* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0.  x[masked_indices] (wavlm.py:541,557) and its scatter-back. */
+int wavlm_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_out, int32_t D, int32_t dtype,
+                      void* stream);
+/* y = a*x + b*y */
+int wavlm_axpby(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, float a, float b, void* stream);
+/* y *= scalar[0] * extra, scalar on the device (upstream loss gradient without a host sync) */
+int wavlm_scale_dev(void* y, int32_t dtype, int64_t n, const float* scalar, float extra, void* stream);
+/* y = dropout(x; p, seed): counter-based (Philox4x32-10) mask, regenerated (not stored) for the backward. */
+int wavlm_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int32_t dtype, void* stream);
+/* out[0] = scale * sum(x^2): features_pen (wavlm.py:486) and the global gradient norm (utils.py:338-388). */
+uint64_t wavlm_sumsq_workspace_bytes(void);
+int wavlm_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out, void* workspace, uint64_t ws_bytes,
+                void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * conv0: Conv1d(1->C, k=10, stride) + GroupNorm(C, C) + GELU, channel-last output [B, T0, C]
+ * (WavLM/WavLM.py:401-428 block(is_group_norm=True); Fp32GroupNorm WavLM/modules.py:45-57).
+ * stats[B, C, 2] = (mean, rstd) saved for backward.  kw must be 10, C <= 512.
+ * ------------------------------------------------------------------------------------------ */
+uint64_t wavlm_conv0_gn_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride);
+int wavlm_conv0_gn_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, const void* gamma, const void* beta,
+                            int32_t param_dtype, void* out, int32_t out_dtype, float* stats, int32_t B, int64_t T,
+                            int32_t C, int32_t kw, int32_t stride, float eps, void* workspace, uint64_t ws_bytes,
+                            void* stream);
+uint64_t wavlm_conv0_gn_bwd_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride);
+int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, const void* gamma, const void* beta,
+                            int32_t param_dtype, const void* g, int32_t g_dtype, const float* stats, void* dW,
+                            void* dgamma, void* dbeta, int32_t B, int64_t T, int32_t C, int32_t kw, int32_t stride,
+                            float gscale, void* workspace, uint64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gated relative-position-bias attention (WavLM/modules.py:417-455, 504-563).
+ * ------------------------------------------------------------------------------------------ */
+/* rel[h][d] = emb[bucket[d]][h], d = (j - i) + T - 1 in [0, 2T-2]; bucket[] is the host-computed int table */
+int wavlm_relpos_gather(const void* emb, int32_t emb_dtype, const int32_t* bucket, float* tab, int32_t H, int32_t L,
+                        void* stream);
+int wavlm_relpos_scatter(const float* dtab, const int32_t* bucket, void* demb, int32_t emb_dtype, int32_t H, int32_t L,
+                         int32_t num_buckets, void* stream);
+/* gate[b,h,t] = ga*(gb*grep_a[h] - 1) + 2 from the un-projected layer input x[B,T,H*hd] (modules.py:523-533) */
+int wavlm_gate_fwd(const void* x, const void* W, const void* bias, const void* grep_a, float* gate, float* ga, float* gb,
+                   int32_t B, int32_t T, int32_t H, int32_t hd, int32_t dtype, int32_t param_dtype, void* stream);
+uint64_t wavlm_gate_bwd_workspace_bytes(int32_t H, int32_t hd);
+int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void* grep_a, const float* ga,
+                   const float* gb, void* dx, void* dW, void* dbias, void* dgrep_a, int32_t B, int32_t T, int32_t H,
+                   int32_t hd, int32_t dtype, int32_t param_dtype, void* workspace, uint64_t ws_bytes, void* stream);
+/* P = dropout(softmax_j(S + gate_i*rel[h, j-i] + keypad)); lse saved.  S: [B*H, T, ldS], P: [B*H, T, ldP]; T <= 1024 */
+int wavlm_attn_softmax_fwd(const void* S, void* P, float* lse, const float* gate, const float* tab, const uint8_t* kpm,
+                           int32_t B, int32_t H, int32_t T, int64_t ldS, int64_t ldP, int32_t s_dtype, int32_t p_dtype,
+                           float p_drop, uint64_t seed, void* stream);
+uint64_t wavlm_attn_softmax_bwd_workspace_bytes(int32_t B, int32_t H, int32_t T);
+int wavlm_attn_softmax_bwd(const void* S, const void* dP, const float* lse, const float* gate, const float* tab,
+                           const uint8_t* kpm, void* dS, float* dgate, float* dtab, int32_t dtab_accumulate, int32_t B,
+                           int32_t H, int32_t T, int64_t ldS, int64_t ldP, int32_t s_dtype, int32_t p_dtype,
+                           float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * pos_conv weight side: weight_norm(dim=2) -> GEMM weight images, and its backward (WavLM/WavLM.py:514-527)
+ * ------------------------------------------------------------------------------------------ */
+uint64_t wavlm_posconv_weight_workspace_bytes(int32_t D, int32_t Cg, int32_t K);
+int wavlm_posconv_weight_fwd(const void* v, const void* g, int32_t param_dtype, void* Wf, void* Wb, int32_t out_dtype,
+                             float* norm, int32_t D, int32_t Cg, int32_t K, void* workspace, uint64_t ws_bytes,
+                             void* stream);
+int wavlm_posconv_weight_bwd(const float* dWf, const void* v, const void* g, const float* norm, int32_t param_dtype,
+                             void* dv, void* dg, int32_t D, int32_t Cg, int32_t K, void* workspace, uint64_t ws_bytes,
+                             void* stream);
+/* x[B,T,D] (optionally * gelu'(aux)) -> group-major, time-padded out[B,G,Tp,D/G]; nat_out optional natural copy */
+int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* nat_out, int32_t B, int32_t T, int32_t D,
+                              int32_t G, int32_t left_pad, int32_t Tp, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Masked-prediction loss (src/fairseq/models/wavlm/wavlm.py:426-438; criterions/wavlm_criterion.py:52-138)
+ * ------------------------------------------------------------------------------------------ */
+int wavlm_l2norm_fwd(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, float* inv_norm, int64_t rows,
+                     int32_t D, float eps, void* stream);
+int wavlm_l2norm_bwd(const void* dy, const void* y, int32_t y_dtype, const float* inv_norm, void* dx, int32_t x_dtype,
+                     int64_t rows, int32_t D, void* stream);
+/* per row: loss = logsumexp(logits) - logits[target]; correct = (logits[target] is the row max);
+ * dlogits (optional) = weight * (softmax - onehot), zero-filled up to ld_dlogits */
+int wavlm_ce_rows(const float* logits, const int32_t* target, float* loss_rows, float* correct_rows, void* dlogits,
+                  int32_t d_dtype, int64_t S, int32_t V, int64_t ld_logits, int64_t ld_dlogits, float weight,
+                  void* stream);
+uint64_t wavlm_sum_workspace_bytes(void);
+int wavlm_sum_f32(const float* x, int64_t n, float* out, void* workspace, uint64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused optimizer step (src/fairseq/optim/adam.py:148-228, fp16_optimizer.py:106-218, utils.py:338-388)
+ * ------------------------------------------------------------------------------------------ */
+int wavlm_adam_step(float* p, float* m, float* v, const void* grad, int32_t grad_dtype, void* p_lowp,
+                    int32_t lowp_dtype, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    int64_t step, float grad_mult, const float* gnorm_sq, float max_norm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+"""ctypes binding of libwavlm_hip.so (include/wavlm_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or a kernel entry point returns an error, this
+module raises.  Loading the library does not need a GPU (the CPU test-suite checks that every symbol declared
+in the header is exported); calling any entry point does.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwavlm_hip.so")
+
+_lib = None
+
+F32, BF16 = 0, 1
+
+c_i32, c_i64, c_u64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("dtype", c_i32), ("c_dtype", c_i32),
+        ("M", c_i32), ("N", c_i32), ("K", c_i32), ("KB", c_i32),
+        ("transA", c_i32), ("transB", c_i32),
+        ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64),
+        ("sA_kb", c_i64), ("sB_kb", c_i64),
+        ("batch_o", c_i32), ("batch_i", c_i32),
+        ("sA_o", c_i64), ("sA_i", c_i64), ("sB_o", c_i64), ("sB_i", c_i64), ("sC_o", c_i64), ("sC_i", c_i64),
+        ("A", c_vp), ("B", c_vp), ("C", c_vp),
+        ("alpha", c_f32), ("epi", c_i32),
+        ("bias", c_vp), ("bias_dtype", c_i32), ("sBias_o", c_i64), ("sBias_i", c_i64),
+        ("aux", c_vp), ("aux_dtype", c_i32), ("ld_aux", c_i64), ("sAux_o", c_i64), ("sAux_i", c_i64),
+        ("res", c_vp), ("res_dtype", c_i32), ("ld_res", c_i64), ("sRes_o", c_i64), ("sRes_i", c_i64),
+        ("accumulate", c_i32), ("split_k", c_i32),
+        ("workspace", c_vp), ("ws_bytes", c_u64),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/wavlm_hip.h one to one
+SIGNATURES = {
+    "wavlm_abi_version": (c_i32, []),
+    "wavlm_gemm_workspace_bytes": (c_u64, [C.POINTER(GemmDesc)]),
+    "wavlm_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
+    "wavlm_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_i32,
+                                    c_i32, c_f32, c_u64, c_f32, c_u64, c_vp]),
+    "wavlm_layernorm_bwd_workspace_bytes": (c_u64, [c_i32]),
+    "wavlm_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
+                                    c_i32, c_i32, c_f32, c_u64, c_f32, c_u64, c_f32, c_i32, c_vp, c_u64, c_vp]),
+    "wavlm_colsum_workspace_bytes": (c_u64, [c_i32]),
+    "wavlm_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_u64, c_vp]),
+    "wavlm_select_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "wavlm_gather_rows": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "wavlm_axpby": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_vp]),
+    "wavlm_scale_dev": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_f32, c_vp]),
+    "wavlm_dropout": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_u64, c_i32, c_vp]),
+    "wavlm_sumsq_workspace_bytes": (c_u64, []),
+    "wavlm_sumsq": (c_i32, [c_vp, c_i32, c_i64, c_f32, c_vp, c_vp, c_u64, c_vp]),
+    "wavlm_conv0_gn_workspace_bytes": (c_u64, [c_i32, c_i64, c_i32, c_i32]),
+    "wavlm_conv0_gn_gelu_fwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32,
+                                        c_i32, c_i32, c_f32, c_vp, c_u64, c_vp]),
+    "wavlm_conv0_gn_bwd_workspace_bytes": (c_u64, [c_i32, c_i64, c_i32, c_i32]),
+    "wavlm_conv0_gn_gelu_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                        c_i32, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_u64, c_vp]),
+    "wavlm_relpos_gather": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "wavlm_relpos_scatter": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "wavlm_gate_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                               c_vp]),
+    "wavlm_gate_bwd_workspace_bytes": (c_u64, [c_i32, c_i32]),
+    "wavlm_gate_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                               c_i32, c_i32, c_vp, c_u64, c_vp]),
+    "wavlm_attn_softmax_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32,
+                                       c_i32, c_f32, c_u64, c_vp]),
+    "wavlm_attn_softmax_bwd_workspace_bytes": (c_u64, [c_i32, c_i32, c_i32]),
+    "wavlm_attn_softmax_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                       c_i32, c_i64, c_i64, c_i32, c_i32, c_f32, c_u64, c_vp, c_u64, c_vp]),
+    "wavlm_posconv_weight_workspace_bytes": (c_u64, [c_i32, c_i32, c_i32]),
+    "wavlm_posconv_weight_fwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_u64,
+                                         c_vp]),
+    "wavlm_posconv_weight_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_u64,
+                                         c_vp]),
+    "wavlm_posconv_group_major": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                          c_vp]),
+    "wavlm_l2norm_fwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_f32, c_vp]),
+    "wavlm_l2norm_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "wavlm_ce_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),
+    "wavlm_sum_workspace_bytes": (c_u64, []),
+    "wavlm_sum_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_u64, c_vp]),
+    "wavlm_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
+                                c_i64, c_f32, c_vp, c_f32, c_vp]),
+}
+
+_ERR = {-1: "invalid argument", -2: "kernel launch failure", -3: "out of memory"}
+
+
+class WavlmHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WavlmHipError(
+                "libwavlm_hip.so not found at %s -- run `python -m unispeech_amd.build` (there is no CPU fallback)"
+                % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if h.wavlm_abi_version() != 1:
+            raise WavlmHipError("libwavlm_hip.so ABI version mismatch")
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise WavlmHipError("%s failed: %s (status %d)" % (what, _ERR.get(rc, "unknown"), rc))

@@ -1,0 +1,365 @@
+// Gated relative-position-bias attention pieces.
+//
+// The reference materialises bias[B*H, T, T] = gate[b,h,i] * rel[h, j - i] in fp32 every layer
+// (WavLM/modules.py:504-535) and hands it to SDPA as an additive mask.  Here the bias is never
+// materialised: it is Toeplitz in (i, j), so a [H, 2T-1] table (built once per forward from the
+// bucket embedding) plus the per-row gate reproduce it inside the softmax row kernel.
+//   scores S = scale * Q.K^T           (MFMA GEMM, fp32 out)
+//   P = softmax_j(S + gate_i * rel[j-i] + keypad(-inf))   -> this file, one wave per row
+//   O = dropout(P).V                    (MFMA GEMM)
+// Backward regenerates P from S and the saved log-sum-exp, and reduces the two bias gradients in the
+// same pass: dgate[b,h,i] = sum_j dS*rel  (wave shuffle) and drel[h,d] = sum_{b,i} gate*dS[i,i+d]
+// (LDS diagonal accumulators per block, then a deterministic cross-block sum).
+#include "common.hpp"
+#include "../../include/wavlm_hip.h"
+
+#define SM_MAXJ 16  // row length up to 1024 keys (T' = 749 @15 s, 999 @20 s)
+#define SM_ROWS_PER_BLOCK 64
+
+__device__ __forceinline__ float ld_s(const void* S, long i, int dt) { return ld_elem(S, i, dt); }
+
+__global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(const void* __restrict__ S, void* __restrict__ P,
+    float* __restrict__ lse, const float* __restrict__ gate, const float* __restrict__ tab,
+    const unsigned char* __restrict__ kpm, int B, int H, int T, long ldS, long ldP, int s_dt, int p_dt, unsigned th,
+    float sc, unsigned long long seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long nrows = (long)B * H * T;
+  const int L = 2 * T - 1;
+  for (long row = (long)blockIdx.x * 4 + wave; row < nrows; row += (long)gridDim.x * 4) {
+    const int i = (int)(row % T);
+    const long bh = row / T;
+    const int h = (int)(bh % H), b = (int)(bh / H);
+    const float g = gate ? gate[row] : 0.f;
+    const float* trow = tab ? tab + (long)h * L + (T - 1 - i) : nullptr;
+    float v[SM_MAXJ];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < SM_MAXJ; ++c) {
+      const int j = lane + 64 * c;
+      float x = -INFINITY;
+      if (j < T) {
+        x = ld_s(S, row * ldS + j, s_dt);
+        if (trow) x += g * trow[j];
+        if (kpm && kpm[(long)b * T + j]) x = -INFINITY;
+      }
+      v[c] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < SM_MAXJ; ++c) {
+      const float e = (v[c] == -INFINITY) ? 0.f : __expf(v[c] - mx);
+      v[c] = e; sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    if (lane == 0) lse[row] = mx + __logf(sum);
+#pragma unroll
+    for (int c = 0; c < SM_MAXJ; ++c) {
+      const int j = lane + 64 * c;
+      if (j < ldP) {
+        float pj = (j < T) ? v[c] * inv : 0.f;
+        if (th && j < T) pj = dropout_keep(seed, (unsigned long long)(row * T + j), th) ? pj * sc : 0.f;
+        st_elem(P, row * ldP + j, p_dt, pj);
+      }
+    }
+  }
+}
+
+// grid: (ceil(T / SM_ROWS_PER_BLOCK), B*H); block = 4 waves; each wave walks rows of its chunk.
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const void* __restrict__ S, const void* __restrict__ dP,
+    const float* __restrict__ lse, const float* __restrict__ gate, const float* __restrict__ tab,
+    const unsigned char* __restrict__ kpm, void* __restrict__ dS, float* __restrict__ dgate,
+    float* __restrict__ dtab_part, int B, int H, int T, long ldS, long ldP, int s_dt, int p_dt, unsigned th, float sc,
+    unsigned long long seed) {
+  extern __shared__ __attribute__((aligned(16))) float diag[];  // [2T-1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = 2 * T - 1;
+  const int bh = blockIdx.y;
+  const int h = bh % H, b = bh / H;
+  const int i0 = blockIdx.x * SM_ROWS_PER_BLOCK;
+  if (tab) {
+    for (int d = threadIdx.x; d < L; d += 256) diag[d] = 0.f;
+    __syncthreads();
+  }
+  for (int ii = wave; ii < SM_ROWS_PER_BLOCK; ii += 4) {
+    const int i = i0 + ii;
+    if (i >= T) break;
+    const long row = (long)bh * T + i;
+    const float g = gate ? gate[row] : 0.f;
+    const float* trow = tab ? tab + (long)h * L + (T - 1 - i) : nullptr;
+    const float l = lse[row];
+    float p[SM_MAXJ], dp[SM_MAXJ];
+    float delta = 0.f;
+#pragma unroll
+    for (int c = 0; c < SM_MAXJ; ++c) {
+      const int j = lane + 64 * c;
+      float pj = 0.f, dpj = 0.f;
+      if (j < T) {
+        float x = ld_s(S, row * ldS + j, s_dt);
+        if (trow) x += g * trow[j];
+        const bool masked = kpm && kpm[(long)b * T + j];
+        pj = masked ? 0.f : __expf(x - l);
+        dpj = ld_elem(dP, row * ldP + j, p_dt);
+        if (th) dpj = dropout_keep(seed, (unsigned long long)(row * T + j), th) ? dpj * sc : 0.f;
+      }
+      p[c] = pj; dp[c] = dpj;
+      delta += pj * dpj;
+    }
+    delta = wave_sum(delta);
+    float dg = 0.f;
+#pragma unroll
+    for (int c = 0; c < SM_MAXJ; ++c) {
+      const int j = lane + 64 * c;
+      if (j < ldP) {
+        const float ds = (j < T) ? p[c] * (dp[c] - delta) : 0.f;
+        st_elem(dS, row * ldP + j, p_dt, ds);
+        if (trow && j < T) {
+          dg += ds * trow[j];
+          atomicAdd(&diag[j - i + T - 1], g * ds);  // LDS float add: distinct d within a row, waves may collide
+        }
+      }
+    }
+    if (dgate) {
+      dg = wave_sum(dg);
+      if (lane == 0) dgate[row] = dg;
+    }
+  }
+  if (tab) {
+    __syncthreads();
+    float* out = dtab_part + ((long)bh * gridDim.x + blockIdx.x) * L;
+    for (int d = threadIdx.x; d < L; d += 256) out[d] = diag[d];
+  }
+}
+
+// drel[h][d] = sum_{b, chunk} part[((b*H + h) * nchunk + chunk)][d]
+__global__ __launch_bounds__(256) void attn_dtab_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                               int B, int H, int nchunk, int L, int accumulate) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y;
+  if (d >= L) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < nchunk; ++c) s += part[(((long)b * H + h) * nchunk + c) * L + d];
+  if (accumulate) s += out[(long)h * L + d];
+  out[(long)h * L + d] = s;
+}
+
+// rel[h][d] = emb[bucket[d]][h]
+__global__ __launch_bounds__(256) void relpos_gather_kernel(const void* __restrict__ emb, int emb_dt,
+    const int* __restrict__ bucket, float* __restrict__ tab, int H, int L) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y;
+  if (d >= L) return;
+  tab[(long)h * L + d] = ld_elem(emb, (long)bucket[d] * H + h, emb_dt);
+}
+// demb[k][h] = sum_{d : bucket[d] == k} drel[h][d]   (one wave per (k, h))
+__global__ __launch_bounds__(64) void relpos_scatter_kernel(const float* __restrict__ dtab,
+    const int* __restrict__ bucket, void* __restrict__ demb, int emb_dt, int H, int L, int nb) {
+  const int k = blockIdx.x, h = blockIdx.y;
+  float s = 0.f;
+  for (int d = threadIdx.x; d < L; d += 64)
+    if (bucket[d] == k) s += dtab[(long)h * L + d];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) st_elem(demb, (long)k * H + h, emb_dt, s);
+}
+
+// ---- gate: g[b,h,t] = ga * (gb * a[h] - 1) + 2, (ga, gb) = sigmoid of the two 4-row sums of grep_linear(x_h) -----
+// WavLM/modules.py:523-533.  One wave per (b, t); lanes stride over the head's channels.
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ x, const TP* __restrict__ W,
+    const TP* __restrict__ bias, const TP* __restrict__ grep_a, float* __restrict__ gate, float* __restrict__ ga_o,
+    float* __restrict__ gb_o, int B, int Tn, int H, int hd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long nbt = (long)B * Tn;
+  const int D = H * hd;
+  float ba = 0.f, bb = 0.f;
+  for (int k = 0; k < 4; ++k) { ba += Elem<TP>::ld(bias + k); bb += Elem<TP>::ld(bias + 4 + k); }
+  for (long bt = (long)blockIdx.x * 4 + wave; bt < nbt; bt += (long)gridDim.x * 4) {
+    const long b = bt / Tn; const int t = (int)(bt - b * Tn);
+    for (int h = 0; h < H; ++h) {
+      float sa = 0.f, sb = 0.f;
+      for (int c = lane; c < hd; c += 64) {
+        const float xv = Elem<T>::ld(x + bt * D + h * hd + c);
+        float wa = 0.f, wb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wa += Elem<TP>::ld(W + k * hd + c); wb += Elem<TP>::ld(W + (4 + k) * hd + c); }
+        sa += xv * wa; sb += xv * wb;
+      }
+      sa = wave_sum(sa) + ba; sb = wave_sum(sb) + bb;
+      const float ga = 1.f / (1.f + __expf(-sa)), gb = 1.f / (1.f + __expf(-sb));
+      if (lane == 0) {
+        const long o = (b * H + h) * Tn + t;
+        gate[o] = ga * (gb * Elem<TP>::ld(grep_a + h) - 1.f) + 2.f;
+        ga_o[o] = ga; gb_o[o] = gb;
+      }
+    }
+  }
+}
+
+#define GATE_BLOCKS 256
+// partial layout per block: [2*hd (dWa, dWb)] [2 (dba, dbb)] [H (da)]
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dgate, const T* __restrict__ x,
+    const TP* __restrict__ W, const TP* __restrict__ grep_a, const float* __restrict__ ga_i,
+    const float* __restrict__ gb_i, T* __restrict__ dx, float* __restrict__ part, int B, int Tn, int H, int hd) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][2*hd + 2 + H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long nbt = (long)B * Tn;
+  const int D = H * hd;
+  const int PW = 2 * hd + 2 + H;
+  float* mine = sm + wave * PW;
+  for (int i = lane; i < PW; i += 64) mine[i] = 0.f;
+  // per-wave accumulators live in LDS (hd may exceed 64); each lane owns channels lane, lane+64, ...
+  float dba = 0.f, dbb = 0.f;
+  for (long bt = (long)blockIdx.x * 4 + wave; bt < nbt; bt += (long)gridDim.x * 4) {
+    const long b = bt / Tn; const int t = (int)(bt - b * Tn);
+    for (int h = 0; h < H; ++h) {
+      const long o = (b * H + h) * Tn + t;
+      const float dg = dgate[o], ga = ga_i[o], gb = gb_i[o];
+      const float a = Elem<TP>::ld(grep_a + h);
+      const float dsa = dg * (gb * a - 1.f) * ga * (1.f - ga);
+      const float dsb = dg * ga * a * gb * (1.f - gb);
+      if (lane == 0) mine[2 * hd + 2 + h] += dg * ga * gb;
+      dba += dsa; dbb += dsb;
+      for (int c = lane; c < hd; c += 64) {
+        const float xv = Elem<T>::ld(x + bt * D + h * hd + c);
+        float wa = 0.f, wb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wa += Elem<TP>::ld(W + k * hd + c); wb += Elem<TP>::ld(W + (4 + k) * hd + c); }
+        Elem<T>::st(dx + bt * D + h * hd + c, dsa * wa + dsb * wb);
+        mine[c] += dsa * xv;
+        mine[hd + c] += dsb * xv;
+      }
+    }
+  }
+  if (lane == 0) { mine[2 * hd] = dba; mine[2 * hd + 1] = dbb; }
+  __syncthreads();
+  float* out = part + (long)blockIdx.x * PW;
+  for (int i = threadIdx.x; i < PW; i += 256) out[i] = sm[i] + sm[PW + i] + sm[2 * PW + i] + sm[3 * PW + i];
+}
+// dW[8][hd], dbias[8], dgrep_a[H] from the block partials
+__global__ __launch_bounds__(256) void gate_bwd_finish_kernel(const float* __restrict__ part, int nblk, int H, int hd,
+    void* dW, void* dbias, void* da, int pdt) {
+  const int PW = 2 * hd + 2 + H;
+  for (int i = threadIdx.x; i < PW; i += 256) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * PW + i];
+    if (i < hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)k * hd + i, pdt, s); }
+    else if (i < 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)(4 + k) * hd + (i - hd), pdt, s); }
+    else if (i == 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dbias, k, pdt, s); }
+    else if (i == 2 * hd + 1) { for (int k = 0; k < 4; ++k) st_elem(dbias, 4 + k, pdt, s); }
+    else st_elem(da, i - (2 * hd + 2), pdt, s);
+  }
+}
+
+extern "C" {
+
+int wavlm_attn_softmax_fwd(const void* S, void* P, float* lse, const float* gate, const float* tab, const uint8_t* kpm,
+                           int32_t B, int32_t H, int32_t T, int64_t ldS, int64_t ldP, int32_t s_dtype, int32_t p_dtype,
+                           float p_drop, uint64_t seed, void* stream) {
+  if (!S || !P || !lse || B <= 0 || H <= 0 || T <= 0 || T > 64 * SM_MAXJ || ldP > 64 * SM_MAXJ || ldS < T || ldP < T)
+    return WL_EINVAL;
+  if ((gate == nullptr) != (tab == nullptr)) return WL_EINVAL;
+  double tt = (double)p_drop * 4294967296.0; if (tt > 4294967295.0) tt = 4294967295.0;
+  const unsigned th = p_drop > 0.f ? (unsigned)tt : 0u;
+  const float sc = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const long nrows = (long)B * H * T;
+  long grid = (nrows + 3) / 4; if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, S, P, lse, gate,
+                     tab, kpm, (int)B, (int)H, (int)T, (long)ldS, (long)ldP, (int)s_dtype, (int)p_dtype, th, sc,
+                     (unsigned long long)seed);
+  return wl_check_launch();
+}
+
+uint64_t wavlm_attn_softmax_bwd_workspace_bytes(int32_t B, int32_t H, int32_t T) {
+  const uint64_t nchunk = (uint64_t)((T + SM_ROWS_PER_BLOCK - 1) / SM_ROWS_PER_BLOCK);
+  return (uint64_t)B * H * nchunk * (2 * (uint64_t)T - 1) * sizeof(float);
+}
+
+int wavlm_attn_softmax_bwd(const void* S, const void* dP, const float* lse, const float* gate, const float* tab,
+                           const uint8_t* kpm, void* dS, float* dgate, float* dtab, int32_t dtab_accumulate, int32_t B,
+                           int32_t H, int32_t T, int64_t ldS, int64_t ldP, int32_t s_dtype, int32_t p_dtype,
+                           float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes, void* stream) {
+  if (!S || !dP || !lse || !dS || B <= 0 || H <= 0 || T <= 0 || T > 64 * SM_MAXJ || ldP > 64 * SM_MAXJ || ldS < T ||
+      ldP < T)
+    return WL_EINVAL;
+  if ((gate == nullptr) != (tab == nullptr)) return WL_EINVAL;
+  if (tab && (!dgate || !dtab || !workspace || ws_bytes < wavlm_attn_softmax_bwd_workspace_bytes(B, H, T)))
+    return WL_EINVAL;
+  double tt = (double)p_drop * 4294967296.0; if (tt > 4294967295.0) tt = 4294967295.0;
+  const unsigned th = p_drop > 0.f ? (unsigned)tt : 0u;
+  const float sc = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunk = (T + SM_ROWS_PER_BLOCK - 1) / SM_ROWS_PER_BLOCK;
+  const int L = 2 * T - 1;
+  hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * H)), dim3(256),
+                     tab ? (size_t)L * sizeof(float) : 0, st, S, dP, lse, gate, tab, kpm, dS, dgate, (float*)workspace,
+                     (int)B, (int)H, (int)T, (long)ldS, (long)ldP, (int)s_dtype, (int)p_dtype, th, sc,
+                     (unsigned long long)seed);
+  int rc = wl_check_launch();
+  if (rc != WL_OK || !tab) return rc;
+  hipLaunchKernelGGL(attn_dtab_reduce_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)H), dim3(256), 0, st,
+                     (const float*)workspace, dtab, (int)B, (int)H, nchunk, L, (int)dtab_accumulate);
+  return wl_check_launch();
+}
+
+int wavlm_relpos_gather(const void* emb, int32_t emb_dtype, const int32_t* bucket, float* tab, int32_t H, int32_t L,
+                        void* stream) {
+  if (!emb || !bucket || !tab || H <= 0 || L <= 0) return WL_EINVAL;
+  hipLaunchKernelGGL(relpos_gather_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)H), dim3(256), 0,
+                     (hipStream_t)stream, emb, (int)emb_dtype, bucket, tab, (int)H, (int)L);
+  return wl_check_launch();
+}
+
+int wavlm_relpos_scatter(const float* dtab, const int32_t* bucket, void* demb, int32_t emb_dtype, int32_t H, int32_t L,
+                         int32_t num_buckets, void* stream) {
+  if (!dtab || !bucket || !demb || H <= 0 || L <= 0 || num_buckets <= 0) return WL_EINVAL;
+  hipLaunchKernelGGL(relpos_scatter_kernel, dim3((unsigned)num_buckets, (unsigned)H), dim3(64), 0, (hipStream_t)stream,
+                     dtab, bucket, demb, (int)emb_dtype, (int)H, (int)L, (int)num_buckets);
+  return wl_check_launch();
+}
+
+int wavlm_gate_fwd(const void* x, const void* W, const void* bias, const void* grep_a, float* gate, float* ga, float* gb,
+                   int32_t B, int32_t T, int32_t H, int32_t hd, int32_t dtype, int32_t param_dtype, void* stream) {
+  if (!x || !W || !bias || !grep_a || !gate || !ga || !gb || B <= 0 || T <= 0 || H <= 0 || hd <= 0) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  long grid = ((long)B * T + 3) / 4; if (grid > 8192) grid = 8192;
+#define GF(TT, TP) hipLaunchKernelGGL((gate_fwd_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), 0, st, (const TT*)x, \
+    (const TP*)W, (const TP*)bias, (const TP*)grep_a, gate, ga, gb, (int)B, (int)T, (int)H, (int)hd)
+  if (dtype == WL_F32 && param_dtype == WL_F32) GF(float, float);
+  else if (dtype == WL_BF16 && param_dtype == WL_BF16) GF(bf16_t, bf16_t);
+  else if (dtype == WL_BF16 && param_dtype == WL_F32) GF(bf16_t, float);
+  else return WL_EINVAL;
+#undef GF
+  return wl_check_launch();
+}
+
+uint64_t wavlm_gate_bwd_workspace_bytes(int32_t H, int32_t hd) {
+  return (uint64_t)GATE_BLOCKS * (2 * (uint64_t)hd + 2 + H) * sizeof(float);
+}
+
+int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void* grep_a, const float* ga,
+                   const float* gb, void* dx, void* dW, void* dbias, void* dgrep_a, int32_t B, int32_t T, int32_t H,
+                   int32_t hd, int32_t dtype, int32_t param_dtype, void* workspace, uint64_t ws_bytes, void* stream) {
+  if (!dgate || !x || !W || !grep_a || !ga || !gb || !dx || !dW || !dbias || !dgrep_a || !workspace) return WL_EINVAL;
+  if (B <= 0 || T <= 0 || H <= 0 || hd <= 0 || ws_bytes < wavlm_gate_bwd_workspace_bytes(H, hd)) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  long grid = ((long)B * T + 3) / 4; if (grid > GATE_BLOCKS) grid = GATE_BLOCKS;
+  const size_t smem = 4 * (2 * (size_t)hd + 2 + H) * sizeof(float);
+#define GB(TT, TP) hipLaunchKernelGGL((gate_bwd_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), smem, st, dgate, \
+    (const TT*)x, (const TP*)W, (const TP*)grep_a, ga, gb, (TT*)dx, (float*)workspace, (int)B, (int)T, (int)H, (int)hd)
+  if (dtype == WL_F32 && param_dtype == WL_F32) GB(float, float);
+  else if (dtype == WL_BF16 && param_dtype == WL_BF16) GB(bf16_t, bf16_t);
+  else if (dtype == WL_BF16 && param_dtype == WL_F32) GB(bf16_t, float);
+  else return WL_EINVAL;
+#undef GB
+  int rc = wl_check_launch();
+  if (rc != WL_OK) return rc;
+  hipLaunchKernelGGL(gate_bwd_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)grid, (int)H,
+                     (int)hd, dW, dbias, dgrep_a, (int)param_dtype);
+  return wl_check_launch();
+}
+
+}  // extern "C"

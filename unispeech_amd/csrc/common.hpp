@@ -1,0 +1,102 @@
+// Shared device helpers for the WavLM hot-path kernels (gfx950 / CDNA4 only).
+// Wave = 64 lanes everywhere in this tree; nothing here is written for 32-wide warps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WL_OK 0
+#define WL_EINVAL (-1)
+#define WL_ELAUNCH (-2)
+#define WL_ENOMEM (-3)
+
+enum { WL_F32 = 0, WL_BF16 = 1 };
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __uint_as_float(((unsigned)v) << 16);
+}
+// round-to-nearest-even, NaN preserved (quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+// typed scalar access by runtime dtype (0 = f32, 1 = bf16)
+__device__ __forceinline__ float ld_elem(const void* p, long i, int dt) {
+  return dt == WL_F32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
+}
+__device__ __forceinline__ void st_elem(void* p, long i, int dt, float v) {
+  if (dt == WL_F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = f2bf(v);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// ---- 64-lane wave reductions (butterfly over DPP/ds_swizzle via __shfl_xor) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- exact (erf) GELU, as torch.nn.functional.gelu(approximate='none') ----
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- Philox4x32-10 counter RNG (dropout masks are regenerated in backward, never stored) ----
+struct Philox4 { unsigned x, y, z, w; };
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsigned long long ctr) {
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  Philox4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3; return o;
+}
+// keep-mask for element index `idx` of a tensor: one Philox call covers 4 consecutive elements.
+// keep iff u32 >= thresh where thresh = p * 2^32.
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, unsigned thresh) {
+  const Philox4 r = philox4x32_10(seed, idx >> 2);
+  const unsigned sel = (unsigned)(idx & 3);
+  const unsigned v = sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
+  return v >= thresh;
+}
+
+static inline int wl_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? WL_OK : WL_ELAUNCH;
+}

@@ -1,0 +1,397 @@
+// First feature-extractor block: Conv1d(1 -> C, k = 10, stride 5, no bias) + GroupNorm(C groups == per-(b, c)
+// statistics over time) + exact GELU, written channel-last [B, T0, C] so that conv1..6 become overlapping-row
+// GEMMs (WavLM/WavLM.py:391-428,485-500; Fp32GroupNorm WavLM/modules.py:45-57).
+//
+// This is the HBM-bound stage of the extractor: 4 B/sample in, C/5 outputs per sample out.  The raw conv
+// output is never written: the statistics pass and the apply pass both recompute the 10-tap conv from an LDS
+// copy of the waveform segment (10 FMA per output on the VALU, far below the write-bandwidth bound), so HBM
+// traffic is: waveform read twice, activation written once.  Lane l of a wave owns channels 8l..8l+7 for all
+// time steps of the wave, so every store is one 16-byte (bf16) / 2 x 16-byte (f32) vector and a wave writes a
+// full contiguous 1 KiB / 2 KiB row.  Backward recomputes the same way (conv0 has no input gradient).
+#include "common.hpp"
+#include "../../include/wavlm_hip.h"
+
+#define C0_KW 10
+#define C0_TCH 512      // time steps per block (forward passes)
+#define C0_TCH_BWD 1024 // time steps per block (backward passes)
+
+template <typename T> struct V8 {
+  static __device__ __forceinline__ void ld(const T* p, float (&v)[8]);
+  static __device__ __forceinline__ void st(T* p, const float (&v)[8]);
+};
+template <> __device__ __forceinline__ void V8<float>::ld(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void V8<float>::st(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void V8<bf16_t>::ld(const bf16_t* p, float (&v)[8]) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void V8<bf16_t>::st(bf16_t* p, const float (&v)[8]) {
+  uint4 o;
+  o.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+  o.z = f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); o.w = f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = o;
+}
+
+// stage the waveform samples feeding time steps [t0, t0 + nt) of batch row b into LDS (as f32)
+template <typename TW>
+__device__ __forceinline__ void stage_wave(const TW* __restrict__ wav, long T, int b, int t0, int nt, int stride,
+                                           float* seg) {
+  const long s0 = (long)t0 * stride;
+  const int ns = (nt - 1) * stride + C0_KW;
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) seg[i] = Elem<TW>::ld(wav + (long)b * T + s0 + i);
+}
+
+// lane's 8 x KW weights (channels 8*lane .. +7)
+template <typename TP>
+__device__ __forceinline__ void load_w(const TP* __restrict__ W, int lane, int C, float (&w)[8][C0_KW]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) {
+      const int c = lane * 8 + e;
+      w[e][k] = c < C ? Elem<TP>::ld(W + (long)c * C0_KW + k) : 0.f;
+    }
+}
+__device__ __forceinline__ void conv_at(const float* seg, int tt, int stride, const float (&w)[8][C0_KW], float (&y)[8]) {
+  float xw[C0_KW];
+#pragma unroll
+  for (int k = 0; k < C0_KW; ++k) xw[k] = seg[tt * stride + k];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) a = fmaf(xw[k], w[e][k], a);
+    y[e] = a;
+  }
+}
+
+// pass 1: per-(b, c) partial sums of y and y^2 over the block's time chunk -> part[(b*nchunk + chunk)][2][C]
+template <typename TW, typename TP>
+__global__ __launch_bounds__(256) void conv0_stats_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
+    float* __restrict__ part, long T, int T0, int C, int stride) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* seg = sm;                                      // [(TCH-1)*stride + KW]
+  float* red = sm + ((C0_TCH - 1) * stride + C0_KW + 3) / 4 * 4;  // [4][2][512]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH;
+  const int nt = min(C0_TCH, T0 - t0);
+  stage_wave(wav, T, b, t0, nt, stride, seg);
+  float w[8][C0_KW];
+  load_w(W, lane, C, w);
+  __syncthreads();
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  for (int tt = wave; tt < nt; tt += 4) {
+    float y[8];
+    conv_at(seg, tt, stride, w, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] += y[e]; s2[e] = fmaf(y[e], y[e], s2[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[(wave * 2 + 0) * 512 + lane * 8 + e] = s1[e]; red[(wave * 2 + 1) * 512 + lane * 8 + e] = s2[e]; }
+  __syncthreads();
+  float* out = part + ((long)b * gridDim.x + blockIdx.x) * 2 * C;
+  for (int i = threadIdx.x; i < 2 * 512; i += 256) {
+    const int which = i >> 9, c = i & 511;
+    if (c < C) out[which * C + c] = red[(0 * 2 + which) * 512 + c] + red[(1 * 2 + which) * 512 + c] +
+                                     red[(2 * 2 + which) * 512 + c] + red[(3 * 2 + which) * 512 + c];
+  }
+}
+
+// stats[b][c] = (mean, rstd) from the chunk partials (double accumulation)
+__global__ __launch_bounds__(256) void conv0_stats_finish_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                                 int nchunk, int C, int T0, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    const float* p = part + ((long)b * nchunk + k) * 2 * C;
+    s1 += p[c]; s2 += p[C + c];
+  }
+  const double mean = s1 / T0;
+  double var = s2 / T0 - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[((long)b * C + c) * 2] = (float)mean;
+  stats[((long)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// pass 2: y0 = gelu((conv - mean) * rstd * gamma + beta), channel-last
+template <typename TW, typename TP, typename TO>
+__global__ __launch_bounds__(256) void conv0_apply_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
+    const TP* __restrict__ gamma, const TP* __restrict__ beta, const float* __restrict__ stats, TO* __restrict__ out,
+    long T, int T0, int C, int stride) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* seg = sm;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH;
+  const int nt = min(C0_TCH, T0 - t0);
+  stage_wave(wav, T, b, t0, nt, stride, seg);
+  float w[8][C0_KW];
+  load_w(W, lane, C, w);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = lane * 8 + e;
+    if (c < C) {
+      const float mean = stats[((long)b * C + c) * 2], rstd = stats[((long)b * C + c) * 2 + 1];
+      const float g = Elem<TP>::ld(gamma + c), bt = Elem<TP>::ld(beta + c);
+      sc[e] = rstd * g; sh[e] = bt - mean * rstd * g;
+    } else { sc[e] = 0.f; sh[e] = 0.f; }
+  }
+  __syncthreads();
+  if (lane * 8 >= C) return;
+  for (int tt = wave; tt < nt; tt += 4) {
+    float y[8];
+    conv_at(seg, tt, stride, w, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = gelu_f(fmaf(y[e], sc[e], sh[e]));
+    V8<TO>::st(out + ((long)b * T0 + t0 + tt) * C + lane * 8, y);
+  }
+}
+
+// backward pass 1: A[b,c] = sum_t dz, Bq[b,c] = sum_t dz * xhat   (dz = g * gelu'(z)) -> chunk partials
+template <typename TW, typename TP, typename TO>
+__global__ __launch_bounds__(256) void conv0_bwd_stats_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
+    const TP* __restrict__ gamma, const TP* __restrict__ beta, const float* __restrict__ stats,
+    const TO* __restrict__ g, float* __restrict__ part, long T, int T0, int C, int stride, float gscale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* seg = sm;
+  float* red = sm + ((C0_TCH_BWD - 1) * stride + C0_KW + 3) / 4 * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH_BWD;
+  const int nt = min(C0_TCH_BWD, T0 - t0);
+  stage_wave(wav, T, b, t0, nt, stride, seg);
+  float w[8][C0_KW];
+  load_w(W, lane, C, w);
+  float mean[8], rstd[8], gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = min(lane * 8 + e, C - 1);
+    mean[e] = stats[((long)b * C + c) * 2]; rstd[e] = stats[((long)b * C + c) * 2 + 1];
+    gm[e] = Elem<TP>::ld(gamma + c); bt[e] = Elem<TP>::ld(beta + c);
+  }
+  __syncthreads();
+  float a1[8], a2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+  if (lane * 8 < C) {
+    for (int tt = wave; tt < nt; tt += 4) {
+      float y[8], gv[8];
+      conv_at(seg, tt, stride, w, y);
+      V8<TO>::ld(g + ((long)b * T0 + t0 + tt) * C + lane * 8, gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (y[e] - mean[e]) * rstd[e];
+        const float dz = gv[e] * gscale * gelu_grad_f(fmaf(xh, gm[e], bt[e]));
+        a1[e] += dz; a2[e] = fmaf(dz, xh, a2[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[(wave * 2 + 0) * 512 + lane * 8 + e] = a1[e]; red[(wave * 2 + 1) * 512 + lane * 8 + e] = a2[e]; }
+  __syncthreads();
+  float* out = part + ((long)b * gridDim.x + blockIdx.x) * 2 * C;
+  for (int i = threadIdx.x; i < 2 * 512; i += 256) {
+    const int which = i >> 9, c = i & 511;
+    if (c < C) out[which * C + c] = red[(0 * 2 + which) * 512 + c] + red[(1 * 2 + which) * 512 + c] +
+                                     red[(2 * 2 + which) * 512 + c] + red[(3 * 2 + which) * 512 + c];
+  }
+}
+// ab[b][c] = (A, Bq) per batch row; dgamma[c] = sum_b Bq, dbeta[c] = sum_b A
+__global__ __launch_bounds__(256) void conv0_bwd_stats_finish_kernel(const float* __restrict__ part,
+    float* __restrict__ ab, void* dgamma, void* dbeta, int pdt, int B, int nchunk, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double ta = 0.0, tb = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* p = part + ((long)b * nchunk + k) * 2 * C;
+      s1 += p[c]; s2 += p[C + c];
+    }
+    ab[((long)b * C + c) * 2] = (float)s1;
+    ab[((long)b * C + c) * 2 + 1] = (float)s2;
+    ta += s1; tb += s2;
+  }
+  st_elem(dbeta, c, pdt, (float)ta);
+  st_elem(dgamma, c, pdt, (float)tb);
+}
+
+// backward pass 2: dconv = rstd*gamma*(dz - A/T0 - xhat*Bq/T0); dW[c][k] = sum dconv * x[5t + k] -> block partials
+template <typename TW, typename TP, typename TO>
+__global__ __launch_bounds__(256) void conv0_bwd_w_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
+    const TP* __restrict__ gamma, const TP* __restrict__ beta, const float* __restrict__ stats,
+    const float* __restrict__ ab, const TO* __restrict__ g, float* __restrict__ part, long T, int T0, int C, int stride,
+    float gscale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* seg = sm;
+  float* red = sm + ((C0_TCH_BWD - 1) * stride + C0_KW + 3) / 4 * 4;  // [4][512]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH_BWD;
+  const int nt = min(C0_TCH_BWD, T0 - t0);
+  stage_wave(wav, T, b, t0, nt, stride, seg);
+  float w[8][C0_KW];
+  load_w(W, lane, C, w);
+  float mean[8], rstd[8], gm[8], bt[8], am[8], bm[8];
+  const float invT = 1.f / (float)T0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = min(lane * 8 + e, C - 1);
+    mean[e] = stats[((long)b * C + c) * 2]; rstd[e] = stats[((long)b * C + c) * 2 + 1];
+    gm[e] = Elem<TP>::ld(gamma + c); bt[e] = Elem<TP>::ld(beta + c);
+    am[e] = ab[((long)b * C + c) * 2] * invT; bm[e] = ab[((long)b * C + c) * 2 + 1] * invT;
+  }
+  __syncthreads();
+  float dw[8][C0_KW];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) dw[e][k] = 0.f;
+  if (lane * 8 < C) {
+    for (int tt = wave; tt < nt; tt += 4) {
+      float y[8], gv[8], xw[C0_KW];
+      conv_at(seg, tt, stride, w, y);
+#pragma unroll
+      for (int k = 0; k < C0_KW; ++k) xw[k] = seg[tt * stride + k];
+      V8<TO>::ld(g + ((long)b * T0 + t0 + tt) * C + lane * 8, gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (y[e] - mean[e]) * rstd[e];
+        const float dz = gv[e] * gscale * gelu_grad_f(fmaf(xh, gm[e], bt[e]));
+        const float dc = rstd[e] * gm[e] * (dz - am[e] - xh * bm[e]);
+#pragma unroll
+        for (int k = 0; k < C0_KW; ++k) dw[e][k] = fmaf(dc, xw[k], dw[e][k]);
+      }
+    }
+  }
+  float* out = part + ((long)b * gridDim.x + blockIdx.x) * (long)C * C0_KW;
+#pragma unroll
+  for (int k = 0; k < C0_KW; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave * 512 + lane * 8 + e] = dw[e][k];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+      out[(long)c * C0_KW + k] = red[c] + red[512 + c] + red[1024 + c] + red[1536 + c];
+  }
+}
+__global__ __launch_bounds__(256) void conv0_bwd_w_finish_kernel(const float* __restrict__ part, int nblk, int n,
+                                                                 void* dW, int pdt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += part[(long)b * n + i];
+  st_elem(dW, i, pdt, (float)s);
+}
+
+static inline size_t seg_floats(int tch, int stride) { return (size_t)(((tch - 1) * stride + C0_KW + 3) / 4 * 4); }
+
+extern "C" {
+
+uint64_t wavlm_conv0_gn_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride) {
+  const long T0 = (T - C0_KW) / stride + 1;
+  const uint64_t nchunk = (uint64_t)((T0 + C0_TCH - 1) / C0_TCH);
+  return (uint64_t)B * nchunk * 2 * C * sizeof(float);
+}
+
+// forward: y0[B, T0, C] and stats[B, C, 2] (mean, rstd) which backward needs
+int wavlm_conv0_gn_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, const void* gamma, const void* beta,
+                            int32_t param_dtype, void* out, int32_t out_dtype, float* stats, int32_t B, int64_t T,
+                            int32_t C, int32_t kw, int32_t stride, float eps, void* workspace, uint64_t ws_bytes,
+                            void* stream) {
+  if (!wav || !W || !gamma || !beta || !out || !stats || !workspace) return WL_EINVAL;
+  if (kw != C0_KW || stride < 1 || stride > 8 || C <= 0 || C > 512 || (C & 7) || B <= 0 || T < kw) return WL_EINVAL;
+  if (ws_bytes < wavlm_conv0_gn_workspace_bytes(B, T, C, stride)) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int T0 = (int)((T - kw) / stride + 1);
+  const int nchunk = (T0 + C0_TCH - 1) / C0_TCH;
+  const dim3 grid((unsigned)nchunk, (unsigned)B);
+  const size_t sm_stats = (seg_floats(C0_TCH, stride) + 4 * 2 * 512) * sizeof(float);
+  const size_t sm_apply = seg_floats(C0_TCH, stride) * sizeof(float);
+  float* part = (float*)workspace;
+#define ST(TW, TP) hipLaunchKernelGGL((conv0_stats_kernel<TW, TP>), grid, dim3(256), sm_stats, st, (const TW*)wav, \
+    (const TP*)W, part, (long)T, T0, (int)C, (int)stride)
+#define AP(TW, TP, TO) hipLaunchKernelGGL((conv0_apply_kernel<TW, TP, TO>), grid, dim3(256), sm_apply, st, (const TW*)wav, \
+    (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (TO*)out, (long)T, T0, (int)C, (int)stride)
+  const int key = wav_dtype * 100 + param_dtype * 10 + out_dtype;
+  if (key == 0) ST(float, float);
+  else if (key == 111) ST(bf16_t, bf16_t);
+  else if (key == 11) ST(float, bf16_t);
+  else if (key == 1) ST(float, float);
+  else return WL_EINVAL;
+  int rc = wl_check_launch();
+  if (rc != WL_OK) return rc;
+  hipLaunchKernelGGL(conv0_stats_finish_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, st, part,
+                     stats, nchunk, (int)C, T0, eps);
+  if (key == 0) AP(float, float, float);
+  else if (key == 111) AP(bf16_t, bf16_t, bf16_t);
+  else if (key == 11) AP(float, bf16_t, bf16_t);
+  else AP(float, float, bf16_t);
+#undef ST
+#undef AP
+  return wl_check_launch();
+}
+
+uint64_t wavlm_conv0_gn_bwd_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride) {
+  const long T0 = (T - C0_KW) / stride + 1;
+  const uint64_t nchunk = (uint64_t)((T0 + C0_TCH_BWD - 1) / C0_TCH_BWD);
+  // chunk partials (2C) + per-block dW partials (C*KW) + ab[B][C][2]
+  return ((uint64_t)B * nchunk * (2 * (uint64_t)C + (uint64_t)C * C0_KW) + (uint64_t)B * C * 2) * sizeof(float);
+}
+
+// backward: dW[C, kw], dgamma[C], dbeta[C] (param dtype); g = dL/dy0 [B, T0, C]; gscale = feature_grad_mult
+int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, const void* gamma, const void* beta,
+                            int32_t param_dtype, const void* g, int32_t g_dtype, const float* stats, void* dW,
+                            void* dgamma, void* dbeta, int32_t B, int64_t T, int32_t C, int32_t kw, int32_t stride,
+                            float gscale, void* workspace, uint64_t ws_bytes, void* stream) {
+  if (!wav || !W || !gamma || !beta || !g || !stats || !dW || !dgamma || !dbeta || !workspace) return WL_EINVAL;
+  if (kw != C0_KW || stride < 1 || stride > 8 || C <= 0 || C > 512 || (C & 7) || B <= 0 || T < kw) return WL_EINVAL;
+  if (ws_bytes < wavlm_conv0_gn_bwd_workspace_bytes(B, T, C, stride)) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int T0 = (int)((T - kw) / stride + 1);
+  const int nchunk = (T0 + C0_TCH_BWD - 1) / C0_TCH_BWD;
+  const dim3 grid((unsigned)nchunk, (unsigned)B);
+  float* part1 = (float*)workspace;
+  float* part2 = part1 + (long)B * nchunk * 2 * C;
+  float* ab = part2 + (long)B * nchunk * C * C0_KW;
+  const size_t sm1 = (seg_floats(C0_TCH_BWD, stride) + 4 * 2 * 512) * sizeof(float);
+  const size_t sm2 = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float);
+#define B1(TW, TP, TO) hipLaunchKernelGGL((conv0_bwd_stats_kernel<TW, TP, TO>), grid, dim3(256), sm1, st, (const TW*)wav, \
+    (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (const TO*)g, part1, (long)T, T0, (int)C, (int)stride, gscale)
+#define B2(TW, TP, TO) hipLaunchKernelGGL((conv0_bwd_w_kernel<TW, TP, TO>), grid, dim3(256), sm2, st, (const TW*)wav, \
+    (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, ab, (const TO*)g, part2, (long)T, T0, (int)C, (int)stride, gscale)
+  const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
+  if (key == 0) B1(float, float, float);
+  else if (key == 111) B1(bf16_t, bf16_t, bf16_t);
+  else if (key == 11) B1(float, bf16_t, bf16_t);
+  else if (key == 1) B1(float, float, bf16_t);
+  else return WL_EINVAL;
+  int rc = wl_check_launch();
+  if (rc != WL_OK) return rc;
+  hipLaunchKernelGGL(conv0_bwd_stats_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part1, ab,
+                     dgamma, dbeta, (int)param_dtype, (int)B, nchunk, (int)C);
+  if (key == 0) B2(float, float, float);
+  else if (key == 111) B2(bf16_t, bf16_t, bf16_t);
+  else if (key == 11) B2(float, bf16_t, bf16_t);
+  else B2(float, float, bf16_t);
+#undef B1
+#undef B2
+  rc = wl_check_launch();
+  if (rc != WL_OK) return rc;
+  const int n = C * C0_KW;
+  hipLaunchKernelGGL(conv0_bwd_w_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part2, B * nchunk, n,
+                     dW, (int)param_dtype);
+  return wl_check_launch();
+}
+
+}  // extern "C"

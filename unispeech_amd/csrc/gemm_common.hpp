@@ -1,0 +1,69 @@
+// Kernel-side GEMM parameter block + the shared epilogue (bias / GELU / GELU' / residual / accumulate).
+#pragma once
+#include "common.hpp"
+#include "../../include/wavlm_hip.h"
+
+struct GemmP {
+  const void* A; const void* B; void* C;
+  int M, N, K, KB;
+  long lda, ldb, ldc, sA_kb, sB_kb;
+  int batch_i;
+  long sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+  float alpha; int epi; int c_dtype;
+  const void* bias; int bias_dtype; long sBias_o, sBias_i;
+  void* aux; int aux_dtype; long ld_aux, sAux_o, sAux_i;
+  const void* res; int res_dtype; long ld_res, sRes_o, sRes_i;
+  int accumulate;
+  int split_k; float* ws;
+  int tiles_m, tiles_n;
+};
+
+static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
+  GemmP p;
+  p.A = d->A; p.B = d->B; p.C = d->C;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.KB = d->KB < 1 ? 1 : d->KB;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.sA_kb = d->sA_kb; p.sB_kb = d->sB_kb;
+  p.batch_i = d->batch_i < 1 ? 1 : d->batch_i;
+  p.sA_o = d->sA_o; p.sA_i = d->sA_i; p.sB_o = d->sB_o; p.sB_i = d->sB_i; p.sC_o = d->sC_o; p.sC_i = d->sC_i;
+  p.alpha = d->alpha; p.epi = d->epi; p.c_dtype = d->c_dtype;
+  p.bias = d->bias; p.bias_dtype = d->bias_dtype; p.sBias_o = d->sBias_o; p.sBias_i = d->sBias_i;
+  p.aux = d->aux; p.aux_dtype = d->aux_dtype; p.ld_aux = d->ld_aux; p.sAux_o = d->sAux_o; p.sAux_i = d->sAux_i;
+  p.res = d->res; p.res_dtype = d->res_dtype; p.ld_res = d->ld_res; p.sRes_o = d->sRes_o; p.sRes_i = d->sRes_i;
+  p.accumulate = d->accumulate;
+  p.split_k = d->split_k < 1 ? 1 : d->split_k;
+  p.ws = (float*)d->workspace;
+  p.tiles_m = 0; p.tiles_n = 0;
+  return p;
+}
+
+// final epilogue for output element (m, n) of batch (zo, zi); acc is the raw fp32 contraction
+__device__ __forceinline__ void gemm_epi_final(const GemmP& p, int zo, int zi, int m, int n, float acc) {
+  float v = p.alpha * acc;
+  if (p.bias) v += ld_elem(p.bias, (long)zo * p.sBias_o + (long)zi * p.sBias_i + n, p.bias_dtype);
+  if (p.epi == 1) {
+    if (p.aux) st_elem(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, p.aux_dtype, v);
+    v = gelu_f(v);
+  } else if (p.epi == 2) {
+    const float u = ld_elem(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, p.aux_dtype);
+    v *= gelu_grad_f(u);
+  }
+  if (p.res) v += ld_elem(p.res, (long)zo * p.sRes_o + (long)zi * p.sRes_i + (long)m * p.ld_res + n, p.res_dtype);
+  const long ci = (long)zo * p.sC_o + (long)zi * p.sC_i + (long)m * p.ldc + n;
+  if (p.accumulate) v += ld_elem(p.C, ci, p.c_dtype);
+  st_elem(p.C, ci, p.c_dtype, v);
+}
+
+// store from a main kernel: either a raw fp32 slab (split-K) or the final epilogue
+__device__ __forceinline__ void gemm_store(const GemmP& p, int z, int split, int m, int n, float acc) {
+  if (p.split_k > 1) {
+    p.ws[((long)z * p.split_k + split) * ((long)p.M * p.N) + (long)m * p.N + n] = acc;
+  } else {
+    gemm_epi_final(p, z / p.batch_i, z % p.batch_i, m, n, acc);
+  }
+}
+
+// flattened reduction-tile range [t0, t1) owned by split `s` (tiles = KB * ceil(K / BK))
+__device__ __forceinline__ void gemm_split_range(int total_tiles, int split_k, int s, int& t0, int& t1) {
+  const int per = (total_tiles + split_k - 1) / split_k;
+  t0 = s * per; t1 = t0 + per; if (t1 > total_tiles) t1 = total_tiles; if (t0 > t1) t0 = t1;
+}

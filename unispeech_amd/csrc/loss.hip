@@ -1,0 +1,152 @@
+// HuBERT-style masked-prediction loss pieces.
+//
+// The reference builds targets[V+1, S, 256] in fp32 (7.2 GB at B=32) to take cosine similarities against
+// every codebook row (src/fairseq/models/wavlm/wavlm.py:426-438, 525-535) and then a (V+1)-way cross entropy
+// with class 0 (src/fairseq/criterions/wavlm_criterion.py:68-71).  Because the duplicated positive among the
+// negatives is masked to -inf, that is exactly a V-way cross entropy over cos(x, E_v) / temp with class =
+// label.  So: L2-normalise the projected frames and the codebook rows (this file), one [S,256]x[V,256]^T
+// MFMA GEMM with alpha = 1/temp, and a fused log-softmax / NLL / accuracy / gradient row kernel (this file).
+#include "common.hpp"
+#include "../../include/wavlm_hip.h"
+
+// y = x / max(||x||, eps); inv[row] = 1 / max(||x||, eps)     (torch.cosine_similarity clamps each norm)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const TI* __restrict__ x, TO* __restrict__ y,
+                                                          float* __restrict__ inv, long rows, int D, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = Elem<TI>::ld(x + row * D + c); s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    const float iv = 1.f / fmaxf(sqrtf(s), eps);
+    if (lane == 0) inv[row] = iv;
+    for (int c = lane; c < D; c += 64) Elem<TO>::st(y + row * D + c, Elem<TI>::ld(x + row * D + c) * iv);
+  }
+}
+// dx = inv * (dy - y * <y, dy>)   (y = normalised row as stored)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const TO* __restrict__ dy, const TO* __restrict__ y,
+    const float* __restrict__ inv, TI* __restrict__ dx, long rows, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s = fmaf(Elem<TO>::ld(y + row * D + c), Elem<TO>::ld(dy + row * D + c), s);
+    s = wave_sum(s);
+    const float iv = inv[row];
+    for (int c = lane; c < D; c += 64)
+      Elem<TI>::st(dx + row * D + c, iv * (Elem<TO>::ld(dy + row * D + c) - Elem<TO>::ld(y + row * D + c) * s));
+  }
+}
+
+// per row: loss = lse(logits) - logits[target]; correct = logits[target] >= max; dlogits = w * (softmax - onehot)
+template <typename TO>
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int* __restrict__ target,
+    float* __restrict__ loss_rows, float* __restrict__ correct_rows, TO* __restrict__ dlogits, long S, int V, long ldl,
+    long ldd, float weight) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * 4 + wave; row < S; row += (long)gridDim.x * 4) {
+    const float* lr = logits + row * ldl;
+    float mx = -INFINITY;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, lr[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < V; c += 64) sum += expf(lr[c] - mx);
+    sum = wave_sum(sum);
+    const int t = target[row];
+    const float lt = lr[t];
+    if (lane == 0) {
+      loss_rows[row] = (mx + logf(sum)) - lt;
+      correct_rows[row] = (lt >= mx) ? 1.f : 0.f;
+    }
+    if (dlogits) {
+      const float inv = 1.f / sum;
+      for (int c = lane; c < ldd; c += 64) {
+        float g = 0.f;
+        if (c < V) g = weight * (expf(lr[c] - mx) * inv - (c == t ? 1.f : 0.f));
+        Elem<TO>::st(dlogits + row * ldd + c, g);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_partial_f32_kernel(const float* __restrict__ x, long n, double* part) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += x[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_finish_kernel(const double* part, int n, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += part[i];
+    out[0] = (float)s;
+  }
+}
+
+extern "C" {
+
+int wavlm_l2norm_fwd(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, float* inv_norm, int64_t rows,
+                     int32_t D, float eps, void* stream) {
+  if (!x || !y || !inv_norm || rows < 0 || D <= 0) return WL_EINVAL;
+  if (rows == 0) return WL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  long grid = (rows + 3) / 4; if (grid > 8192) grid = 8192;
+#define L2F(TI, TO) hipLaunchKernelGGL((l2norm_fwd_kernel<TI, TO>), dim3((unsigned)grid), dim3(256), 0, st, (const TI*)x, \
+    (TO*)y, inv_norm, (long)rows, (int)D, eps)
+  if (x_dtype == WL_F32 && y_dtype == WL_F32) L2F(float, float);
+  else if (x_dtype == WL_BF16 && y_dtype == WL_BF16) L2F(bf16_t, bf16_t);
+  else if (x_dtype == WL_F32 && y_dtype == WL_BF16) L2F(float, bf16_t);
+  else return WL_EINVAL;
+#undef L2F
+  return wl_check_launch();
+}
+
+int wavlm_l2norm_bwd(const void* dy, const void* y, int32_t y_dtype, const float* inv_norm, void* dx, int32_t x_dtype,
+                     int64_t rows, int32_t D, void* stream) {
+  if (!dy || !y || !inv_norm || !dx || rows < 0 || D <= 0) return WL_EINVAL;
+  if (rows == 0) return WL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  long grid = (rows + 3) / 4; if (grid > 8192) grid = 8192;
+#define L2B(TI, TO) hipLaunchKernelGGL((l2norm_bwd_kernel<TI, TO>), dim3((unsigned)grid), dim3(256), 0, st, (const TO*)dy, \
+    (const TO*)y, inv_norm, (TI*)dx, (long)rows, (int)D)
+  if (x_dtype == WL_F32 && y_dtype == WL_F32) L2B(float, float);
+  else if (x_dtype == WL_BF16 && y_dtype == WL_BF16) L2B(bf16_t, bf16_t);
+  else if (x_dtype == WL_F32 && y_dtype == WL_BF16) L2B(float, bf16_t);
+  else return WL_EINVAL;
+#undef L2B
+  return wl_check_launch();
+}
+
+int wavlm_ce_rows(const float* logits, const int32_t* target, float* loss_rows, float* correct_rows, void* dlogits,
+                  int32_t d_dtype, int64_t S, int32_t V, int64_t ld_logits, int64_t ld_dlogits, float weight,
+                  void* stream) {
+  if (!logits || !target || !loss_rows || !correct_rows || S < 0 || V <= 0 || ld_logits < V) return WL_EINVAL;
+  if (dlogits && ld_dlogits < V) return WL_EINVAL;
+  if (S == 0) return WL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  long grid = (S + 3) / 4; if (grid > 8192) grid = 8192;
+  if (!dlogits || d_dtype == WL_F32)
+    hipLaunchKernelGGL((ce_rows_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, logits, target, loss_rows,
+                       correct_rows, (float*)dlogits, (long)S, (int)V, (long)ld_logits, (long)ld_dlogits, weight);
+  else if (d_dtype == WL_BF16)
+    hipLaunchKernelGGL((ce_rows_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, logits, target, loss_rows,
+                       correct_rows, (bf16_t*)dlogits, (long)S, (int)V, (long)ld_logits, (long)ld_dlogits, weight);
+  else return WL_EINVAL;
+  return wl_check_launch();
+}
+
+uint64_t wavlm_sum_workspace_bytes(void) { return 1024 * sizeof(double); }
+
+int wavlm_sum_f32(const float* x, int64_t n, float* out, void* workspace, uint64_t ws_bytes, void* stream) {
+  if (!x || !out || !workspace || n < 0 || ws_bytes < wavlm_sum_workspace_bytes()) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  long grid = (n + 256 * 8 - 1) / (256 * 8); if (grid < 1) grid = 1; if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(sum_partial_f32_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, (long)n, (double*)workspace);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)grid, out);
+  return wl_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// Convolutional position embedding, weight side (WavLM/WavLM.py:514-527).
+//
+// pos_conv = weight_norm(Conv1d(D, D, k=K, padding=K/2, groups=G), dim=2): w[co,ci,k] = g[k] * v[co,ci,k] / ||v[:,:,k]||.
+// The convolution itself runs on the MFMA GEMM as G*B overlapping-row GEMMs over a group-major activation
+// copy; this file produces the two GEMM-ready weight images from (g, v) and the (g, v) gradients from the
+// GEMM-layout weight gradient:
+//   Wf[g][col][tap*Cg + ci]  = w[g*Cg + col, ci, tap]            (forward,   B operand, N = Cg, K = K*Cg)
+//   Wb[g][ci][tap*Cg + col]  = w[g*Cg + col, ci, K-1-tap]        (backward-data: correlation with flipped taps)
+#include "common.hpp"
+#include "../../include/wavlm_hip.h"
+
+#define PC_BLOCKS 64
+
+// part[blk][k] = sum over the block's rows r=(co,ci) of a[r][k]*b[r][k]   (a == b gives squared norms)
+template <typename TA, typename TB>
+__global__ void pc_rowdot_partial_kernel(const TA* __restrict__ a, const TB* __restrict__ b, long rows, int K,
+                                         float* __restrict__ part) {
+  const int k = threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (long r = blockIdx.x; r < rows; r += gridDim.x) s = fmaf(Elem<TA>::ld(a + r * K + k), Elem<TB>::ld(b + r * K + k), s);
+  part[(long)blockIdx.x * K + k] = s;
+}
+
+// tot[k] = sum_b part[b][k] (optionally sqrt) -- K threads
+__global__ void pc_finish_kernel(const float* __restrict__ part, int nblk, int K, float* __restrict__ tot, int do_sqrt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += part[(long)b * K + k];
+  tot[k] = do_sqrt ? (float)sqrt(s) : (float)s;
+}
+
+// one thread per (co, ci, k): writes both GEMM images and norm[k]
+template <typename TP, typename TO>
+__global__ __launch_bounds__(256) void pc_weight_kernel(const TP* __restrict__ v, const TP* __restrict__ g,
+    const float* __restrict__ norm, TO* __restrict__ Wf, TO* __restrict__ Wb, int D, int Cg, int K) {
+  const long total = (long)D * Cg * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const long r = i / K;
+    const int ci = (int)(r % Cg), co = (int)(r / Cg);
+    const int grp = co / Cg, col = co % Cg;
+    const float nrm = norm[k];
+    const float w = Elem<TP>::ld(g + k) * Elem<TP>::ld(v + i) / nrm;
+    const long KC = (long)K * Cg;
+    Elem<TO>::st(Wf + ((long)grp * Cg + col) * KC + (long)k * Cg + ci, w);
+    Elem<TO>::st(Wb + ((long)grp * Cg + ci) * KC + (long)(K - 1 - k) * Cg + col, w);
+  }
+}
+
+// dWf (GEMM layout, f32) -> dw in (co,ci,k) order (f32 scratch), so the row-dot kernel can be reused
+__global__ __launch_bounds__(256) void pc_unpack_dw_kernel(const float* __restrict__ dWf, float* __restrict__ dw, int D,
+                                                           int Cg, int K) {
+  const long total = (long)D * Cg * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const long r = i / K;
+    const int ci = (int)(r % Cg), co = (int)(r / Cg);
+    const int grp = co / Cg, col = co % Cg;
+    dw[i] = dWf[((long)grp * Cg + col) * ((long)K * Cg) + (long)k * Cg + ci];
+  }
+}
+// dv = g/n * (dw - v * S/n^2), dg[k] = S/n with S[k] = sum dw*v
+template <typename TP>
+__global__ __launch_bounds__(256) void pc_weight_bwd_kernel(const float* __restrict__ dw, const TP* __restrict__ v,
+    const TP* __restrict__ g, const float* __restrict__ norm, const float* __restrict__ Stot,
+    TP* __restrict__ dv, TP* __restrict__ dg, int D, int Cg, int K) {
+  const long total = (long)D * Cg * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const float S = Stot[k];
+    const float n = norm[k];
+    const float gk = Elem<TP>::ld(g + k);
+    Elem<TP>::st(dv + i, gk / n * (dw[i] - Elem<TP>::ld(v + i) * S / (n * n)));
+    if (i < K) Elem<TP>::st(dg + k, S / n);
+  }
+}
+
+// activation relayout for the grouped conv: x[B,T,D] (optionally times gelu'(aux)) -> out[B,G,Tp,Cg], zero rows
+// outside [left_pad, left_pad + T).  nat (optional) receives the same values in the natural [B,T,D] layout.
+template <typename T>
+__global__ __launch_bounds__(256) void pc_group_major_kernel(const T* __restrict__ x, const T* __restrict__ aux,
+    T* __restrict__ out, T* __restrict__ nat, int B, int Tn, int D, int G, int left_pad, int Tp) {
+  const int Cg = D / G, c8n = Cg >> 3;
+  const long total = (long)B * G * Tp * c8n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % c8n);
+    long r = i / c8n;
+    const int tp = (int)(r % Tp); r /= Tp;
+    const int g = (int)(r % G);
+    const int b = (int)(r / G);
+    const int t = tp - left_pad;
+    unsigned short o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (t >= 0 && t < Tn) {
+      const long src = ((long)b * Tn + t) * D + g * Cg + c8 * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = Elem<T>::ld(x + src + e);
+      if (aux) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(Elem<T>::ld(aux + src + e));
+      }
+      if (nat) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Elem<T>::st(nat + src + e, v[e]);
+      }
+    }
+    const long dst = (((long)b * G + g) * Tp + tp) * Cg + c8 * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Elem<T>::st(out + dst + e, v[e]);
+  }
+}
+
+extern "C" {
+
+uint64_t wavlm_posconv_weight_workspace_bytes(int32_t D, int32_t Cg, int32_t K) {
+  return ((uint64_t)(PC_BLOCKS + 1) * K + (uint64_t)D * Cg * K) * sizeof(float);
+}
+
+int wavlm_posconv_weight_fwd(const void* v, const void* g, int32_t param_dtype, void* Wf, void* Wb, int32_t out_dtype,
+                             float* norm, int32_t D, int32_t Cg, int32_t K, void* workspace, uint64_t ws_bytes,
+                             void* stream) {
+  if (!v || !g || !Wf || !Wb || !norm || !workspace || D <= 0 || Cg <= 0 || K <= 0 || K > 1024 || D % Cg) return WL_EINVAL;
+  if (ws_bytes < wavlm_posconv_weight_workspace_bytes(D, Cg, K)) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  const long rows = (long)D * Cg;
+  const unsigned th = (unsigned)((K + 63) / 64 * 64);
+  const long total = rows * K;
+  long grid = (total + 255) / 256; if (grid > 4096) grid = 4096;
+  if (param_dtype == WL_F32) {
+    hipLaunchKernelGGL((pc_rowdot_partial_kernel<float, float>), dim3(PC_BLOCKS), dim3(th), 0, st, (const float*)v,
+                       (const float*)v, rows, (int)K, part);
+    hipLaunchKernelGGL(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, norm, 1);
+    if (out_dtype == WL_F32)
+      hipLaunchKernelGGL((pc_weight_kernel<float, float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)v,
+                         (const float*)g, norm, (float*)Wf, (float*)Wb, (int)D, (int)Cg, (int)K);
+    else
+      hipLaunchKernelGGL((pc_weight_kernel<float, bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)v,
+                         (const float*)g, norm, (bf16_t*)Wf, (bf16_t*)Wb, (int)D, (int)Cg, (int)K);
+  } else if (param_dtype == WL_BF16 && out_dtype == WL_BF16) {
+    hipLaunchKernelGGL((pc_rowdot_partial_kernel<bf16_t, bf16_t>), dim3(PC_BLOCKS), dim3(th), 0, st, (const bf16_t*)v,
+                       (const bf16_t*)v, rows, (int)K, part);
+    hipLaunchKernelGGL(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, norm, 1);
+    hipLaunchKernelGGL((pc_weight_kernel<bf16_t, bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)v,
+                       (const bf16_t*)g, norm, (bf16_t*)Wf, (bf16_t*)Wb, (int)D, (int)Cg, (int)K);
+  } else return WL_EINVAL;
+  return wl_check_launch();
+}
+
+// dWf: f32 [G, Cg, K*Cg] (the weight-gradient GEMM's output); outputs dv [D,Cg,K], dg [K] in param dtype
+int wavlm_posconv_weight_bwd(const float* dWf, const void* v, const void* g, const float* norm, int32_t param_dtype,
+                             void* dv, void* dg, int32_t D, int32_t Cg, int32_t K, void* workspace, uint64_t ws_bytes,
+                             void* stream) {
+  if (!dWf || !v || !g || !norm || !dv || !dg || !workspace || D <= 0 || Cg <= 0 || K <= 0 || K > 1024 || D % Cg)
+    return WL_EINVAL;
+  if (ws_bytes < wavlm_posconv_weight_workspace_bytes(D, Cg, K)) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* Stot = part + (long)PC_BLOCKS * K;
+  float* dw = Stot + K;
+  const long rows = (long)D * Cg;
+  const long total = rows * K;
+  long grid = (total + 255) / 256; if (grid > 4096) grid = 4096;
+  const unsigned th = (unsigned)((K + 63) / 64 * 64);
+  hipLaunchKernelGGL(pc_unpack_dw_kernel, dim3((unsigned)grid), dim3(256), 0, st, dWf, dw, (int)D, (int)Cg, (int)K);
+  if (param_dtype == WL_F32) {
+    hipLaunchKernelGGL((pc_rowdot_partial_kernel<float, float>), dim3(PC_BLOCKS), dim3(th), 0, st, (const float*)dw,
+                       (const float*)v, rows, (int)K, part);
+    hipLaunchKernelGGL(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, Stot, 0);
+    hipLaunchKernelGGL((pc_weight_bwd_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)dw,
+                       (const float*)v, (const float*)g, norm, Stot, (float*)dv, (float*)dg, (int)D, (int)Cg, (int)K);
+  } else if (param_dtype == WL_BF16) {
+    hipLaunchKernelGGL((pc_rowdot_partial_kernel<float, bf16_t>), dim3(PC_BLOCKS), dim3(th), 0, st, (const float*)dw,
+                       (const bf16_t*)v, rows, (int)K, part);
+    hipLaunchKernelGGL(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, Stot, 0);
+    hipLaunchKernelGGL((pc_weight_bwd_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)dw,
+                       (const bf16_t*)v, (const bf16_t*)g, norm, Stot, (bf16_t*)dv, (bf16_t*)dg, (int)D, (int)Cg, (int)K);
+  } else return WL_EINVAL;
+  return wl_check_launch();
+}
+
+int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* nat_out, int32_t B, int32_t T, int32_t D,
+                              int32_t G, int32_t left_pad, int32_t Tp, int32_t dtype, void* stream) {
+  if (!x || !out || B <= 0 || T <= 0 || D <= 0 || G <= 0 || D % G || ((D / G) & 7) || left_pad < 0 || Tp < left_pad + T)
+    return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)B * G * Tp * ((D / G) >> 3);
+  long grid = (total + 255) / 256; if (grid > 8192) grid = 8192;
+  if (dtype == WL_F32)
+    hipLaunchKernelGGL((pc_group_major_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)x,
+                       (const float*)aux, (float*)out, (float*)nat_out, (int)B, (int)T, (int)D, (int)G, (int)left_pad, (int)Tp);
+  else if (dtype == WL_BF16)
+    hipLaunchKernelGGL((pc_group_major_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)x,
+                       (const bf16_t*)aux, (bf16_t*)out, (bf16_t*)nat_out, (int)B, (int)T, (int)D, (int)G, (int)left_pad,
+                       (int)Tp);
+  else return WL_EINVAL;
+  return wl_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,534 @@
+// Row kernels of the WavLM hot path: LayerNorm (+residual, +dropout, +GELU) forward/backward, column sums
+// (bias / affine gradients), row select / gather (mask embedding, padding zero-fill, masked-frame gather),
+// element-wise helpers.  All are HBM-bound: one 64-lane wave owns a row, 16-byte vector loads, row
+// statistics through wave shuffles, column gradients accumulated in registers per lane and reduced
+// across waves/blocks deterministically (per-block partials + a finishing kernel, no atomics).
+#include "common.hpp"
+#include "../../include/wavlm_hip.h"
+
+// ---- 8-wide vector access ------------------------------------------------------------------------
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  uint4 o;
+  o.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+  o.z = f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); o.w = f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = o;
+}
+// 8 keep-bits for elements idx .. idx+7 (idx % 8 == 0): two Philox calls
+__device__ __forceinline__ unsigned keep8(unsigned long long seed, unsigned long long idx, unsigned thresh) {
+  const Philox4 a = philox4x32_10(seed, idx >> 2), b = philox4x32_10(seed, (idx >> 2) + 1);
+  return (a.x >= thresh ? 1u : 0u) | (a.y >= thresh ? 2u : 0u) | (a.z >= thresh ? 4u : 0u) | (a.w >= thresh ? 8u : 0u) |
+         (b.x >= thresh ? 16u : 0u) | (b.y >= thresh ? 32u : 0u) | (b.z >= thresh ? 64u : 0u) | (b.w >= thresh ? 128u : 0u);
+}
+static inline unsigned drop_thresh(float p) {
+  if (p <= 0.f) return 0u;
+  double t = (double)p * 4294967296.0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (unsigned)t;
+}
+
+#define LN_MAXC 4  // 64 lanes x 4 chunks x 8 = rows up to 2048 channels
+
+// y = dropout_out( act( LN( x + dropout_in(r) ) ) ); optionally stores s = x + dropout_in(r), mean, rstd
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ y,
+    T* __restrict__ s, float* __restrict__ mean_o, float* __restrict__ rstd_o, const TP* __restrict__ gamma,
+    const TP* __restrict__ beta, long rows, int D, float eps, int act, unsigned th_in, float sc_in,
+    unsigned long long seed_in, unsigned th_out, float sc_out, unsigned long long seed_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    float v[LN_MAXC][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        const long off = row * D + ch * 8;
+        load8(x + off, v[c]);
+        if (r) {
+          float rv[8];
+          load8(r + off, rv);
+          if (th_in) {
+            const unsigned k = keep8(seed_in, (unsigned long long)off, th_in);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rv[e] = ((k >> e) & 1u) ? rv[e] * sc_in : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[c][e] += rv[e];
+          // statistics are taken on the sum as it is stored (bf16-rounded in bf16 mode): that is the
+          // tensor the reference normalises, and what backward re-reads from s
+          if (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = bf2f(f2bf(v[c][e]));
+          }
+        }
+        if (s) store8(s + off, v[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += v[c][e];
+      }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    if (lane == 0) { if (mean_o) mean_o[row] = mean; if (rstd_o) rstd_o[row] = rstd; }
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        const long off = row * D + ch * 8;
+        float g[8], b[8], o[8];
+        load8(gamma + ch * 8, g);
+        load8(beta + ch * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = (v[c][e] - mean) * rstd * g[e] + b[e];
+          if (act) z = gelu_f(z);
+          o[e] = z;
+        }
+        if (th_out) {
+          const unsigned k = keep8(seed_out, (unsigned long long)off, th_out);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = ((k >> e) & 1u) ? o[e] * sc_out : 0.f;
+        }
+        store8(y + off, o);
+      }
+    }
+  }
+}
+
+// backward of the above.  dx -> gradient of x (and of the un-dropped residual path); dr (optional) ->
+// gradient of r (= dx with the input-dropout mask).  dgamma/dbeta partials: part[block][2][D].
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+    const float* __restrict__ mean_i, const float* __restrict__ rstd_i, const TP* __restrict__ gamma,
+    const TP* __restrict__ beta, T* __restrict__ dx, T* __restrict__ dr, float* __restrict__ part, long rows, int D,
+    int act, unsigned th_in, float sc_in, unsigned long long seed_in, unsigned th_out, float sc_out,
+    unsigned long long seed_out, float grad_scale) {
+  __shared__ float red[4][2][64 * LN_MAXC * 8 / 4];  // cross-wave reduce, processed in 4 column quarters
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  float ag[LN_MAXC][8], ab[LN_MAXC][8], gm[LN_MAXC][8], bt[LN_MAXC][8];
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int ch = lane + 64 * c;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; gm[c][e] = 0.f; bt[c][e] = 0.f; }
+    if (ch < nch) { load8(gamma + ch * 8, gm[c]); if (act) load8(beta + ch * 8, bt[c]); }
+  }
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float h[LN_MAXC][8], xh[LN_MAXC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        const long off = row * D + ch * 8;
+        float g[8], sv[8];
+        load8(dy + off, g);
+        load8(s + off, sv);
+        if (th_out) {
+          const unsigned k = keep8(seed_out, (unsigned long long)off, th_out);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = ((k >> e) & 1u) ? g[e] * sc_out : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xhat = (sv[e] - mean) * rstd;
+          float ge = g[e] * grad_scale;
+          if (act) ge *= gelu_grad_f(xhat * gm[c][e] + bt[c][e]);
+          ag[c][e] += ge * xhat;
+          ab[c][e] += ge;
+          const float hh = ge * gm[c][e];
+          h[c][e] = hh; xh[c][e] = xhat;
+          s1 += hh; s2 += hh * xhat;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        const long off = row * D + ch * 8;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (h[c][e] - s1 - xh[c][e] * s2);
+        store8(dx + off, o);
+        if (dr) {
+          if (th_in) {
+            const unsigned k = keep8(seed_in, (unsigned long long)off, th_in);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = ((k >> e) & 1u) ? o[e] * sc_in : 0.f;
+          }
+          store8(dr + off, o);
+        }
+      }
+    }
+  }
+  // cross-wave reduction of the column accumulators, one chunk-slot at a time
+  float* pg = part + (long)blockIdx.x * 2 * D;
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[wave][0][lane * 8 + e] = ag[c][e]; red[wave][1][lane * 8 + e] = ab[c][e]; }
+    __syncthreads();
+    // 512 columns of this slot, 256 threads -> 2 each, for both arrays
+    for (int i = threadIdx.x; i < 512; i += 256) {
+      const int ch = (i >> 3) + 64 * c;
+      if (ch < nch) {
+        const int col = ch * 8 + (i & 7);
+        pg[col] = red[0][0][i] + red[1][0][i] + red[2][0][i] + red[3][0][i];
+        pg[D + col] = red[0][1][i] + red[1][1][i] + red[2][1][i] + red[3][1][i];
+      }
+    }
+  }
+}
+
+// out[c] (+)= sum_b part[b * stride + c]
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nblk, long stride, int n,
+                                                             void* out, int out_dtype, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(long)b * stride + c];
+  if (accumulate) s += ld_elem(out, c, out_dtype);
+  st_elem(out, c, out_dtype, s);
+}
+
+#define CS_MAXC 8  // up to 4096 columns
+// column sums of x[rows, N] (row stride ld) with optional row masks: a row is counted iff
+// (!inc || inc[row]) && (!exc || !exc[row]).  part[block][N]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long rows, int N, long ld,
+    const unsigned char* __restrict__ inc, const unsigned char* __restrict__ exc, float* __restrict__ part) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = N >> 3;
+  float acc[CS_MAXC][8];
+#pragma unroll
+  for (int c = 0; c < CS_MAXC; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    if (inc && !inc[row]) continue;
+    if (exc && exc[row]) continue;
+#pragma unroll
+    for (int c = 0; c < CS_MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        float v[8];
+        load8(x + row * ld + ch * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[c][e] += v[e];
+      }
+    }
+  }
+  float* pg = part + (long)blockIdx.x * N;
+#pragma unroll
+  for (int c = 0; c < CS_MAXC; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = acc[c][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+      const int ch = (i >> 3) + 64 * c;
+      if (ch < nch) pg[ch * 8 + (i & 7)] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+  }
+}
+
+// y[row] = zero[row] ? 0 : (sel[row] ? emb (or 0 if emb == NULL) : x[row])
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void select_rows_kernel(const T* __restrict__ x, T* __restrict__ y,
+    const unsigned char* __restrict__ sel, const TP* __restrict__ emb, const unsigned char* __restrict__ zero,
+    long rows, int D) {
+  const int nch = D >> 3;
+  const long total = rows * nch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / nch; const int ch = (int)(i - row * nch);
+    float v[8];
+    if (zero && zero[row]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    } else if (sel && sel[row]) {
+      if (emb) load8(emb + ch * 8, v);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+    } else {
+      load8(x + row * D + ch * 8, v);
+    }
+    store8(y + row * D + ch * 8, v);
+  }
+}
+
+// dst[i] = idx[i] >= 0 ? src[idx[i]] : 0   (rows of D elements)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, const int* __restrict__ idx,
+                                                           T* __restrict__ dst, long n_out, int D) {
+  const int nch = D >> 3;
+  const long total = n_out * nch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / nch; const int ch = (int)(i - row * nch);
+    const int srow = idx[row];
+    float v[8];
+    if (srow >= 0) load8(src + (long)srow * D + ch * 8, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    store8(dst + row * D + ch * 8, v);
+  }
+}
+
+// y = a * x + b * y (element-wise; mixed dtypes)
+__global__ __launch_bounds__(256) void axpby_kernel(const void* x, int xdt, void* y, int ydt, long n, float a, float b) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = a * ld_elem(x, i, xdt);
+    if (b != 0.f) v += b * ld_elem(y, i, ydt);
+    st_elem(y, i, ydt, v);
+  }
+}
+
+
+// y *= s[0] (device scalar): lets a backward pass apply the upstream scalar gradient without a host sync
+__global__ __launch_bounds__(256) void scale_dev_kernel(void* y, int ydt, long n, const float* __restrict__ s, float extra) {
+  const float a = s[0] * extra;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    st_elem(y, i, ydt, a * ld_elem(y, i, ydt));
+}
+
+// y = dropout(x) with the counter-based mask (same call regenerates the mask for the gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n8, unsigned th,
+                                                       float sc, unsigned long long seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    load8(x + i * 8, v);
+    const unsigned k = keep8(seed, (unsigned long long)i * 8, th);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ((k >> e) & 1u) ? v[e] * sc : 0.f;
+    store8(y + i * 8, v);
+  }
+}
+
+// block partial sums of x^2 (features_pen) -> part[block] (double)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const void* x, int dt, long n, double* part) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = ld_elem(x, i, dt);
+    s += (double)v * v;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_finish_d_kernel(const double* part, int n, float* out, float scale) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += part[i];
+    out[0] = (float)(s * scale);
+  }
+}
+
+static inline unsigned grid_for(long work_items, int per_block, unsigned cap) {
+  long g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+#define LN_BWD_BLOCKS 512
+#define CS_BLOCKS 512
+
+extern "C" {
+
+int wavlm_abi_version(void) { return WAVLM_HIP_ABI_VERSION; }
+
+int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* mean, float* rstd, const void* gamma,
+                        const void* beta, int64_t rows, int32_t D, float eps, int32_t dtype, int32_t param_dtype,
+                        int32_t act, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, void* stream) {
+  if (!x || !y || !gamma || !beta || rows < 0 || D <= 0 || (D & 7) || D > LN_MAXC * 512) return WL_EINVAL;
+  if (rows == 0) return WL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned ti = drop_thresh(p_in), to = drop_thresh(p_out);
+  const float si = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, so = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+  const unsigned grid = grid_for(rows, 4, 8192);
+#define LN_FWD(T, TP) hipLaunchKernelGGL((layernorm_fwd_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)x, \
+    (const T*)r, (T*)y, (T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (long)rows, (int)D, eps, (int)act, ti, si, \
+    (unsigned long long)seed_in, to, so, (unsigned long long)seed_out)
+  if (dtype == WL_F32 && param_dtype == WL_F32) LN_FWD(float, float);
+  else if (dtype == WL_BF16 && param_dtype == WL_BF16) LN_FWD(bf16_t, bf16_t);
+  else if (dtype == WL_BF16 && param_dtype == WL_F32) LN_FWD(bf16_t, float);
+  else return WL_EINVAL;
+#undef LN_FWD
+  return wl_check_launch();
+}
+
+uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D) { return (uint64_t)LN_BWD_BLOCKS * 2 * D * sizeof(float); }
+
+int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd, const void* gamma,
+                        const void* beta, void* dx, void* dr, void* dgamma, void* dbeta, int64_t rows, int32_t D,
+                        int32_t dtype, int32_t param_dtype, int32_t act, float p_in, uint64_t seed_in, float p_out,
+                        uint64_t seed_out, float grad_scale, int32_t accumulate_params, void* workspace,
+                        uint64_t ws_bytes, void* stream) {
+  if (!dy || !s || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return WL_EINVAL;
+  if (rows <= 0 || D <= 0 || (D & 7) || D > LN_MAXC * 512) return WL_EINVAL;
+  if (act && !beta) return WL_EINVAL;
+  if (ws_bytes < wavlm_layernorm_bwd_workspace_bytes(D)) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned ti = drop_thresh(p_in), to = drop_thresh(p_out);
+  const float si = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, so = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+  const unsigned grid = grid_for(rows, 4, LN_BWD_BLOCKS);
+  float* part = (float*)workspace;
+#define LN_BWD(T, TP) hipLaunchKernelGGL((layernorm_bwd_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
+    (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, part, (long)rows, (int)D, (int)act, ti, si, \
+    (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale)
+  if (dtype == WL_F32 && param_dtype == WL_F32) LN_BWD(float, float);
+  else if (dtype == WL_BF16 && param_dtype == WL_BF16) LN_BWD(bf16_t, bf16_t);
+  else if (dtype == WL_BF16 && param_dtype == WL_F32) LN_BWD(bf16_t, float);
+  else return WL_EINVAL;
+#undef LN_BWD
+  int rc = wl_check_launch();
+  if (rc != WL_OK) return rc;
+  const unsigned g2 = (unsigned)((D + 255) / 256);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(g2), dim3(256), 0, st, part, (int)grid, (long)(2 * D), (int)D, dgamma,
+                     (int)param_dtype, (int)accumulate_params);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(g2), dim3(256), 0, st, part + D, (int)grid, (long)(2 * D), (int)D, dbeta,
+                     (int)param_dtype, (int)accumulate_params);
+  return wl_check_launch();
+}
+
+uint64_t wavlm_colsum_workspace_bytes(int32_t N) { return (uint64_t)CS_BLOCKS * N * sizeof(float); }
+
+int wavlm_colsum(const void* x, int64_t rows, int32_t N, int64_t ld, int32_t dtype, const uint8_t* include_mask,
+                 const uint8_t* exclude_mask, void* out, int32_t out_dtype, int32_t accumulate, void* workspace,
+                 uint64_t ws_bytes, void* stream) {
+  if (!x || !out || !workspace || rows < 0 || N <= 0 || (N & 7) || N > CS_MAXC * 512 || (ld & 7)) return WL_EINVAL;
+  if (ws_bytes < wavlm_colsum_workspace_bytes(N)) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = grid_for(rows > 0 ? rows : 1, 4, CS_BLOCKS);
+  float* part = (float*)workspace;
+  if (dtype == WL_F32)
+    hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (long)rows, (int)N,
+                       (long)ld, include_mask, exclude_mask, part);
+  else if (dtype == WL_BF16)
+    hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (long)rows, (int)N,
+                       (long)ld, include_mask, exclude_mask, part);
+  else return WL_EINVAL;
+  int rc = wl_check_launch();
+  if (rc != WL_OK) return rc;
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, part, (int)grid, (long)N,
+                     (int)N, out, (int)out_dtype, (int)accumulate);
+  return wl_check_launch();
+}
+
+int wavlm_select_rows(const void* x, void* y, const uint8_t* sel, const void* emb, const uint8_t* zero, int64_t rows,
+                      int32_t D, int32_t dtype, int32_t emb_dtype, void* stream) {
+  if (!x || !y || rows < 0 || D <= 0 || (D & 7)) return WL_EINVAL;
+  if (rows == 0) return WL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = grid_for(rows * (D >> 3), 256, 4096);
+#define SEL(T, TP) hipLaunchKernelGGL((select_rows_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)x, (T*)y, sel, \
+    (const TP*)emb, zero, (long)rows, (int)D)
+  if (dtype == WL_F32 && emb_dtype == WL_F32) SEL(float, float);
+  else if (dtype == WL_BF16 && emb_dtype == WL_BF16) SEL(bf16_t, bf16_t);
+  else if (dtype == WL_BF16 && emb_dtype == WL_F32) SEL(bf16_t, float);
+  else return WL_EINVAL;
+#undef SEL
+  return wl_check_launch();
+}
+
+int wavlm_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_out, int32_t D, int32_t dtype,
+                      void* stream) {
+  if (!src || !idx || !dst || n_out < 0 || D <= 0 || (D & 7)) return WL_EINVAL;
+  if (n_out == 0) return WL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = grid_for(n_out * (D >> 3), 256, 4096);
+  if (dtype == WL_F32)
+    hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, idx, (float*)dst,
+                       (long)n_out, (int)D);
+  else if (dtype == WL_BF16)
+    hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, idx, (bf16_t*)dst,
+                       (long)n_out, (int)D);
+  else return WL_EINVAL;
+  return wl_check_launch();
+}
+
+int wavlm_axpby(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, float a, float b, void* stream) {
+  if (!x || !y || n < 0) return WL_EINVAL;
+  if (n == 0) return WL_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, (int)x_dtype, y,
+                     (int)y_dtype, (long)n, a, b);
+  return wl_check_launch();
+}
+
+int wavlm_scale_dev(void* y, int32_t dtype, int64_t n, const float* scalar, float extra, void* stream) {
+  if (!y || !scalar || n < 0) return WL_EINVAL;
+  if (n == 0) return WL_OK;
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, y, (int)dtype,
+                     (long)n, scalar, extra);
+  return wl_check_launch();
+}
+
+int wavlm_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int32_t dtype, void* stream) {
+  if (!x || !y || n < 0 || (n & 7) || p < 0.f || p >= 1.f) return WL_EINVAL;
+  if (n == 0) return WL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned th = drop_thresh(p);
+  const float sc = 1.f / (1.f - p);
+  const unsigned grid = grid_for(n >> 3, 256, 8192);
+  if (dtype == WL_F32)
+    hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, (long)(n >> 3), th,
+                       sc, (unsigned long long)seed);
+  else if (dtype == WL_BF16)
+    hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
+                       (long)(n >> 3), th, sc, (unsigned long long)seed);
+  else return WL_EINVAL;
+  return wl_check_launch();
+}
+
+uint64_t wavlm_sumsq_workspace_bytes(void) { return 1024 * sizeof(double); }
+
+// out[0] = scale * sum(x^2)
+int wavlm_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out, void* workspace, uint64_t ws_bytes,
+                void* stream) {
+  if (!x || !out || !workspace || n <= 0 || ws_bytes < wavlm_sumsq_workspace_bytes()) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = grid_for(n, 256 * 16, 1024);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, st, x, (int)dtype, (long)n, (double*)workspace);
+  hipLaunchKernelGGL(sum_finish_d_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)grid, out, scale);
+  return wl_check_launch();
+}
+
+}  // extern "C"

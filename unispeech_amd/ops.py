@@ -1,0 +1,403 @@
+"""Thin functional layer over the C ABI: torch tensors in, kernel launches on torch's current HIP stream.
+
+torch is used here for device memory (allocation, views), the current stream and nothing else: every function
+below ends in exactly one (or a fixed short sequence of) libwavlm_hip.so entry points.  There is no CPU path --
+a CPU tensor raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, GemmDesc, check
+
+_WS = {}
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.WavlmHipError("unispeech_amd kernels need a HIP device tensor (no CPU fallback)")
+    return t.device
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, offset=0):
+    """device address of element `offset` of tensor t (None -> NULL)"""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + offset * t.element_size())
+
+
+def workspace(device, nbytes, tag="main"):
+    """grow-only scratch buffer; reuse is safe because all launches are ordered on one stream"""
+    key = (device.index, tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _contig(t):
+    if t is not None and not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    return t
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+def gemm(A, B, Cc, M, N, K, *, lda, ldb, ldc, transA=False, transB=False, KB=1, sA_kb=0, sB_kb=0, batch=(1, 1),
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0, bias=None, bias_off=0, sBias=(0, 0),
+         epi=0, aux=None, aux_off=0, ld_aux=0, sAux=(0, 0), res=None, res_off=0, ld_res=0, sRes=(0, 0),
+         accumulate=False, split_k=1):
+    """C = epi(alpha * sum_kb A.B^T + bias) (+res) (+C); see include/wavlm_hip.h for the addressing rules."""
+    dev = _dev(A)
+    if A.dtype != B.dtype:
+        raise TypeError("A and B must share a dtype")
+    d = GemmDesc()
+    d.dtype, d.c_dtype = dt(A), dt(Cc)
+    d.M, d.N, d.K, d.KB = int(M), int(N), int(K), int(KB)
+    d.transA, d.transB = int(bool(transA)), int(bool(transB))
+    d.lda, d.ldb, d.ldc = int(lda), int(ldb), int(ldc)
+    d.sA_kb, d.sB_kb = int(sA_kb), int(sB_kb)
+    d.batch_o, d.batch_i = int(batch[0]), int(batch[1])
+    d.sA_o, d.sA_i = int(sA[0]), int(sA[1])
+    d.sB_o, d.sB_i = int(sB[0]), int(sB[1])
+    d.sC_o, d.sC_i = int(sC[0]), int(sC[1])
+    d.A, d.B, d.C = ptr(A, a_off), ptr(B, b_off), ptr(Cc, c_off)
+    d.alpha, d.epi = float(alpha), int(epi)
+    d.bias = ptr(bias, bias_off)
+    d.bias_dtype = dt(bias) if bias is not None else 0
+    d.sBias_o, d.sBias_i = int(sBias[0]), int(sBias[1])
+    d.aux = ptr(aux, aux_off)
+    d.aux_dtype = dt(aux) if aux is not None else 0
+    d.ld_aux, d.sAux_o, d.sAux_i = int(ld_aux), int(sAux[0]), int(sAux[1])
+    d.res = ptr(res, res_off)
+    d.res_dtype = dt(res) if res is not None else 0
+    d.ld_res, d.sRes_o, d.sRes_i = int(ld_res), int(sRes[0]), int(sRes[1])
+    d.accumulate = int(bool(accumulate))
+    d.split_k = int(split_k)
+    L = _lib.lib()
+    if d.split_k > 1:
+        need = L.wavlm_gemm_workspace_bytes(C.byref(d))
+        ws = workspace(dev, need, "gemm")
+        d.workspace, d.ws_bytes = ptr(ws), need
+    else:
+        d.workspace, d.ws_bytes = None, 0
+    check(L.wavlm_gemm(C.byref(d), stream()), "wavlm_gemm[M=%d N=%d K=%d KB=%d tA=%d tB=%d]" % (M, N, K, KB, transA, transB))
+
+
+def pick_split(M, N, ktiles, nbatch=1, target_blocks=768):
+    """split-K factor so that a small-output / long-reduction GEMM still fills 256 CUs"""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * nbatch
+    s = max(1, min(ktiles, (target_blocks + tiles - 1) // tiles))
+    return min(s, 64)
+
+
+# ---------------------------------------------------------------------------------------- row kernels
+def layernorm_fwd(x, r, gamma, beta, eps, *, act=0, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, save=True):
+    """returns (y, s, mean, rstd); s is the pre-norm sum (== x when r is None)"""
+    dev = _dev(x)
+    _contig(x); _contig(r)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    s = None
+    mean = rstd = None
+    if save:
+        mean = torch.empty(rows, dtype=torch.float32, device=dev)
+        rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+        s = torch.empty_like(x) if r is not None else x
+    check(_lib.lib().wavlm_layernorm_fwd(ptr(x), ptr(r), ptr(y), ptr(s) if (save and r is not None) else None,
+                                         ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), rows, D, float(eps), dt(x),
+                                         dt(gamma), int(act), float(p_in), int(seed_in), float(p_out), int(seed_out),
+                                         stream()), "wavlm_layernorm_fwd")
+    return y, s, mean, rstd
+
+
+def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0,
+                  grad_scale=1.0, need_dr=False):
+    """returns (dx, dr, dgamma, dbeta)"""
+    dev = _dev(dy)
+    _contig(dy); _contig(s)
+    D = dy.shape[-1]
+    rows = dy.numel() // D
+    dx = torch.empty_like(dy)
+    dr = torch.empty_like(dy) if need_dr else None
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(beta)
+    L = _lib.lib()
+    need = L.wavlm_layernorm_bwd_workspace_bytes(D)
+    ws = workspace(dev, need)
+    check(L.wavlm_layernorm_bwd(ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dr),
+                                ptr(dgamma), ptr(dbeta), rows, D, dt(dy), dt(gamma), int(act), float(p_in),
+                                int(seed_in), float(p_out), int(seed_out), float(grad_scale), 0, ptr(ws), need,
+                                stream()), "wavlm_layernorm_bwd")
+    return dx, dr, dgamma, dbeta
+
+
+def colsum(x2d, out_dtype, *, include=None, exclude=None, rows=None, N=None, ld=None):
+    """column sums of a [rows, N] matrix (row stride ld) -> [N] tensor of out_dtype"""
+    dev = _dev(x2d)
+    if rows is None:
+        N = x2d.shape[-1]
+        rows = x2d.numel() // N
+        ld = N
+        _contig(x2d)
+    out = torch.empty(N, dtype=out_dtype, device=dev)
+    L = _lib.lib()
+    need = L.wavlm_colsum_workspace_bytes(N)
+    ws = workspace(dev, need)
+    check(L.wavlm_colsum(ptr(x2d), rows, N, ld, dt(x2d), ptr(include), ptr(exclude), ptr(out), dt(out), 0, ptr(ws),
+                         need, stream()), "wavlm_colsum")
+    return out
+
+
+def select_rows(x, sel, emb, zero):
+    """y[row] = zero[row] ? 0 : sel[row] ? emb : x[row]   (sel / zero: uint8 [rows] or None; emb None -> 0)"""
+    _dev(x); _contig(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    check(_lib.lib().wavlm_select_rows(ptr(x), ptr(y), ptr(sel), ptr(emb), ptr(zero), rows, D, dt(x),
+                                       dt(emb) if emb is not None else dt(x), stream()), "wavlm_select_rows")
+    return y
+
+
+def gather_rows(src2d, idx, n_out):
+    """dst[i] = src[idx[i]] (idx int32; -1 -> zero row)"""
+    dev = _dev(src2d); _contig(src2d)
+    D = src2d.shape[-1]
+    dst = torch.empty((n_out, D), dtype=src2d.dtype, device=dev)
+    check(_lib.lib().wavlm_gather_rows(ptr(src2d), ptr(idx), ptr(dst), n_out, D, dt(src2d), stream()),
+          "wavlm_gather_rows")
+    return dst
+
+
+def axpby_(y, x, a, b):
+    """y = a*x + b*y in place"""
+    _dev(y); _contig(y); _contig(x)
+    check(_lib.lib().wavlm_axpby(ptr(x), dt(x), ptr(y), dt(y), y.numel(), float(a), float(b), stream()), "wavlm_axpby")
+    return y
+
+
+def scale_dev_(y, scalar, extra=1.0):
+    """y *= scalar[0] * extra with `scalar` a 1-element fp32 device tensor"""
+    _dev(y); _contig(y)
+    check(_lib.lib().wavlm_scale_dev(ptr(y), dt(y), y.numel(), ptr(scalar), float(extra), stream()), "wavlm_scale_dev")
+    return y
+
+
+def dropout(x, p, seed):
+    _dev(x); _contig(x)
+    y = torch.empty_like(x)
+    check(_lib.lib().wavlm_dropout(ptr(x), ptr(y), x.numel(), float(p), int(seed), dt(x), stream()), "wavlm_dropout")
+    return y
+
+
+def sumsq(x, scale=1.0, out=None):
+    """scale * sum(x^2) as a 1-element fp32 device tensor (no host sync)"""
+    dev = _dev(x); _contig(x)
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    need = L.wavlm_sumsq_workspace_bytes()
+    ws = workspace(dev, need, "reduce")
+    check(L.wavlm_sumsq(ptr(x), dt(x), x.numel(), float(scale), ptr(out), ptr(ws), need, stream()), "wavlm_sumsq")
+    return out
+
+
+def sum_f32(x, out=None):
+    dev = _dev(x); _contig(x)
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    need = L.wavlm_sum_workspace_bytes()
+    ws = workspace(dev, need, "reduce")
+    check(L.wavlm_sum_f32(ptr(x), x.numel(), ptr(out), ptr(ws), need, stream()), "wavlm_sum_f32")
+    return out
+
+
+# -------------------------------------------------------------------------------------------- conv0
+def conv0_gn_gelu_fwd(wav, W, gamma, beta, stride, eps, out_dtype):
+    dev = _dev(wav); _contig(wav); _contig(W)
+    B, T = wav.shape
+    Cc, _, kw = W.shape
+    T0 = (T - kw) // stride + 1
+    out = torch.empty((B, T0, Cc), dtype=out_dtype, device=dev)
+    stats = torch.empty((B, Cc, 2), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    need = L.wavlm_conv0_gn_workspace_bytes(B, T, Cc, stride)
+    ws = workspace(dev, need)
+    check(L.wavlm_conv0_gn_gelu_fwd(ptr(wav), dt(wav), ptr(W), ptr(gamma), ptr(beta), dt(W), ptr(out), dt(out),
+                                    ptr(stats), B, T, Cc, kw, stride, float(eps), ptr(ws), need, stream()),
+          "wavlm_conv0_gn_gelu_fwd")
+    return out, stats
+
+
+def conv0_gn_gelu_bwd(wav, W, gamma, beta, g, stats, stride, gscale=1.0):
+    dev = _dev(wav); _contig(g)
+    B, T = wav.shape
+    Cc, _, kw = W.shape
+    dW = torch.empty_like(W)
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(beta)
+    L = _lib.lib()
+    need = L.wavlm_conv0_gn_bwd_workspace_bytes(B, T, Cc, stride)
+    ws = workspace(dev, need)
+    check(L.wavlm_conv0_gn_gelu_bwd(ptr(wav), dt(wav), ptr(W), ptr(gamma), ptr(beta), dt(W), ptr(g), dt(g),
+                                    ptr(stats), ptr(dW), ptr(dgamma), ptr(dbeta), B, T, Cc, kw, stride,
+                                    float(gscale), ptr(ws), need, stream()), "wavlm_conv0_gn_gelu_bwd")
+    return dW, dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------------------- attention
+def relpos_gather(emb, bucket, H, L_):
+    dev = _dev(emb)
+    tab = torch.empty((H, L_), dtype=torch.float32, device=dev)
+    check(_lib.lib().wavlm_relpos_gather(ptr(emb), dt(emb), ptr(bucket), ptr(tab), H, L_, stream()),
+          "wavlm_relpos_gather")
+    return tab
+
+
+def relpos_scatter(dtab, bucket, like_emb):
+    H, L_ = dtab.shape
+    demb = torch.empty_like(like_emb)
+    check(_lib.lib().wavlm_relpos_scatter(ptr(dtab), ptr(bucket), ptr(demb), dt(demb), H, L_, like_emb.shape[0],
+                                          stream()), "wavlm_relpos_scatter")
+    return demb
+
+
+def gate_fwd(x, W, bias, grep_a, H):
+    dev = _dev(x); _contig(x)
+    B, T, D = x.shape
+    hd = D // H
+    gate = torch.empty((B, H, T), dtype=torch.float32, device=dev)
+    ga = torch.empty_like(gate)
+    gb = torch.empty_like(gate)
+    check(_lib.lib().wavlm_gate_fwd(ptr(x), ptr(W), ptr(bias), ptr(grep_a), ptr(gate), ptr(ga), ptr(gb), B, T, H, hd,
+                                    dt(x), dt(W), stream()), "wavlm_gate_fwd")
+    return gate, ga, gb
+
+
+def gate_bwd(dgate, x, W, bias, grep_a, ga, gb, H):
+    dev = _dev(x)
+    B, T, D = x.shape
+    hd = D // H
+    dx = torch.empty_like(x)
+    dW = torch.empty_like(W)
+    dbias = torch.empty_like(bias)
+    da = torch.empty_like(grep_a)
+    L = _lib.lib()
+    need = L.wavlm_gate_bwd_workspace_bytes(H, hd)
+    ws = workspace(dev, need)
+    check(L.wavlm_gate_bwd(ptr(dgate), ptr(x), ptr(W), ptr(grep_a), ptr(ga), ptr(gb), ptr(dx), ptr(dW), ptr(dbias),
+                           ptr(da), B, T, H, hd, dt(x), dt(W), ptr(ws), need, stream()), "wavlm_gate_bwd")
+    return dx, dW, dbias, da
+
+
+def attn_softmax_fwd(S, P, lse, gate, tab, kpm, B, H, T, ldS, ldP, p_drop, seed):
+    check(_lib.lib().wavlm_attn_softmax_fwd(ptr(S), ptr(P), ptr(lse), ptr(gate), ptr(tab), ptr(kpm), B, H, T, ldS, ldP,
+                                            dt(S), dt(P), float(p_drop), int(seed), stream()),
+          "wavlm_attn_softmax_fwd")
+
+
+def attn_softmax_bwd(S, dP, lse, gate, tab, kpm, dS, dgate, dtab, B, H, T, ldS, ldP, p_drop, seed):
+    dev = _dev(S)
+    L = _lib.lib()
+    need = L.wavlm_attn_softmax_bwd_workspace_bytes(B, H, T) if tab is not None else 0
+    ws = workspace(dev, need) if need else None
+    check(L.wavlm_attn_softmax_bwd(ptr(S), ptr(dP), ptr(lse), ptr(gate), ptr(tab), ptr(kpm), ptr(dS), ptr(dgate),
+                                   ptr(dtab), 0, B, H, T, ldS, ldP, dt(S), dt(dS), float(p_drop), int(seed), ptr(ws),
+                                   need, stream()), "wavlm_attn_softmax_bwd")
+
+
+# ------------------------------------------------------------------------------------------ pos_conv
+def posconv_weight_fwd(v, g, out_dtype):
+    dev = _dev(v); _contig(v)
+    D, Cg, K = v.shape
+    G = D // Cg
+    Wf = torch.empty((G, Cg, K * Cg), dtype=out_dtype, device=dev)
+    Wb = torch.empty((G, Cg, K * Cg), dtype=out_dtype, device=dev)
+    norm = torch.empty(K, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    need = L.wavlm_posconv_weight_workspace_bytes(D, Cg, K)
+    ws = workspace(dev, need)
+    check(L.wavlm_posconv_weight_fwd(ptr(v), ptr(g), dt(v), ptr(Wf), ptr(Wb), dt(Wf), ptr(norm), D, Cg, K, ptr(ws),
+                                     need, stream()), "wavlm_posconv_weight_fwd")
+    return Wf, Wb, norm
+
+
+def posconv_weight_bwd(dWf, v, g, norm):
+    dev = _dev(v)
+    D, Cg, K = v.shape
+    dv = torch.empty_like(v)
+    dg = torch.empty_like(g)
+    L = _lib.lib()
+    need = L.wavlm_posconv_weight_workspace_bytes(D, Cg, K)
+    ws = workspace(dev, need)
+    check(L.wavlm_posconv_weight_bwd(ptr(dWf), ptr(v), ptr(g), ptr(norm), dt(v), ptr(dv), ptr(dg), D, Cg, K, ptr(ws),
+                                     need, stream()), "wavlm_posconv_weight_bwd")
+    return dv, dg
+
+
+def group_major(x, aux, G, left_pad, Tp, want_nat=False):
+    """x[B,T,D] (* gelu'(aux)) -> [B,G,Tp,D/G] with zero rows outside [left_pad, left_pad+T)"""
+    dev = _dev(x); _contig(x); _contig(aux)
+    B, T, D = x.shape
+    out = torch.empty((B, G, Tp, D // G), dtype=x.dtype, device=dev)
+    nat = torch.empty_like(x) if want_nat else None
+    check(_lib.lib().wavlm_posconv_group_major(ptr(x), ptr(aux), ptr(out), ptr(nat), B, T, D, G, left_pad, Tp, dt(x),
+                                               stream()), "wavlm_posconv_group_major")
+    return out, nat
+
+
+# ---------------------------------------------------------------------------------------------- loss
+def l2norm_fwd(x, out_dtype, eps=1e-8):
+    dev = _dev(x); _contig(x)
+    rows, D = x.shape
+    y = torch.empty((rows, D), dtype=out_dtype, device=dev)
+    inv = torch.empty(rows, dtype=torch.float32, device=dev)
+    check(_lib.lib().wavlm_l2norm_fwd(ptr(x), dt(x), ptr(y), dt(y), ptr(inv), rows, D, float(eps), stream()),
+          "wavlm_l2norm_fwd")
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv, x_dtype):
+    dev = _dev(dy); _contig(dy)
+    rows, D = y.shape
+    dx = torch.empty((rows, D), dtype=x_dtype, device=dev)
+    check(_lib.lib().wavlm_l2norm_bwd(ptr(dy), ptr(y), dt(y), ptr(inv), ptr(dx), dt(dx), rows, D, stream()),
+          "wavlm_l2norm_bwd")
+    return dx
+
+
+def ce_rows(logits, target, V, ld_logits, dlogits, ld_dlogits, weight):
+    dev = _dev(logits)
+    S = target.numel()
+    loss_rows = torch.empty(max(S, 1), dtype=torch.float32, device=dev)
+    correct_rows = torch.empty(max(S, 1), dtype=torch.float32, device=dev)
+    check(_lib.lib().wavlm_ce_rows(ptr(logits), ptr(target), ptr(loss_rows), ptr(correct_rows), ptr(dlogits),
+                                   dt(dlogits) if dlogits is not None else 0, S, V, ld_logits, ld_dlogits,
+                                   float(weight), stream()), "wavlm_ce_rows")
+    return loss_rows[:S], correct_rows[:S]
+
+
+# --------------------------------------------------------------------------------------------- optim
+def adam_step(p32, m, v, grad, p_lowp, *, lr, beta1, beta2, eps, weight_decay, step, grad_mult=1.0, gnorm_sq=None,
+              max_norm=0.0):
+    _dev(p32)
+    check(_lib.lib().wavlm_adam_step(ptr(p32), ptr(m), ptr(v), ptr(grad), dt(grad), ptr(p_lowp),
+                                     dt(p_lowp) if p_lowp is not None else 0, p32.numel(), float(lr), float(beta1),
+                                     float(beta2), float(eps), float(weight_decay), int(step), float(grad_mult),
+                                     ptr(gnorm_sq), float(max_norm), stream()), "wavlm_adam_step")
