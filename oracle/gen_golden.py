@@ -1,0 +1,206 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python (build container only; needs /root/reference).
+
+    python oracle/gen_golden.py
+
+Fixtures (all seeds fixed, fp32, CPU):
+  masks.npz      reference compute_mask_indices outputs + the next numpy draw (pins RNG consumption)
+  buckets.npz    reference _relative_positions_bucket tables
+  tiny_wavlm.npz standalone WavLM (tiny, relpos + gate): seeded state dict, inputs, extract_features outputs
+  tiny_pretrain.npz fairseq WavLMModel + WavLMCriterion (tiny): state dict, inputs, logits, loss, all gradients
+The tiny configuration keeps every structural feature of WavLM-Base (7 conv blocks with the same kernels/strides,
+GroupNorm on block 0, grouped weight-normed pos_conv, post-LN layers, bucketed gated relative position bias) at
+sizes small enough to commit.
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+TINY = dict(
+    extractor_mode="default", encoder_layers=2, encoder_embed_dim=64, encoder_ffn_embed_dim=128,
+    encoder_attention_heads=2, activation_fn="gelu", layer_norm_first=False,
+    conv_feature_layers="[(32,10,5)] + [(32,3,2)] * 4 + [(32,2,2)] * 2", conv_bias=False, feature_grad_mult=0.1,
+    dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, dropout_input=0.0,
+    dropout_features=0.0, mask_length=4, mask_prob=0.65, mask_selection="static", mask_other=0,
+    no_mask_overlap=False, mask_min_space=1, mask_channel_prob=0.0, conv_pos=16, conv_pos_groups=4,
+    relative_position_embedding=True, num_buckets=32, max_distance=64, gru_rel_pos=True,
+)
+
+
+def sd_to_np(sd):
+    return {"sd/" + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def gen_masks():
+    _, _, _, _, cmi = ref_shim.fairseq_wavlm()
+    out = {}
+    cases = [
+        dict(shape=(4, 49), pad=None, p=0.65, l=4, kind="static", other=0.0, min_masks=2, no=False, space=1, seed=1),
+        dict(shape=(3, 749), pad=None, p=0.8, l=10, kind="static", other=0.0, min_masks=2, no=False, space=1, seed=2),
+        dict(shape=(3, 749), pad=[749, 600, 375], p=0.8, l=10, kind="static", other=0.0, min_masks=2, no=False,
+             space=1, seed=3),
+        dict(shape=(2, 200), pad=None, p=0.5, l=10, kind="uniform", other=2.0, min_masks=0, no=False, space=1, seed=4),
+        dict(shape=(2, 200), pad=None, p=0.5, l=10, kind="normal", other=3.0, min_masks=0, no=False, space=1, seed=5),
+        dict(shape=(2, 200), pad=None, p=0.5, l=10, kind="poisson", other=0.0, min_masks=0, no=False, space=1, seed=6),
+        dict(shape=(2, 300), pad=None, p=0.5, l=10, kind="static", other=0.0, min_masks=2, no=True, space=2, seed=7),
+        dict(shape=(8, 999), pad=[999, 999, 900, 800, 700, 999, 500, 999], p=0.65, l=10, kind="static", other=0.0,
+             min_masks=2, no=False, space=1, seed=8),
+    ]
+    for i, c in enumerate(cases):
+        pm = None
+        if c["pad"] is not None:
+            pm = torch.zeros(c["shape"], dtype=torch.bool)
+            for b, n in enumerate(c["pad"]):
+                pm[b, n:] = True
+        np.random.seed(c["seed"])
+        m = cmi(c["shape"], pm, c["p"], c["l"], c["kind"], c["other"], min_masks=c["min_masks"], no_overlap=c["no"],
+                min_space=c["space"])
+        nxt = np.random.random()
+        out[f"case{i}/mask"] = m
+        out[f"case{i}/next"] = np.float64(nxt)
+        out[f"case{i}/args"] = np.array([c["shape"][0], c["shape"][1], c["l"], c["min_masks"], int(c["no"]),
+                                         c["space"], c["seed"]], dtype=np.int64)
+        out[f"case{i}/fargs"] = np.array([c["p"], c["other"]], dtype=np.float64)
+        out[f"case{i}/kind"] = np.array(c["kind"])
+        out[f"case{i}/pad"] = np.array(c["pad"] if c["pad"] is not None else [], dtype=np.int64)
+    out["ncases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(OUT, "masks.npz"), **out)
+
+
+def gen_buckets():
+    _, mods = ref_shim.standalone()
+    out = {}
+    for (T, nb, md) in [(49, 32, 64), (749, 320, 800), (999, 320, 800), (749, 320, 1280), (1500, 320, 800)]:
+        mha = mods.MultiheadAttention(64, 2, has_relative_attention_bias=True, num_buckets=nb, max_distance=md)
+        ctx = torch.arange(T, dtype=torch.long)[:, None]
+        mem = torch.arange(T, dtype=torch.long)[None, :]
+        full = mha._relative_positions_bucket(mem - ctx, bidirectional=True)
+        # Toeplitz: first column reversed + first row
+        line = torch.cat([full[:, 0].flip(0), full[0, 1:]])
+        for i in range(T):  # verify the Toeplitz claim on the full grid before trusting the 1-D table
+            assert torch.equal(full[i], line[T - 1 - i: 2 * T - 1 - i])
+        out[f"T{T}_nb{nb}_md{md}"] = line.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "buckets.npz"), **out)
+
+
+def gen_tiny_wavlm():
+    ref, _ = ref_shim.standalone()
+    cfg = ref.WavLMConfig(dict(TINY))
+    torch.manual_seed(0)
+    model = ref.WavLM(cfg)
+    model.eval()
+    out = sd_to_np(model.state_dict())
+    g = torch.Generator().manual_seed(1234)
+    wav = torch.randn(2, 16000, generator=g)
+    out["in/source"] = wav.numpy()
+    with torch.no_grad():
+        x, _ = model.extract_features(wav.clone())
+        out["out/x"] = x.numpy()
+        feat, _ = model.extract_features(wav.clone(), ret_conv=True)
+        out["out/features_ret_conv"] = feat.numpy()
+        (x3, lr), _ = model.extract_features(wav.clone(), output_layer=1, ret_layer_results=True)
+        out["out/x_layer1"] = x3.numpy()
+        out["out/nlayer_results_layer1"] = np.int64(len(lr))
+        out["out/layer_results0"] = lr[0][0].numpy()
+        out["out/layer_results1"] = lr[1][0].numpy()
+        # padded batch
+        pm = torch.zeros(2, 16000, dtype=torch.bool)
+        pm[1, 12000:] = True
+        wav_p = wav.clone()
+        wav_p[1, 12000:] = 0
+        xp, pmo = model.extract_features(wav_p, padding_mask=pm)
+        out["in/padding_mask"] = pm.numpy()
+        out["out/x_padded"] = xp.numpy()
+        out["out/padding_mask_frames"] = pmo.numpy()
+        # masked: the mask consumed is the one compute_mask_indices yields under the same numpy seed
+        np.random.seed(123)
+        xm, _ = model.extract_features(wav.clone(), mask=True)
+        out["out/x_masked"] = xm.numpy()
+        np.random.seed(123)
+        m = ref.compute_mask_indices((2, 49), None, cfg.mask_prob, cfg.mask_length, cfg.mask_selection, cfg.mask_other,
+                                     min_masks=2, no_overlap=cfg.no_mask_overlap, min_space=cfg.mask_min_space)
+        out["out/mask_seed123"] = m
+        # conv stack output alone
+        out["out/conv_features"] = model.feature_extractor(wav).numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_wavlm.npz"), **out)
+
+
+class _Dict:
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
+def gen_tiny_pretrain():
+    WavLMModel, WavLMConfig, WavLMCriterion, _, _ = ref_shim.fairseq_wavlm()
+    cfg = WavLMConfig()
+    for k, v in TINY.items():
+        setattr(cfg, k, v)
+    cfg.label_rate = 50
+    cfg.final_dim = 32
+    cfg.logit_temp = 0.1
+    cfg.skip_masked = False
+    cfg.skip_nomask = False
+    cfg.untie_final_proj = False
+    cfg.target_glu = False
+    cfg.boundary_mask = False
+    cfg.expand_attention_head_size = -1
+    V = 23
+    torch.manual_seed(0)
+    model = WavLMModel(cfg, SimpleNamespace(sample_rate=16000), [_Dict(V)])
+    model.train()  # dropouts are all 0; train() so that the mask/loss path is the training one
+    crit = WavLMCriterion(SimpleNamespace(), 1.0, 0.0, loss_weights=[10.0])
+    out = sd_to_np(model.state_dict())
+    g = torch.Generator().manual_seed(1234)
+    wav = torch.randn(2, 16000, generator=g)
+    target = torch.randint(4, V, (2, 50), generator=g)
+    pm = torch.zeros(2, 16000, dtype=torch.bool)
+    sample = {"id": torch.arange(2), "net_input": {"source": wav, "padding_mask": pm}, "target_list": [target]}
+    np.random.seed(123)
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    np.random.seed(123)
+    net = model(target_list=[target], source=wav, padding_mask=pm)
+    out["in/source"] = wav.numpy()
+    out["in/target"] = target.numpy()
+    out["in/padding_mask"] = pm.numpy()
+    out["out/loss"] = np.float64(loss.item())
+    out["out/sample_size"] = np.int64(sample_size)
+    for k, v in log.items():
+        out["log/" + k] = np.float64(v)
+    out["out/logit_m"] = net["logit_m_list"][0].detach().float().numpy()
+    out["out/logit_u"] = net["logit_u_list"][0].detach().float().numpy()
+    out["out/x"] = net["x"].detach().numpy()
+    out["out/features_pen"] = np.float64(net["features_pen"].item())
+    # the mask the forward consumed under seed 123 (padding mask given -> per-row rand draws)
+    np.random.seed(123)
+    from fairseq.data.data_utils import compute_mask_indices
+    T = net["x"].shape[1]
+    m = compute_mask_indices((2, T), torch.zeros(2, T, dtype=torch.bool), cfg.mask_prob, cfg.mask_length,
+                             cfg.mask_selection, cfg.mask_other, min_masks=2, no_overlap=False, min_space=1)
+    out["out/mask_seed123"] = m
+    for n, p in model.named_parameters():
+        out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_pretrain.npz"), **out)
+
+
+if __name__ == "__main__":
+    if not ref_shim.available():
+        raise SystemExit("reference tree not found at %s" % ref_shim.REF_ROOT)
+    os.makedirs(OUT, exist_ok=True)
+    gen_masks()
+    gen_buckets()
+    gen_tiny_wavlm()
+    gen_tiny_pretrain()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

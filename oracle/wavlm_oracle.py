@@ -1,0 +1,317 @@
+"""CPU oracle of the WavLM / UniSpeech pre-training hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is a plain fp32 PyTorch-on-CPU restatement of the reference algorithm.  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it, and only as the checker / the timed
+CPU baseline -- never as part of the product path (unispeech_amd/ imports nothing from here and has no CPU fallback).
+
+Why a restatement and not the reference itself: /root/reference does not exist on the GPU box, so parity tests
+there need a self-contained checker.  Pinning: tests/test_oracle_vs_golden.py checks every function here against
+fixtures in tests/golden/ that oracle/gen_golden.py produced by running the *reference's own Python*
+(WavLM/WavLM.py and src/fairseq WavLMModel + WavLMCriterion) in the build container, and -- when /root/reference is
+present -- tests/test_oracle_vs_reference.py re-runs the reference live at larger sizes.  The reference ships no
+golden vectors or tests of its own, so those reference-generated fixtures are the pin.
+
+All functions take a parameter dict `sd` keyed exactly like the reference state_dict and a config object with the
+reference's field names.  Shapes follow the reference ([B, C, T] inside the extractor, [T, B, C] inside the encoder).
+Arithmetic living in PyTorch itself (conv1d, group_norm, layer_norm, gelu, softmax, cosine_similarity,
+cross_entropy) is used through the same torch.nn.functional entry points the reference calls.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------- feature extractor
+def conv_feature_extractor(sd, cfg, source, prefix="feature_extractor."):
+    """ConvFeatureExtractionModel.forward, conv_type 'default' (WavLM/WavLM.py:485-504; blocks 391-428):
+    x.unsqueeze(1); per block Conv1d(bias=conv_bias) -> Dropout(0) -> [GroupNorm(dim, dim) on block 0 in 'default'
+    mode | LayerNorm over channels on every block in 'layer_norm' mode, both evaluated in fp32] -> nn.GELU()."""
+    layers = eval(cfg.conv_feature_layers)
+    x = source.unsqueeze(1)
+    for i, (dim, k, stride) in enumerate(layers):
+        w = sd[f"{prefix}conv_layers.{i}.0.weight"]
+        b = sd.get(f"{prefix}conv_layers.{i}.0.bias")
+        x = F.conv1d(x, w, b, stride=stride)
+        if cfg.extractor_mode == "layer_norm":
+            g = sd[f"{prefix}conv_layers.{i}.2.1.weight"]
+            bt = sd[f"{prefix}conv_layers.{i}.2.1.bias"]
+            x = F.layer_norm(x.transpose(-2, -1).float(), (dim,), g.float(), bt.float(), 1e-5).type_as(x)
+            x = x.transpose(-2, -1)
+        elif i == 0:
+            g = sd[f"{prefix}conv_layers.0.2.weight"]
+            bt = sd[f"{prefix}conv_layers.0.2.bias"]
+            x = F.group_norm(x.float(), dim, g.float(), bt.float(), 1e-5).type_as(x)
+        x = F.gelu(x)
+    return x  # [B, C, T']
+
+
+def forward_padding_mask(n_frames, padding_mask):
+    """WavLM.forward_padding_mask (WavLM/WavLM.py:311-321)"""
+    extra = padding_mask.size(1) % n_frames
+    if extra > 0:
+        padding_mask = padding_mask[:, :-extra]
+    return padding_mask.view(padding_mask.size(0), n_frames, -1).all(-1)
+
+
+# ---------------------------------------------------------------------------------------------------- attention
+def relative_positions_bucket(relative_positions, num_buckets, max_distance):
+    """MultiheadAttention._relative_positions_bucket, bidirectional (WavLM/modules.py:417-442)"""
+    num_buckets = num_buckets // 2
+    buckets = (relative_positions > 0).to(torch.long) * num_buckets
+    n = torch.abs(relative_positions)
+    max_exact = num_buckets // 2
+    is_small = n < max_exact
+    if_large = max_exact + (
+        torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (num_buckets - max_exact)
+    ).to(torch.long)
+    if_large = torch.min(if_large, torch.full_like(if_large, num_buckets - 1))
+    return buckets + torch.where(is_small, n, if_large)
+
+
+def compute_bias(emb_weight, q_len, k_len, num_buckets, max_distance):
+    """MultiheadAttention.compute_bias (WavLM/modules.py:444-455): [H, q_len, k_len]"""
+    ctx = torch.arange(q_len, dtype=torch.long)[:, None]
+    mem = torch.arange(k_len, dtype=torch.long)[None, :]
+    bucket = relative_positions_bucket(mem - ctx, num_buckets, max_distance)
+    return F.embedding(bucket, emb_weight).permute([2, 0, 1])
+
+
+def self_attention(sd, pre, x, key_padding_mask, position_bias, cfg, first_layer_emb=None):
+    """MultiheadAttention.forward fast path (WavLM/modules.py:504-564) with the F.multi_head_attention_forward
+    call written out: q/k/v projections, q scaled by head_dim**-0.5, additive float mask = gated position bias,
+    key padding -> -inf, softmax in fp32, out_proj.  x: [T, B, D].  Returns (out [T, B, D], position_bias)."""
+    T, B, D = x.shape
+    H = cfg.encoder_attention_heads
+    hd = D // H
+    if position_bias is None and first_layer_emb is not None:
+        pb = compute_bias(first_layer_emb, T, T, cfg.num_buckets, cfg.max_distance)
+        position_bias = pb.unsqueeze(0).repeat(B, 1, 1, 1).view(B * H, T, T)
+    mask = None
+    if position_bias is not None:
+        mask = position_bias
+        if cfg.gru_rel_pos:
+            ql = x.transpose(0, 1).view(B, T, H, hd).permute(0, 2, 1, 3)  # un-projected input, per head
+            lin = F.linear(ql, sd[pre + "grep_linear.weight"], sd[pre + "grep_linear.bias"])
+            gate_a, gate_b = torch.sigmoid(lin.view(B, H, T, 2, 4).sum(-1)).chunk(2, dim=-1)
+            gate = gate_a * (gate_b * sd[pre + "grep_a"] - 1.0) + 2.0
+            mask = gate.view(B * H, -1, 1) * position_bias
+        mask = mask.view(-1, T, T)
+    q = F.linear(x, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"])
+    k = F.linear(x, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"])
+    v = F.linear(x, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"])
+    q = q.contiguous().view(T, B * H, hd).transpose(0, 1) * (hd ** -0.5)
+    k = k.contiguous().view(T, B * H, hd).transpose(0, 1)
+    v = v.contiguous().view(T, B * H, hd).transpose(0, 1)
+    w = torch.bmm(q, k.transpose(1, 2))
+    if mask is not None:
+        w = w + mask
+    if key_padding_mask is not None:
+        w = w.view(B, H, T, T).masked_fill(key_padding_mask.unsqueeze(1).unsqueeze(2), float("-inf")).view(B * H, T, T)
+    p = F.softmax(w, dim=-1)
+    o = torch.bmm(p, v).transpose(0, 1).contiguous().view(T, B, D)
+    o = F.linear(o, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
+    return o, position_bias
+
+
+def encoder_layer(sd, pre, x, key_padding_mask, position_bias, cfg, first_layer_emb=None):
+    """TransformerSentenceEncoderLayer.forward with all dropouts 0 (WavLM/WavLM.py:677-742); gelu upcasts to fp32
+    (WavLM/modules.py:140-141)."""
+    D = x.shape[-1]
+
+    def ln(name, t):
+        return F.layer_norm(t, (D,), sd[pre + name + ".weight"], sd[pre + name + ".bias"], 1e-5)
+
+    def ffn(t):
+        h = F.linear(t, sd[pre + "fc1.weight"], sd[pre + "fc1.bias"])
+        h = F.gelu(h.float()).type_as(h)
+        return F.linear(h, sd[pre + "fc2.weight"], sd[pre + "fc2.bias"])
+
+    residual = x
+    if cfg.layer_norm_first:
+        a, position_bias = self_attention(sd, pre + "self_attn.", ln("self_attn_layer_norm", x), key_padding_mask,
+                                          position_bias, cfg, first_layer_emb)
+        x = residual + a
+        x = x + ffn(ln("final_layer_norm", x))
+    else:
+        a, position_bias = self_attention(sd, pre + "self_attn.", x, key_padding_mask, position_bias, cfg,
+                                          first_layer_emb)
+        x = ln("self_attn_layer_norm", residual + a)
+        x = ln("final_layer_norm", x + ffn(x))
+    return x, position_bias
+
+
+def pos_conv(sd, cfg, x, prefix="encoder."):
+    """weight_norm(dim=2) Conv1d(D, D, k, padding=k//2, groups) -> SamePad -> GELU (WavLM/WavLM.py:514-527;
+    SamePad WavLM/modules.py:72-83).  x: [B, T, D] -> [B, T, D]"""
+    g = sd[prefix + "pos_conv.0.weight_g"]
+    v = sd[prefix + "pos_conv.0.weight_v"]
+    w = g * v / v.norm(dim=(0, 1), keepdim=True)  # torch._weight_norm(v, g, dim=2)
+    y = F.conv1d(x.transpose(1, 2), w, sd[prefix + "pos_conv.0.bias"], padding=cfg.conv_pos // 2,
+                 groups=cfg.conv_pos_groups)
+    if cfg.conv_pos % 2 == 0:
+        y = y[:, :, :-1]
+    return F.gelu(y).transpose(1, 2)
+
+
+def transformer_encoder(sd, cfg, x, padding_mask=None, tgt_layer=None, prefix="encoder."):
+    """TransformerEncoder.forward / extract_features, eval-equivalent (dropout, layerdrop = 0)
+    (WavLM/WavLM.py:564-612).  x: [B, T, D].  Returns (x [B, T, D], layer_results [(x_l [T,B,D], None)],
+    conv_sum [B, T, D])."""
+    D = x.shape[-1]
+    if padding_mask is not None:
+        x = x.masked_fill(padding_mask.unsqueeze(-1), 0.0)
+    x = x + pos_conv(sd, cfg, x, prefix)  # out-of-place form of `x += x_conv` (value-identical forward)
+    conv_sum = x
+    if not cfg.layer_norm_first:
+        x = F.layer_norm(x, (D,), sd[prefix + "layer_norm.weight"], sd[prefix + "layer_norm.bias"], 1e-5)
+    x = x.transpose(0, 1)
+    layer_results = []
+    if tgt_layer is not None:
+        layer_results.append((x, None))
+    pos_bias = None
+    emb = sd.get(prefix + "layers.0.self_attn.relative_attention_bias.weight") \
+        if getattr(cfg, "relative_position_embedding", False) else None
+    r = None
+    for i in range(cfg.encoder_layers):
+        x, pos_bias = encoder_layer(sd, f"{prefix}layers.{i}.", x, padding_mask, pos_bias, cfg,
+                                    first_layer_emb=emb if i == 0 else None)
+        if tgt_layer is not None:
+            layer_results.append((x, None))
+        if i == tgt_layer:
+            r = x
+            break
+    if r is not None:
+        x = r
+    x = x.transpose(0, 1)
+    if cfg.layer_norm_first and tgt_layer is None:
+        x = F.layer_norm(x, (D,), sd[prefix + "layer_norm.weight"], sd[prefix + "layer_norm.bias"], 1e-5)
+    return x, layer_results, conv_sum
+
+
+# ---------------------------------------------------------------------------------------------------- model
+def project_features(sd, cfg, source):
+    """extractor -> transpose -> LayerNorm(C) -> post_extract_proj (WavLM/WavLM.py:333-348).
+    Returns (projected [B, T', D], raw conv features [B, C, T'])"""
+    feats = conv_feature_extractor(sd, cfg, source)
+    x = feats.transpose(1, 2)
+    C = x.shape[-1]
+    x = F.layer_norm(x, (C,), sd["layer_norm.weight"], sd["layer_norm.bias"], 1e-5)
+    if "post_extract_proj.weight" in sd:
+        x = F.linear(x, sd["post_extract_proj.weight"], sd["post_extract_proj.bias"])
+    return x, feats
+
+
+def extract_features(sd, cfg, source, padding_mask=None, mask_indices=None, output_layer=None):
+    """WavLM.extract_features (WavLM/WavLM.py:323-375) with the mask given explicitly (bool [B, T'] or None).
+    Returns dict(x, padding_mask, features, layer_results) -- `features` carries the reference's three in-place
+    updates (mask_emb fill, padding zero-fill, += pos_conv)."""
+    x, _ = project_features(sd, cfg, source)
+    if padding_mask is not None:
+        padding_mask = forward_padding_mask(x.shape[1], padding_mask)
+    if mask_indices is not None:
+        x = torch.where(mask_indices.unsqueeze(-1), sd["mask_emb"].view(1, 1, -1), x)
+    y, layer_results, conv_sum = transformer_encoder(sd, cfg, x, padding_mask,
+                                                     None if output_layer is None else output_layer - 1)
+    return {"x": y, "padding_mask": padding_mask, "features": conv_sum, "layer_results": layer_results}
+
+
+def compute_nce(x, pos, negs, logit_temp):
+    """WavLMModel.compute_nce (src/fairseq/models/wavlm/wavlm.py:426-438)"""
+    neg_is_pos = (pos == negs).all(-1)
+    targets = torch.cat([pos.unsqueeze(0), negs], dim=0)
+    logits = torch.cosine_similarity(x.float(), targets.float(), dim=-1).type_as(x)
+    logits = logits / logit_temp
+    if neg_is_pos.any():
+        logits = torch.cat([logits[:1], logits[1:].masked_fill(neg_is_pos, float("-inf"))], dim=0)
+    return logits.transpose(0, 1)
+
+
+def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, num_classes):
+    """WavLMModel.forward with dropouts 0 (src/fairseq/models/wavlm/wavlm.py:465-576), mask given explicitly."""
+    x, feats = project_features(sd, cfg, source)
+    T = x.shape[1]
+    layers = eval(cfg.conv_feature_layers)
+    ds = 1
+    for _, _, s in layers:
+        ds *= s
+    ratio = cfg.label_rate * ds / 16000
+    targ_T = min(t.size(1) for t in target_list)
+    if ratio * T > targ_T:
+        T = int(targ_T / ratio)
+        x = x[:, :T]
+        feats = feats[..., :T]
+    tinds = (torch.arange(T).float() * ratio).long()
+    target_list = [t[:, tinds] for t in target_list]
+    features_pen = feats.float().pow(2).mean()
+    if padding_mask is not None:
+        padding_mask = forward_padding_mask(T, padding_mask)
+    if mask_indices is not None:
+        x = torch.where(mask_indices.unsqueeze(-1), sd["mask_emb"].view(1, 1, -1), x)
+    y, _, conv_sum = transformer_encoder(sd, cfg, x, padding_mask, None)
+    pad = padding_mask if padding_mask is not None else torch.zeros(y.shape[:2], dtype=torch.bool)
+    label_embs_list = sd["label_embs_concat"].split(num_classes, 0)
+
+    def pred(sel):
+        proj = F.linear(y[sel], sd["final_proj.weight"], sd["final_proj.bias"])
+        out = []
+        for i, t in enumerate(target_list):
+            emb = label_embs_list[i]
+            pos = torch.index_select(emb, 0, t[sel].long())
+            negs = emb.unsqueeze(1).expand(-1, proj.size(0), -1)
+            out.append(compute_nce(proj, pos, negs, cfg.logit_temp))
+        return out
+
+    m = mask_indices if mask_indices is not None else torch.zeros_like(pad)
+    return {"x": y, "features": conv_sum, "padding_mask": padding_mask, "features_pen": features_pen,
+            "logit_m_list": pred(torch.logical_and(~pad, m)), "logit_u_list": pred(torch.logical_and(~pad, ~m))}
+
+
+def criterion(net_output, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_weights=None):
+    """WavLMCriterion.get_loss (src/fairseq/criterions/wavlm_criterion.py:52-138), sum reduction."""
+    loss = 0.0
+    sample_size = 0
+    log = {}
+    lm = [l.float() for l in net_output["logit_m_list"]]
+    lu = [l.float() for l in net_output["logit_u_list"]]
+    for i, l in enumerate(lm):
+        li = F.cross_entropy(l, l.new_zeros(l.size(0), dtype=torch.long), reduction="sum")
+        log[f"loss_m_{i}"] = li
+        if pred_masked_weight > 0:
+            loss = loss + pred_masked_weight * li
+    if pred_masked_weight > 0:
+        sample_size += lm[0].size(0)
+    for i, l in enumerate(lu):
+        li = F.cross_entropy(l, l.new_zeros(l.size(0), dtype=torch.long), reduction="sum")
+        log[f"loss_u_{i}"] = li
+        if pred_nomask_weight > 0:
+            loss = loss + pred_nomask_weight * li
+    if pred_nomask_weight > 0:
+        sample_size += lu[0].size(0)
+    if loss_weights is not None:
+        p = loss_weights[0] * net_output["features_pen"].float() * sample_size
+        loss = loss + p
+        log["loss_features_pen"] = p
+    for name, ls in (("m", lm), ("u", lu)):
+        for i, l in enumerate(ls):
+            if l.numel() == 0:
+                log[f"correct_{name}_{i}"], log[f"count_{name}_{i}"] = 0, 0
+                continue
+            mx = l.argmax(-1) == 0
+            mn = l.argmin(-1) == 0
+            log[f"correct_{name}_{i}"] = int(mx.long().sum().item() - (mx & mn).long().sum().item())
+            log[f"count_{name}_{i}"] = int(mx.numel())
+    return loss, sample_size, log
+
+
+# ---------------------------------------------------------------------------------------------------- optimizer
+def adam_reference_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
+    """fairseq Adam.step for one tensor (src/fairseq/optim/adam.py:203-224), fp32, out-of-place"""
+    m = m * beta1 + g * (1 - beta1)
+    v = v * beta2 + g * g * (1 - beta2)
+    denom = v.sqrt() + eps
+    step_size = lr * math.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
+    if weight_decay != 0:
+        p = p + p * (-weight_decay * lr)
+    p = p - step_size * (m / denom)
+    return p, m, v

@@ -1,0 +1,536 @@
+"""Autograd boundary of the hot path: each torch.autograd.Function below is a fused forward/backward pair built
+from the HIP entry points in ops.py.  torch supplies the graph, gradient accumulation and memory; all arithmetic
+on activations happens in libwavlm_hip.so.  torch ops that remain are pure data movement on parameter-sized
+tensors (cat / permute / contiguous of weights) and scalar bookkeeping.
+
+Layout: activations are channel-last [B, T, C]; the reference's [T, B, C] tensors are transposed views of these.
+"""
+import torch
+
+from . import ops
+
+_SEED_CTR = [0]
+
+
+def next_seed():
+    """64-bit dropout seed: torch's current seed mixed with a per-process call counter (the fairseq Trainer reseeds
+    torch every update, trainer.py:1194-1198, so masks are reproducible per update)."""
+    _SEED_CTR[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED_CTR[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------ Linear
+def _linear_fwd(x2d, W, b, *, epi=0, aux=None, res=None, out_dtype=None):
+    n, K = x2d.shape
+    N = W.shape[0]
+    y = torch.empty((n, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
+    ops.gemm(x2d, W, y, n, N, K, lda=K, ldb=K, ldc=N, bias=b, epi=epi, aux=aux, ld_aux=N, res=res, ld_res=N)
+    return y
+
+
+def _linear_bwd_x(dy2d, W, *, epi=0, aux=None, res=None):
+    """dx[n, K] = dy[n, N] @ W[N, K]  (W consumed K-strided: no transposed weight copy)"""
+    n, N = dy2d.shape
+    K = W.shape[1]
+    dx = torch.empty((n, K), dtype=dy2d.dtype, device=dy2d.device)
+    ops.gemm(dy2d, W, dx, n, K, N, lda=N, ldb=K, ldc=K, transB=True, epi=epi, aux=aux, ld_aux=K, res=res, ld_res=K)
+    return dx
+
+
+def _linear_bwd_w(dy2d, x2d, w_dtype):
+    """dW[N, K] = dy[n, N]^T @ x[n, K]: both operands K-strided, split-K over the n rows"""
+    n, N = dy2d.shape
+    K = x2d.shape[1]
+    dW = torch.empty((N, K), dtype=w_dtype, device=dy2d.device)
+    split = ops.pick_split(N, K, (n + 63) // 64)
+    ops.gemm(dy2d, x2d, dW, N, K, n, lda=N, ldb=K, ldc=K, transA=True, transB=True, split_k=split)
+    return dW
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b  (nn.Linear: WavLM/WavLM.py:348 post_extract_proj, modules.py q/k/v/out_proj, final_proj)"""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x2d = x.reshape(-1, x.shape[-1])
+        if not x2d.is_contiguous():
+            x2d = x2d.contiguous()
+        y = _linear_fwd(x2d, W, b)
+        ctx.save_for_backward(x2d, W)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, W = ctx.saved_tensors
+        dy2d = dy.reshape(-1, dy.shape[-1])
+        if not dy2d.is_contiguous():
+            dy2d = dy2d.contiguous()
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _linear_bwd_x(dy2d, W).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dW = _linear_bwd_w(dy2d, x2d, W.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy2d, W.dtype)
+        return dx, dW, db
+
+
+class FFNFn(torch.autograd.Function):
+    """y = fc2(dropout(gelu(fc1 x)))  (WavLM/WavLM.py:732-737; gelu = exact erf, WavLM/modules.py:140-141).
+    GELU runs in fc1's GEMM epilogue (pre-activation kept for backward); GELU' runs in the epilogue of fc2's
+    input-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, p_act, seed):
+        x2d = x.reshape(-1, x.shape[-1])
+        if not x2d.is_contiguous():
+            x2d = x2d.contiguous()
+        n = x2d.shape[0]
+        F = W1.shape[0]
+        u = torch.empty((n, F), dtype=x2d.dtype, device=x2d.device)
+        h = _linear_fwd(x2d, W1, b1, epi=1, aux=u)
+        hd = ops.dropout(h, p_act, seed) if p_act > 0 else h
+        y = _linear_fwd(hd, W2, b2)
+        ctx.save_for_backward(x2d, W1, W2, u, hd)
+        ctx.p_act, ctx.seed, ctx.xshape = p_act, seed, x.shape
+        return y.view(*x.shape[:-1], W2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, W1, W2, u, hd = ctx.saved_tensors
+        dy2d = dy.reshape(-1, dy.shape[-1])
+        if not dy2d.is_contiguous():
+            dy2d = dy2d.contiguous()
+        dW2 = _linear_bwd_w(dy2d, hd, W2.dtype)
+        db2 = ops.colsum(dy2d, W2.dtype)
+        if ctx.p_act > 0:
+            dh = _linear_bwd_x(dy2d, W2)
+            dh = ops.dropout(dh, ctx.p_act, ctx.seed)
+            n, F = dh.shape
+            du, _ = ops.group_major(dh.view(1, n, F), u.view(1, n, F), 1, 0, n)
+            du = du.view(n, F)
+        else:
+            du = _linear_bwd_x(dy2d, W2, epi=2, aux=u)
+        dW1 = _linear_bwd_w(du, x2d, W1.dtype)
+        db1 = ops.colsum(du, W1.dtype)
+        dx = _linear_bwd_x(du, W1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        return dx, dW1, db1, dW2, db2, None, None
+
+
+# --------------------------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(torch.autograd.Function):
+    """y = dropout_out(act(LN(x + dropout_in(r)))); returns (y, s) with s = the pre-norm sum (not differentiable).
+    grad_scale multiplies the incoming gradient (GradMultiply at the extractor output)."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps, act, p_in, seed_in, p_out, seed_out, grad_scale):
+        xc = x.contiguous()
+        rc = r.contiguous() if r is not None else None
+        y, s, mean, rstd = ops.layernorm_fwd(xc, rc, gamma, beta, eps, act=act, p_in=p_in, seed_in=seed_in,
+                                             p_out=p_out, seed_out=seed_out, save=True)
+        ctx.save_for_backward(s, mean, rstd, gamma, beta)
+        ctx.cfg = (act, p_in, seed_in, p_out, seed_out, grad_scale, r is not None)
+        s_out = s.detach()
+        ctx.mark_non_differentiable(s_out)
+        return y, s_out
+
+    @staticmethod
+    def backward(ctx, dy, _ds):
+        s, mean, rstd, gamma, beta = ctx.saved_tensors
+        act, p_in, seed_in, p_out, seed_out, grad_scale, has_r = ctx.cfg
+        dx, dr, dgamma, dbeta = ops.layernorm_bwd(dy.contiguous(), s, mean, rstd, gamma, beta, act=act, p_in=p_in,
+                                                  seed_in=seed_in, p_out=p_out, seed_out=seed_out,
+                                                  grad_scale=grad_scale, need_dr=has_r and p_in > 0)
+        if has_r and dr is None:
+            dr = dx
+        return dx, (dr if has_r else None), dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, *, residual=None, act=0, p_in=0.0, p_out=0.0, training=True,
+               grad_scale=1.0):
+    p_in = p_in if training else 0.0
+    p_out = p_out if training else 0.0
+    return LayerNormFn.apply(x, residual, gamma, beta, eps, act, p_in, next_seed() if p_in > 0 else 0, p_out,
+                             next_seed() if p_out > 0 else 0, grad_scale)
+
+
+# ------------------------------------------------------------------------------------- feature extractor
+class Conv0Fn(torch.autograd.Function):
+    """conv0 (k=10) + GroupNorm(C, C) + GELU -> [B, T0, C]  (WavLM/WavLM.py:420-426)"""
+
+    @staticmethod
+    def forward(ctx, wav, W, gamma, beta, stride, eps, out_dtype):
+        wav = wav.contiguous()
+        y, stats = ops.conv0_gn_gelu_fwd(wav, W.contiguous(), gamma, beta, stride, eps, out_dtype)
+        ctx.save_for_backward(wav, W, gamma, beta, stats)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        wav, W, gamma, beta, stats = ctx.saved_tensors
+        dW, dgamma, dbeta = ops.conv0_gn_gelu_bwd(wav, W.contiguous(), gamma, beta, g.contiguous(), stats, ctx.stride)
+        return None, dW, dgamma, dbeta, None, None, None
+
+
+def _conv_geometry(T_in, k, s):
+    T_out = (T_in - k) // s + 1
+    J = [len(range(r, k, s)) for r in range(s)]
+    fp = max(J) - 1
+    bp = (T_in + s - 1) // s - T_out
+    return T_out, J, fp, max(bp, 0)
+
+
+class ConvStackFn(torch.autograd.Function):
+    """conv1..convL of the feature extractor in 'default' mode: Conv1d(no bias) -> GELU, channel-last.
+    (WavLM/WavLM.py:428, 499-500).  Forward: one overlapping-row GEMM per layer (row t of A is the k*C_in
+    contiguous values starting at frame s*t: lda = s*C_in < K), GELU in the epilogue.  Backward per layer: weight
+    gradient = K-strided GEMM reduced over (batch, time); data gradient = one GEMM per stride phase writing
+    du_{i-1} = dx * gelu'(u_{i-1}) straight into the zero-padded buffer the next (earlier) layer consumes."""
+
+    @staticmethod
+    def forward(ctx, x, specs, *weights):
+        B = x.shape[0]
+        xs, us, wfs = [], [], []
+        cur = x.contiguous()
+        for (k, s), W in zip(specs, weights):
+            Cout, Cin, _ = W.shape
+            T_in = cur.shape[1]
+            T_out = (T_in - k) // s + 1
+            Wf = W.permute(0, 2, 1).reshape(Cout, k * Cin).contiguous()
+            y = torch.empty((B, T_out, Cout), dtype=cur.dtype, device=cur.device)
+            u = torch.empty_like(y)
+            ops.gemm(cur, Wf, y, T_out, Cout, k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout, batch=(B, 1),
+                     sA=(T_in * Cin, 0), sC=(T_out * Cout, 0), epi=1, aux=u, ld_aux=Cout, sAux=(T_out * Cout, 0))
+            xs.append(cur); us.append(u); wfs.append(Wf)
+            cur = y
+        ctx.specs = specs
+        ctx.nl = len(specs)
+        ctx.save_for_backward(*xs, *us, *weights)
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        nl, specs = ctx.nl, ctx.specs
+        saved = ctx.saved_tensors
+        xs, us, weights = saved[:nl], saved[nl:2 * nl], saved[2 * nl:]
+        B = dy.shape[0]
+        dev = dy.device
+        grads = [None] * nl
+        # du_L = dy * gelu'(u_L), laid out with the zero rows layer L's data-gradient GEMMs read
+        k, s = specs[-1]
+        T_out, J, fp, bp = _conv_geometry(xs[-1].shape[1], k, s)
+        Cout = weights[-1].shape[0]
+        P, _ = ops.group_major(dy.contiguous(), us[-1], 1, fp, fp + T_out + bp)
+        P = P.view(B, fp + T_out + bp, Cout)
+        for i in range(nl - 1, -1, -1):
+            k, s = specs[i]
+            W = weights[i]
+            Cout, Cin, _ = W.shape
+            x = xs[i]
+            T_in = x.shape[1]
+            T_out, J, fp, bp = _conv_geometry(T_in, k, s)
+            Tp = fp + T_out + bp
+            # ---- weight gradient: dWf[co, (kk, ci)] = sum_{b,t} du[b,t,co] * x[b, s*t + kk, ci]
+            if ctx.needs_input_grad[2 + i]:
+                dWf = torch.empty((Cout, k * Cin), dtype=W.dtype, device=dev)
+                split = ops.pick_split(Cout, k * Cin, B * ((T_out + 63) // 64))
+                ops.gemm(P, x, dWf, Cout, k * Cin, T_out, lda=Cout, ldb=s * Cin, ldc=k * Cin, transA=True, transB=True,
+                         a_off=fp * Cout, KB=B, sA_kb=Tp * Cout, sB_kb=T_in * Cin, split_k=split)
+                grads[i] = dWf.view(Cout, k, Cin).permute(0, 2, 1)
+            # ---- data gradient
+            need_dx = i > 0 or ctx.needs_input_grad[0]
+            if not need_dx:
+                break
+            if i > 0:
+                kp, sp = specs[i - 1]
+                _, _, fpp, bpp = _conv_geometry(xs[i - 1].shape[1], kp, sp)
+                Tpp = fpp + T_in + bpp
+                nxt = torch.empty((B, Tpp, Cin), dtype=dy.dtype, device=dev)
+                if fpp:
+                    nxt[:, :fpp].zero_()
+                if bpp:
+                    nxt[:, fpp + T_in:].zero_()
+                aux = us[i - 1]
+            else:
+                fpp, Tpp = 0, T_in
+                nxt = torch.empty((B, T_in, Cin), dtype=dy.dtype, device=dev)
+                aux = None
+            for r in range(s):
+                Jr = J[r]
+                if Jr == 0:
+                    raise NotImplementedError("conv kernel narrower than its stride")
+                taps = [r + s * (Jr - 1 - jj) for jj in range(Jr)]
+                Wb = W[:, :, taps].permute(1, 2, 0).reshape(Cin, Jr * Cout).contiguous()
+                Mr = (T_in - r + s - 1) // s
+                ops.gemm(P, Wb, nxt, Mr, Cin, Jr * Cout, lda=Cout, ldb=Jr * Cout, ldc=s * Cin, batch=(B, 1),
+                         a_off=(fp - Jr + 1) * Cout, sA=(Tp * Cout, 0), c_off=(fpp + r) * Cin, sC=(Tpp * Cin, 0),
+                         epi=2 if aux is not None else 0, aux=aux, aux_off=r * Cin, ld_aux=s * Cin,
+                         sAux=(T_in * Cin, 0))
+            P = nxt
+        dx = P if ctx.needs_input_grad[0] else None
+        return (dx, None) + tuple(grads)
+
+
+# ---------------------------------------------------------------------------------------------- pos_conv
+class PosConvFn(torch.autograd.Function):
+    """out = x + gelu(weight_norm_conv1d(x) + bias)[:, :T]  (WavLM/WavLM.py:514-527, 577-579; SamePad drops the last
+    frame).  G*B overlapping-row GEMMs over a group-major, time-padded copy of x; bias, GELU and the residual add
+    run in the GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, v, g, bias, groups):
+        B, T, D = x.shape
+        K = v.shape[2]
+        Cg = D // groups
+        xc = x.contiguous()
+        Wf, Wb, norm = ops.posconv_weight_fwd(v.contiguous(), g.contiguous().view(-1), xc.dtype)
+        Tp = T + K - 1
+        xg, _ = ops.group_major(xc, None, groups, K // 2, Tp)
+        out = torch.empty_like(xc)
+        u = torch.empty_like(xc)
+        ops.gemm(xg, Wf, out, T, Cg, K * Cg, lda=Cg, ldb=K * Cg, ldc=D, batch=(B, groups),
+                 sA=(groups * Tp * Cg, Tp * Cg), sB=(0, Cg * K * Cg), sC=(T * D, Cg), bias=bias, sBias=(0, Cg), epi=1,
+                 aux=u, ld_aux=D, sAux=(T * D, Cg), res=xc, ld_res=D, sRes=(T * D, Cg))
+        ctx.save_for_backward(xg, u, Wb, norm, v, g)
+        ctx.dims = (B, T, D, K, Cg, groups, Tp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xg, u, Wb, norm, v, g = ctx.saved_tensors
+        B, T, D, K, Cg, G, Tp = ctx.dims
+        dyc = dy.contiguous()
+        dug, du = ops.group_major(dyc, u, G, K // 2 - 1, Tp, want_nat=True)
+        dbias = ops.colsum(du.view(B * T, D), v.dtype)
+        # weight gradient in the forward GEMM layout, fp32: dWf[g][col][(tap, ci)]
+        dWf = torch.empty((G, Cg, K * Cg), dtype=torch.float32, device=dy.device)
+        ops.gemm(dug, xg, dWf, Cg, K * Cg, T, lda=Cg, ldb=Cg, ldc=K * Cg, transA=True, transB=True,
+                 a_off=(K // 2 - 1) * Cg, KB=B, sA_kb=G * Tp * Cg, sB_kb=G * Tp * Cg, batch=(1, G),
+                 sA=(0, Tp * Cg), sB=(0, Tp * Cg), sC=(0, Cg * K * Cg))
+        dv, dg = ops.posconv_weight_bwd(dWf, v.contiguous(), g.contiguous().view(-1), norm)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dyc)
+            ops.gemm(dug, Wb, dx, T, Cg, K * Cg, lda=Cg, ldb=K * Cg, ldc=D, batch=(B, G),
+                     sA=(G * Tp * Cg, Tp * Cg), sB=(0, Cg * K * Cg), sC=(T * D, Cg), res=dyc, ld_res=D,
+                     sRes=(T * D, Cg))
+        return dx, dv, dg.view_as(g), dbias, None
+
+
+# --------------------------------------------------------------------------------------------- attention
+class RelPosTableFn(torch.autograd.Function):
+    """rel[h, d] = relative_attention_bias.weight[bucket[d], h]  (compute_bias, WavLM/modules.py:444-455): the
+    [T, T] bias of head h is Toeplitz, so only its 2T-1 distinct values are kept."""
+
+    @staticmethod
+    def forward(ctx, emb, bucket):
+        H = emb.shape[1]
+        tab = ops.relpos_gather(emb.contiguous(), bucket, H, bucket.numel())
+        ctx.save_for_backward(emb, bucket)
+        return tab
+
+    @staticmethod
+    def backward(ctx, dtab):
+        emb, bucket = ctx.saved_tensors
+        return ops.relpos_scatter(dtab.contiguous(), bucket, emb), None
+
+
+class GateFn(torch.autograd.Function):
+    """gate[b,h,t] from the un-projected layer input (gru_rel_pos, WavLM/modules.py:523-533)"""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, grep_a, H):
+        xc = x.contiguous()
+        a = grep_a.contiguous().view(-1)
+        gate, ga, gb = ops.gate_fwd(xc, W.contiguous(), bias.contiguous(), a, H)
+        ctx.save_for_backward(xc, W, bias, grep_a, ga, gb)
+        ctx.H = H
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        xc, W, bias, grep_a, ga, gb = ctx.saved_tensors
+        dx, dW, dbias, da = ops.gate_bwd(dgate.contiguous(), xc, W.contiguous(), bias, grep_a.contiguous().view(-1),
+                                         ga, gb, ctx.H)
+        return dx, dW, dbias, da.view_as(grep_a), None
+
+
+class AttnCoreFn(torch.autograd.Function):
+    """O = dropout(softmax(scale * Q K^T + gate_i * rel[j-i] + key_padding)) V from the packed qkv [B, T, 3D].
+    Round-1 form: batched MFMA GEMMs + one softmax row kernel that applies the Toeplitz bias on the fly (the
+    [B*H, T, T] bias tensor of the reference is never built); S (fp32) and P are kept for backward."""
+
+    @staticmethod
+    def forward(ctx, qkv, gate, tab, kpm, H, scale, p_drop, seed):
+        B, T, D3 = qkv.shape
+        D = D3 // 3
+        hd = D // H
+        dev = qkv.device
+        qkvc = qkv.contiguous()
+        ld = _rup(T, 8)
+        S = torch.empty((B * H, T, ld), dtype=torch.float32, device=dev)
+        ops.gemm(qkvc, qkvc, S, T, T, hd, lda=D3, ldb=D3, ldc=ld, batch=(B, H), sA=(T * D3, hd), sB=(T * D3, hd),
+                 b_off=D, sC=(H * T * ld, T * ld), alpha=scale)
+        P = torch.empty((B * H, T, ld), dtype=qkv.dtype, device=dev)
+        lse = torch.empty((B * H, T), dtype=torch.float32, device=dev)
+        ops.attn_softmax_fwd(S, P, lse, gate, tab, kpm, B, H, T, ld, ld, p_drop, seed)
+        O = torch.empty((B, T, D), dtype=qkv.dtype, device=dev)
+        ops.gemm(P, qkvc, O, T, hd, T, lda=ld, ldb=D3, ldc=D, transB=True, batch=(B, H), sA=(H * T * ld, T * ld),
+                 sB=(T * D3, hd), b_off=2 * D, sC=(T * D, hd))
+        ctx.save_for_backward(qkvc, S, P, lse, gate, tab, kpm)
+        ctx.cfg = (B, T, D, H, hd, ld, scale, p_drop, seed)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkvc, S, P, lse, gate, tab, kpm = ctx.saved_tensors
+        B, T, D, H, hd, ld, scale, p_drop, seed = ctx.cfg
+        D3 = 3 * D
+        dev = dO.device
+        dOc = dO.contiguous()
+        dP = torch.empty((B * H, T, ld), dtype=P.dtype, device=dev)
+        ops.gemm(dOc, qkvc, dP, T, T, hd, lda=D, ldb=D3, ldc=ld, batch=(B, H), sA=(T * D, hd), sB=(T * D3, hd),
+                 b_off=2 * D, sC=(H * T * ld, T * ld))
+        dS = torch.empty_like(dP)
+        dgate = dtab = None
+        if tab is not None:
+            dgate = torch.empty((B, H, T), dtype=torch.float32, device=dev)
+            dtab = torch.empty_like(tab)
+        ops.attn_softmax_bwd(S, dP, lse, gate, tab, kpm, dS, dgate, dtab, B, H, T, ld, ld, p_drop, seed)
+        dqkv = torch.empty_like(qkvc)
+        # dQ = scale * dS K ; dK = scale * dS^T Q ; dV = P^T dO
+        ops.gemm(dS, qkvc, dqkv, T, hd, T, lda=ld, ldb=D3, ldc=D3, transB=True, batch=(B, H),
+                 sA=(H * T * ld, T * ld), sB=(T * D3, hd), b_off=D, sC=(T * D3, hd), c_off=0, alpha=scale)
+        ops.gemm(dS, qkvc, dqkv, T, hd, T, lda=ld, ldb=D3, ldc=D3, transA=True, transB=True, batch=(B, H),
+                 sA=(H * T * ld, T * ld), sB=(T * D3, hd), b_off=0, sC=(T * D3, hd), c_off=D, alpha=scale)
+        ops.gemm(P, dOc, dqkv, T, hd, T, lda=ld, ldb=D, ldc=D3, transA=True, transB=True, batch=(B, H),
+                 sA=(H * T * ld, T * ld), sB=(T * D, hd), sC=(T * D3, hd), c_off=2 * D)
+        return dqkv, dgate, dtab, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------ masking / rows
+class SelectRowsFn(torch.autograd.Function):
+    """y = x; y[sel] = emb; y[zero] = 0  (apply_mask + the encoder's padding zero-fill, WavLM/WavLM.py:286, 574-575)"""
+
+    @staticmethod
+    def forward(ctx, x, sel, emb, zero):
+        xc = x.contiguous()
+        y = ops.select_rows(xc, sel, emb, zero)
+        ctx.save_for_backward(sel, zero, emb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sel, zero, emb = ctx.saved_tensors
+        dyc = dy.contiguous()
+        dx = ops.select_rows(dyc, sel, None, zero) if ctx.needs_input_grad[0] else None
+        demb = None
+        if emb is not None and sel is not None and ctx.needs_input_grad[2]:
+            demb = ops.colsum(dyc.view(-1, dyc.shape[-1]), emb.dtype, include=sel, exclude=zero)
+        return dx, None, demb, None
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """y = x2d[idx]; backward scatters through the inverse index (rows are unique)"""
+
+    @staticmethod
+    def forward(ctx, x2d, idx, inv_idx):
+        ctx.save_for_backward(inv_idx)
+        ctx.n = x2d.shape[0]
+        return ops.gather_rows(x2d.contiguous(), idx, idx.numel())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (inv_idx,) = ctx.saved_tensors
+        return ops.gather_rows(dy.contiguous(), inv_idx, ctx.n), None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x.contiguous(), p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p, training=True):
+    if not training or p <= 0:
+        return x
+    return DropoutFn.apply(x, p, next_seed())
+
+
+# -------------------------------------------------------------------------------------------------- loss
+class MaskedPredLossFn(torch.autograd.Function):
+    """sum-reduced cross entropy of cos(proj_x, label_embs) / temp against the frame labels, plus the count of
+    correct frames.  Identical to compute_nce + F.cross_entropy(logits, 0, 'sum') of the reference
+    (src/fairseq/models/wavlm/wavlm.py:426-438; criterions/wavlm_criterion.py:68-71, 115-125) without the
+    [V+1, S, 256] targets tensor.  Returns (loss_sum[1], n_correct[1]) as fp32 device tensors."""
+
+    @staticmethod
+    def forward(ctx, proj, label_embs, target, temp, need_grad):
+        S, F = proj.shape
+        V = label_embs.shape[0]
+        dev = proj.device
+        act_dtype = proj.dtype
+        pn, inv_p = ops.l2norm_fwd(proj.contiguous(), act_dtype)
+        en, inv_e = ops.l2norm_fwd(label_embs.contiguous(), act_dtype)
+        logits = torch.empty((max(S, 1), V), dtype=torch.float32, device=dev)
+        if S > 0:
+            ops.gemm(pn, en, logits, S, V, F, lda=F, ldb=F, ldc=V, alpha=1.0 / temp)
+        ldd = _rup(V, 8)
+        dlog = torch.empty((max(S, 1), ldd), dtype=act_dtype, device=dev) if need_grad else None
+        loss_rows, correct_rows = ops.ce_rows(logits, target, V, V, dlog, ldd, 1.0)
+        loss = ops.sum_f32(loss_rows) if S > 0 else torch.zeros(1, dtype=torch.float32, device=dev)
+        ncorrect = ops.sum_f32(correct_rows) if S > 0 else torch.zeros(1, dtype=torch.float32, device=dev)
+        ctx.save_for_backward(pn, en, inv_p, inv_e, dlog, proj, label_embs)
+        ctx.dims = (S, V, F, ldd, temp)
+        ctx.mark_non_differentiable(ncorrect)
+        return loss, ncorrect
+
+    @staticmethod
+    def backward(ctx, dloss, _dc):
+        pn, en, inv_p, inv_e, dlog, proj, label_embs = ctx.saved_tensors
+        S, V, F, ldd, temp = ctx.dims
+        dev = pn.device
+        if S == 0:
+            return torch.zeros_like(proj), torch.zeros_like(label_embs), None, None, None
+        g = dloss.reshape(1).to(torch.float32)
+        # d pn = dlogits @ en / temp ; d en = dlogits^T @ pn / temp
+        dpn = torch.empty((S, F), dtype=pn.dtype, device=dev)
+        ops.gemm(dlog, en, dpn, S, F, V, lda=ldd, ldb=F, ldc=F, transB=True, alpha=1.0 / temp)
+        den = torch.empty((V, F), dtype=en.dtype, device=dev)
+        ops.gemm(dlog, pn, den, V, F, S, lda=ldd, ldb=F, ldc=F, transA=True, transB=True, alpha=1.0 / temp,
+                 split_k=ops.pick_split(V, F, (S + 63) // 64))
+        dproj = ops.l2norm_bwd(dpn, pn, inv_p, proj.dtype)
+        demb = ops.l2norm_bwd(den, en, inv_e, label_embs.dtype)
+        ops.scale_dev_(dproj, g)
+        ops.scale_dev_(demb, g)
+        return dproj, demb, None, None, None
+
+
+class FeaturesPenFn(torch.autograd.Function):
+    """features.float().pow(2).mean()  (src/fairseq/models/wavlm/wavlm.py:486)"""
+
+    @staticmethod
+    def forward(ctx, feats):
+        fc = feats.contiguous()
+        ctx.save_for_backward(fc)
+        return ops.sumsq(fc, 1.0 / fc.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        (fc,) = ctx.saved_tensors
+        d = torch.empty_like(fc)
+        ops.axpby_(d, fc, 2.0 / fc.numel(), 0.0)
+        ops.scale_dev_(d, g.reshape(1).to(torch.float32))
+        return d

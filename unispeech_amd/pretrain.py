@@ -1,0 +1,386 @@
+"""Pre-training model and criterion: the fairseq-side surface of the hot path.
+
+`WavLMPretrainModel` mirrors src/fairseq/models/wavlm/wavlm.py:255-627 (WavLMModel: constructor arguments,
+forward() keyword arguments, net_output keys, extract_features / get_logits / get_targets / get_extra_losses /
+remove_pretraining_modules) and `WavLMCriterion` mirrors src/fairseq/criterions/wavlm_criterion.py:38-207
+(== hubert_criterion.py for these models).  fairseq itself is not needed to use them; when it is importable,
+unispeech_amd.fairseq_plugin registers them through fairseq's own decorators.
+
+What differs from the reference is only *how* the numbers are produced:
+  * the masked-prediction head never builds the [V+1, S, 256] targets tensor: a fused cosine/cross-entropy loss
+    returns the summed loss and the accuracy counters directly (functional.MaskedPredLossFn); `get_logits()`
+    still materialises reference-shaped [S, V+1] logits on demand for callers that want them;
+  * all index lists (masked / unmasked frame indices) are derived on the host from the host-generated mask, so no
+    device-side nonzero()/boolean indexing (each is a host sync in the reference) is needed.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from .wavlm import ConvFeatureExtractionModel, TransformerEncoder, WavLM
+
+
+@dataclass
+class WavLMPretrainConfig:
+    """Field names and defaults of fairseq's WavLMConfig (src/fairseq/models/wavlm/wavlm.py:48-252)."""
+    label_rate: int = 50
+    extractor_mode: str = "default"
+    encoder_layers: int = 12
+    encoder_embed_dim: int = 768
+    encoder_ffn_embed_dim: int = 3072
+    encoder_attention_heads: int = 12
+    activation_fn: str = "gelu"
+    dropout: float = 0.1
+    attention_dropout: float = 0.1
+    activation_dropout: float = 0.0
+    encoder_layerdrop: float = 0.0
+    dropout_input: float = 0.0
+    dropout_features: float = 0.0
+    final_dim: int = 0
+    untie_final_proj: bool = False
+    layer_norm_first: bool = False
+    conv_feature_layers: str = "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"
+    conv_bias: bool = False
+    logit_temp: float = 0.1
+    target_glu: bool = False
+    feature_grad_mult: float = 1.0
+    boundary_mask: bool = False
+    mask_length: int = 10
+    mask_prob: float = 0.65
+    mask_selection: str = "static"
+    mask_other: float = 0
+    no_mask_overlap: bool = False
+    mask_min_space: int = 1
+    mask_channel_length: int = 10
+    mask_channel_prob: float = 0.0
+    mask_channel_selection: str = "static"
+    mask_channel_other: float = 0
+    no_mask_channel_overlap: bool = False
+    mask_channel_min_space: int = 1
+    conv_pos: int = 128
+    conv_pos_groups: int = 16
+    skip_masked: bool = False
+    skip_nomask: bool = False
+    relative_position_embedding: bool = False
+    num_buckets: int = 320
+    max_distance: int = 1280
+    gru_rel_pos: bool = False
+    expand_attention_head_size: int = -1
+
+
+@dataclass
+class TaskConfig:
+    sample_rate: int = 16000
+
+
+class WavLMPretrainModel(WavLM):
+    """WavLMModel(cfg, task_cfg, dictionaries) of the reference; `dictionaries` only needs len() per label set."""
+
+    def __init__(self, cfg, task_cfg=None, dictionaries=None) -> None:
+        # parameter creation order follows the reference constructor (wavlm.py:257-345)
+        super().__init__(cfg)
+        if getattr(cfg, "target_glu", False):
+            raise NotImplementedError("target_glu is not supported by the HIP path")
+        if getattr(cfg, "expand_attention_head_size", -1) > 0:
+            raise NotImplementedError("expand_attention_head_size disables the reference fast path; unsupported")
+        task_cfg = task_cfg or TaskConfig()
+        feature_enc_layers = eval(cfg.conv_feature_layers)
+        feature_ds_rate = np.prod([s for _, _, s in feature_enc_layers])
+        self.feat2tar_ratio = cfg.label_rate * feature_ds_rate / task_cfg.sample_rate
+        self.boundary_mask = getattr(cfg, "boundary_mask", False)
+        self.logit_temp = cfg.logit_temp
+        self.skip_masked = cfg.skip_masked
+        self.skip_nomask = cfg.skip_nomask
+        final_dim = cfg.final_dim if cfg.final_dim > 0 else cfg.encoder_embed_dim
+        self.untie_final_proj = cfg.untie_final_proj
+        dictionaries = dictionaries or []
+        if self.untie_final_proj:
+            self.final_proj = nn.Linear(cfg.encoder_embed_dim, final_dim * len(dictionaries))
+        else:
+            self.final_proj = nn.Linear(cfg.encoder_embed_dim, final_dim)
+        if len(dictionaries) == 0 or any(d is None for d in dictionaries):
+            self.num_classes = None
+        else:
+            self.num_classes = [len(d) for d in dictionaries]
+            self.label_embs_concat = nn.Parameter(torch.FloatTensor(sum(self.num_classes), final_dim))
+            nn.init.uniform_(self.label_embs_concat)
+
+    @classmethod
+    def build_model(cls, cfg, task):
+        return cls(cfg, task.cfg, task.dictionaries)
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        return state_dict
+
+    def set_num_updates(self, num_updates):
+        self.num_updates = num_updates
+
+    def max_positions(self):
+        return None
+
+    # ---- host-side target / mask bookkeeping -----------------------------------------------------------------
+    def forward_targets(self, feat_tsz: int, target_list: List[torch.Tensor]):
+        """frame count after trimming to the label length, and the label index of every kept frame
+        (wavlm.py:440-451)"""
+        targ_tsz = min(t.size(1) for t in target_list)
+        if self.feat2tar_ratio * feat_tsz > targ_tsz:
+            feat_tsz = int(targ_tsz / self.feat2tar_ratio)
+        target_inds = (torch.arange(feat_tsz).float() * self.feat2tar_ratio).long()
+        return feat_tsz, target_inds
+
+    def _mask_numpy(self, B, T, padding_cpu, boundary):
+        if self.mask_prob <= 0:
+            return None
+        if boundary is not None and len(boundary) == B:
+            from .masking import compute_mask_indices
+            m = np.full((B, T), False)
+            for i in range(B):
+                if len(boundary[i]) > 0:
+                    start, end = boundary[i][:-1], boundary[i][1:]
+                    coin = np.random.binomial(1, 0.5, size=len(start))
+                    for j in np.argwhere(coin == 1)[:, 0]:
+                        m[i][start[j]:end[j]] = True
+                else:
+                    m[i] = compute_mask_indices((1, T), None, self.mask_prob, self.mask_length, self.mask_selection,
+                                                self.mask_other, min_masks=2, no_overlap=self.no_mask_overlap,
+                                                min_space=self.mask_min_space)
+            return m
+        return self.compute_mask(B, T, padding_cpu)
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def forward(self, source: torch.Tensor, target_list: Optional[List[torch.Tensor]] = None,
+                padding_mask: Optional[torch.Tensor] = None, boundary=None, mask: bool = True,
+                features_only: bool = False, output_layer: Optional[int] = None,
+                padding_mask_cpu: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """output_layer is 1-based.  `padding_mask_cpu` (optional) is a host copy of padding_mask: with it the
+        forward needs no device->host transfer at all."""
+        if self.mask_channel_prob > 0 and mask:
+            raise NotImplementedError("channel masking is not supported by the HIP path")
+        x, feats = self._features(source)
+        B, T, _ = x.shape
+        dev = x.device
+        target_inds = None
+        if target_list is not None:
+            new_T, target_inds = self.forward_targets(T, target_list)
+            if new_T != T:
+                x = x[:, :new_T].contiguous()
+                feats = feats[:, :new_T].contiguous()
+                T = new_T
+        features_pen = F.FeaturesPenFn.apply(feats) if not features_only else None
+
+        pad_cpu = None
+        if padding_mask is not None:
+            padding_mask = self.forward_padding_mask(T, padding_mask)
+            if padding_mask_cpu is not None:
+                pad_cpu = self.forward_padding_mask(T, padding_mask_cpu)
+            else:
+                pad_cpu = padding_mask.cpu()
+        x = F.dropout(x, self.dropout_input.p, self.training)
+
+        mask_np = None
+        if mask:
+            mask_np = self._mask_numpy(B, T, pad_cpu, boundary if self.boundary_mask else None)
+        sel = torch.from_numpy(mask_np).to(dev).to(torch.uint8).view(-1) if mask_np is not None else None
+        kpm = padding_mask.to(torch.uint8).contiguous().view(-1) if padding_mask is not None else None
+        if sel is not None or kpm is not None:
+            x = F.SelectRowsFn.apply(x, sel, self.mask_emb if sel is not None else None, kpm)
+        layer = None if output_layer is None else output_layer - 1
+        x, layer_results, conv_sum = self.encoder(x, padding_mask=padding_mask, layer=layer,
+                                                  fairseq_layer_results=True, prezeroed=True)
+        result = {"x": x, "padding_mask": padding_mask, "features": conv_sum, "layer_results": layer_results}
+        if features_only:
+            return result
+
+        pad_np = pad_cpu.numpy() if pad_cpu is not None else np.zeros((B, T), dtype=bool)
+        m_np = mask_np if mask_np is not None else np.zeros((B, T), dtype=bool)
+        label_embs_list = self.label_embs_concat.split(self.num_classes, 0)
+        x2d = x.reshape(B * T, -1)
+        n = B * T
+
+        def head(frame_sel_np, need_grad):
+            idx_np = np.flatnonzero(frame_sel_np.reshape(-1)).astype(np.int32)
+            S = int(idx_np.size)
+            inv_np = np.full(n, -1, dtype=np.int32)
+            inv_np[idx_np] = np.arange(S, dtype=np.int32)
+            idx = torch.from_numpy(idx_np).to(dev)
+            inv = torch.from_numpy(inv_np).to(dev)
+            rows = F.GatherRowsFn.apply(x2d, idx, inv)
+            proj = F.LinearFn.apply(rows, self.final_proj.weight, self.final_proj.bias)
+            projs = proj.chunk(len(target_list), dim=-1) if self.untie_final_proj else [proj] * len(target_list)
+            out = []
+            idx64 = idx.long()
+            for i, (pj, t) in enumerate(zip(projs, target_list)):
+                tt = t[:, target_inds.to(t.device)].reshape(-1).index_select(0, idx64).to(torch.int32)
+                loss, ncorrect = F.MaskedPredLossFn.apply(pj.contiguous(), label_embs_list[i], tt, self.logit_temp,
+                                                          need_grad)
+                out.append({"loss": loss, "correct": ncorrect, "count": S, "proj": pj, "target": tt,
+                            "label_embs": label_embs_list[i]})
+            return out
+
+        result["masked"] = head(np.logical_and(~pad_np, m_np), True) if not self.skip_masked else None
+        result["nomask"] = head(np.logical_and(~pad_np, ~m_np), self.training_nomask_grad) \
+            if not self.skip_nomask else None
+        result["logit_m_list"] = None  # materialised lazily by get_logits()
+        result["logit_u_list"] = None
+        result["features_pen"] = features_pen
+        return result
+
+    # gradient through the unmasked head is only needed when pred_nomask_weight > 0 (criterion sets this)
+    training_nomask_grad = False
+
+    def extract_features(self, source, padding_mask=None, mask=False, ret_conv=False, output_layer=None,
+                         ret_layer_results=False):
+        res = self.forward(source, padding_mask=padding_mask, mask=mask, features_only=True,
+                           output_layer=output_layer)
+        feature = res["features"] if ret_conv else res["x"]
+        if ret_layer_results:
+            feature = (feature, res["layer_results"])
+        return feature, res["padding_mask"]
+
+    # ---- reference-shaped logits, on demand --------------------------------------------------------------------
+    def _logits_v1(self, h):
+        """[S, V+1] logits laid out as the reference's compute_nce output: column 0 = positive, column 1+v =
+        codebook row v, with the positive's own row set to -inf (wavlm.py:426-438)"""
+        pj, emb, tt = h["proj"], h["label_embs"], h["target"]
+        S, V = pj.shape[0], emb.shape[0]
+        pn, _ = F.ops.l2norm_fwd(pj.detach().contiguous(), torch.float32 if pj.dtype == torch.float32 else pj.dtype)
+        en, _ = F.ops.l2norm_fwd(emb.detach().contiguous(), pn.dtype)
+        logits = torch.empty((max(S, 1), V), dtype=torch.float32, device=pj.device)
+        if S > 0:
+            F.ops.gemm(pn, en, logits, S, V, pj.shape[1], lda=pj.shape[1], ldb=pj.shape[1], ldc=V,
+                       alpha=1.0 / self.logit_temp)
+        logits = logits[:S]
+        t64 = tt.long().unsqueeze(1)
+        pos = logits.gather(1, t64)
+        negs = logits.scatter(1, t64, float("-inf"))
+        return torch.cat([pos, negs], dim=1)
+
+    def get_logits(self, net_output, is_masked=True):
+        heads = net_output["masked" if is_masked else "nomask"]
+        if heads is None:
+            return []
+        return [self._logits_v1(h).float() for h in heads]
+
+    def get_targets(self, net_output, is_masked=True):
+        return [x.new_zeros(x.size(0), dtype=torch.long) for x in self.get_logits(net_output, is_masked)]
+
+    def get_extra_losses(self, net_output):
+        extra_losses, names = [], []
+        if "features_pen" in net_output:
+            extra_losses.append(net_output["features_pen"])
+            names.append("features_pen")
+        return extra_losses, names
+
+    def remove_pretraining_modules(self):
+        self.final_proj = None
+        self.label_embs_concat = None
+
+
+class WavLMCriterion(nn.Module):
+    """criterion 'wavlm' (== 'hubert' for these models): weighted sum-reduced masked / unmasked prediction loss
+    + loss_weights * extra losses * sample_size; accuracy counters (wavlm_criterion.py:52-138).
+
+    defer_logging=True keeps every logging value a device tensor (no .item()): the reference synchronises the host
+    at least four times per micro-batch here."""
+
+    def __init__(self, task=None, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_weights=None, log_keys=None,
+                 defer_logging=False):
+        super().__init__()
+        self.task = task
+        self.pred_masked_weight = pred_masked_weight
+        self.pred_nomask_weight = pred_nomask_weight
+        self.loss_weights = loss_weights
+        self.log_keys = [] if log_keys is None else log_keys
+        self.defer_logging = defer_logging
+
+    def forward(self, model, sample, reduce=True, log_pred=False):
+        model.training_nomask_grad = self.pred_nomask_weight > 0
+        net_output = model(target_list=sample["target_list"], **sample["net_input"])
+        return self.get_loss(model, sample, net_output, reduce)
+
+    def get_loss(self, model, sample, net_output, reduce=True):
+        if not reduce:
+            raise NotImplementedError("the fused loss is sum-reduced (reduce=True), as every recipe uses it")
+        num = (lambda t: t) if self.defer_logging else (lambda t: t.item())
+        loss = 0.0
+        sample_size = 0
+        logging_output = {}
+        heads_m = net_output["masked"] or []
+        heads_u = net_output["nomask"] or []
+        assert self.pred_masked_weight == 0 or len(heads_m) > 0
+        for i, h in enumerate(heads_m):
+            logging_output[f"loss_m_{i}"] = num(h["loss"].detach()[0])
+        if self.pred_masked_weight > 0:
+            loss = loss + self.pred_masked_weight * sum(h["loss"][0] for h in heads_m)
+            sample_size += heads_m[0]["count"]
+        assert self.pred_nomask_weight == 0 or len(heads_u) > 0
+        for i, h in enumerate(heads_u):
+            logging_output[f"loss_u_{i}"] = num(h["loss"].detach()[0])
+        if self.pred_nomask_weight > 0:
+            loss = loss + self.pred_nomask_weight * sum(h["loss"][0] for h in heads_u)
+            sample_size += heads_u[0]["count"]
+
+        if self.loss_weights is not None:
+            extra_losses, names = model.get_extra_losses(net_output)
+            weights = list(self.loss_weights)
+            if len(weights) == 1 and len(extra_losses) != 1:
+                weights = [weights[0]] * len(extra_losses)
+            assert len(extra_losses) == len(weights), f"{len(extra_losses)}, {len(weights)}"
+            for p, n, coef in zip(extra_losses, names, weights):
+                if coef != 0 and p is not None:
+                    p = coef * p.float().reshape(()) * sample_size
+                    loss = loss + p
+                    logging_output[f"loss_{n}"] = num(p.detach())
+
+        nsent = sample["id"].numel() if "id" in sample else sample["net_input"]["source"].size(0)
+        logging_output = {"loss": num(loss.detach()), "ntokens": sample_size, "nsentences": nsent,
+                          "sample_size": sample_size, **logging_output}
+        for lk in self.log_keys:
+            if lk in net_output:
+                logging_output[lk] = float(net_output[lk])
+        for i, h in enumerate(heads_m):
+            logging_output[f"correct_m_{i}"] = num(h["correct"][0]) if self.defer_logging else int(h["correct"].item())
+            logging_output[f"count_m_{i}"] = h["count"]
+        for i, h in enumerate(heads_u):
+            logging_output[f"correct_u_{i}"] = num(h["correct"][0]) if self.defer_logging else int(h["correct"].item())
+            logging_output[f"count_u_{i}"] = h["count"]
+        return loss, sample_size, logging_output
+
+    @staticmethod
+    def reduce_metrics(logging_outputs, log_scalar=None) -> Dict[str, float]:
+        """Same aggregation as wavlm_criterion.py:145-193; returns the scalars (and forwards them to fairseq's
+        metrics.log_scalar when given)."""
+        def val(v):
+            return float(v.item()) if torch.is_tensor(v) else float(v)
+        out = {}
+        loss_sum = sum(val(l.get("loss", 0)) for l in logging_outputs)
+        ntokens = sum(val(l.get("ntokens", 0)) for l in logging_outputs)
+        sample_size = sum(val(l.get("sample_size", 0)) for l in logging_outputs)
+        nsentences = sum(val(l.get("nsentences", 0)) for l in logging_outputs)
+        out["loss"] = loss_sum / sample_size / math.log(2)
+        if sample_size != ntokens:
+            out["nll_loss"] = loss_sum / ntokens / math.log(2)
+        out["ntokens"], out["nsentences"] = ntokens, nsentences
+        counts = {}
+        for lk in logging_outputs[0].keys():
+            if lk.startswith("count_"):
+                counts[lk] = sum(val(l[lk]) for l in logging_outputs)
+                out[lk] = counts[lk]
+        for lk in logging_outputs[0].keys():
+            if lk.startswith("loss_"):
+                out[lk] = sum(val(l[lk]) for l in logging_outputs) / sample_size / math.log(2)
+            elif lk.startswith("correct_"):
+                out[lk] = sum(val(l[lk]) for l in logging_outputs) / max(counts[lk.replace("correct", "count")], 1)
+        if log_scalar is not None:
+            for k, v in out.items():
+                log_scalar(k, v)
+        return out
+
+    @staticmethod
+    def logging_outputs_can_be_summed() -> bool:
+        return False

@@ -1,0 +1,441 @@
+"""WavLM on MI355X: the standalone `WavLM` / `WavLMConfig` / `extract_features` surface of the reference
+(WavLM/WavLM.py:162-375) over the HIP kernels in libwavlm_hip.so.
+
+The module tree mirrors the reference one-to-one (same attribute names, same registration order, same
+initialisers called in the same order), so that
+  * `load_state_dict(checkpoint["model"])` works on released checkpoints unchanged, and
+  * `torch.manual_seed(s); WavLM(cfg)` yields bit-identical parameters to the reference constructor
+    (SURVEY.md 8(a) row Q).
+The nn.Conv1d / nn.Linear / nn.LayerNorm objects are parameter containers only: their torch forward is never
+called.  Every forward below routes through unispeech_amd.functional (HIP); there is no CPU execution path.
+
+Activations are [B, T, C]; where the reference API exposes [T, B, C] tensors (layer_results) transposed views are
+returned.
+"""
+import math
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from .masking import compute_mask_indices, relative_position_buckets
+
+
+class WavLMConfig:
+    """Same fields and defaults as WavLM/WavLM.py:162-217."""
+
+    def __init__(self, cfg=None):
+        self.extractor_mode: str = "default"
+        self.encoder_layers: int = 12
+        self.encoder_embed_dim: int = 768
+        self.encoder_ffn_embed_dim: int = 3072
+        self.encoder_attention_heads: int = 12
+        self.activation_fn: str = "gelu"
+        self.layer_norm_first: bool = False
+        self.conv_feature_layers: str = "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"
+        self.conv_bias: bool = False
+        self.feature_grad_mult: float = 1.0
+        self.normalize: bool = False
+        self.dropout: float = 0.1
+        self.attention_dropout: float = 0.1
+        self.activation_dropout: float = 0.0
+        self.encoder_layerdrop: float = 0.0
+        self.dropout_input: float = 0.0
+        self.dropout_features: float = 0.0
+        self.mask_length: int = 10
+        self.mask_prob: float = 0.65
+        self.mask_selection: str = "static"
+        self.mask_other: float = 0
+        self.no_mask_overlap: bool = False
+        self.mask_min_space: int = 1
+        self.mask_channel_length: int = 10
+        self.mask_channel_prob: float = 0.0
+        self.mask_channel_selection: str = "static"
+        self.mask_channel_other: float = 0
+        self.no_mask_channel_overlap: bool = False
+        self.mask_channel_min_space: int = 1
+        self.conv_pos: int = 128
+        self.conv_pos_groups: int = 16
+        self.relative_position_embedding: bool = False
+        self.num_buckets: int = 320
+        self.max_distance: int = 1280
+        self.gru_rel_pos: bool = False
+        if cfg is not None:
+            self.update(cfg)
+
+    def update(self, cfg: dict):
+        self.__dict__.update(cfg)
+
+
+# ------------------------------------------------------------------------------------------ parameter init
+def _bert_normal_(t):
+    # drawn on the CPU generator exactly like the reference (init_bert_params.normal_)
+    t.copy_(t.cpu().normal_(mean=0.0, std=0.02).to(t.device))
+
+
+def init_bert_params(module):
+    """BERT-style re-initialisation applied post-order over the encoder (WavLM/modules.py:168-200): every Linear
+    and Embedding weight ~ N(0, 0.02), biases zero, then q/k/v of each attention block once more."""
+    if isinstance(module, nn.Linear):
+        _bert_normal_(module.weight.data)
+        if module.bias is not None:
+            module.bias.data.zero_()
+    if isinstance(module, nn.Embedding):
+        _bert_normal_(module.weight.data)
+        if module.padding_idx is not None:
+            module.weight.data[module.padding_idx].zero_()
+    if isinstance(module, MultiheadAttention):
+        _bert_normal_(module.q_proj.weight.data)
+        _bert_normal_(module.k_proj.weight.data)
+        _bert_normal_(module.v_proj.weight.data)
+
+
+# ------------------------------------------------------------------------------------------ feature extractor
+class ConvFeatureExtractionModel(nn.Module):
+    """7 x {Conv1d(no bias) -> [GroupNorm on block 0 | LayerNorm every block] -> GELU}
+    (WavLM/WavLM.py:378-504, conv_type 'default').  State-dict keys: conv_layers.{i}.0.weight,
+    conv_layers.0.2.{weight,bias} (GroupNorm) or conv_layers.{i}.2.1.{weight,bias} (layer_norm mode)."""
+
+    def __init__(self, conv_layers: List[Tuple[int, int, int]], dropout: float = 0.0, mode: str = "default",
+                 conv_bias: bool = False):
+        super().__init__()
+        assert mode in {"default", "layer_norm"}
+        self.mode = mode
+        self.specs = [(k, s) for (_, k, s) in conv_layers]
+        self.conv_layers = nn.ModuleList()
+        in_d = 1
+        for i, (dim, k, stride) in enumerate(conv_layers):
+            conv = nn.Conv1d(in_d, dim, k, stride=stride, bias=conv_bias)
+            nn.init.kaiming_normal_(conv.weight)
+            if mode == "layer_norm":
+                norm = nn.Sequential(nn.Identity(), nn.LayerNorm(dim, elementwise_affine=True), nn.Identity())
+                block = nn.Sequential(conv, nn.Dropout(p=dropout), norm, nn.GELU())
+            elif i == 0:
+                block = nn.Sequential(conv, nn.Dropout(p=dropout), nn.GroupNorm(dim, dim, affine=True), nn.GELU())
+            else:
+                block = nn.Sequential(conv, nn.Dropout(p=dropout), nn.GELU())
+            self.conv_layers.append(block)
+            in_d = dim
+
+    def forward(self, x):
+        """x: waveform [B, T] -> features [B, T', C] (channel-last; the reference returns [B, C, T'])"""
+        if self.mode != "default":
+            raise NotImplementedError("extractor_mode='layer_norm' is not wired to the HIP path yet")
+        blk0 = self.conv_layers[0]
+        conv0, gn = blk0[0], blk0[2]
+        if conv0.bias is not None:
+            raise NotImplementedError("conv_bias=True is not supported by the HIP path")
+        wdt = conv0.weight.dtype
+        if x.dtype != wdt:
+            x = x.to(wdt)
+        y = F.Conv0Fn.apply(x, conv0.weight, gn.weight, gn.bias, self.specs[0][1], gn.eps, wdt)
+        weights = [blk[0].weight for blk in list(self.conv_layers)[1:]]
+        if weights:
+            y = F.ConvStackFn.apply(y, tuple(self.specs[1:]), *weights)
+        return y
+
+
+# ----------------------------------------------------------------------------------------------- attention
+class MultiheadAttention(nn.Module):
+    """Self-attention with the gated relative position bias (WavLM/modules.py:303-563, the 'fast path' that all
+    WavLM checkpoints were trained with).  Submodule names / order follow the reference so state dicts and seeded
+    initialisation line up."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0, has_relative_attention_bias=False, num_buckets=32,
+                 max_distance=128, gru_rel_pos=False):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.dropout_module = nn.Dropout(dropout)
+        self.has_relative_attention_bias = has_relative_attention_bias
+        self.num_buckets = num_buckets
+        self.max_distance = max_distance
+        if has_relative_attention_bias:
+            self.relative_attention_bias = nn.Embedding(num_buckets, num_heads)
+        self.head_dim = embed_dim // num_heads
+        assert self.head_dim * num_heads == embed_dim, "embed_dim must be divisible by num_heads"
+        self.scaling = self.head_dim ** -0.5
+        self.k_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+        self.v_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+        self.q_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+        self.gru_rel_pos = gru_rel_pos
+        if gru_rel_pos:
+            self.grep_linear = nn.Linear(self.head_dim, 8)
+            self.grep_a = nn.Parameter(torch.ones(1, num_heads, 1, 1))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        g = 1 / math.sqrt(2)
+        nn.init.xavier_uniform_(self.k_proj.weight, gain=g)
+        nn.init.xavier_uniform_(self.v_proj.weight, gain=g)
+        nn.init.xavier_uniform_(self.q_proj.weight, gain=g)
+        nn.init.xavier_uniform_(self.out_proj.weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+        if self.has_relative_attention_bias:
+            nn.init.xavier_normal_(self.relative_attention_bias.weight)
+
+    def position_table(self, T, device):
+        """[H, 2T-1] fp32 Toeplitz generator of compute_bias(T, T) (modules.py:444-455)"""
+        bucket = relative_position_buckets(T, self.num_buckets, self.max_distance).to(device)
+        return F.RelPosTableFn.apply(self.relative_attention_bias.weight, bucket)
+
+    def forward(self, x, key_padding_u8=None, position_table=None):
+        """x [B, T, D] -> (attn_out [B, T, D], position_table)"""
+        B, T, D = x.shape
+        if self.has_relative_attention_bias and position_table is None:
+            position_table = self.position_table(T, x.device)
+        gate = None
+        if position_table is not None:
+            if self.gru_rel_pos:
+                gate = F.GateFn.apply(x, self.grep_linear.weight, self.grep_linear.bias, self.grep_a, self.num_heads)
+            else:
+                gate = torch.ones((B, self.num_heads, T), dtype=torch.float32, device=x.device)
+        w = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
+        b = torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0)
+        qkv = F.LinearFn.apply(x, w, b)
+        p = self.dropout_module.p if self.training else 0.0
+        o = F.AttnCoreFn.apply(qkv, gate, position_table, key_padding_u8, self.num_heads, self.scaling, p,
+                               F.next_seed() if p > 0 else 0)
+        out = F.LinearFn.apply(o, self.out_proj.weight, self.out_proj.bias)
+        return out, position_table
+
+
+class ResidualAddFn(torch.autograd.Function):
+    """y = x + dropout(r) (pre-LN blocks, where no LayerNorm follows the add)"""
+
+    @staticmethod
+    def forward(ctx, x, r, p, seed):
+        from . import ops
+        y = x.contiguous().clone()
+        rd = ops.dropout(r.contiguous(), p, seed) if p > 0 else r.contiguous()
+        ops.axpby_(y, rd, 1.0, 1.0)
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        dr = ops.dropout(dy.contiguous(), ctx.p, ctx.seed) if ctx.p > 0 else dy
+        return dy, dr, None, None
+
+
+class TransformerSentenceEncoderLayer(nn.Module):
+    """post-LN (Base) / pre-LN (Large) encoder block (WavLM/WavLM.py:615-742)"""
+
+    def __init__(self, embedding_dim=768, ffn_embedding_dim=3072, num_attention_heads=8, dropout=0.1,
+                 attention_dropout=0.1, activation_dropout=0.1, activation_fn="relu", layer_norm_first=False,
+                 has_relative_attention_bias=False, num_buckets=0, max_distance=0, gru_rel_pos=False):
+        super().__init__()
+        if activation_fn != "gelu":
+            raise NotImplementedError("only activation_fn='gelu' (every released WavLM/UniSpeech model) is supported")
+        self.embedding_dim = embedding_dim
+        self.dropout = dropout
+        self.activation_dropout = activation_dropout
+        self.self_attn = MultiheadAttention(embedding_dim, num_attention_heads, dropout=attention_dropout,
+                                            has_relative_attention_bias=has_relative_attention_bias,
+                                            num_buckets=num_buckets, max_distance=max_distance, gru_rel_pos=gru_rel_pos)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(activation_dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.layer_norm_first = layer_norm_first
+        self.self_attn_layer_norm = nn.LayerNorm(embedding_dim)
+        self.fc1 = nn.Linear(embedding_dim, ffn_embedding_dim)
+        self.fc2 = nn.Linear(ffn_embedding_dim, embedding_dim)
+        self.final_layer_norm = nn.LayerNorm(embedding_dim)
+
+    def _ffn(self, x):
+        p = self.activation_dropout if self.training else 0.0
+        return F.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p,
+                             F.next_seed() if p > 0 else 0)
+
+    def forward(self, x, key_padding_u8=None, position_table=None):
+        ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
+        p = self.dropout if self.training else 0.0
+        if self.layer_norm_first:
+            h, _ = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps)
+            a, position_table = self.self_attn(h, key_padding_u8, position_table)
+            x = ResidualAddFn.apply(x, a, p, F.next_seed() if p > 0 else 0)
+            h, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps)
+            f = self._ffn(h)
+            x = ResidualAddFn.apply(x, f, p, F.next_seed() if p > 0 else 0)
+        else:
+            a, position_table = self.self_attn(x, key_padding_u8, position_table)
+            x, _ = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps, residual=a, p_in=p, training=self.training)
+            f = self._ffn(x)
+            x, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps, residual=f, p_in=p, training=self.training)
+        return x, None, position_table
+
+
+class TransformerEncoder(nn.Module):
+    """pos_conv + N layers (WavLM/WavLM.py:507-612; fairseq twin src/fairseq/models/wavlm/wavlm.py:630-754)"""
+
+    def __init__(self, args):
+        super().__init__()
+        self.dropout = args.dropout
+        self.embedding_dim = args.encoder_embed_dim
+        self.conv_pos = args.conv_pos
+        self.conv_pos_groups = args.conv_pos_groups
+        pos_conv = nn.Conv1d(self.embedding_dim, self.embedding_dim, kernel_size=args.conv_pos,
+                             padding=args.conv_pos // 2, groups=args.conv_pos_groups)
+        std = math.sqrt(4.0 / (args.conv_pos * self.embedding_dim))
+        nn.init.normal_(pos_conv.weight, mean=0, std=std)
+        nn.init.constant_(pos_conv.bias, 0)
+        # old-style weight norm (weight_g / weight_v parameters) for checkpoint-key compatibility
+        pos_conv = nn.utils.weight_norm(pos_conv, name="weight", dim=2)
+        self.pos_conv = nn.Sequential(pos_conv, nn.Identity(), nn.GELU())
+        self.relative_position_embedding = getattr(args, "relative_position_embedding", False)
+        self.num_buckets = getattr(args, "num_buckets", 0) if self.relative_position_embedding else 0
+        self.max_distance = getattr(args, "max_distance", 0) if self.relative_position_embedding else 0
+        gru = getattr(args, "gru_rel_pos", False)
+        self.layers = nn.ModuleList([
+            TransformerSentenceEncoderLayer(
+                embedding_dim=self.embedding_dim, ffn_embedding_dim=args.encoder_ffn_embed_dim,
+                num_attention_heads=args.encoder_attention_heads, dropout=self.dropout,
+                attention_dropout=args.attention_dropout, activation_dropout=args.activation_dropout,
+                activation_fn=args.activation_fn, layer_norm_first=args.layer_norm_first,
+                has_relative_attention_bias=(self.relative_position_embedding and i == 0),
+                num_buckets=self.num_buckets, max_distance=self.max_distance, gru_rel_pos=gru)
+            for i in range(args.encoder_layers)
+        ])
+        self.layer_norm_first = args.layer_norm_first
+        self.layer_norm = nn.LayerNorm(self.embedding_dim)
+        self.layerdrop = args.encoder_layerdrop
+        self.apply(init_bert_params)
+
+    def forward(self, x, padding_mask=None, layer=None, fairseq_layer_results=False, prezeroed=False):
+        x, layer_results, pre_ln = self.extract_features(x, padding_mask, layer, fairseq_layer_results, prezeroed)
+        if self.layer_norm_first and layer is None:
+            x, _ = F.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return x, layer_results, pre_ln
+
+    def extract_features(self, x, padding_mask=None, tgt_layer=None, fairseq_layer_results=False, prezeroed=False):
+        """x [B, T, D].  Returns (x, layer_results, conv_sum) where conv_sum = x + pos_conv(x): the tensor the
+        reference's in-place `x += x_conv` leaves behind in `features` (WavLM/WavLM.py:579)."""
+        kpm = None
+        if padding_mask is not None:
+            kpm = padding_mask.to(torch.uint8).contiguous()
+            if not prezeroed:
+                x = F.SelectRowsFn.apply(x, None, None, kpm.view(-1))
+        conv = self.pos_conv[0]
+        xs = F.PosConvFn.apply(x, conv.weight_v, conv.weight_g, conv.bias, self.conv_pos_groups)
+        if not self.layer_norm_first:
+            ln = self.layer_norm
+            x, _ = F.layer_norm(xs, ln.weight, ln.bias, ln.eps, p_out=self.dropout, training=self.training)
+        else:
+            x = F.dropout(xs, self.dropout, self.training)
+
+        layer_results = []
+        if tgt_layer is not None and not fairseq_layer_results:
+            layer_results.append((x.transpose(0, 1), None))
+        r = None
+        table = None
+        for i, layer in enumerate(self.layers):
+            # one host draw per layer, training or not: keeps the numpy stream aligned with the reference
+            dropout_probability = np.random.random()
+            if not self.training or (dropout_probability > self.layerdrop):
+                x, z, table = layer(x, kpm, table)
+            else:
+                z = None
+            if fairseq_layer_results:
+                if isinstance(tgt_layer, list) and i + 1 in tgt_layer:
+                    layer_results.append((x.transpose(0, 1), z))
+                elif isinstance(tgt_layer, int) and i == tgt_layer:
+                    r = x
+                    break
+            else:
+                if tgt_layer is not None:
+                    layer_results.append((x.transpose(0, 1), z))
+                if i == tgt_layer:
+                    r = x
+                    break
+        if r is not None:
+            x = r
+        return x, layer_results, xs
+
+
+# -------------------------------------------------------------------------------------------------- model
+class WavLM(nn.Module):
+    """Drop-in for WavLM/WavLM.py:220-375 (`extract_features` API), HIP-only."""
+
+    def __init__(self, cfg: WavLMConfig) -> None:
+        super().__init__()
+        self.cfg = cfg
+        feature_enc_layers = eval(cfg.conv_feature_layers)
+        self.embed = feature_enc_layers[-1][0]
+        self.feature_extractor = ConvFeatureExtractionModel(conv_layers=feature_enc_layers, dropout=0.0,
+                                                            mode=cfg.extractor_mode, conv_bias=cfg.conv_bias)
+        self.post_extract_proj = (nn.Linear(self.embed, cfg.encoder_embed_dim)
+                                  if self.embed != cfg.encoder_embed_dim else None)
+        self.mask_prob = cfg.mask_prob
+        self.mask_selection = cfg.mask_selection
+        self.mask_other = cfg.mask_other
+        self.mask_length = cfg.mask_length
+        self.no_mask_overlap = cfg.no_mask_overlap
+        self.mask_min_space = cfg.mask_min_space
+        self.mask_channel_prob = cfg.mask_channel_prob
+        self.dropout_input = nn.Dropout(cfg.dropout_input)
+        self.dropout_features = nn.Dropout(cfg.dropout_features)
+        self.feature_grad_mult = cfg.feature_grad_mult
+        self.mask_emb = nn.Parameter(torch.FloatTensor(cfg.encoder_embed_dim).uniform_())
+        self.encoder = TransformerEncoder(cfg)
+        self.layer_norm = nn.LayerNorm(self.embed)
+
+    # -- host-side pieces -------------------------------------------------------------------------------------
+    def compute_mask(self, B, T, padding_mask):
+        """bool numpy [B, T]; consumes the global numpy RNG exactly like apply_mask (WavLM.py:271-285)"""
+        if self.mask_prob <= 0:
+            return None
+        return compute_mask_indices((B, T), padding_mask, self.mask_prob, self.mask_length, self.mask_selection,
+                                    self.mask_other, min_masks=2, no_overlap=self.no_mask_overlap,
+                                    min_space=self.mask_min_space)
+
+    def forward_padding_mask(self, n_frames: int, padding_mask: torch.Tensor) -> torch.Tensor:
+        extra = padding_mask.size(1) % n_frames
+        if extra > 0:
+            padding_mask = padding_mask[:, :-extra]
+        padding_mask = padding_mask.view(padding_mask.size(0), n_frames, -1)
+        return padding_mask.all(-1)
+
+    # -- device path -------------------------------------------------------------------------------------------
+    def _features(self, source):
+        """waveform -> (LayerNorm'ed, projected features [B, T', D], raw conv features [B, T', C])"""
+        if self.feature_grad_mult > 0:
+            feats = self.feature_extractor(source)
+        else:
+            with torch.no_grad():
+                feats = self.feature_extractor(source)
+        gscale = self.feature_grad_mult if (self.feature_grad_mult > 0 and self.feature_grad_mult != 1.0) else 1.0
+        ln = self.layer_norm
+        x, _ = F.layer_norm(feats, ln.weight, ln.bias, ln.eps, grad_scale=gscale)
+        if self.post_extract_proj is not None:
+            x = F.LinearFn.apply(x, self.post_extract_proj.weight, self.post_extract_proj.bias)
+        return x, feats
+
+    def extract_features(self, source: torch.Tensor, padding_mask: Optional[torch.Tensor] = None, mask: bool = False,
+                         ret_conv: bool = False, output_layer: Optional[int] = None,
+                         ret_layer_results: bool = False):
+        if self.mask_channel_prob > 0 and mask:
+            raise NotImplementedError("channel masking is not supported by the HIP path")
+        x, _ = self._features(source)
+        B, T, _ = x.shape
+        if padding_mask is not None:
+            padding_mask = self.forward_padding_mask(T, padding_mask)
+        x = F.dropout(x, self.dropout_input.p, self.training)
+        sel = None
+        if mask:
+            m = self.compute_mask(B, T, padding_mask)
+            if m is not None:
+                sel = torch.from_numpy(m).to(x.device).to(torch.uint8).view(-1)
+        kpm = padding_mask.to(torch.uint8).contiguous().view(-1) if padding_mask is not None else None
+        if sel is not None or kpm is not None:
+            x = F.SelectRowsFn.apply(x, sel, self.mask_emb if sel is not None else None, kpm)
+        x, layer_results, conv_sum = self.encoder(
+            x, padding_mask=padding_mask, layer=None if output_layer is None else output_layer - 1, prezeroed=True)
+        # the reference returns `features` after three in-place updates (mask, padding zero-fill, += pos_conv)
+        feature = conv_sum if ret_conv else x
+        if ret_layer_results:
+            feature = (feature, layer_results)
+        return feature, padding_mask
