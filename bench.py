@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""Headline benchmark: WavLM-Base pre-training throughput in audio-seconds/sec (BASELINE.json metric), config[1]:
+bf16, 32 x 15 s utterances per GPU, masked-prediction loss, forward + backward + gradient reduction + fused Adam.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W          # one rank per GPU over RCCL, weak scaling
+
+Synthetic data of the real shape (randn waveform, random k-means labels), random-init weights of the real
+architecture; recipe dropouts on (dropout 0.1, attention_dropout 0.1, dropout_input 0.1), layerdrop 0 (no layer is
+ever skipped inside the timed region).  Rank 0 prints ONE JSON line.  Extra legs outside the timed region:
+`roofline` (HIP-event timing of every bf16 MFMA GEMM launch during two extra steps) and `cpu_baseline` (the CPU
+oracle timed on the host cores on a bounded 2 x 15 s sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SECONDS = 15.0
+SR = 16000
+BATCH_PER_GPU = 32
+V = 504
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md line 42
+
+
+def base_cfg(training_dropouts=True):
+    from unispeech_amd.pretrain import WavLMPretrainConfig
+    d = 0.1 if training_dropouts else 0.0
+    return WavLMPretrainConfig(
+        encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, encoder_attention_heads=12,
+        dropout=d, attention_dropout=d, activation_dropout=0.0, encoder_layerdrop=0.0, dropout_input=d,
+        dropout_features=d, feature_grad_mult=0.1, mask_prob=0.80, mask_length=10, final_dim=256, logit_temp=0.1,
+        relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True, label_rate=50,
+        extractor_mode="default", conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2")
+
+
+def algorithmic_flops_per_step(B, T):
+    """forward FLOPs of WavLM-Base for B utterances of T samples, x3 for forward+backward"""
+    fl = 0.0
+    t, cin = T, 1
+    for (c, k, s) in [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2:
+        t = (t - k) // s + 1
+        fl += 2.0 * B * t * c * cin * k
+        cin = c
+    n, D, Fd, H = B * t, 768, 3072, 12
+    fl += 2.0 * n * 512 * D                      # post_extract_proj
+    fl += 2.0 * n * D * (D // 16) * 128          # pos_conv
+    per_layer = 2.0 * n * D * D * 4 + 2.0 * n * D * Fd * 2 + 2.0 * B * H * t * t * (D // H) * 2
+    fl += 12 * per_layer
+    return 3.0 * fl
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """reference algorithm (CPU oracle, fp32, all host cores) on a 2 x 15 s sample: forward + loss + backward"""
+    from oracle import wavlm_oracle as O
+    from unispeech_amd.masking import compute_mask_indices
+    from unispeech_amd.pretrain import WavLMPretrainModel
+    cfg = base_cfg(False)
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point())
+          for k, v in WavLMPretrainModel(cfg, None, [range(V)]).state_dict().items()}
+    B, T = 2, int(SECONDS * SR)
+    g = torch.Generator().manual_seed(1234)
+    wav = torch.randn(B, T, generator=g)
+    target = torch.randint(4, V, (B, int(50 * SECONDS)), generator=g)
+    pm = torch.zeros(B, T, dtype=torch.bool)
+    np.random.seed(123)
+    mask = torch.from_numpy(compute_mask_indices((B, 749), torch.zeros(B, 749, dtype=torch.bool), cfg.mask_prob,
+                                                 cfg.mask_length, "static", 0, min_masks=2))
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        for p in sd.values():
+            p.grad = None
+        t0 = time.time()
+        net = O.pretrain_forward(sd, cfg, wav, [target], pm, mask, [V])
+        loss, _, _ = O.criterion(net, 1.0, 0.0, [10.0])
+        loss.backward()
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if time.time() - t_start > seconds_budget and times:
+            break
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(B * SECONDS / med, 2), "unit": "audio-s/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": "oracle fwd+loss+bwd fp32, B=2 x 15 s, median of %d after 1 warm-up" % len(times)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from unispeech_amd import ops
+    from unispeech_amd.dp import DataParallelWavLM
+    from unispeech_amd.optim import FusedAdam
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainModel
+
+    cfg = base_cfg(True)
+    torch.manual_seed(0)
+    model = WavLMPretrainModel(cfg, None, [range(V)]).to(dev).to(torch.bfloat16).train()
+    opt = FusedAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=10.0)
+    net = DataParallelWavLM(model, opt) if world > 1 else model
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0], defer_logging=True)
+
+    B, T = args.batch, int(SECONDS * SR)
+    g = torch.Generator().manual_seed(1234 + rank)
+    wav = torch.randn(B, T, generator=g).to(dev).to(torch.bfloat16)
+    pm_cpu = torch.zeros(B, T, dtype=torch.bool)
+    sample = {"id": torch.arange(B),
+              "net_input": {"source": wav, "padding_mask": pm_cpu.to(dev), "padding_mask_cpu": pm_cpu},
+              "target_list": [torch.randint(4, V, (B, int(50 * SECONDS)), generator=g).to(dev)]}
+    np.random.seed(1337 + rank)
+    torch.manual_seed(1337)
+
+    def step():
+        opt.zero_grad()
+        loss, ss, _ = crit(net, sample)
+        loss.backward()
+        if world > 1:
+            net.all_reduce_grads()
+            sst = torch.tensor([float(ss)], dtype=torch.float32, device=dev)
+            dist.all_reduce(sst)
+            opt.step(grad_mult=1.0, grad_mult_dev=sst.reciprocal())
+        else:
+            opt.step(grad_mult=1.0 / max(ss, 1))
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    final_loss = float(loss.item())
+
+    roof = None
+    if not args.no_roofline:
+        ops.prof_enable(True)
+        for _ in range(2):
+            step()
+        n_l, ms, fl = ops.prof_collect(1)
+        ops.prof_enable(False)
+        if ms > 0:
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all instantiations, every dense contraction of the step)",
+                    "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": n_l // 2, "gemm_ms_per_step": round(ms / 2, 3),
+                    "gemm_algorithmic_tflop_per_step": round(fl / 2 / 1e12, 3),
+                    "avg_launch_us": round(ms / max(n_l, 1) * 1e3, 2)}
+    fence()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * B * SECONDS * args.steps / dt
+        out = {
+            "metric": "audio-seconds/sec pretraining, WavLM-Base 15s@16kHz", "value": round(value, 1),
+            "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "WavLM-Base (12L, d=768) pretrain fwd+bwd+grad-reduce+fused-Adam, bf16, "
+                                   "batch=%dx15s per GPU, masked-pred loss (BASELINE.json configs[1]%s)"
+                                   % (B, "" if world == 1 else ", dp%d" % world),
+                       "global_batch": world * B, "seconds_per_utt": SECONDS, "frames_per_utt": 749,
+                       "parallelism": "dp%d" % world, "dropout": 0.1, "attention_dropout": 0.1, "layerdrop": 0.0,
+                       "mask_prob": 0.8, "optimizer": "fused Adam, fp32 master, clip 10"},
+            "final_loss": final_loss,
+            "model_tflops": round(algorithmic_flops_per_step(B, T) / (ms_per_step * 1e-3) / 1e12, 1),
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -184,9 +184,18 @@ int wavlm_sum_f32(const float* x, int64_t n, float* out, void* workspace, uint64
 /* ------------------------------------------------------------------------------------------
  * Fused optimizer step (src/fairseq/optim/adam.py:148-228, fp16_optimizer.py:106-218, utils.py:338-388)
  * ------------------------------------------------------------------------------------------ */
+/* grad is scaled by grad_mult (* grad_mult_dev[0] when given: a device scalar such as 1 / global sample size) and
+ * clipped to max_norm using the device scalar *gnorm_sq (sum of squares of the unscaled gradient) -- no host sync. */
 int wavlm_adam_step(float* p, float* m, float* v, const void* grad, int32_t grad_dtype, void* p_lowp,
                     int32_t lowp_dtype, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                    int64_t step, float grad_mult, const float* gnorm_sq, float max_norm, void* stream);
+                    int64_t step, float grad_mult, const float* grad_mult_dev, const float* gnorm_sq, float max_norm,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py roofline leg): HIP events around every wavlm_gemm launch while enabled.
+ * ------------------------------------------------------------------------------------------ */
+void wavlm_prof_enable(int on);
+int wavlm_prof_collect(int dtype, double* total_ms, double* total_flops);
 
 #ifdef __cplusplus
 }

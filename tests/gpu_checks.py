@@ -1,0 +1,497 @@
+"""Kernel-level parity checks: each HIP entry point / autograd function against a plain PyTorch fp32 (fp64 where
+cheap) CPU reference of the same op on seeded inputs.  Used by tests/test_kernels_gpu.py (pytest -m gpu) and by
+tools/gpu_report.py (crash-isolated report).  Every check returns a list of (name, error, tolerance).
+
+Error metric: max |a - b| / max(|b|_max, tiny) -- "relative to the tensor scale" -- unless noted.
+Tolerances: fp32 mode 1e-4 (BASELINE.json north_star) except long fp32 reductions (2e-4); bf16 mode 2e-2.
+"""
+import math
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+sys.path.insert(0, __file__.rsplit("/tests/", 1)[0])
+from unispeech_amd import functional as F  # noqa: E402
+from unispeech_amd import ops  # noqa: E402
+
+DEV = "cuda"
+TOL32, TOLBF = 1e-4, 2e-2
+
+
+def err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    if a.shape != b.shape:
+        return float("inf")
+    if b.numel() == 0:
+        return 0.0
+    if not torch.isfinite(a).all():
+        return float("inf")
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def tol_for(dtype):
+    return TOL32 if dtype == torch.float32 else TOLBF
+
+
+def q(t, dtype):
+    """round a CPU fp32 tensor through `dtype` so that device and reference see identical inputs"""
+    return t.to(dtype).float()
+
+
+# ------------------------------------------------------------------------------------------------------ GEMM
+def check_gemm():
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        for (M, N, K, tA, tB) in [(200, 136, 72, 0, 0), (129, 64, 264, 0, 1), (260, 130, 200, 1, 0), (77, 48, 333, 1, 1),
+                                  (512, 256, 512, 0, 0), (48, 640, 749, 1, 1), (100, 72, 749, 0, 0), (100, 64, 749, 0, 1)]:
+            Kp = (K + 7) // 8 * 8
+            Mp = (M + 7) // 8 * 8
+            Np = (N + 7) // 8 * 8
+            A = q(gen(M, K, seed=1), dtype)
+            B = q(gen(N, K, seed=2), dtype)
+            ref = A.double() @ B.double().t()
+            # storage: K-contiguous [rows, Kp] or K-strided [K, rows_p]
+            if tA:
+                Ad = torch.zeros(K, Mp); Ad[:, :M] = A.t(); lda = Mp
+            else:
+                Ad = torch.zeros(M, Kp); Ad[:, :K] = A; lda = Kp
+            if tB:
+                Bd = torch.zeros(K, Np); Bd[:, :N] = B.t(); ldb = Np
+            else:
+                Bd = torch.zeros(N, Kp); Bd[:, :K] = B; ldb = Kp
+            # poison the padding with NaN where it must be ignored (K tail of K-contiguous operands)
+            if not tA and Kp > K:
+                Ad[:, K:] = float("nan")
+            if not tB and Kp > K:
+                Bd[:, K:] = float("nan")
+            Ad = Ad.to(dtype).to(DEV); Bd = Bd.to(dtype).to(DEV)
+            C = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+            ops.gemm(Ad, Bd, C, M, N, K, lda=lda, ldb=ldb, ldc=N, transA=tA, transB=tB)
+            out.append((f"gemm[{dtype}] {M}x{N}x{K} tA={tA} tB={tB}", err(C, ref), tol))
+            for split in (3,):
+                C2 = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+                ops.gemm(Ad, Bd, C2, M, N, K, lda=lda, ldb=ldb, ldc=N, transA=tA, transB=tB, split_k=split)
+                out.append((f"gemm[{dtype}] {M}x{N}x{K} tA={tA} tB={tB} split={split}", err(C2, ref), tol))
+        # batched + K-batch + epilogues
+        Bo, Bi, KB, M, N, K = 2, 3, 2, 70, 40, 64
+        A = q(gen(Bo, Bi, KB, M, K, seed=3), dtype)
+        B = q(gen(Bo, Bi, KB, N, K, seed=4), dtype)
+        bias = q(gen(Bi, N, seed=5), dtype)
+        res = q(gen(Bo, Bi, M, N, seed=6), dtype)
+        pre = torch.einsum("oikmc,oiknc->oimn", A.double(), B.double()) * 0.5 + bias.double()[None, :, None, :]
+        ref = TF.gelu(pre) + res.double()
+        Ad, Bd = A.to(dtype).to(DEV), B.to(dtype).to(DEV)
+        C = torch.empty(Bo, Bi, M, N, dtype=dtype, device=DEV)
+        aux = torch.empty(Bo, Bi, M, N, dtype=dtype, device=DEV)
+        ops.gemm(Ad, Bd, C, M, N, K, lda=K, ldb=K, ldc=N, KB=KB, sA_kb=M * K, sB_kb=N * K, batch=(Bo, Bi),
+                 sA=(Bi * KB * M * K, KB * M * K), sB=(Bi * KB * N * K, KB * N * K), sC=(Bi * M * N, M * N), alpha=0.5,
+                 bias=bias.to(dtype).to(DEV), sBias=(0, N), epi=1, aux=aux, ld_aux=N, sAux=(Bi * M * N, M * N),
+                 res=res.to(dtype).to(DEV), ld_res=N, sRes=(Bi * M * N, M * N))
+        out.append((f"gemm[{dtype}] batched+KB+bias+gelu+res", err(C, ref), tol))
+        out.append((f"gemm[{dtype}] aux(pre-activation)", err(aux, pre), tol))
+        # epi 2: multiply by gelu'(aux)
+        u = q(gen(M, N, seed=7), dtype)
+        A2, B2 = q(gen(M, K, seed=8), dtype), q(gen(N, K, seed=9), dtype)
+        ud = u.double().requires_grad_(True)
+        gp = torch.autograd.grad(TF.gelu(ud).sum(), ud)[0]
+        ref2 = (A2.double() @ B2.double().t()) * gp
+        C = torch.empty(M, N, dtype=dtype, device=DEV)
+        ops.gemm(A2.to(dtype).to(DEV), B2.to(dtype).to(DEV), C, M, N, K, lda=K, ldb=K, ldc=N, epi=2,
+                 aux=u.to(dtype).to(DEV), ld_aux=N)
+        out.append((f"gemm[{dtype}] epi=gelu'", err(C, ref2), tol))
+        # overlapping rows == strided conv1d over a channel-last activation
+        Bb, Tin, Cin, Cout, k, s = 2, 41, 16, 24, 3, 2
+        x = q(gen(Bb, Tin, Cin, seed=10), dtype)
+        w = q(gen(Cout, Cin, k, seed=11, scale=0.2), dtype)
+        refc = TF.conv1d(x.double().transpose(1, 2), w.double(), stride=s).transpose(1, 2)
+        Tout = refc.shape[1]
+        Wf = w.permute(0, 2, 1).reshape(Cout, k * Cin).contiguous()
+        y = torch.empty(Bb, Tout, Cout, dtype=dtype, device=DEV)
+        ops.gemm(x.to(dtype).to(DEV), Wf.to(dtype).to(DEV), y, Tout, Cout, k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout,
+                 batch=(Bb, 1), sA=(Tin * Cin, 0), sC=(Tout * Cout, 0))
+        out.append((f"gemm[{dtype}] overlapping-row conv1d k3 s2", err(y, refc), tol))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------- row ops
+def check_layernorm():
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        for D in (64, 512, 768, 1024):
+            rows = 37
+            x, r = q(gen(rows, D, seed=1), dtype), q(gen(rows, D, seed=2), dtype)
+            g, b = q(1 + 0.1 * gen(D, seed=3), dtype), q(0.1 * gen(D, seed=4), dtype)
+            dy = q(gen(rows, D, seed=5), dtype)
+            for act in (0, 1):
+                xr, rr, gr, br = [t.clone().requires_grad_(True) for t in (x, r, g, b)]
+                s = xr + rr
+                if dtype == torch.bfloat16:
+                    s = s + (s.detach().to(dtype).float() - s.detach())  # straight-through bf16 rounding of the sum
+                z = TF.layer_norm(s, (D,), gr, br, 1e-5)
+                yr = TF.gelu(z) if act else z
+                (yr * dy).sum().backward()
+                xd, rd, gd, bd = [t.to(dtype).to(DEV).requires_grad_(True) for t in (x, r, g, b)]
+                y, s_out = F.LayerNormFn.apply(xd, rd, gd, bd, 1e-5, act, 0.0, 0, 0.0, 0, 1.0)
+                y.backward(dy.to(dtype).to(DEV))
+                tag = f"layernorm[{dtype}] D={D} act={act}"
+                out.append((tag + " y", err(y, yr), tol))
+                out.append((tag + " s", err(s_out, s), tol))
+                out.append((tag + " dx", err(xd.grad, xr.grad), tol))
+                out.append((tag + " dr", err(rd.grad, rr.grad), tol))
+                out.append((tag + " dgamma", err(gd.grad, gr.grad), tol * 2))
+                out.append((tag + " dbeta", err(bd.grad, br.grad), tol * 2))
+        # dropout consistency: y(p) on kept elements == y(0)/(1-p); grads use the same mask
+        D, rows, p = 768, 64, 0.25
+        x = gen(rows, D, seed=1).to(dtype).to(DEV).requires_grad_(True)
+        r = gen(rows, D, seed=2).to(dtype).to(DEV).requires_grad_(True)
+        g = torch.ones(D, dtype=dtype, device=DEV, requires_grad=True)
+        b = torch.zeros(D, dtype=dtype, device=DEV, requires_grad=True)
+        y0, _ = F.LayerNormFn.apply(x, None, g, b, 1e-5, 0, 0.0, 0, 0.0, 0, 1.0)
+        yp, _ = F.LayerNormFn.apply(x, None, g, b, 1e-5, 0, 0.0, 0, p, 777, 1.0)
+        keep = (yp != 0)
+        frac = keep.float().mean().item()
+        out.append((f"layernorm[{dtype}] out-dropout keep fraction", abs(frac - (1 - p)), 0.02))
+        out.append((f"layernorm[{dtype}] out-dropout values", err(yp[keep], (y0 / (1 - p))[keep]), tol))
+        yp.backward(torch.ones_like(yp))
+        # in-dropout: s - x must be r/(1-p) on kept elements, and dr must carry the same mask
+        y2, s2 = F.LayerNormFn.apply(x.detach(), r, g, b, 1e-5, 0, p, 999, 0.0, 0, 1.0)
+        dlt = (s2.float() - x.detach().float())
+        keep2 = dlt.abs() > 1e-6
+        out.append((f"layernorm[{dtype}] in-dropout keep fraction", abs(keep2.float().mean().item() - (1 - p)), 0.02))
+        y2.backward(gen(rows, D, seed=9).to(dtype).to(DEV))
+        out.append((f"layernorm[{dtype}] in-dropout grad mask", float(((r.grad != 0) != keep2).float().mean().item()), 0.01))
+    return out
+
+
+def check_rowops():
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        rows, D = 301, 768
+        x = q(gen(rows, D, seed=1), dtype)
+        xd = x.to(dtype).to(DEV)
+        inc = (torch.arange(rows) % 3 == 0)
+        exc = (torch.arange(rows) % 5 == 0)
+        cs = ops.colsum(xd, torch.float32)
+        out.append((f"colsum[{dtype}]", err(cs, x.double().sum(0)), tol))
+        cs2 = ops.colsum(xd, torch.float32, include=inc.to(torch.uint8).to(DEV), exclude=exc.to(torch.uint8).to(DEV))
+        out.append((f"colsum[{dtype}] masked", err(cs2, x.double()[inc & ~exc].sum(0)), tol))
+        emb = q(gen(D, seed=2), dtype)
+        y = ops.select_rows(xd, inc.to(torch.uint8).to(DEV), emb.to(dtype).to(DEV), exc.to(torch.uint8).to(DEV))
+        ref = x.clone(); ref[inc] = emb; ref[exc] = 0
+        out.append((f"select_rows[{dtype}]", err(y, ref), 1e-6))
+        idx = torch.tensor([5, -1, 0, 300, 17], dtype=torch.int32)
+        gth = ops.gather_rows(xd, idx.to(DEV), 5)
+        ref = torch.stack([x[5], torch.zeros(D), x[0], x[300], x[17]])
+        out.append((f"gather_rows[{dtype}]", err(gth, ref), 1e-6))
+        yv = q(gen(rows, D, seed=3), dtype)
+        yd = yv.to(dtype).to(DEV)
+        ops.axpby_(yd, xd, 0.5, 2.0)
+        out.append((f"axpby[{dtype}]", err(yd, 0.5 * x + 2.0 * yv), tol))
+        d1 = ops.dropout(xd, 0.1, 42)
+        d2 = ops.dropout(xd, 0.1, 42)
+        keep = d1 != 0
+        out.append((f"dropout[{dtype}] deterministic", float((d1 != d2).float().mean().item()), 0.0))
+        out.append((f"dropout[{dtype}] keep fraction", abs(keep.float().mean().item() - 0.9), 0.01))
+        out.append((f"dropout[{dtype}] scale", err(d1[keep], (xd.float() / 0.9)[keep]), tol))
+        ss = ops.sumsq(xd, 0.25)
+        out.append((f"sumsq[{dtype}]", err(ss, (x.double() ** 2).sum().reshape(1) * 0.25), tol))
+        sc = torch.tensor([3.0], device=DEV)
+        z = xd.clone(); ops.scale_dev_(z, sc, 0.5)
+        out.append((f"scale_dev[{dtype}]", err(z, x * 1.5), tol))
+    lr = gen(1000, seed=4).to(DEV)
+    out.append(("sum_f32", err(ops.sum_f32(lr), lr.double().sum().reshape(1)), 1e-5))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------- conv0
+def check_conv0():
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        for (B, T, C) in [(2, 16000, 512), (3, 4005, 32)]:
+            wav = q(gen(B, T, seed=1), dtype)
+            W = q(gen(C, 1, 10, seed=2, scale=0.4), dtype)
+            g, b = q(1 + 0.1 * gen(C, seed=3), dtype), q(0.1 * gen(C, seed=4), dtype)
+            wr, Wr, gr, br = wav.clone(), W.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = TF.gelu(TF.group_norm(TF.conv1d(wr.unsqueeze(1), Wr, stride=5), C, gr, br, 1e-5)).transpose(1, 2)
+            dy = q(gen(*y.shape, seed=5), dtype)
+            (y * dy).sum().backward()
+            Wd, gd, bd = [t.to(dtype).to(DEV).requires_grad_(True) for t in (W, g, b)]
+            yd = F.Conv0Fn.apply(wav.to(dtype).to(DEV), Wd, gd, bd, 5, 1e-5, dtype)
+            yd.backward(dy.to(dtype).to(DEV))
+            tag = f"conv0[{dtype}] B={B} T={T} C={C}"
+            out.append((tag + " y", err(yd, y), tol))
+            out.append((tag + " dW", err(Wd.grad, Wr.grad), tol * 3))
+            out.append((tag + " dgamma", err(gd.grad, gr.grad), tol * 3))
+            out.append((tag + " dbeta", err(bd.grad, br.grad), tol * 3))
+    return out
+
+
+def check_convstack():
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        B, T0, C = 2, 403, 32
+        specs = ((3, 2), (3, 2), (2, 2), (2, 2))
+        x = q(gen(B, T0, C, seed=1), dtype)
+        Ws = [q(gen(C, C, k, seed=10 + i, scale=1.0 / math.sqrt(C * k)), dtype) for i, (k, s) in enumerate(specs)]
+        xr = x.clone().requires_grad_(True)
+        Wr = [w.clone().requires_grad_(True) for w in Ws]
+        h = xr.transpose(1, 2)
+        for (k, s), w in zip(specs, Wr):
+            h = TF.gelu(TF.conv1d(h, w, stride=s))
+        yr = h.transpose(1, 2)
+        dy = q(gen(*yr.shape, seed=5), dtype)
+        (yr * dy).sum().backward()
+        xd = x.to(dtype).to(DEV).requires_grad_(True)
+        Wd = [w.to(dtype).to(DEV).requires_grad_(True) for w in Ws]
+        yd = F.ConvStackFn.apply(xd, specs, *Wd)
+        yd.backward(dy.to(dtype).to(DEV))
+        tag = f"convstack[{dtype}]"
+        out.append((tag + " y", err(yd, yr), tol))
+        out.append((tag + " dx", err(xd.grad, xr.grad), tol * 2))
+        for i in range(len(specs)):
+            out.append((tag + f" dW{i}", err(Wd[i].grad, Wr[i].grad), tol * 2))
+    return out
+
+
+# -------------------------------------------------------------------------------------------------- attention
+def _ref_attention(qkv, gate, tab, kpm, H, scale):
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // H
+    qh = qkv[..., :D].view(B, T, H, hd).permute(0, 2, 1, 3)
+    kh = qkv[..., D:2 * D].view(B, T, H, hd).permute(0, 2, 1, 3)
+    vh = qkv[..., 2 * D:].view(B, T, H, hd).permute(0, 2, 1, 3)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if tab is not None:
+        i = torch.arange(T)[:, None]
+        j = torch.arange(T)[None, :]
+        rel = tab[:, (j - i) + T - 1]  # [H, T, T]
+        s = s + gate.unsqueeze(-1) * rel.unsqueeze(0)
+    if kpm is not None:
+        s = s.masked_fill(kpm.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, T, D)
+
+
+def check_attention():
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        for (B, T, H, hd, use_pad) in [(2, 49, 2, 32, False), (2, 131, 4, 64, True)]:
+            D = H * hd
+            qkv = q(gen(B, T, 3 * D, seed=1), dtype)
+            gate = 1 + 0.5 * gen(B, H, T, seed=2)
+            tab = 0.5 * gen(H, 2 * T - 1, seed=3)
+            kpm = None
+            if use_pad:
+                kpm = torch.zeros(B, T, dtype=torch.uint8)
+                kpm[1, T - 20:] = 1
+            dO = q(gen(B, T, D, seed=4), dtype)
+            qr, gr, tr = qkv.clone().double().requires_grad_(True), gate.clone().double().requires_grad_(True), tab.clone().double().requires_grad_(True)
+            Or = _ref_attention(qr, gr, tr, kpm, H, hd ** -0.5)
+            (Or * dO.double()).sum().backward()
+            qd = qkv.to(dtype).to(DEV).requires_grad_(True)
+            gd = gate.to(DEV).requires_grad_(True)
+            td = tab.to(DEV).requires_grad_(True)
+            kd = kpm.to(DEV) if kpm is not None else None
+            Od = F.AttnCoreFn.apply(qd, gd, td, kd, H, hd ** -0.5, 0.0, 0)
+            Od.backward(dO.to(dtype).to(DEV))
+            tag = f"attn[{dtype}] B={B} T={T} H={H} hd={hd} pad={use_pad}"
+            out.append((tag + " O", err(Od, Or), tol))
+            out.append((tag + " dqkv", err(qd.grad, qr.grad), tol * 2))
+            out.append((tag + " dgate", err(gd.grad, gr.grad), tol * 2))
+            out.append((tag + " dtab", err(td.grad, tr.grad), tol * 2))
+        # no-bias path
+        B, T, H, hd = 1, 40, 2, 32
+        qkv = q(gen(B, T, 3 * H * hd, seed=7), dtype)
+        Or = _ref_attention(qkv.double(), None, None, None, H, hd ** -0.5)
+        Od = F.AttnCoreFn.apply(qkv.to(dtype).to(DEV), None, None, None, H, hd ** -0.5, 0.0, 0)
+        out.append((f"attn[{dtype}] no bias O", err(Od, Or), tol))
+    # gate
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        B, T, H, hd = 2, 33, 3, 64
+        x = q(gen(B, T, H * hd, seed=1), dtype)
+        W, b = q(0.2 * gen(8, hd, seed=2), dtype), q(0.1 * gen(8, seed=3), dtype)
+        a = q(1 + 0.1 * gen(1, H, 1, 1, seed=4), dtype)
+        xr, Wr, br, ar = [t.clone().requires_grad_(True) for t in (x, W, b, a)]
+        ql = xr.view(B, T, H, hd).permute(0, 2, 1, 3)
+        ga, gb = torch.sigmoid(TF.linear(ql, Wr, br).view(B, H, T, 2, 4).sum(-1)).chunk(2, dim=-1)
+        gr = (ga * (gb * ar - 1.0) + 2.0).squeeze(-1)
+        dg = gen(B, H, T, seed=5)
+        (gr * dg).sum().backward()
+        xd, Wd, bd, ad = [t.to(dtype).to(DEV).requires_grad_(True) for t in (x, W, b, a)]
+        gdv = F.GateFn.apply(xd, Wd, bd, ad, H)
+        gdv.backward(dg.to(DEV))
+        tag = f"gate[{dtype}]"
+        out.append((tag + " gate", err(gdv, gr), tol))
+        out.append((tag + " dx", err(xd.grad, xr.grad), tol * 2))
+        out.append((tag + " dW", err(Wd.grad, Wr.grad), tol * 2))
+        out.append((tag + " dbias", err(bd.grad, br.grad), tol * 2))
+        out.append((tag + " dgrep_a", err(ad.grad, ar.grad), tol * 2))
+    # relpos table
+    emb = gen(32, 4, seed=1).requires_grad_(True)
+    bucket = torch.randint(0, 32, (97,), generator=torch.Generator().manual_seed(0)).to(torch.int32)
+    tr = emb[bucket.long()].t()
+    dt_ = gen(4, 97, seed=2)
+    (tr * dt_).sum().backward()
+    ed = emb.detach().to(DEV).requires_grad_(True)
+    td = F.RelPosTableFn.apply(ed, bucket.to(DEV))
+    td.backward(dt_.to(DEV))
+    out.append(("relpos table", err(td, tr), 1e-6))
+    out.append(("relpos table grad", err(ed.grad, emb.grad), 1e-5))
+    return out
+
+
+# ---------------------------------------------------------------------------------------- pos_conv / FFN / linear
+def check_posconv():
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        for (B, T, D, K, G) in [(2, 49, 64, 16, 4), (2, 75, 768, 128, 16)]:
+            Cg = D // G
+            x = q(gen(B, T, D, seed=1), dtype)
+            v = q(gen(D, Cg, K, seed=2, scale=math.sqrt(4.0 / (K * D))), dtype)
+            g = q(v.norm(dim=(0, 1), keepdim=True) * (1 + 0.1 * gen(1, 1, K, seed=3)), dtype)
+            bias = q(0.1 * gen(D, seed=4), dtype)
+            xr, vr, gr, br = [t.clone().requires_grad_(True) for t in (x, v, g, bias)]
+            w = gr * vr / vr.norm(dim=(0, 1), keepdim=True)
+            yc = TF.conv1d(xr.transpose(1, 2), w, br, padding=K // 2, groups=G)[:, :, :T]
+            yr = xr + TF.gelu(yc).transpose(1, 2)
+            dy = q(gen(B, T, D, seed=5), dtype)
+            (yr * dy).sum().backward()
+            xd, vd, gd, bd = [t.to(dtype).to(DEV).requires_grad_(True) for t in (x, v, g, bias)]
+            yd = F.PosConvFn.apply(xd, vd, gd, bd, G)
+            yd.backward(dy.to(dtype).to(DEV))
+            tag = f"posconv[{dtype}] D={D} K={K} G={G}"
+            out.append((tag + " y", err(yd, yr), tol))
+            out.append((tag + " dx", err(xd.grad, xr.grad), tol * 2))
+            out.append((tag + " dv", err(vd.grad, vr.grad), tol * 3))
+            out.append((tag + " dg", err(gd.grad, gr.grad), tol * 3))
+            out.append((tag + " dbias", err(bd.grad, br.grad), tol * 2))
+    return out
+
+
+def check_linear_ffn():
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        n, D, Fd = 300, 768, 3072
+        x = q(gen(2, n // 2, D, seed=1), dtype)
+        W1, b1 = q(0.03 * gen(Fd, D, seed=2), dtype), q(0.1 * gen(Fd, seed=3), dtype)
+        W2, b2 = q(0.03 * gen(D, Fd, seed=4), dtype), q(0.1 * gen(D, seed=5), dtype)
+        dy = q(gen(2, n // 2, D, seed=6), dtype)
+        xr, W1r, b1r, W2r, b2r = [t.clone().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+        yr = TF.linear(TF.gelu(TF.linear(xr, W1r, b1r)), W2r, b2r)
+        (yr * dy).sum().backward()
+        xd, W1d, b1d, W2d, b2d = [t.to(dtype).to(DEV).requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+        yd = F.FFNFn.apply(xd, W1d, b1d, W2d, b2d, 0.0, 0)
+        yd.backward(dy.to(dtype).to(DEV))
+        tag = f"ffn[{dtype}]"
+        for nm, a, b in [("y", yd, yr), ("dx", xd.grad, xr.grad), ("dW1", W1d.grad, W1r.grad), ("db1", b1d.grad, b1r.grad),
+                         ("dW2", W2d.grad, W2r.grad), ("db2", b2d.grad, b2r.grad)]:
+            out.append((f"{tag} {nm}", err(a, b), tol * (1 if nm == "y" else 2)))
+        xr2, Wr2, br2 = x.clone().requires_grad_(True), W1.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+        y2 = TF.linear(xr2, Wr2, br2)
+        dy2 = q(gen(*y2.shape, seed=7), dtype)
+        (y2 * dy2).sum().backward()
+        xd2, Wd2, bd2 = [t.to(dtype).to(DEV).requires_grad_(True) for t in (x, W1, b1)]
+        yd2 = F.LinearFn.apply(xd2, Wd2, bd2)
+        yd2.backward(dy2.to(dtype).to(DEV))
+        for nm, a, b in [("y", yd2, y2), ("dx", xd2.grad, xr2.grad), ("dW", Wd2.grad, Wr2.grad), ("db", bd2.grad, br2.grad)]:
+            out.append((f"linear[{dtype}] {nm}", err(a, b), tol * (1 if nm == "y" else 2)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------- loss
+def check_loss():
+    from oracle import wavlm_oracle as O
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        for (S, V, Fd) in [(57, 23, 32), (700, 504, 256)]:
+            proj = q(gen(S, Fd, seed=1), dtype)
+            emb = q(torch.rand(V, Fd, generator=torch.Generator().manual_seed(2)), dtype)
+            tgt = torch.randint(0, V, (S,), generator=torch.Generator().manual_seed(3))
+            pr, er = proj.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+            pos = er[tgt]
+            negs = er.unsqueeze(1).expand(-1, S, -1)
+            logits = O.compute_nce(pr, pos, negs, 0.1)
+            lossr = TF.cross_entropy(logits.float(), torch.zeros(S, dtype=torch.long), reduction="sum")
+            corr = ((logits.argmax(-1) == 0) & ~(logits.argmin(-1) == 0)).sum()
+            (lossr * 1.7).backward()
+            pd, ed = proj.to(dtype).to(DEV).requires_grad_(True), emb.to(dtype).to(DEV).requires_grad_(True)
+            loss, nc = F.MaskedPredLossFn.apply(pd, ed, tgt.to(torch.int32).to(DEV), 0.1, True)
+            (loss * 1.7).sum().backward()
+            tag = f"loss[{dtype}] S={S} V={V}"
+            out.append((tag + " loss", err(loss, lossr.reshape(1)), tol))
+            out.append((tag + " correct", abs(nc.item() - corr.item()), 0.0 if dtype == torch.float32 else max(2.0, 0.02 * S)))
+            out.append((tag + " dproj", err(pd.grad, pr.grad), tol * 3))
+            out.append((tag + " demb", err(ed.grad, er.grad), tol * 3))
+    f = gen(2, 49, 32, seed=1)
+    fr = f.clone().requires_grad_(True)
+    (fr.pow(2).mean() * 3.0).backward()
+    fd = f.to(DEV).requires_grad_(True)
+    pen = F.FeaturesPenFn.apply(fd)
+    (pen * 3.0).sum().backward()
+    out.append(("features_pen", err(pen, f.pow(2).mean().reshape(1)), 1e-5))
+    out.append(("features_pen grad", err(fd.grad, fr.grad), 1e-5))
+    return out
+
+
+def check_adam():
+    from oracle import wavlm_oracle as O
+    out = []
+    n = 10007
+    p, g = gen(n, seed=1), gen(n, seed=2, scale=0.1)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, md, vd = p.clone().to(DEV), m.clone().to(DEV), v.clone().to(DEV)
+    plow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    gd = g.to(torch.bfloat16).to(DEV)
+    gq = g.to(torch.bfloat16).float()
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    gn = ops.sumsq(gd)
+    mult, max_norm = 0.5, 1.0
+    total = gq.norm().item() * mult
+    clip = min(1.0, max_norm / (total + 1e-6))
+    for step in (1, 2, 3):
+        ops.adam_step(pd, md, vd, gd, plow, lr=5e-4, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.01, step=step,
+                      grad_mult=mult, gnorm_sq=gn, max_norm=max_norm)
+        pr, mr, vr = O.adam_reference_step(pr, gq * mult * clip, mr, vr, step, 5e-4, 0.9, 0.98, 1e-6, 0.01)
+    out.append(("adam p", err(pd, pr), 1e-5))
+    out.append(("adam m", err(md, mr), 1e-5))
+    out.append(("adam v", err(vd, vr), 1e-5))
+    out.append(("adam low-precision copy", err(plow, pr), 1e-2))
+    return out
+
+
+GROUPS = {
+    "gemm": check_gemm, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
+    "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv,
+    "linear_ffn": check_linear_ffn, "loss": check_loss, "adam": check_adam,
+}
+
+if __name__ == "__main__":
+    import json
+    name = sys.argv[1]
+    res = GROUPS[name]()
+    bad = 0
+    for (nm, e, t) in res:
+        ok = e <= t
+        bad += (not ok)
+        print(("ok   " if ok else "FAIL ") + f"{nm}: err={e:.3e} tol={t:.1e}")
+    print(json.dumps({"group": name, "n": len(res), "failed": bad}))
+    sys.exit(1 if bad else 0)

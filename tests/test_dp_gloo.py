@@ -1,0 +1,85 @@
+"""world_size-2 test of the bucketed gradient reducer on the gloo backend (CPU): gradients equal the sum over ranks,
+no_sync() accumulates locally, finish() also reduces buckets whose hooks never fired (unused parameters), and the
+reducer's scale turns the sum into LegacyDDP's average."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(seed):
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
+    unused = torch.nn.Parameter(torch.randn(40))
+    params = list(net.parameters()) + [unused]
+    offsets, off = [], 0
+    for p in params:
+        offsets.append(off)
+        off += (p.numel() + 7) // 8 * 8
+    flat = torch.zeros(off)
+    for p, o in zip(params, offsets):
+        p.grad = flat[o:o + p.numel()].view_as(p)
+    return net, params, offsets, flat
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unispeech_amd.dp import GradReducer
+    net, params, offsets, flat = _build(0)  # same weights on both ranks
+    red = GradReducer(params, flat, offsets, bucket_bytes=1024)  # several buckets
+    assert len(red.buckets) >= 2
+    x = torch.randn(4, 16, generator=torch.Generator().manual_seed(100 + rank))
+    # local reference gradients of both ranks, computed independently
+    refs = []
+    for r in range(world):
+        n2, p2, o2, f2 = _build(0)
+        xr = torch.randn(4, 16, generator=torch.Generator().manual_seed(100 + r))
+        n2(xr).pow(2).sum().backward()
+        refs.append(f2.clone())
+    # 1) plain step
+    net(x).pow(2).sum().backward()
+    red.finish()
+    ok1 = torch.allclose(flat, refs[0] + refs[1], atol=1e-6)
+    ok_avg = torch.allclose(flat * red.scale, (refs[0] + refs[1]) / world, atol=1e-6)
+    # 2) accumulation: first micro-batch under no_sync, second synced -> sum over ranks of 2x local grad
+    flat.zero_()
+    with red.no_sync():
+        net(x).pow(2).sum().backward()
+    local_only = torch.allclose(flat, refs[rank], atol=1e-6)
+    net(x).pow(2).sum().backward()
+    red.finish()
+    ok2 = torch.allclose(flat, 2 * (refs[0] + refs[1]), atol=1e-5)
+    q.put((rank, ok1, ok_avg, local_only, ok2))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r

@@ -1,0 +1,212 @@
+"""End-to-end parity on the GPU: the HIP path (through the C ABI) against (a) the committed reference-generated
+goldens and (b) the CPU oracle on seeded inputs, forward, loss and every parameter gradient.
+
+Tolerances: fp32 mode 1e-4 relative to the tensor scale for activations and loss (BASELINE.json north_star),
+5e-4 for gradients (long fp32 reductions in a different summation order); bf16 mode is compared with the fp32
+mode at 5e-2 (activations) -- bf16 has 8 mantissa bits, the bound is a sanity bound, not a parity claim.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Cfg, TINY, golden_state_dict, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL, GTOL = 1e-4, 5e-4
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def _tiny_model(dtype=torch.float32):
+    from unispeech_amd.wavlm import WavLM, WavLMConfig
+    z = load_golden("tiny_wavlm.npz")
+    m = WavLM(WavLMConfig(dict(TINY)))
+    m.load_state_dict(golden_state_dict(z))
+    return m.to("cuda").to(dtype).eval(), z
+
+
+def test_extract_features_vs_reference_golden():
+    model, z = _tiny_model()
+    wav = torch.from_numpy(z["in/source"]).cuda()
+    with torch.no_grad():
+        x, pm = model.extract_features(wav)
+        assert pm is None
+        assert rel_err(x, z["out/x"]) < RTOL
+        feat, _ = model.extract_features(wav, ret_conv=True)
+        assert rel_err(feat, z["out/features_ret_conv"]) < RTOL
+        (x1, lr), _ = model.extract_features(wav, output_layer=1, ret_layer_results=True)
+        assert rel_err(x1, z["out/x_layer1"]) < RTOL
+        assert len(lr) == int(z["out/nlayer_results_layer1"])
+        assert rel_err(lr[0][0], z["out/layer_results0"]) < RTOL
+        assert rel_err(lr[1][0], z["out/layer_results1"]) < RTOL
+        # padded batch
+        pmask = torch.from_numpy(z["in/padding_mask"])
+        wav_p = torch.from_numpy(z["in/source"]).clone()
+        wav_p[1, 12000:] = 0
+        xp, pmo = model.extract_features(wav_p.cuda(), padding_mask=pmask.cuda())
+        assert torch.equal(pmo.cpu(), torch.from_numpy(z["out/padding_mask_frames"]))
+        assert rel_err(xp, z["out/x_padded"]) < RTOL
+        # masked: same numpy seed -> bit-identical mask -> same activations
+        np.random.seed(123)
+        xm, _ = model.extract_features(wav, mask=True)
+        assert rel_err(xm, z["out/x_masked"]) < RTOL
+        # conv stack alone ([B, T', C] here, [B, C, T'] in the reference)
+        conv = model.feature_extractor(wav)
+        assert rel_err(conv.transpose(1, 2), z["out/conv_features"]) < RTOL
+
+
+def _tiny_pretrain(dtype=torch.float32):
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
+    z = load_golden("tiny_pretrain.npz")
+    cfg = WavLMPretrainConfig(**{k: v for k, v in TINY.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    m = WavLMPretrainModel(cfg, None, [range(23)])
+    m.load_state_dict(golden_state_dict(z))
+    m = m.to("cuda").to(dtype).train()
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0])
+    return m, crit, z
+
+
+def test_pretrain_loss_and_grads_vs_reference_golden():
+    model, crit, z = _tiny_pretrain()
+    sample = {"id": torch.arange(2),
+              "net_input": {"source": torch.from_numpy(z["in/source"]).cuda(),
+                            "padding_mask": torch.from_numpy(z["in/padding_mask"]).cuda()},
+              "target_list": [torch.from_numpy(z["in/target"]).cuda()]}
+    np.random.seed(123)
+    loss, sample_size, log = crit(model, sample)
+    assert sample_size == int(z["out/sample_size"])
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
+    for k in ("loss_m_0", "loss_u_0", "loss_features_pen"):
+        assert abs(log[k] - float(z["log/" + k])) < RTOL * abs(float(z["log/" + k])) + 1e-6, k
+    for k in ("correct_m_0", "count_m_0", "correct_u_0", "count_u_0"):
+        assert int(log[k]) == int(z["log/" + k]), k
+    loss.backward()
+    bad = []
+    for n, p in model.named_parameters():
+        ref = torch.from_numpy(z["grad/" + n])
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        scale = ref.abs().max().item()
+        e = (g.detach().cpu().double() - ref.double()).abs().max().item()
+        if not e <= GTOL * scale + 1e-8:
+            bad.append((n, e, scale))
+    assert not bad, "\n".join("%s: abs err %.3e, scale %.3e" % b for b in bad)
+    # reference-shaped logits on demand
+    np.random.seed(123)
+    with torch.no_grad():
+        net = model(target_list=sample["target_list"], **sample["net_input"])
+        lm = model.get_logits(net, True)[0].cpu()
+        lu = model.get_logits(net, False)[0].cpu()
+    gm, gu = torch.from_numpy(z["out/logit_m"]), torch.from_numpy(z["out/logit_u"])
+    for a, b in ((lm, gm), (lu, gu)):
+        fin = torch.isfinite(b)
+        assert torch.equal(torch.isfinite(a), fin)
+        assert rel_err(a[fin], b[fin]) < RTOL
+    assert rel_err(net["x"], z["out/x"]) < RTOL
+
+
+BASE = dict(TINY)
+BASE.update(encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, encoder_attention_heads=12,
+            conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2", conv_pos=128, conv_pos_groups=16,
+            num_buckets=320, max_distance=800, mask_length=10, mask_prob=0.8, final_dim=256)
+
+
+def _base_models(n_layers, V=504):
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
+    cfgd = dict(BASE)
+    cfgd["encoder_layers"] = n_layers
+    cfg = WavLMPretrainConfig(**{k: v for k, v in cfgd.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    torch.manual_seed(0)
+    m = WavLMPretrainModel(cfg, None, [range(V)])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m, sd, Cfg(**cfgd), WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0])
+
+
+@pytest.mark.parametrize("n_layers,seconds,padded", [(2, 3.0, False), (2, 3.0, True), (12, 15.0, False)])
+def test_base_width_vs_oracle(n_layers, seconds, padded):
+    """WavLM-Base dimensions (config 0 of BASELINE.json at 12 layers / 2x15 s) against the CPU oracle:
+    forward activations, loss, and all parameter gradients."""
+    from oracle import wavlm_oracle as O
+    from unispeech_amd.masking import compute_mask_indices
+    model, sd, cfg, crit = _base_models(n_layers)
+    B, T = 2, int(16000 * seconds)
+    g = torch.Generator().manual_seed(1234)
+    wav = torch.randn(B, T, generator=g)
+    pm = torch.zeros(B, T, dtype=torch.bool)
+    if padded:
+        pm[1, int(T * 0.7):] = True
+        wav[1, int(T * 0.7):] = 0
+    target = torch.randint(4, 504, (B, int(50 * seconds)), generator=g)
+    # ---- HIP path
+    model = model.cuda().train()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    model.encoder.dropout = 0.0
+    for layer in model.encoder.layers:
+        layer.dropout = 0.0
+        layer.activation_dropout = 0.0
+    sample = {"id": torch.arange(B), "net_input": {"source": wav.cuda(), "padding_mask": pm.cuda()},
+              "target_list": [target.cuda()]}
+    np.random.seed(123)
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    # ---- oracle with the identical mask (same numpy seed -> same draws)
+    sdp = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    np.random.seed(123)
+    Tp = T
+    for _, k, s in eval(cfg.conv_feature_layers):
+        Tp = (Tp - k) // s + 1
+    Tp = min(Tp, target.shape[1])  # label rate 50 Hz == frame rate: forward_targets trims to the label length
+    pmf = O.forward_padding_mask(Tp, pm)
+    m = compute_mask_indices((B, Tp), pmf, cfg.mask_prob, cfg.mask_length, cfg.mask_selection, cfg.mask_other,
+                             min_masks=2, no_overlap=False, min_space=1)
+    net = O.pretrain_forward(sdp, cfg, wav, [target], pm, torch.from_numpy(m), [504])
+    oloss, oss, olog = O.criterion(net, 1.0, 0.0, [10.0])
+    oloss.backward()
+    assert sample_size == oss
+    assert abs(loss.item() - oloss.item()) < RTOL * abs(oloss.item())
+    assert int(log["correct_m_0"]) == olog["correct_m_0"] and int(log["count_u_0"]) == olog["count_u_0"]
+    worst = ("", 0.0)
+    bad = []
+    # absolute floor for analytically-zero gradients (k_proj.bias: softmax is invariant to a key bias)
+    gmax = max(v.grad.abs().max().item() for v in sdp.values() if v.grad is not None)
+    for n, p in model.named_parameters():
+        ref = sdp[n].grad if sdp[n].grad is not None else torch.zeros_like(sdp[n])
+        if n.startswith("feature_extractor."):
+            ref = ref * cfg.feature_grad_mult
+        scale = ref.abs().max().item()
+        e = (p.grad.detach().cpu().double() - ref.double()).abs().max().item()
+        rel = e / (scale + 1e-30)
+        if e > 1e-6 * gmax and rel > worst[1]:
+            worst = (n, rel)
+        if not e <= GTOL * scale + 1e-6 * gmax:
+            bad.append((n, e, scale))
+    print("worst gradient rel err:", worst)
+    assert not bad, "\n".join("%s: abs err %.3e, scale %.3e" % b for b in bad)
+    # features-only API against the oracle as well
+    model.eval()
+    with torch.no_grad():
+        x, _ = model.extract_features(wav.cuda(), padding_mask=pm.cuda() if padded else None)
+        r = O.extract_features(sd, cfg, wav, padding_mask=pm if padded else None)
+    assert rel_err(x, r["x"]) < RTOL
+
+
+def test_bf16_mode_tracks_fp32_mode():
+    model, sd, cfg, crit = _base_models(2)
+    B, T = 2, 32000
+    g = torch.Generator().manual_seed(1)
+    wav = torch.randn(B, T, generator=g).cuda()
+    model = model.cuda().eval()
+    with torch.no_grad():
+        x32, _ = model.extract_features(wav)
+        m16 = model.to(torch.bfloat16)
+        x16, _ = m16.extract_features(wav.to(torch.bfloat16))
+    assert x16.dtype == torch.bfloat16
+    assert rel_err(x16.float(), x32) < 5e-2

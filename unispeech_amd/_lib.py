@@ -86,7 +86,9 @@ SIGNATURES = {
     "wavlm_sum_workspace_bytes": (c_u64, []),
     "wavlm_sum_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_u64, c_vp]),
     "wavlm_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
-                                c_i64, c_f32, c_vp, c_f32, c_vp]),
+                                c_i64, c_f32, c_vp, c_vp, c_f32, c_vp]),
+    "wavlm_prof_enable": (None, [c_i32]),
+    "wavlm_prof_collect": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _ERR = {-1: "invalid argument", -2: "kernel launch failure", -3: "out of memory"}

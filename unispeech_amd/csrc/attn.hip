@@ -13,10 +13,35 @@
 #include "common.hpp"
 #include "../../include/wavlm_hip.h"
 
-#define SM_MAXJ 16  // row length up to 1024 keys (T' = 749 @15 s, 999 @20 s)
+#define SM_NCH 4  // chunks of 256 keys: row length up to 1024 (T' = 749 @15 s, 999 @20 s)
 #define SM_ROWS_PER_BLOCK 64
 
-__device__ __forceinline__ float ld_s(const void* S, long i, int dt) { return ld_elem(S, i, dt); }
+// lane l of chunk c owns the 4 consecutive keys j = 256*c + 4*l .. +3: 16-byte score loads, 8/16-byte probability
+// stores, and ONE Philox4x32 call per lane per chunk for the dropout mask (counter = row * 256 + j / 4).
+__device__ __forceinline__ void sm_load4(const void* p, long off, int dt, float (&v)[4]) {
+  if (dt == WL_F32) {
+    const float4 a = *reinterpret_cast<const float4*>((const float*)p + off);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  } else {
+    const uint2 a = *reinterpret_cast<const uint2*>((const bf16_t*)p + off);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void sm_store4(void* p, long off, int dt, const float (&v)[4]) {
+  if (dt == WL_F32) {
+    *reinterpret_cast<float4*>((float*)p + off) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    uint2 o;
+    o.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>((bf16_t*)p + off) = o;
+  }
+}
+__device__ __forceinline__ void sm_keep4(unsigned long long seed, long row, int j, unsigned th, bool (&k)[4]) {
+  const Philox4 r = philox4x32_10(seed, (unsigned long long)row * 256ull + (unsigned)(j >> 2));
+  k[0] = r.x >= th; k[1] = r.y >= th; k[2] = r.z >= th; k[3] = r.w >= th;
+}
 
 __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(const void* __restrict__ S, void* __restrict__ P,
     float* __restrict__ lse, const float* __restrict__ gate, const float* __restrict__ tab,
@@ -31,37 +56,51 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(const void* __res
     const int h = (int)(bh % H), b = (int)(bh / H);
     const float g = gate ? gate[row] : 0.f;
     const float* trow = tab ? tab + (long)h * L + (T - 1 - i) : nullptr;
-    float v[SM_MAXJ];
+    float v[SM_NCH][4];
     float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < SM_MAXJ; ++c) {
-      const int j = lane + 64 * c;
-      float x = -INFINITY;
-      if (j < T) {
-        x = ld_s(S, row * ldS + j, s_dt);
-        if (trow) x += g * trow[j];
-        if (kpm && kpm[(long)b * T + j]) x = -INFINITY;
+    for (int c = 0; c < SM_NCH; ++c) {
+      const int j0 = 256 * c + 4 * lane;
+      if (j0 < ldS) sm_load4(S, row * ldS + j0, s_dt, v[c]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j0 + e;
+        float x = -INFINITY;
+        if (j < T) {
+          x = v[c][e];
+          if (trow) x += g * trow[j];
+          if (kpm && kpm[(long)b * T + j]) x = -INFINITY;
+        }
+        v[c][e] = x;
+        mx = fmaxf(mx, x);
       }
-      v[c] = x;
-      mx = fmaxf(mx, x);
     }
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < SM_MAXJ; ++c) {
-      const float e = (v[c] == -INFINITY) ? 0.f : __expf(v[c] - mx);
-      v[c] = e; sum += e;
-    }
+    for (int c = 0; c < SM_NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ex = (v[c][e] == -INFINITY) ? 0.f : __expf(v[c][e] - mx);
+        v[c][e] = ex; sum += ex;
+      }
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     if (lane == 0) lse[row] = mx + __logf(sum);
 #pragma unroll
-    for (int c = 0; c < SM_MAXJ; ++c) {
-      const int j = lane + 64 * c;
-      if (j < ldP) {
-        float pj = (j < T) ? v[c] * inv : 0.f;
-        if (th && j < T) pj = dropout_keep(seed, (unsigned long long)(row * T + j), th) ? pj * sc : 0.f;
-        st_elem(P, row * ldP + j, p_dt, pj);
+    for (int c = 0; c < SM_NCH; ++c) {
+      const int j0 = 256 * c + 4 * lane;
+      if (j0 < ldP) {
+        float o[4];
+        bool keep[4] = {true, true, true, true};
+        if (th) sm_keep4(seed, row, j0, th, keep);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pj = v[c][e] * inv;  // exactly 0 for j >= T and for padded keys
+          if (th) pj = keep[e] ? pj * sc : 0.f;
+          o[e] = pj;
+        }
+        sm_store4(P, row * ldP + j0, p_dt, o);
       }
     }
   }
@@ -90,35 +129,50 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const void* __res
     const float g = gate ? gate[row] : 0.f;
     const float* trow = tab ? tab + (long)h * L + (T - 1 - i) : nullptr;
     const float l = lse[row];
-    float p[SM_MAXJ], dp[SM_MAXJ];
+    float p[SM_NCH][4], dp[SM_NCH][4];
     float delta = 0.f;
 #pragma unroll
-    for (int c = 0; c < SM_MAXJ; ++c) {
-      const int j = lane + 64 * c;
-      float pj = 0.f, dpj = 0.f;
-      if (j < T) {
-        float x = ld_s(S, row * ldS + j, s_dt);
-        if (trow) x += g * trow[j];
-        const bool masked = kpm && kpm[(long)b * T + j];
-        pj = masked ? 0.f : __expf(x - l);
-        dpj = ld_elem(dP, row * ldP + j, p_dt);
-        if (th) dpj = dropout_keep(seed, (unsigned long long)(row * T + j), th) ? dpj * sc : 0.f;
+    for (int c = 0; c < SM_NCH; ++c) {
+      const int j0 = 256 * c + 4 * lane;
+      float sv[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+      bool keep[4] = {true, true, true, true};
+      if (j0 < ldS) sm_load4(S, row * ldS + j0, s_dt, sv);
+      if (j0 < ldP) sm_load4(dP, row * ldP + j0, p_dt, dv);
+      if (th && j0 < T) sm_keep4(seed, row, j0, th, keep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j0 + e;
+        float pj = 0.f, dpj = 0.f;
+        if (j < T) {
+          float x = sv[e];
+          if (trow) x += g * trow[j];
+          const bool masked = kpm && kpm[(long)b * T + j];
+          pj = masked ? 0.f : __expf(x - l);
+          dpj = dv[e];
+          if (th) dpj = keep[e] ? dpj * sc : 0.f;
+        }
+        p[c][e] = pj; dp[c][e] = dpj;
+        delta += pj * dpj;
       }
-      p[c] = pj; dp[c] = dpj;
-      delta += pj * dpj;
     }
     delta = wave_sum(delta);
     float dg = 0.f;
 #pragma unroll
-    for (int c = 0; c < SM_MAXJ; ++c) {
-      const int j = lane + 64 * c;
-      if (j < ldP) {
-        const float ds = (j < T) ? p[c] * (dp[c] - delta) : 0.f;
-        st_elem(dS, row * ldP + j, p_dt, ds);
-        if (trow && j < T) {
-          dg += ds * trow[j];
-          atomicAdd(&diag[j - i + T - 1], g * ds);  // LDS float add: distinct d within a row, waves may collide
+    for (int c = 0; c < SM_NCH; ++c) {
+      const int j0 = 256 * c + 4 * lane;
+      if (j0 < ldP) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = j0 + e;
+          const float ds = p[c][e] * (dp[c][e] - delta);  // 0 for j >= T (p == 0)
+          o[e] = ds;
+          if (trow && j < T) {
+            dg += ds * trow[j];
+            atomicAdd(&diag[j - i + T - 1], g * ds);  // LDS float add; waves (different rows) may collide
+          }
         }
+        sm_store4(dS, row * ldP + j0, p_dt, o);
       }
     }
     if (dgate) {
@@ -259,7 +313,7 @@ extern "C" {
 int wavlm_attn_softmax_fwd(const void* S, void* P, float* lse, const float* gate, const float* tab, const uint8_t* kpm,
                            int32_t B, int32_t H, int32_t T, int64_t ldS, int64_t ldP, int32_t s_dtype, int32_t p_dtype,
                            float p_drop, uint64_t seed, void* stream) {
-  if (!S || !P || !lse || B <= 0 || H <= 0 || T <= 0 || T > 64 * SM_MAXJ || ldP > 64 * SM_MAXJ || ldS < T || ldP < T)
+  if (!S || !P || !lse || B <= 0 || H <= 0 || T <= 0 || T > 256 * SM_NCH || ldP > 256 * SM_NCH || (ldS & 3) || (ldP & 3) || ldS < T || ldP < T)
     return WL_EINVAL;
   if ((gate == nullptr) != (tab == nullptr)) return WL_EINVAL;
   double tt = (double)p_drop * 4294967296.0; if (tt > 4294967295.0) tt = 4294967295.0;
@@ -267,7 +321,7 @@ int wavlm_attn_softmax_fwd(const void* S, void* P, float* lse, const float* gate
   const float sc = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const long nrows = (long)B * H * T;
   long grid = (nrows + 3) / 4; if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, S, P, lse, gate,
+  WL_LAUNCH(attn_softmax_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, S, P, lse, gate,
                      tab, kpm, (int)B, (int)H, (int)T, (long)ldS, (long)ldP, (int)s_dtype, (int)p_dtype, th, sc,
                      (unsigned long long)seed);
   return wl_check_launch();
@@ -282,7 +336,7 @@ int wavlm_attn_softmax_bwd(const void* S, const void* dP, const float* lse, cons
                            const uint8_t* kpm, void* dS, float* dgate, float* dtab, int32_t dtab_accumulate, int32_t B,
                            int32_t H, int32_t T, int64_t ldS, int64_t ldP, int32_t s_dtype, int32_t p_dtype,
                            float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes, void* stream) {
-  if (!S || !dP || !lse || !dS || B <= 0 || H <= 0 || T <= 0 || T > 64 * SM_MAXJ || ldP > 64 * SM_MAXJ || ldS < T ||
+  if (!S || !dP || !lse || !dS || B <= 0 || H <= 0 || T <= 0 || T > 256 * SM_NCH || ldP > 256 * SM_NCH || (ldS & 3) || (ldP & 3) || ldS < T ||
       ldP < T)
     return WL_EINVAL;
   if ((gate == nullptr) != (tab == nullptr)) return WL_EINVAL;
@@ -294,13 +348,13 @@ int wavlm_attn_softmax_bwd(const void* S, const void* dP, const float* lse, cons
   hipStream_t st = (hipStream_t)stream;
   const int nchunk = (T + SM_ROWS_PER_BLOCK - 1) / SM_ROWS_PER_BLOCK;
   const int L = 2 * T - 1;
-  hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * H)), dim3(256),
+  WL_LAUNCH(attn_softmax_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * H)), dim3(256),
                      tab ? (size_t)L * sizeof(float) : 0, st, S, dP, lse, gate, tab, kpm, dS, dgate, (float*)workspace,
                      (int)B, (int)H, (int)T, (long)ldS, (long)ldP, (int)s_dtype, (int)p_dtype, th, sc,
                      (unsigned long long)seed);
   int rc = wl_check_launch();
   if (rc != WL_OK || !tab) return rc;
-  hipLaunchKernelGGL(attn_dtab_reduce_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)H), dim3(256), 0, st,
+  WL_LAUNCH(attn_dtab_reduce_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)H), dim3(256), 0, st,
                      (const float*)workspace, dtab, (int)B, (int)H, nchunk, L, (int)dtab_accumulate);
   return wl_check_launch();
 }
@@ -308,7 +362,7 @@ int wavlm_attn_softmax_bwd(const void* S, const void* dP, const float* lse, cons
 int wavlm_relpos_gather(const void* emb, int32_t emb_dtype, const int32_t* bucket, float* tab, int32_t H, int32_t L,
                         void* stream) {
   if (!emb || !bucket || !tab || H <= 0 || L <= 0) return WL_EINVAL;
-  hipLaunchKernelGGL(relpos_gather_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)H), dim3(256), 0,
+  WL_LAUNCH(relpos_gather_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)H), dim3(256), 0,
                      (hipStream_t)stream, emb, (int)emb_dtype, bucket, tab, (int)H, (int)L);
   return wl_check_launch();
 }
@@ -316,7 +370,7 @@ int wavlm_relpos_gather(const void* emb, int32_t emb_dtype, const int32_t* bucke
 int wavlm_relpos_scatter(const float* dtab, const int32_t* bucket, void* demb, int32_t emb_dtype, int32_t H, int32_t L,
                          int32_t num_buckets, void* stream) {
   if (!dtab || !bucket || !demb || H <= 0 || L <= 0 || num_buckets <= 0) return WL_EINVAL;
-  hipLaunchKernelGGL(relpos_scatter_kernel, dim3((unsigned)num_buckets, (unsigned)H), dim3(64), 0, (hipStream_t)stream,
+  WL_LAUNCH(relpos_scatter_kernel, dim3((unsigned)num_buckets, (unsigned)H), dim3(64), 0, (hipStream_t)stream,
                      dtab, bucket, demb, (int)emb_dtype, (int)H, (int)L, (int)num_buckets);
   return wl_check_launch();
 }
@@ -326,7 +380,7 @@ int wavlm_gate_fwd(const void* x, const void* W, const void* bias, const void* g
   if (!x || !W || !bias || !grep_a || !gate || !ga || !gb || B <= 0 || T <= 0 || H <= 0 || hd <= 0) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   long grid = ((long)B * T + 3) / 4; if (grid > 8192) grid = 8192;
-#define GF(TT, TP) hipLaunchKernelGGL((gate_fwd_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), 0, st, (const TT*)x, \
+#define GF(TT, TP) WL_LAUNCH((gate_fwd_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), 0, st, (const TT*)x, \
     (const TP*)W, (const TP*)bias, (const TP*)grep_a, gate, ga, gb, (int)B, (int)T, (int)H, (int)hd)
   if (dtype == WL_F32 && param_dtype == WL_F32) GF(float, float);
   else if (dtype == WL_BF16 && param_dtype == WL_BF16) GF(bf16_t, bf16_t);
@@ -348,7 +402,7 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
   hipStream_t st = (hipStream_t)stream;
   long grid = ((long)B * T + 3) / 4; if (grid > GATE_BLOCKS) grid = GATE_BLOCKS;
   const size_t smem = 4 * (2 * (size_t)hd + 2 + H) * sizeof(float);
-#define GB(TT, TP) hipLaunchKernelGGL((gate_bwd_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), smem, st, dgate, \
+#define GB(TT, TP) WL_LAUNCH((gate_bwd_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), smem, st, dgate, \
     (const TT*)x, (const TP*)W, (const TP*)grep_a, ga, gb, (TT*)dx, (float*)workspace, (int)B, (int)T, (int)H, (int)hd)
   if (dtype == WL_F32 && param_dtype == WL_F32) GB(float, float);
   else if (dtype == WL_BF16 && param_dtype == WL_BF16) GB(bf16_t, bf16_t);
@@ -357,7 +411,7 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
 #undef GB
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  hipLaunchKernelGGL(gate_bwd_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)grid, (int)H,
+  WL_LAUNCH(gate_bwd_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)grid, (int)H,
                      (int)hd, dW, dbias, dgrep_a, (int)param_dtype);
   return wl_check_launch();
 }

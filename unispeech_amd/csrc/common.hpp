@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #define WL_OK 0
 #define WL_EINVAL (-1)
@@ -96,7 +97,22 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned l
   return v >= thresh;
 }
 
+// Launch-status bookkeeping.  hipGetLastError() is per-thread *sticky state shared with every other HIP user in the
+// process* (torch's allocator leaves e.g. hipErrorNotReady behind after an event query), so each launch first
+// clears it, launches, and records only its own status; an entry point reports the union of its launches.
+static thread_local int wl_launch_failed = 0;
+#define WL_LAUNCH(...)                                            \
+  do {                                                            \
+    (void)hipGetLastError();                                      \
+    hipLaunchKernelGGL(__VA_ARGS__);                              \
+    const hipError_t wl_e_ = hipGetLastError();                   \
+    if (wl_e_ != hipSuccess) {                                    \
+      wl_launch_failed = 1;                                       \
+      fprintf(stderr, "[wavlm_hip] kernel launch failed: %s (%s:%d)\n", hipGetErrorString(wl_e_), __FILE__, __LINE__); \
+    }                                                             \
+  } while (0)
 static inline int wl_check_launch() {
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? WL_OK : WL_ELAUNCH;
+  const int e = wl_launch_failed;
+  wl_launch_failed = 0;
+  return e ? WL_ELAUNCH : WL_OK;
 }

@@ -207,22 +207,32 @@ __global__ __launch_bounds__(256) void conv0_bwd_stats_kernel(const TW* __restri
                                      red[(2 * 2 + which) * 512 + c] + red[(3 * 2 + which) * 512 + c];
   }
 }
-// ab[b][c] = (A, Bq) per batch row; dgamma[c] = sum_b Bq, dbeta[c] = sum_b A
+// ab[b][c] = (A, Bq) per batch row: block = 64 channels x 4 chunk slices of one batch row
 __global__ __launch_bounds__(256) void conv0_bwd_stats_finish_kernel(const float* __restrict__ part,
-    float* __restrict__ ab, void* dgamma, void* dbeta, int pdt, int B, int nchunk, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double ta = 0.0, tb = 0.0;
-  for (int b = 0; b < B; ++b) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
+    float* __restrict__ ab, int nchunk, int C) {
+  __shared__ double red[4][2][64];
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + col, b = blockIdx.y;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int k = slice; k < nchunk; k += 4) {
       const float* p = part + ((long)b * nchunk + k) * 2 * C;
       s1 += p[c]; s2 += p[C + c];
     }
-    ab[((long)b * C + c) * 2] = (float)s1;
-    ab[((long)b * C + c) * 2 + 1] = (float)s2;
-    ta += s1; tb += s2;
+  red[slice][0][col] = s1; red[slice][1][col] = s2;
+  __syncthreads();
+  if (slice == 0 && c < C) {
+    ab[((long)b * C + c) * 2] = (float)(red[0][0][col] + red[1][0][col] + red[2][0][col] + red[3][0][col]);
+    ab[((long)b * C + c) * 2 + 1] = (float)(red[0][1][col] + red[1][1][col] + red[2][1][col] + red[3][1][col]);
   }
+}
+// dgamma[c] = sum_b Bq[b][c], dbeta[c] = sum_b A[b][c]
+__global__ __launch_bounds__(256) void conv0_bwd_affine_kernel(const float* __restrict__ ab, void* dgamma, void* dbeta,
+                                                               int pdt, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double ta = 0.0, tb = 0.0;
+  for (int b = 0; b < B; ++b) { ta += ab[((long)b * C + c) * 2]; tb += ab[((long)b * C + c) * 2 + 1]; }
   st_elem(dbeta, c, pdt, (float)ta);
   st_elem(dgamma, c, pdt, (float)tb);
 }
@@ -287,11 +297,15 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(const TW* __restrict__
 }
 __global__ __launch_bounds__(256) void conv0_bwd_w_finish_kernel(const float* __restrict__ part, int nblk, int n,
                                                                  void* dW, int pdt) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  __shared__ double red[4][64];
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += part[(long)b * n + i];
-  st_elem(dW, i, pdt, (float)s);
+  if (i < n)
+    for (int b = slice; b < nblk; b += 4) s += part[(long)b * n + i];
+  red[slice][col] = s;
+  __syncthreads();
+  if (slice == 0 && i < n) st_elem(dW, i, pdt, (float)(red[0][col] + red[1][col] + red[2][col] + red[3][col]));
 }
 
 static inline size_t seg_floats(int tch, int stride) { return (size_t)(((tch - 1) * stride + C0_KW + 3) / 4 * 4); }
@@ -319,9 +333,9 @@ int wavlm_conv0_gn_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
   const size_t sm_stats = (seg_floats(C0_TCH, stride) + 4 * 2 * 512) * sizeof(float);
   const size_t sm_apply = seg_floats(C0_TCH, stride) * sizeof(float);
   float* part = (float*)workspace;
-#define ST(TW, TP) hipLaunchKernelGGL((conv0_stats_kernel<TW, TP>), grid, dim3(256), sm_stats, st, (const TW*)wav, \
+#define ST(TW, TP) WL_LAUNCH((conv0_stats_kernel<TW, TP>), grid, dim3(256), sm_stats, st, (const TW*)wav, \
     (const TP*)W, part, (long)T, T0, (int)C, (int)stride)
-#define AP(TW, TP, TO) hipLaunchKernelGGL((conv0_apply_kernel<TW, TP, TO>), grid, dim3(256), sm_apply, st, (const TW*)wav, \
+#define AP(TW, TP, TO) WL_LAUNCH((conv0_apply_kernel<TW, TP, TO>), grid, dim3(256), sm_apply, st, (const TW*)wav, \
     (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (TO*)out, (long)T, T0, (int)C, (int)stride)
   const int key = wav_dtype * 100 + param_dtype * 10 + out_dtype;
   if (key == 0) ST(float, float);
@@ -331,7 +345,7 @@ int wavlm_conv0_gn_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
   else return WL_EINVAL;
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  hipLaunchKernelGGL(conv0_stats_finish_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, st, part,
+  WL_LAUNCH(conv0_stats_finish_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, st, part,
                      stats, nchunk, (int)C, T0, eps);
   if (key == 0) AP(float, float, float);
   else if (key == 111) AP(bf16_t, bf16_t, bf16_t);
@@ -366,9 +380,9 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   float* ab = part2 + (long)B * nchunk * C * C0_KW;
   const size_t sm1 = (seg_floats(C0_TCH_BWD, stride) + 4 * 2 * 512) * sizeof(float);
   const size_t sm2 = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float);
-#define B1(TW, TP, TO) hipLaunchKernelGGL((conv0_bwd_stats_kernel<TW, TP, TO>), grid, dim3(256), sm1, st, (const TW*)wav, \
+#define B1(TW, TP, TO) WL_LAUNCH((conv0_bwd_stats_kernel<TW, TP, TO>), grid, dim3(256), sm1, st, (const TW*)wav, \
     (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (const TO*)g, part1, (long)T, T0, (int)C, (int)stride, gscale)
-#define B2(TW, TP, TO) hipLaunchKernelGGL((conv0_bwd_w_kernel<TW, TP, TO>), grid, dim3(256), sm2, st, (const TW*)wav, \
+#define B2(TW, TP, TO) WL_LAUNCH((conv0_bwd_w_kernel<TW, TP, TO>), grid, dim3(256), sm2, st, (const TW*)wav, \
     (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, ab, (const TO*)g, part2, (long)T, T0, (int)C, (int)stride, gscale)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
   if (key == 0) B1(float, float, float);
@@ -378,8 +392,10 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   else return WL_EINVAL;
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  hipLaunchKernelGGL(conv0_bwd_stats_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part1, ab,
-                     dgamma, dbeta, (int)param_dtype, (int)B, nchunk, (int)C);
+  WL_LAUNCH(conv0_bwd_stats_finish_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0, st, part1, ab,
+            nchunk, (int)C);
+  WL_LAUNCH(conv0_bwd_affine_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, ab, dgamma, dbeta,
+            (int)param_dtype, (int)B, (int)C);
   if (key == 0) B2(float, float, float);
   else if (key == 111) B2(bf16_t, bf16_t, bf16_t);
   else if (key == 11) B2(float, bf16_t, bf16_t);
@@ -389,7 +405,7 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   const int n = C * C0_KW;
-  hipLaunchKernelGGL(conv0_bwd_w_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part2, B * nchunk, n,
+  WL_LAUNCH(conv0_bwd_w_finish_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part2, B * nchunk, n,
                      dW, (int)param_dtype);
   return wl_check_launch();
 }

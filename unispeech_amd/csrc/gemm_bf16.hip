@@ -241,7 +241,7 @@ static int launch_cfg(GemmP& p, int nbatch, hipStream_t st) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)nbatch, (unsigned)p.split_k);
-  hipLaunchKernelGGL((gemm_bf16_kernel<TA, TB, BM, BN, WM, WN>), grid, dim3(256), 0, st, p);
+  WL_LAUNCH((gemm_bf16_kernel<TA, TB, BM, BN, WM, WN>), grid, dim3(256), 0, st, p);
   return wl_check_launch();
 }
 
@@ -255,6 +255,54 @@ int gemm_f32_launch(const wavlm_gemm_desc* d, hipStream_t st);  // gemm_f32.hip
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// ---- optional per-launch timing (bench.py roofline leg): HIP events recorded on the launch stream around every
+// wavlm_gemm call while enabled.  Single-threaded use only (one stream, one host thread).
+#define PROF_MAX 16384
+static struct {
+  int enabled, n;
+  hipEvent_t ev0[PROF_MAX], ev1[PROF_MAX];
+  double flops[PROF_MAX];
+  int dtype[PROF_MAX];
+  int created;
+} g_prof;
+
+static int prof_begin(const wavlm_gemm_desc* d, hipStream_t st) {
+  if (!g_prof.enabled || g_prof.n >= PROF_MAX) return -1;
+  const int i = g_prof.n;
+  if (i >= g_prof.created) {
+    if (hipEventCreate(&g_prof.ev0[i]) != hipSuccess || hipEventCreate(&g_prof.ev1[i]) != hipSuccess) return -1;
+    g_prof.created = i + 1;
+  }
+  const double nb = (double)(d->batch_o < 1 ? 1 : d->batch_o) * (d->batch_i < 1 ? 1 : d->batch_i);
+  g_prof.flops[i] = 2.0 * d->M * d->N * (double)d->K * (d->KB < 1 ? 1 : d->KB) * nb;
+  g_prof.dtype[i] = d->dtype;
+  hipEventRecord(g_prof.ev0[i], st);
+  return i;
+}
+static void prof_end(int i, hipStream_t st) {
+  if (i < 0) return;
+  hipEventRecord(g_prof.ev1[i], st);
+  g_prof.n = i + 1;
+}
+
+extern "C" void wavlm_prof_enable(int on) { g_prof.enabled = on; if (on) g_prof.n = 0; }
+// Sums over the launches recorded since wavlm_prof_enable(1) with element type `dtype` (-1: all).
+// Blocks until those launches have finished.  Returns the number of launches.
+extern "C" int wavlm_prof_collect(int dtype, double* total_ms, double* total_flops) {
+  double ms = 0.0, fl = 0.0;
+  int cnt = 0;
+  for (int i = 0; i < g_prof.n; ++i) {
+    if (dtype >= 0 && g_prof.dtype[i] != dtype) continue;
+    if (hipEventSynchronize(g_prof.ev1[i]) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev0[i], g_prof.ev1[i]) != hipSuccess) continue;
+    ms += t; fl += g_prof.flops[i]; ++cnt;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  return cnt;
+}
+
 extern "C" uint64_t wavlm_gemm_workspace_bytes(const wavlm_gemm_desc* d) {
   if (!d || d->split_k <= 1) return 0;
   const uint64_t nb = (uint64_t)(d->batch_o < 1 ? 1 : d->batch_o) * (d->batch_i < 1 ? 1 : d->batch_i);
@@ -267,7 +315,12 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   if (d->epi == 2 && !d->aux) return WL_EINVAL;
   if (d->split_k > 1 && (!d->workspace || d->ws_bytes < wavlm_gemm_workspace_bytes(d))) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == WL_F32) return gemm_f32_launch(d, st);
+  if (d->dtype == WL_F32) {
+    const int pi = prof_begin(d, st);
+    const int r = gemm_f32_launch(d, st);
+    prof_end(pi, st);
+    return r;
+  }
   if (d->dtype != WL_BF16) return WL_EINVAL;
   // 16-byte vector loads: base pointers and every stride must be multiples of 8 elements
   if (!aligned16(d->A) || !aligned16(d->B)) return WL_EINVAL;
@@ -275,17 +328,18 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   for (int64_t s : strides) if (s % 8 != 0) return WL_EINVAL;
   GemmP p = make_gemm_params(d);
   const int nbatch = (d->batch_o < 1 ? 1 : d->batch_o) * p.batch_i;
+  const int pi = prof_begin(d, st);
   int rc;
   if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, st);
   else if (!d->transA && d->transB) rc = launch_t<false, true>(p, nbatch, st);
   else if (d->transA && !d->transB) rc = launch_t<true, false>(p, nbatch, st);
   else rc = launch_t<true, true>(p, nbatch, st);
-  if (rc != WL_OK) return rc;
-  if (p.split_k > 1) {
+  if (rc == WL_OK && p.split_k > 1) {
     const long total = (long)p.M * p.N * nbatch;
     long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, nbatch);
+    WL_LAUNCH(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, nbatch);
     rc = wl_check_launch();
   }
+  prof_end(pi, st);
   return rc;
 }

@@ -93,13 +93,13 @@ int gemm_f32_launch(const wavlm_gemm_desc* d, hipStream_t st) {
   p.tiles_m = (p.M + F32_BM - 1) / F32_BM;
   p.tiles_n = (p.N + F32_BN - 1) / F32_BN;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)nbatch, (unsigned)p.split_k);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, p, d->transA ? 1 : 0, d->transB ? 1 : 0);
+  WL_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, st, p, d->transA ? 1 : 0, d->transB ? 1 : 0);
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   if (p.split_k > 1) {
     const long total = (long)p.M * p.N * nbatch;
     long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gemm_f32_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, nbatch);
+    WL_LAUNCH(gemm_f32_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, nbatch);
     rc = wl_check_launch();
   }
   return rc;

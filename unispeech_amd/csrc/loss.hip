@@ -94,7 +94,7 @@ int wavlm_l2norm_fwd(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, f
   if (rows == 0) return WL_OK;
   hipStream_t st = (hipStream_t)stream;
   long grid = (rows + 3) / 4; if (grid > 8192) grid = 8192;
-#define L2F(TI, TO) hipLaunchKernelGGL((l2norm_fwd_kernel<TI, TO>), dim3((unsigned)grid), dim3(256), 0, st, (const TI*)x, \
+#define L2F(TI, TO) WL_LAUNCH((l2norm_fwd_kernel<TI, TO>), dim3((unsigned)grid), dim3(256), 0, st, (const TI*)x, \
     (TO*)y, inv_norm, (long)rows, (int)D, eps)
   if (x_dtype == WL_F32 && y_dtype == WL_F32) L2F(float, float);
   else if (x_dtype == WL_BF16 && y_dtype == WL_BF16) L2F(bf16_t, bf16_t);
@@ -110,7 +110,7 @@ int wavlm_l2norm_bwd(const void* dy, const void* y, int32_t y_dtype, const float
   if (rows == 0) return WL_OK;
   hipStream_t st = (hipStream_t)stream;
   long grid = (rows + 3) / 4; if (grid > 8192) grid = 8192;
-#define L2B(TI, TO) hipLaunchKernelGGL((l2norm_bwd_kernel<TI, TO>), dim3((unsigned)grid), dim3(256), 0, st, (const TO*)dy, \
+#define L2B(TI, TO) WL_LAUNCH((l2norm_bwd_kernel<TI, TO>), dim3((unsigned)grid), dim3(256), 0, st, (const TO*)dy, \
     (const TO*)y, inv_norm, (TI*)dx, (long)rows, (int)D)
   if (x_dtype == WL_F32 && y_dtype == WL_F32) L2B(float, float);
   else if (x_dtype == WL_BF16 && y_dtype == WL_BF16) L2B(bf16_t, bf16_t);
@@ -129,10 +129,10 @@ int wavlm_ce_rows(const float* logits, const int32_t* target, float* loss_rows, 
   hipStream_t st = (hipStream_t)stream;
   long grid = (S + 3) / 4; if (grid > 8192) grid = 8192;
   if (!dlogits || d_dtype == WL_F32)
-    hipLaunchKernelGGL((ce_rows_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, logits, target, loss_rows,
+    WL_LAUNCH((ce_rows_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, logits, target, loss_rows,
                        correct_rows, (float*)dlogits, (long)S, (int)V, (long)ld_logits, (long)ld_dlogits, weight);
   else if (d_dtype == WL_BF16)
-    hipLaunchKernelGGL((ce_rows_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, logits, target, loss_rows,
+    WL_LAUNCH((ce_rows_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, logits, target, loss_rows,
                        correct_rows, (bf16_t*)dlogits, (long)S, (int)V, (long)ld_logits, (long)ld_dlogits, weight);
   else return WL_EINVAL;
   return wl_check_launch();
@@ -144,8 +144,8 @@ int wavlm_sum_f32(const float* x, int64_t n, float* out, void* workspace, uint64
   if (!x || !out || !workspace || n < 0 || ws_bytes < wavlm_sum_workspace_bytes()) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   long grid = (n + 256 * 8 - 1) / (256 * 8); if (grid < 1) grid = 1; if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(sum_partial_f32_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, (long)n, (double*)workspace);
-  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)grid, out);
+  WL_LAUNCH(sum_partial_f32_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, (long)n, (double*)workspace);
+  WL_LAUNCH(sum_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)grid, out);
   return wl_check_launch();
 }
 

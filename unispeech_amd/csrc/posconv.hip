@@ -134,20 +134,20 @@ int wavlm_posconv_weight_fwd(const void* v, const void* g, int32_t param_dtype, 
   const long total = rows * K;
   long grid = (total + 255) / 256; if (grid > 4096) grid = 4096;
   if (param_dtype == WL_F32) {
-    hipLaunchKernelGGL((pc_rowdot_partial_kernel<float, float>), dim3(PC_BLOCKS), dim3(th), 0, st, (const float*)v,
+    WL_LAUNCH((pc_rowdot_partial_kernel<float, float>), dim3(PC_BLOCKS), dim3(th), 0, st, (const float*)v,
                        (const float*)v, rows, (int)K, part);
-    hipLaunchKernelGGL(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, norm, 1);
+    WL_LAUNCH(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, norm, 1);
     if (out_dtype == WL_F32)
-      hipLaunchKernelGGL((pc_weight_kernel<float, float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)v,
+      WL_LAUNCH((pc_weight_kernel<float, float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)v,
                          (const float*)g, norm, (float*)Wf, (float*)Wb, (int)D, (int)Cg, (int)K);
     else
-      hipLaunchKernelGGL((pc_weight_kernel<float, bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)v,
+      WL_LAUNCH((pc_weight_kernel<float, bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)v,
                          (const float*)g, norm, (bf16_t*)Wf, (bf16_t*)Wb, (int)D, (int)Cg, (int)K);
   } else if (param_dtype == WL_BF16 && out_dtype == WL_BF16) {
-    hipLaunchKernelGGL((pc_rowdot_partial_kernel<bf16_t, bf16_t>), dim3(PC_BLOCKS), dim3(th), 0, st, (const bf16_t*)v,
+    WL_LAUNCH((pc_rowdot_partial_kernel<bf16_t, bf16_t>), dim3(PC_BLOCKS), dim3(th), 0, st, (const bf16_t*)v,
                        (const bf16_t*)v, rows, (int)K, part);
-    hipLaunchKernelGGL(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, norm, 1);
-    hipLaunchKernelGGL((pc_weight_kernel<bf16_t, bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)v,
+    WL_LAUNCH(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, norm, 1);
+    WL_LAUNCH((pc_weight_kernel<bf16_t, bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)v,
                        (const bf16_t*)g, norm, (bf16_t*)Wf, (bf16_t*)Wb, (int)D, (int)Cg, (int)K);
   } else return WL_EINVAL;
   return wl_check_launch();
@@ -168,18 +168,18 @@ int wavlm_posconv_weight_bwd(const float* dWf, const void* v, const void* g, con
   const long total = rows * K;
   long grid = (total + 255) / 256; if (grid > 4096) grid = 4096;
   const unsigned th = (unsigned)((K + 63) / 64 * 64);
-  hipLaunchKernelGGL(pc_unpack_dw_kernel, dim3((unsigned)grid), dim3(256), 0, st, dWf, dw, (int)D, (int)Cg, (int)K);
+  WL_LAUNCH(pc_unpack_dw_kernel, dim3((unsigned)grid), dim3(256), 0, st, dWf, dw, (int)D, (int)Cg, (int)K);
   if (param_dtype == WL_F32) {
-    hipLaunchKernelGGL((pc_rowdot_partial_kernel<float, float>), dim3(PC_BLOCKS), dim3(th), 0, st, (const float*)dw,
+    WL_LAUNCH((pc_rowdot_partial_kernel<float, float>), dim3(PC_BLOCKS), dim3(th), 0, st, (const float*)dw,
                        (const float*)v, rows, (int)K, part);
-    hipLaunchKernelGGL(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, Stot, 0);
-    hipLaunchKernelGGL((pc_weight_bwd_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)dw,
+    WL_LAUNCH(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, Stot, 0);
+    WL_LAUNCH((pc_weight_bwd_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)dw,
                        (const float*)v, (const float*)g, norm, Stot, (float*)dv, (float*)dg, (int)D, (int)Cg, (int)K);
   } else if (param_dtype == WL_BF16) {
-    hipLaunchKernelGGL((pc_rowdot_partial_kernel<float, bf16_t>), dim3(PC_BLOCKS), dim3(th), 0, st, (const float*)dw,
+    WL_LAUNCH((pc_rowdot_partial_kernel<float, bf16_t>), dim3(PC_BLOCKS), dim3(th), 0, st, (const float*)dw,
                        (const bf16_t*)v, rows, (int)K, part);
-    hipLaunchKernelGGL(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, Stot, 0);
-    hipLaunchKernelGGL((pc_weight_bwd_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)dw,
+    WL_LAUNCH(pc_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, part, PC_BLOCKS, (int)K, Stot, 0);
+    WL_LAUNCH((pc_weight_bwd_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)dw,
                        (const bf16_t*)v, (const bf16_t*)g, norm, Stot, (bf16_t*)dv, (bf16_t*)dg, (int)D, (int)Cg, (int)K);
   } else return WL_EINVAL;
   return wl_check_launch();
@@ -193,10 +193,10 @@ int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* n
   const long total = (long)B * G * Tp * ((D / G) >> 3);
   long grid = (total + 255) / 256; if (grid > 8192) grid = 8192;
   if (dtype == WL_F32)
-    hipLaunchKernelGGL((pc_group_major_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)x,
+    WL_LAUNCH((pc_group_major_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)x,
                        (const float*)aux, (float*)out, (float*)nat_out, (int)B, (int)T, (int)D, (int)G, (int)left_pad, (int)Tp);
   else if (dtype == WL_BF16)
-    hipLaunchKernelGGL((pc_group_major_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)x,
+    WL_LAUNCH((pc_group_major_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)x,
                        (const bf16_t*)aux, (bf16_t*)out, (bf16_t*)nat_out, (int)B, (int)T, (int)D, (int)G, (int)left_pad,
                        (int)Tp);
   else return WL_EINVAL;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float xhat = (sv[e] - mean) * rstd;
-          float ge = g[e] * grad_scale;
+          float ge = g[e];
           if (act) ge *= gelu_grad_f(xhat * gm[c][e] + bt[c][e]);
           ag[c][e] += ge * xhat;
           ab[c][e] += ge;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         const long off = row * D + ch * 8;
         float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rstd * (h[c][e] - s1 - xh[c][e] * s2);
+        for (int e = 0; e < 8; ++e) o[e] = grad_scale * rstd * (h[c][e] - s1 - xh[c][e] * s2);  // grad_scale: input gradient only, not dgamma/dbeta
         store8(dx + off, o);
         if (dr) {
           if (th_in) {
@@ -211,15 +211,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// out[c] (+)= sum_b part[b * stride + c]
+// out[c] (+)= sum_b part[b * stride + c].  Block = 64 columns x 4 row slices (coalesced 256-B reads per slice),
+// slices combined through LDS; grid = ceil(n / 64).
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nblk, long stride, int n,
                                                              void* out, int out_dtype, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + col;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(long)b * stride + c];
-  if (accumulate) s += ld_elem(out, c, out_dtype);
-  st_elem(out, c, out_dtype, s);
+  if (c < n)
+    for (int b = slice; b < nblk; b += 4) s += part[(long)b * stride + c];
+  red[slice][col] = s;
+  __syncthreads();
+  if (slice == 0 && c < n) {
+    s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+    if (accumulate) s += ld_elem(out, c, out_dtype);
+    st_elem(out, c, out_dtype, s);
+  }
 }
 
 #define CS_MAXC 8  // up to 4096 columns
@@ -384,7 +392,7 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   const unsigned ti = drop_thresh(p_in), to = drop_thresh(p_out);
   const float si = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, so = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
   const unsigned grid = grid_for(rows, 4, 8192);
-#define LN_FWD(T, TP) hipLaunchKernelGGL((layernorm_fwd_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)x, \
+#define LN_FWD(T, TP) WL_LAUNCH((layernorm_fwd_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)x, \
     (const T*)r, (T*)y, (T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (long)rows, (int)D, eps, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out)
   if (dtype == WL_F32 && param_dtype == WL_F32) LN_FWD(float, float);
@@ -411,7 +419,7 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   const float si = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, so = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
   const unsigned grid = grid_for(rows, 4, LN_BWD_BLOCKS);
   float* part = (float*)workspace;
-#define LN_BWD(T, TP) hipLaunchKernelGGL((layernorm_bwd_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
+#define LN_BWD(T, TP) WL_LAUNCH((layernorm_bwd_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
     (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, part, (long)rows, (int)D, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale)
   if (dtype == WL_F32 && param_dtype == WL_F32) LN_BWD(float, float);
@@ -421,10 +429,10 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
 #undef LN_BWD
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  const unsigned g2 = (unsigned)((D + 255) / 256);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(g2), dim3(256), 0, st, part, (int)grid, (long)(2 * D), (int)D, dgamma,
+  const unsigned g2 = (unsigned)((D + 63) / 64);
+  WL_LAUNCH(colsum_finish_kernel, dim3(g2), dim3(256), 0, st, part, (int)grid, (long)(2 * D), (int)D, dgamma,
                      (int)param_dtype, (int)accumulate_params);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(g2), dim3(256), 0, st, part + D, (int)grid, (long)(2 * D), (int)D, dbeta,
+  WL_LAUNCH(colsum_finish_kernel, dim3(g2), dim3(256), 0, st, part + D, (int)grid, (long)(2 * D), (int)D, dbeta,
                      (int)param_dtype, (int)accumulate_params);
   return wl_check_launch();
 }
@@ -440,15 +448,15 @@ int wavlm_colsum(const void* x, int64_t rows, int32_t N, int64_t ld, int32_t dty
   const unsigned grid = grid_for(rows > 0 ? rows : 1, 4, CS_BLOCKS);
   float* part = (float*)workspace;
   if (dtype == WL_F32)
-    hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (long)rows, (int)N,
+    WL_LAUNCH((colsum_partial_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (long)rows, (int)N,
                        (long)ld, include_mask, exclude_mask, part);
   else if (dtype == WL_BF16)
-    hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (long)rows, (int)N,
+    WL_LAUNCH((colsum_partial_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (long)rows, (int)N,
                        (long)ld, include_mask, exclude_mask, part);
   else return WL_EINVAL;
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, part, (int)grid, (long)N,
+  WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, part, (int)grid, (long)N,
                      (int)N, out, (int)out_dtype, (int)accumulate);
   return wl_check_launch();
 }
@@ -459,7 +467,7 @@ int wavlm_select_rows(const void* x, void* y, const uint8_t* sel, const void* em
   if (rows == 0) return WL_OK;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = grid_for(rows * (D >> 3), 256, 4096);
-#define SEL(T, TP) hipLaunchKernelGGL((select_rows_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)x, (T*)y, sel, \
+#define SEL(T, TP) WL_LAUNCH((select_rows_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)x, (T*)y, sel, \
     (const TP*)emb, zero, (long)rows, (int)D)
   if (dtype == WL_F32 && emb_dtype == WL_F32) SEL(float, float);
   else if (dtype == WL_BF16 && emb_dtype == WL_BF16) SEL(bf16_t, bf16_t);
@@ -476,10 +484,10 @@ int wavlm_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = grid_for(n_out * (D >> 3), 256, 4096);
   if (dtype == WL_F32)
-    hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, idx, (float*)dst,
+    WL_LAUNCH((gather_rows_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, idx, (float*)dst,
                        (long)n_out, (int)D);
   else if (dtype == WL_BF16)
-    hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, idx, (bf16_t*)dst,
+    WL_LAUNCH((gather_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, idx, (bf16_t*)dst,
                        (long)n_out, (int)D);
   else return WL_EINVAL;
   return wl_check_launch();
@@ -488,7 +496,7 @@ int wavlm_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_
 int wavlm_axpby(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, float a, float b, void* stream) {
   if (!x || !y || n < 0) return WL_EINVAL;
   if (n == 0) return WL_OK;
-  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, (int)x_dtype, y,
+  WL_LAUNCH(axpby_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, (int)x_dtype, y,
                      (int)y_dtype, (long)n, a, b);
   return wl_check_launch();
 }
@@ -496,7 +504,7 @@ int wavlm_axpby(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_
 int wavlm_scale_dev(void* y, int32_t dtype, int64_t n, const float* scalar, float extra, void* stream) {
   if (!y || !scalar || n < 0) return WL_EINVAL;
   if (n == 0) return WL_OK;
-  hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, y, (int)dtype,
+  WL_LAUNCH(scale_dev_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, y, (int)dtype,
                      (long)n, scalar, extra);
   return wl_check_launch();
 }
@@ -509,10 +517,10 @@ int wavlm_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int
   const float sc = 1.f / (1.f - p);
   const unsigned grid = grid_for(n >> 3, 256, 8192);
   if (dtype == WL_F32)
-    hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, (long)(n >> 3), th,
+    WL_LAUNCH((dropout_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, (long)(n >> 3), th,
                        sc, (unsigned long long)seed);
   else if (dtype == WL_BF16)
-    hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
+    WL_LAUNCH((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
                        (long)(n >> 3), th, sc, (unsigned long long)seed);
   else return WL_EINVAL;
   return wl_check_launch();
@@ -526,8 +534,8 @@ int wavlm_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out
   if (!x || !out || !workspace || n <= 0 || ws_bytes < wavlm_sumsq_workspace_bytes()) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = grid_for(n, 256 * 16, 1024);
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, st, x, (int)dtype, (long)n, (double*)workspace);
-  hipLaunchKernelGGL(sum_finish_d_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)grid, out, scale);
+  WL_LAUNCH(sumsq_partial_kernel, dim3(grid), dim3(256), 0, st, x, (int)dtype, (long)n, (double*)workspace);
+  WL_LAUNCH(sum_finish_d_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)grid, out, scale);
   return wl_check_launch();
 }
 

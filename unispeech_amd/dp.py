@@ -1,0 +1,134 @@
+"""Data-parallel gradient reduction over RCCL / xGMI.
+
+The reference recipes use LegacyDistributedDataParallel: copy every gradient into one flat buffer *after* the
+whole backward, divide by world size, one blocking all-reduce (src/fairseq/distributed/
+legacy_distributed_data_parallel.py:76-165).  Here gradients already live in one flat arena (optim.FusedAdam), so
+there is nothing to pack: the arena is cut into buckets in reverse parameter order, a post-accumulate hook counts
+the gradients of a bucket as backward produces them, and a finished bucket is all-reduced immediately on a side
+HIP stream while the rest of backward keeps the compute stream busy.  xGMI is point-to-point (7 links x ~153 GB/s
+per GPU): a ring all-reduce is bound by one link, so buckets are kept large (default 32 MiB -> ~6 collectives for
+WavLM-Base) -- the goal is overlap, not message count.  The 1/world factor is not applied here: it is folded into
+the optimizer's gradient multiplier (one fewer pass over the arena).
+
+Semantics kept from the reference wrapper: `no_sync()` (gradient accumulation), `all_reduce_grads()` as the
+explicit completion point the fairseq Trainer calls (trainer.py:781-785), sum-then-divide == average.
+"""
+from contextlib import contextmanager
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, params, flat_grad, offsets, process_group=None, bucket_bytes=32 << 20):
+        self.params = list(params)
+        self.flat_grad = flat_grad
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.enabled = self.world > 1
+        self.sync = True
+        self.is_cuda = flat_grad.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.is_cuda and self.enabled) else None
+        # buckets over contiguous arena ranges, built from the END of the arena (gradients of the last layers
+        # are produced first)
+        esize = flat_grad.element_size()
+        self.buckets = []  # dict(lo, hi, nparams)
+        self.bucket_of = {}
+        cur = None
+        for idx in range(len(self.params) - 1, -1, -1):
+            p, o = self.params[idx], offsets[idx]
+            if cur is None:
+                cur = {"lo": o, "hi": o + p.numel(), "n": 0}
+            cur["lo"] = min(cur["lo"], o)
+            cur["n"] += 1
+            self.bucket_of[idx] = len(self.buckets)
+            if (cur["hi"] - cur["lo"]) * esize >= bucket_bytes:
+                self.buckets.append(cur)
+                cur = None
+        if cur is not None:
+            self.buckets.append(cur)
+        self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        if self.enabled:
+            for idx, p in enumerate(self.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(idx))
+
+    def _make_hook(self, idx):
+        def hook(_p):
+            if not (self.enabled and self.sync):
+                return
+            b = self.bucket_of[idx]
+            self._ready[b] += 1
+            if self._ready[b] == self.buckets[b]["n"] and not self._launched[b]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        bk = self.buckets[b]
+        view = self.flat_grad[bk["lo"]:bk["hi"]]
+        self._launched[b] = True
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    @contextmanager
+    def no_sync(self):
+        old = self.sync
+        self.sync = False
+        try:
+            yield
+        finally:
+            self.sync = old
+
+    def finish(self):
+        """Complete the reduction of this step: launch buckets whose hooks never all fired (unused parameters,
+        accumulation steps), then make the compute stream wait for every collective.  Gradients hold the SUM over
+        ranks afterwards; multiply by `self.scale` (1/world) for the average."""
+        if not self.enabled:
+            return
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._works = []
+        self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+
+    @property
+    def scale(self):
+        return 1.0 / self.world
+
+
+class DataParallelWavLM(torch.nn.Module):
+    """LegacyDDP-shaped wrapper (forward / no_sync / all_reduce_grads / attribute pass-through) around a model
+    whose gradients live in a FusedAdam arena."""
+
+    def __init__(self, module, optimizer, process_group=None, bucket_bytes=32 << 20):
+        super().__init__()
+        self.module = module
+        self.reducer = GradReducer(optimizer.params, optimizer.flat_grad, optimizer.offsets, process_group,
+                                   bucket_bytes)
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def no_sync(self):
+        return self.reducer.no_sync()
+
+    def all_reduce_grads(self):
+        self.reducer.finish()
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("module"), name)

@@ -522,15 +522,18 @@ class FeaturesPenFn(torch.autograd.Function):
     """features.float().pow(2).mean()  (src/fairseq/models/wavlm/wavlm.py:486)"""
 
     @staticmethod
-    def forward(ctx, feats):
+    def forward(ctx, feats, grad_scale=1.0):
+        # grad_scale: the reference takes features_pen AFTER GradMultiply (wavlm.py:479,486), so the penalty's
+        # gradient into the extractor is scaled by feature_grad_mult as well
         fc = feats.contiguous()
         ctx.save_for_backward(fc)
+        ctx.grad_scale = grad_scale
         return ops.sumsq(fc, 1.0 / fc.numel())
 
     @staticmethod
     def backward(ctx, g):
         (fc,) = ctx.saved_tensors
         d = torch.empty_like(fc)
-        ops.axpby_(d, fc, 2.0 / fc.numel(), 0.0)
+        ops.axpby_(d, fc, 2.0 * ctx.grad_scale / fc.numel(), 0.0)
         ops.scale_dev_(d, g.reshape(1).to(torch.float32))
-        return d
+        return d, None

@@ -394,10 +394,21 @@ def ce_rows(logits, target, V, ld_logits, dlogits, ld_dlogits, weight):
 
 
 # --------------------------------------------------------------------------------------------- optim
-def adam_step(p32, m, v, grad, p_lowp, *, lr, beta1, beta2, eps, weight_decay, step, grad_mult=1.0, gnorm_sq=None,
-              max_norm=0.0):
+def adam_step(p32, m, v, grad, p_lowp, *, lr, beta1, beta2, eps, weight_decay, step, grad_mult=1.0,
+              grad_mult_dev=None, gnorm_sq=None, max_norm=0.0):
     _dev(p32)
     check(_lib.lib().wavlm_adam_step(ptr(p32), ptr(m), ptr(v), ptr(grad), dt(grad), ptr(p_lowp),
                                      dt(p_lowp) if p_lowp is not None else 0, p32.numel(), float(lr), float(beta1),
                                      float(beta2), float(eps), float(weight_decay), int(step), float(grad_mult),
-                                     ptr(gnorm_sq), float(max_norm), stream()), "wavlm_adam_step")
+                                     ptr(grad_mult_dev), ptr(gnorm_sq), float(max_norm), stream()), "wavlm_adam_step")
+
+
+def prof_enable(on):
+    _lib.lib().wavlm_prof_enable(1 if on else 0)
+
+
+def prof_collect(dtype=-1):
+    """(launches, total_ms, total_flops) of the GEMM launches recorded since prof_enable(True); synchronises"""
+    ms, fl = C.c_double(0.0), C.c_double(0.0)
+    n = _lib.lib().wavlm_prof_collect(int(dtype), C.byref(ms), C.byref(fl))
+    return n, ms.value, fl.value

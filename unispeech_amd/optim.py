@@ -1,0 +1,78 @@
+"""Flat-arena fused Adam (reference: src/fairseq/optim/fp16_optimizer.py:16-330 +
+optim/adam.py:148-228 + utils.py:338-388).
+
+All parameters are re-homed into ONE contiguous low-precision arena (their .data become views), all gradients
+into one contiguous gradient arena (their .grad are views, so autograd accumulates in place and the data-parallel
+reducer can all-reduce arena slices without packing), and the fp32 master copy / Adam moments live in three more
+flat fp32 arrays.  One optimizer step = one sum-of-squares reduction over the gradient arena + one update kernel
+(unscale, clip, moments, decoupled weight decay, update, low-precision copy-back), with the clip coefficient
+derived on the device: no host synchronisation, 28 B/param of HBM traffic in bf16 mode.
+"""
+import torch
+
+from . import ops
+
+_ALIGN = 64  # elements; keeps every parameter 128-byte aligned in bf16 (16-byte vector loads need 8)
+
+
+class FusedAdam:
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no parameters")
+        dev, dtype = self.params[0].device, self.params[0].dtype
+        for p in self.params:
+            if p.device != dev or p.dtype != dtype:
+                raise ValueError("all parameters must share device and dtype")
+        self.lr, self.betas, self.eps, self.weight_decay, self.clip_norm = lr, betas, eps, weight_decay, clip_norm
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = off
+        self.flat_param = torch.zeros(off, dtype=dtype, device=dev)
+        self.flat_grad = torch.zeros(off, dtype=dtype, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat_param[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+        self.lowp = dtype != torch.float32
+        self.master = self.flat_param.float() if self.lowp else self.flat_param
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
+                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+
+    def step(self, grad_mult=1.0, grad_mult_dev=None):
+        """grads are used as grad * grad_mult (* grad_mult_dev[0]); clipping uses the norm of the scaled gradient"""
+        self.step_count += 1
+        ops.sumsq(self.flat_grad, 1.0, out=self.gnorm_sq)
+        ops.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.flat_grad,
+                      self.flat_param if self.lowp else None, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                      eps=self.eps, weight_decay=self.weight_decay, step=self.step_count, grad_mult=grad_mult,
+                      grad_mult_dev=grad_mult_dev, gnorm_sq=self.gnorm_sq, max_norm=self.clip_norm)
+
+    def grad_norm(self, grad_mult=1.0):
+        """host value of the (scaled) global gradient norm -- synchronises; logging only"""
+        return float(self.gnorm_sq.sqrt().item()) * abs(grad_mult)
+
+    def state_dict(self):
+        return {"step": self.step_count, "master": self.master, "exp_avg": self.exp_avg,
+                "exp_avg_sq": self.exp_avg_sq, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd["step"]
+        self.master.copy_(sd["master"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if self.lowp:
+            self.flat_param.copy_(self.master)

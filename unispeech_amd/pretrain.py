@@ -171,7 +171,7 @@ class WavLMPretrainModel(WavLM):
                 x = x[:, :new_T].contiguous()
                 feats = feats[:, :new_T].contiguous()
                 T = new_T
-        features_pen = F.FeaturesPenFn.apply(feats) if not features_only else None
+        features_pen = F.FeaturesPenFn.apply(feats, self.feat_grad_scale) if not features_only else None
 
         pad_cpu = None
         if padding_mask is not None:

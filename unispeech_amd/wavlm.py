@@ -399,6 +399,11 @@ class WavLM(nn.Module):
         padding_mask = padding_mask.view(padding_mask.size(0), n_frames, -1)
         return padding_mask.all(-1)
 
+    @property
+    def feat_grad_scale(self):
+        """GradMultiply factor applied to every gradient entering the extractor (WavLM.py:333-336)"""
+        return self.feature_grad_mult if (self.feature_grad_mult > 0 and self.feature_grad_mult != 1.0) else 1.0
+
     # -- device path -------------------------------------------------------------------------------------------
     def _features(self, source):
         """waveform -> (LayerNorm'ed, projected features [B, T', D], raw conv features [B, T', C])"""
@@ -407,7 +412,7 @@ class WavLM(nn.Module):
         else:
             with torch.no_grad():
                 feats = self.feature_extractor(source)
-        gscale = self.feature_grad_mult if (self.feature_grad_mult > 0 and self.feature_grad_mult != 1.0) else 1.0
+        gscale = self.feat_grad_scale
         ln = self.layer_norm
         x, _ = F.layer_norm(feats, ln.weight, ln.bias, ln.eps, grad_scale=gscale)
         if self.post_extract_proj is not None:
