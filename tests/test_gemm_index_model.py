@@ -29,6 +29,29 @@ def fill_lds_kc(tile, rows):
     return lds
 
 
+def fill_lds_glds(tile, rows):
+    """K-contiguous fast path: global_load_lds_dwordx4 writes lane l of wave w at base + 16*l, base =
+    (ps*32 + 8*w)*128; the lane fetches the logical chunk (t&7) ^ swizzle(row) (Operand<false>::init/issue)."""
+    lds = np.zeros(rows * 128, dtype=np.uint8)
+    raw = tile.view(np.uint8).reshape(rows, 128)
+    for t in range(256):
+        wave, lane = t >> 6, t & 63
+        row, pc = t >> 3, t & 7
+        for ps in range(rows // 32):
+            rr = row + ps * 32
+            c = pc ^ ((rr >> 1) & 7)
+            dst = (ps * 32 + wave * 8) * 128 + lane * 16
+            lds[dst: dst + 16] = raw[rr, c * 16: c * 16 + 16]
+    return lds
+
+
+def test_glds_image_equals_register_path_image():
+    rng = np.random.default_rng(0)
+    for rows in (128, 64):
+        tile = rng.integers(0, 60000, size=(rows, BK)).astype(np.uint16)
+        assert np.array_equal(fill_lds_glds(tile, rows), fill_lds_kc(tile, rows))
+
+
 def fill_lds_ks(tile_t, rows):
     """tile_t: [64 k, rows] uint16 (rows contiguous), K-strided loader (load_ks/store_ks)."""
     lds = np.zeros(rows * 128, dtype=np.uint8)

@@ -106,6 +106,10 @@ def lib():
             raise WavlmHipError(
                 "libwavlm_hip.so not found at %s -- run `python -m unispeech_amd.build` (there is no CPU fallback)"
                 % LIB_PATH)
+        # torch ships its own libamdhip64 / libhsa-runtime64; it must be in the process BEFORE this library so that
+        # both resolve to ONE HIP runtime (loading the system runtime first leaves torch and the kernels on two
+        # different runtimes: "no ROCm-capable device is detected" at the first launch)
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol

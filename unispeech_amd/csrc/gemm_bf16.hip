@@ -116,31 +116,99 @@ __device__ __forceinline__ void store_ks(unsigned char* lds, const uint4 (&r)[4]
   }
 }
 
-template <bool TR, int ROWS> struct Stage {
-  uint4 r[TR ? 4 : ROWS / 32];
-  __device__ __forceinline__ void load(const bf16_t* base, long ld, int rows_valid, int k_valid) {
-    if constexpr (TR) load_ks<ROWS>(base, ld, rows_valid, k_valid, r);
-    else load_kc<ROWS>(base, ld, rows_valid, k_valid, r);
+typedef const __attribute__((address_space(1))) void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+
+// One operand of the block tile.  Loop-invariant per-thread state (pointers, predicates) is set up once; per K
+// tile only a uniform element offset is added.
+//   K-contiguous, full 64-wide K tile : global_load_lds_dwordx4 straight into the swizzled LDS image (no VGPR
+//       staging, no ds_write).  LDS-DMA writes lane l at base + 16*l, so thread t owns physical chunk t&7 of row
+//       t>>3 and fetches the *logical* chunk (t&7) ^ swizzle(row) from HBM (the swizzle lives on the source
+//       address); rows past the edge are clamped to the last valid row (they only feed outputs never stored).
+//   K-contiguous, K-tail tile         : register path with zero fill beyond K.
+//   K-strided                         : 4 x 16-B loads -> in-register 4x8 transpose -> ds_write_b64.
+template <bool TR, int ROWS> struct Operand {
+  static constexpr int NP = TR ? 4 : ROWS / 32;
+  const bf16_t* gp[NP];
+  const bf16_t* base;
+  long ld;
+  int rows_valid;
+  int mode;  // K-strided: 0 inactive, 1 whole 8-row chunk valid, 2 partial chunk (slow loads)
+  uint4 r[NP];
+
+  __device__ __forceinline__ void init(const bf16_t* tile_base, long ld_, int rows_valid_) {
+    base = tile_base; ld = ld_; rows_valid = rows_valid_;
+    const int t = threadIdx.x;
+    if constexpr (!TR) {
+      const int row = t >> 3, pc = t & 7;
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int rr = row + ps * 32;
+        const int rc = rr < rows_valid ? rr : rows_valid - 1;
+        gp[ps] = tile_base + (long)rc * ld + ((pc ^ ((rr >> 1) & 7)) << 3);
+      }
+      mode = 1;
+    } else {
+      const int kb4 = t & 15, nb = (t >> 6) * 4 + ((t >> 4) & 3);
+      const int n = nb * 8;
+      mode = (nb < ROWS / 8 && n < rows_valid) ? ((n + 8 <= rows_valid) ? 1 : 2) : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        gp[i] = tile_base + (long)(kb4 * 4 + i) * ld + n;
+        r[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
   }
-  __device__ __forceinline__ void store(unsigned char* lds) {
-    if constexpr (TR) store_ks<ROWS>(lds, r);
-    else store_kc<ROWS>(lds, r);
+  // koff: element offset of this K tile from the tile base (kb * s_kb + k0 [* ld if K-strided])
+  __device__ __forceinline__ void issue(long koff, int k_valid, unsigned char* lds_tile, int wave_u) {
+    if constexpr (!TR) {
+      if (k_valid >= GEMM_BK) {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+          __builtin_amdgcn_global_load_lds((gas_ptr)(gp[ps] + koff), (las_ptr)(lds_tile + (ps * 32 + wave_u * 8) * 128),
+                                           16, 0, 0);
+      } else {
+        load_kc<ROWS>(base + koff, ld, rows_valid, k_valid, r);
+      }
+    } else {
+      if (k_valid >= GEMM_BK && mode == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(gp[i] + koff);
+      } else if (mode != 0) {
+        load_ks<ROWS>(base + koff, ld, rows_valid, k_valid, r);
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(int k_valid, unsigned char* lds_tile) {
+    if constexpr (!TR) {
+      if (k_valid < GEMM_BK) store_kc<ROWS>(lds_tile, r);
+    } else {
+      store_ks<ROWS>(lds_tile, r);
+    }
   }
 };
 
-template <bool TA, bool TB, int BM, int BN, int WM, int WN>
+template <bool TA, bool TB, int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
   static_assert(WM * WN == 4 && FM >= 1 && FN >= 1, "4 waves");
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
 
-  const int tile = blockIdx.x;
+  // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (private L2 per XCD); remap so each XCD walks
+  // a contiguous range of tiles (neighbours share the A row panel and all of B).  Pure speed, any placement is valid.
+  int tile;
+  {
+    const int nt = p.tiles_m * p.tiles_n, bid = blockIdx.x;
+    const int q = nt >> 3, rem = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
   const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
   const int z = blockIdx.y, split = blockIdx.z;
   const int zo = z / p.batch_i, zi = z % p.batch_i;
   const int m0 = tm * BM, n0 = tn * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int wm = wave / WN, wn = wave % WN;
 
   const bf16_t* Ab = (const bf16_t*)p.A + (long)zo * p.sA_o + (long)zi * p.sA_i;
@@ -157,27 +225,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Stage<TA, BM> sa;
-  Stage<TB, BN> sb;
-  auto issue = [&](int t) {
-    const int kb = t / kt_per, k0 = (t % kt_per) * GEMM_BK;
-    const bf16_t* a = Ab + (long)kb * p.sA_kb + (TA ? ((long)k0 * p.lda + m0) : ((long)m0 * p.lda + k0));
-    const bf16_t* b = Bb + (long)kb * p.sB_kb + (TB ? ((long)k0 * p.ldb + n0) : ((long)n0 * p.ldb + k0));
-    sa.load(a, p.lda, p.M - m0, p.K - k0);
-    sb.load(b, p.ldb, p.N - n0, p.K - k0);
+  Operand<TA, BM> oa;
+  Operand<TB, BN> ob;
+  oa.init(Ab + (TA ? (long)m0 : (long)m0 * p.lda), p.lda, p.M - m0);
+  ob.init(Bb + (TB ? (long)n0 : (long)n0 * p.ldb), p.ldb, p.N - n0);
+  auto issue = [&](int t, unsigned char* buf) {
+    const int kb = t / kt_per, k0 = (t - kb * kt_per) * GEMM_BK;
+    oa.issue((long)kb * p.sA_kb + (TA ? (long)k0 * p.lda : (long)k0), p.K - k0, buf, wave_u);
+    ob.issue((long)kb * p.sB_kb + (TB ? (long)k0 * p.ldb : (long)k0), p.K - k0, buf + A_BYTES, wave_u);
+    return p.K - k0;
   };
 
   int cur = 0;
   if (t0 < t1) {
-    issue(t0);
-    sa.store(smem);
-    sb.store(smem + A_BYTES);
+    const int kv = issue(t0, smem);
+    oa.commit(kv, smem);
+    ob.commit(kv, smem + A_BYTES);
   }
   __syncthreads();
 
   for (int t = t0; t < t1; ++t) {
     const bool more = (t + 1 < t1);
-    if (more) issue(t + 1);
+    unsigned char* nbuf = smem + (cur ^ 1) * (A_BYTES + B_BYTES);
+    int kv = GEMM_BK;
+    if (more) kv = issue(t + 1, nbuf);
     const unsigned char* la = smem + cur * (A_BYTES + B_BYTES);
     const unsigned char* lb = la + A_BYTES;
 #pragma unroll
@@ -201,26 +272,62 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].b, fb[j].b, acc[i][j], 0, 0, 0);
     }
     if (more) {
-      unsigned char* na = smem + (cur ^ 1) * (A_BYTES + B_BYTES);
-      sa.store(na);
-      sb.store(na + A_BYTES);
+      oa.commit(kv, nbuf);
+      ob.commit(kv, nbuf + A_BYTES);
     }
     __syncthreads();
     cur ^= 1;
   }
 
-  // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  // ---- epilogue ------------------------------------------------------------------------------------------
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  if constexpr (!VEC) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int nn = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+      for (int j = 0; j < FN; ++j) {
+        const int nn = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int mm = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (mm < p.M && nn < p.N) gemm_store(p, z, split, mm, nn, acc[i][j][r]);
+        for (int r = 0; r < 16; ++r) {
+          const int mm = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (mm < p.M && nn < p.N) gemm_store(p, z, split, mm, nn, acc[i][j][r]);
+        }
       }
+  } else {
+    // Row-vector epilogue: each wave stages one 32-row block of its accumulators through its private LDS
+    // slice as fp32 (ds_write_b32: 32 lanes -> 32 consecutive dwords, conflict-free), then every lane owns
+    // 8 consecutive columns of a row: bias / aux / residual are 16-byte loads and C is written as full
+    // 16-byte (bf16) or 2 x 16-byte (f32) vectors -- 8 rows x 128 B per wave-instruction instead of 2-byte
+    // scatters.  The main loop's last barrier has already retired every LDS read of the operand tiles.
+    constexpr int WCOLS = BN / WN;          // columns of the wave tile (FN * 32)
+    constexpr int EP_LD = WCOLS + 4;        // padded fp32 row: keeps 16-B alignment, rotates banks by 4
+    constexpr int CH = WCOLS / 8;           // 8-column chunks per row
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    const int zo2 = zo, zi2 = zi;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < (32 * CH) / 64; ++q) {
+        const int id = lane + 64 * q;
+        const int rl = id / CH, ch = id % CH;
+        const int mm = m0 + wm * (BM / WM) + i * 32 + rl;
+        const int nn = n0 + wn * WCOLS + ch * 8;
+        if (mm < p.M && nn < p.N) {
+          const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          gemm_store8(p, zo2, zi2, z, split, mm, nn, v);
+        }
+      }
+      __syncthreads();
     }
+  }
 }
 
 // sums the split-K slabs and applies the final epilogue
@@ -237,18 +344,32 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmP p, int nb
 }
 
 template <bool TA, bool TB, int BM, int BN, int WM, int WN>
-static int launch_cfg(GemmP& p, int nbatch, hipStream_t st) {
+static int launch_cfg(GemmP& p, int nbatch, bool vec, hipStream_t st) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)nbatch, (unsigned)p.split_k);
-  WL_LAUNCH((gemm_bf16_kernel<TA, TB, BM, BN, WM, WN>), grid, dim3(256), 0, st, p);
+  if (vec) WL_LAUNCH((gemm_bf16_kernel<TA, TB, BM, BN, WM, WN, true>), grid, dim3(256), 0, st, p);
+  else WL_LAUNCH((gemm_bf16_kernel<TA, TB, BM, BN, WM, WN, false>), grid, dim3(256), 0, st, p);
   return wl_check_launch();
 }
 
 template <bool TA, bool TB>
-static int launch_t(GemmP& p, int nbatch, hipStream_t st) {
-  if (p.N <= 64) return launch_cfg<TA, TB, 128, 64, 2, 2>(p, nbatch, st);
-  return launch_cfg<TA, TB, 128, 128, 2, 2>(p, nbatch, st);
+static int launch_t(GemmP& p, int nbatch, bool vec, hipStream_t st) {
+  if (p.N <= 64) return launch_cfg<TA, TB, 128, 64, 2, 2>(p, nbatch, vec, st);
+  return launch_cfg<TA, TB, 128, 128, 2, 2>(p, nbatch, vec, st);
+}
+
+// the row-vector epilogue needs every row start of C / aux / res / bias 16-byte aligned for 8-element vectors
+static bool vec_epilogue_ok(const wavlm_gemm_desc* d) {
+  auto ok = [](const void* ptr, int64_t a, int64_t b, int64_t c) {
+    return (((uintptr_t)ptr) & 15) == 0 && a % 8 == 0 && b % 8 == 0 && c % 8 == 0;
+  };
+  if (d->split_k > 1) return (((uintptr_t)d->workspace) & 15) == 0 && d->N % 8 == 0;
+  if (!ok(d->C, d->ldc, d->sC_o, d->sC_i)) return false;
+  if (d->bias && !ok(d->bias, 0, d->sBias_o, d->sBias_i)) return false;
+  if (d->aux && !ok(d->aux, d->ld_aux, d->sAux_o, d->sAux_i)) return false;
+  if (d->res && !ok(d->res, d->ld_res, d->sRes_o, d->sRes_i)) return false;
+  return true;
 }
 
 int gemm_f32_launch(const wavlm_gemm_desc* d, hipStream_t st);  // gemm_f32.hip
@@ -330,10 +451,11 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   const int nbatch = (d->batch_o < 1 ? 1 : d->batch_o) * p.batch_i;
   const int pi = prof_begin(d, st);
   int rc;
-  if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, st);
-  else if (!d->transA && d->transB) rc = launch_t<false, true>(p, nbatch, st);
-  else if (d->transA && !d->transB) rc = launch_t<true, false>(p, nbatch, st);
-  else rc = launch_t<true, true>(p, nbatch, st);
+  const bool vec = vec_epilogue_ok(d);
+  if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, vec, st);
+  else if (!d->transA && d->transB) rc = launch_t<false, true>(p, nbatch, vec, st);
+  else if (d->transA && !d->transB) rc = launch_t<true, false>(p, nbatch, vec, st);
+  else rc = launch_t<true, true>(p, nbatch, vec, st);
   if (rc == WL_OK && p.split_k > 1) {
     const long total = (long)p.M * p.N * nbatch;
     long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;

@@ -62,6 +62,81 @@ __device__ __forceinline__ void gemm_store(const GemmP& p, int z, int split, int
   }
 }
 
+
+// ---- 8-wide row-vector epilogue (all row starts 16-byte aligned; see vec_epilogue_ok) ---------------------------
+__device__ __forceinline__ void ld8_dt(const void* p, long idx, int dt, float (&v)[8]) {
+  if (dt == WL_F32) {
+    const float4 a = *reinterpret_cast<const float4*>((const float*)p + idx);
+    const float4 b = *reinterpret_cast<const float4*>((const float*)p + idx + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    const uint4 a = *reinterpret_cast<const uint4*>((const bf16_t*)p + idx);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void st8_dt(void* p, long idx, int dt, const float (&v)[8]) {
+  if (dt == WL_F32) {
+    *reinterpret_cast<float4*>((float*)p + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>((float*)p + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint4 o;
+    o.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    o.z = f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); o.w = f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    *reinterpret_cast<uint4*>((bf16_t*)p + idx) = o;
+  }
+}
+
+// columns n .. n+7 of output row m (n % 8 == 0).  A chunk that straddles N falls back to the scalar path.
+__device__ __forceinline__ void gemm_store8(const GemmP& p, int zo, int zi, int z, int split, int m, int n,
+                                            float (&acc)[8]) {
+  if (n + 8 > p.N) {
+    for (int e = 0; e < 8 && n + e < p.N; ++e) gemm_store(p, z, split, m, n + e, acc[e]);
+    return;
+  }
+  if (p.split_k > 1) {
+    float* dst = p.ws + ((long)z * p.split_k + split) * ((long)p.M * p.N) + (long)m * p.N + n;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    return;
+  }
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = p.alpha * acc[e];
+  if (p.bias) {
+    float b[8];
+    ld8_dt(p.bias, (long)zo * p.sBias_o + (long)zi * p.sBias_i + n, p.bias_dtype, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += b[e];
+  }
+  if (p.epi == 1) {
+    if (p.aux) st8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, p.aux_dtype, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+  } else if (p.epi == 2) {
+    float u[8];
+    ld8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, p.aux_dtype, u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(u[e]);
+  }
+  if (p.res) {
+    float r[8];
+    ld8_dt(p.res, (long)zo * p.sRes_o + (long)zi * p.sRes_i + (long)m * p.ld_res + n, p.res_dtype, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += r[e];
+  }
+  const long ci = (long)zo * p.sC_o + (long)zi * p.sC_i + (long)m * p.ldc + n;
+  if (p.accumulate) {
+    float c[8];
+    ld8_dt(p.C, ci, p.c_dtype, c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += c[e];
+  }
+  st8_dt(p.C, ci, p.c_dtype, v);
+}
+
 // flattened reduction-tile range [t0, t1) owned by split `s` (tiles = KB * ceil(K / BK))
 __device__ __forceinline__ void gemm_split_range(int total_tiles, int split_k, int s, int& t0, int& t1) {
   const int per = (total_tiles + split_k - 1) / split_k;
