@@ -152,6 +152,18 @@ int wavlm_attn_softmax_bwd(const void* S, const void* dP, const float* lse, cons
                            int32_t H, int32_t T, int64_t ldS, int64_t ldP, int32_t s_dtype, int32_t p_dtype,
                            float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes, void* stream);
 
+/* Fused attention (bf16, head_dim 64): scores, Toeplitz bias, key padding, online softmax, dropout and PV in one
+ * kernel; nothing of size [B*H, T, T] is written.  qkv: packed [B, T, 3*H*64]; O: [B, T, H*64]; lse: [B*H, T].
+ * Replaces F.multi_head_attention_forward + the materialised gated bias (WavLM/modules.py:504-563). */
+int wavlm_attn_fused_fwd(const void* qkv, void* O, float* lse, const float* gate, const float* tab, const uint8_t* kpm,
+                         int32_t B, int32_t H, int32_t T, int32_t head_dim, float scale, float p_drop, uint64_t seed,
+                         void* stream);
+uint64_t wavlm_attn_fused_bwd_workspace_bytes(int32_t B, int32_t H, int32_t T);
+int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
+                         const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, int32_t B,
+                         int32_t H, int32_t T, int32_t head_dim, float scale, float p_drop, uint64_t seed,
+                         void* workspace, uint64_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * pos_conv weight side: weight_norm(dim=2) -> GEMM weight images, and its backward (WavLM/WavLM.py:514-527)
  * ------------------------------------------------------------------------------------------ */

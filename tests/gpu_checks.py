@@ -320,6 +320,59 @@ def check_attention():
         Or = _ref_attention(qkv.double(), None, None, None, H, hd ** -0.5)
         Od = F.AttnCoreFn.apply(qkv.to(dtype).to(DEV), None, None, None, H, hd ** -0.5, 0.0, 0)
         out.append((f"attn[{dtype}] no bias O", err(Od, Or), tol))
+    # fused kernels (bf16, head_dim 64) at the real frame count, with padding, vs the fp64 reference
+    for (B, T, H, use_pad) in [(2, 749, 3, True), (1, 300, 2, False)]:
+        hd, D, dtype, tol = 64, 64 * H, torch.bfloat16, TOLBF
+        qkv = q(gen(B, T, 3 * D, seed=11), dtype)
+        gate = 1 + 0.5 * gen(B, H, T, seed=12)
+        tab = 0.5 * gen(H, 2 * T - 1, seed=13)
+        kpm = None
+        if use_pad:
+            kpm = torch.zeros(B, T, dtype=torch.uint8)
+            kpm[1, T - 100:] = 1
+        dO = q(gen(B, T, D, seed=14), dtype)
+        qr, gr, tr = qkv.double().requires_grad_(True), gate.double().requires_grad_(True), tab.double().requires_grad_(True)
+        Or = _ref_attention(qr, gr, tr, kpm, H, hd ** -0.5)
+        (Or * dO.double()).sum().backward()
+        qd = qkv.to(dtype).to(DEV).requires_grad_(True)
+        gd, td = gate.to(DEV).requires_grad_(True), tab.to(DEV).requires_grad_(True)
+        kd = kpm.to(DEV) if kpm is not None else None
+        for fused in (True, False):
+            F.USE_FUSED_ATTENTION = fused
+            for t in (qd, gd, td):
+                t.grad = None
+            Od = F.AttnCoreFn.apply(qd, gd, td, kd, H, hd ** -0.5, 0.0, 0)
+            Od.backward(dO.to(dtype).to(DEV))
+            tag = f"attn[{'fused' if fused else 'unfused'} bf16] B={B} T={T} H={H} pad={use_pad}"
+            out.append((tag + " O", err(Od, Or), tol))
+            out.append((tag + " dqkv", err(qd.grad, qr.grad), tol * 2))
+            out.append((tag + " dgate", err(gd.grad, gr.grad), tol * 2))
+            out.append((tag + " dtab", err(td.grad, tr.grad), tol * 2))
+        F.USE_FUSED_ATTENTION = True
+    # fused dropout: deterministic per seed, keep fraction, and forward/backward agree on the mask
+    B, T, H, hd = 1, 256, 2, 64
+    D = H * hd
+    qkv = (0.5 * gen(B, T, 3 * D, seed=21)).to(torch.bfloat16).to(DEV)
+    ones_v = qkv.clone()
+    ones_v[..., 2 * D:] = 1.0  # V = 1 -> O = sum_j P_drop = (kept mass) / (1 - p)
+    O1 = F.AttnCoreFn.apply(ones_v, None, None, None, H, hd ** -0.5, 0.25, 77)
+    O2 = F.AttnCoreFn.apply(ones_v, None, None, None, H, hd ** -0.5, 0.25, 77)
+    O3 = F.AttnCoreFn.apply(ones_v, None, None, None, H, hd ** -0.5, 0.25, 78)
+    out.append(("attn[fused] dropout deterministic", float((O1 != O2).float().mean().item()), 0.0))
+    out.append(("attn[fused] dropout seed changes mask", 0.0 if (O1 != O3).any().item() else 1.0, 0.0))
+    out.append(("attn[fused] dropout E[kept mass] ~ 1", abs(O1.float().mean().item() - 1.0), 0.02))
+    R = gen(B, T, D, seed=22).to(torch.bfloat16).to(DEV)
+    x0 = qkv.clone().float()
+    delta = gen(B, T, 3 * D, seed=23).to(DEV)
+    xq = x0.to(torch.bfloat16).requires_grad_(True)
+    Od = F.AttnCoreFn.apply(xq, None, None, None, H, hd ** -0.5, 0.25, 99)
+    (Od.float() * R.float()).sum().backward()
+    lin = (xq.grad.float() * delta).sum().item()
+    eps = 0.05
+    Lp = (F.AttnCoreFn.apply((x0 + eps * delta).to(torch.bfloat16), None, None, None, H, hd ** -0.5, 0.25, 99).float() * R.float()).sum().item()
+    Lm = (F.AttnCoreFn.apply((x0 - eps * delta).to(torch.bfloat16), None, None, None, H, hd ** -0.5, 0.25, 99).float() * R.float()).sum().item()
+    fd = (Lp - Lm) / (2 * eps)
+    out.append(("attn[fused] dropout fwd/bwd mask consistency (finite difference)", abs(fd - lin) / max(abs(fd), 1e-6), 0.2))
     # gate
     for dtype in (torch.float32, torch.bfloat16):
         tol = tol_for(dtype)

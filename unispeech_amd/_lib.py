@@ -73,6 +73,11 @@ SIGNATURES = {
     "wavlm_attn_softmax_bwd_workspace_bytes": (c_u64, [c_i32, c_i32, c_i32]),
     "wavlm_attn_softmax_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                                        c_i32, c_i64, c_i64, c_i32, c_i32, c_f32, c_u64, c_vp, c_u64, c_vp]),
+    "wavlm_attn_fused_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64,
+                                     c_vp]),
+    "wavlm_attn_fused_bwd_workspace_bytes": (c_u64, [c_i32, c_i32, c_i32]),
+    "wavlm_attn_fused_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                     c_i32, c_f32, c_f32, c_u64, c_vp, c_u64, c_vp]),
     "wavlm_posconv_weight_workspace_bytes": (c_u64, [c_i32, c_i32, c_i32]),
     "wavlm_posconv_weight_fwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_u64,
                                          c_vp]),

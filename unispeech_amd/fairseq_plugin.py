@@ -1,0 +1,76 @@
+"""Registration of the MI355X hot path through fairseq's own plugin decorators.
+
+Use from the reference tree:  `python train.py ... --user-dir /path/to/unispeech_amd --arch wavlm_mi355x
+--criterion wavlm_mi355x` (fairseq imports this package through utils.import_user_module,
+src/fairseq_cli/train.py:53).  The reference refuses duplicate registrations
+(src/fairseq/models/__init__.py:124-125, src/fairseq/registry.py:66-67), so the built-in names `wavlm` / `hubert`
+stay untouched and the HIP implementations register as `*_mi355x`; `register(override=True)` replaces the
+built-ins in fairseq's registries instead, for drop-in use of unmodified recipes.
+
+Registered:
+  models     wavlm_mi355x  (WavLMPretrainModel  <- src/fairseq/models/wavlm/wavlm.py:255  @register_model("wavlm"))
+  criterions wavlm_mi355x, hubert_mi355x  (WavLMCriterion  <- criterions/wavlm_criterion.py:38, hubert_criterion.py:39)
+Tasks (`hubert_pretraining`, `utterance_mixing_pretraining`) are the reference's own: they are the *caller* of this
+path; the sample dict they collate is consumed unchanged.
+
+fairseq (with omegaconf / hydra) is not installed in the build image; importing this module without it raises
+ImportError and nothing else in unispeech_amd depends on it.
+"""
+from dataclasses import dataclass, field, make_dataclass
+from typing import List, Optional
+
+from .pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
+
+_REGISTERED = False
+
+
+def register(override: bool = False):
+    """Call once (importing the package via --user-dir does it).  Returns (model_cls, criterion_cls)."""
+    global _REGISTERED
+    from fairseq.criterions import FairseqCriterion, register_criterion
+    from fairseq.dataclass import FairseqDataclass
+    from fairseq.models import BaseFairseqModel, register_model
+
+    # dataclasses with fairseq's base so that argparse / hydra generation works (dataclass/utils.py)
+    cfg_fields = [(n, f.type, field(default=f.default)) for n, f in WavLMPretrainConfig.__dataclass_fields__.items()]
+    ModelCfg = make_dataclass("WavLMMI355XConfig", cfg_fields, bases=(FairseqDataclass,))
+
+    @dataclass
+    class CritCfg(FairseqDataclass):
+        pred_masked_weight: float = field(default=1.0, metadata={"help": "weight for masked-frame loss"})
+        pred_nomask_weight: float = field(default=0.0, metadata={"help": "weight for unmasked-frame loss"})
+        loss_weights: Optional[List[float]] = field(default=None, metadata={"help": "weights of extra losses"})
+        log_keys: List[str] = field(default_factory=lambda: [], metadata={"help": "output keys to log"})
+
+    class Model(WavLMPretrainModel, BaseFairseqModel):
+        @classmethod
+        def build_model(cls, cfg, task):
+            return cls(cfg, task.cfg, task.dictionaries)
+
+    class Criterion(WavLMCriterion, FairseqCriterion):
+        def __init__(self, task, pred_masked_weight, pred_nomask_weight, loss_weights=None, log_keys=None):
+            WavLMCriterion.__init__(self, task, pred_masked_weight, pred_nomask_weight, loss_weights, log_keys)
+
+        @staticmethod
+        def reduce_metrics(logging_outputs) -> None:
+            from fairseq import metrics
+            WavLMCriterion.reduce_metrics(logging_outputs, log_scalar=lambda k, v: metrics.log_scalar(k, v, round=3))
+
+    if _REGISTERED:
+        return Model, Criterion
+    if override:
+        from fairseq.criterions import CRITERION_DATACLASS_REGISTRY, CRITERION_REGISTRY  # noqa: F401
+        from fairseq.models import ARCH_MODEL_REGISTRY, MODEL_DATACLASS_REGISTRY, MODEL_REGISTRY
+        for name in ("wavlm",):
+            MODEL_REGISTRY[name] = Model
+            ARCH_MODEL_REGISTRY[name] = Model
+            MODEL_DATACLASS_REGISTRY[name] = ModelCfg
+        for name in ("wavlm", "hubert"):
+            CRITERION_REGISTRY[name] = Criterion
+            CRITERION_DATACLASS_REGISTRY[name] = CritCfg
+    else:
+        register_model("wavlm_mi355x", dataclass=ModelCfg)(Model)
+        register_criterion("wavlm_mi355x", dataclass=CritCfg)(Criterion)
+        register_criterion("hubert_mi355x", dataclass=CritCfg)(type("HubertCriterionMI355X", (Criterion,), {}))
+    _REGISTERED = True
+    return Model, Criterion

@@ -10,6 +10,7 @@ import torch
 from . import ops
 
 _SEED_CTR = [0]
+USE_FUSED_ATTENTION = True  # bf16 + head_dim 64 -> fused kernels; otherwise GEMM + softmax-row-kernel composition
 
 
 def next_seed():
@@ -374,6 +375,12 @@ class AttnCoreFn(torch.autograd.Function):
         hd = D // H
         dev = qkv.device
         qkvc = qkv.contiguous()
+        ctx.fused = USE_FUSED_ATTENTION and qkv.dtype == torch.bfloat16 and hd == 64
+        if ctx.fused:
+            O, lse = ops.attn_fused_fwd(qkvc, gate, tab, kpm, H, scale, p_drop, seed)
+            ctx.save_for_backward(qkvc, O, lse, gate, tab, kpm)
+            ctx.cfg = (B, T, D, H, hd, 0, scale, p_drop, seed)
+            return O
         ld = _rup(T, 8)
         S = torch.empty((B * H, T, ld), dtype=torch.float32, device=dev)
         ops.gemm(qkvc, qkvc, S, T, T, hd, lda=D3, ldb=D3, ldc=ld, batch=(B, H), sA=(T * D3, hd), sB=(T * D3, hd),
@@ -390,6 +397,11 @@ class AttnCoreFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dO):
+        if ctx.fused:
+            qkvc, O, lse, gate, tab, kpm = ctx.saved_tensors
+            B, T, D, H, hd, _, scale, p_drop, seed = ctx.cfg
+            dqkv, dgate, dtab = ops.attn_fused_bwd(qkvc, O, dO.contiguous(), lse, gate, tab, kpm, H, scale, p_drop, seed)
+            return dqkv, dgate, dtab, None, None, None, None, None
         qkvc, S, P, lse, gate, tab, kpm = ctx.saved_tensors
         B, T, D, H, hd, ld, scale, p_drop, seed = ctx.cfg
         D3 = 3 * D

@@ -322,6 +322,37 @@ def attn_softmax_bwd(S, dP, lse, gate, tab, kpm, dS, dgate, dtab, B, H, T, ldS, 
                                    need, stream()), "wavlm_attn_softmax_bwd")
 
 
+def attn_fused_fwd(qkv, gate, tab, kpm, H, scale, p_drop, seed):
+    """fused bf16 attention forward (head_dim 64): returns (O [B,T,D], lse [B*H,T])"""
+    dev = _dev(qkv); _contig(qkv)
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    O = torch.empty((B, T, D), dtype=qkv.dtype, device=dev)
+    lse = torch.empty((B * H, T), dtype=torch.float32, device=dev)
+    check(_lib.lib().wavlm_attn_fused_fwd(ptr(qkv), ptr(O), ptr(lse), ptr(gate), ptr(tab), ptr(kpm), B, H, T, D // H,
+                                          float(scale), float(p_drop), int(seed), stream()), "wavlm_attn_fused_fwd")
+    return O, lse
+
+
+def attn_fused_bwd(qkv, O, dO, lse, gate, tab, kpm, H, scale, p_drop, seed):
+    """returns (dqkv, dgate, dtab)"""
+    dev = _dev(qkv); _contig(dO)
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    dqkv = torch.empty_like(qkv)
+    dgate = dtab = None
+    if tab is not None:
+        dgate = torch.empty((B, H, T), dtype=torch.float32, device=dev)
+        dtab = torch.empty_like(tab)
+    L = _lib.lib()
+    need = L.wavlm_attn_fused_bwd_workspace_bytes(B, H, T)
+    ws = workspace(dev, need, "attn")
+    check(L.wavlm_attn_fused_bwd(ptr(qkv), ptr(O), ptr(dO), ptr(lse), ptr(gate), ptr(tab), ptr(kpm), ptr(dqkv),
+                                 ptr(dgate), ptr(dtab), B, H, T, D // H, float(scale), float(p_drop), int(seed),
+                                 ptr(ws), need, stream()), "wavlm_attn_fused_bwd")
+    return dqkv, dgate, dtab
+
+
 # ------------------------------------------------------------------------------------------ pos_conv
 def posconv_weight_fwd(v, g, out_dtype):
     dev = _dev(v); _contig(v)
