@@ -33,8 +33,8 @@ __device__ __forceinline__ void sm_store4(void* p, long off, int dt, const float
     *reinterpret_cast<float4*>((float*)p + off) = make_float4(v[0], v[1], v[2], v[3]);
   } else {
     uint2 o;
-    o.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>((bf16_t*)p + off) = o;
   }
 }
@@ -220,7 +220,9 @@ __global__ __launch_bounds__(64) void relpos_scatter_kernel(const float* __restr
 }
 
 // ---- gate: g[b,h,t] = ga * (gb * a[h] - 1) + 2, (ga, gb) = sigmoid of the two 4-row sums of grep_linear(x_h) -----
-// WavLM/modules.py:523-533.  One wave per (b, t); lanes stride over the head's channels.
+// WavLM/modules.py:523-533.  One wave per (b, t); lane c (+64) owns channel c of every head, so the summed weight
+// rows wa = sum_{k<4} W[k], wb = sum_{k>=4} W[k] and (backward) their gradient accumulators stay in registers.
+#define GATE_NC 2  // head_dim up to 128
 template <typename T, typename TP>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ x, const TP* __restrict__ W,
     const TP* __restrict__ bias, const TP* __restrict__ grep_a, float* __restrict__ gate, float* __restrict__ ga_o,
@@ -230,16 +232,25 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ x, 
   const int D = H * hd;
   float ba = 0.f, bb = 0.f;
   for (int k = 0; k < 4; ++k) { ba += Elem<TP>::ld(bias + k); bb += Elem<TP>::ld(bias + 4 + k); }
+  float wa[GATE_NC], wb[GATE_NC];
+#pragma unroll
+  for (int q = 0; q < GATE_NC; ++q) {
+    const int c = lane + 64 * q;
+    wa[q] = 0.f; wb[q] = 0.f;
+    if (c < hd)
+      for (int k = 0; k < 4; ++k) { wa[q] += Elem<TP>::ld(W + k * hd + c); wb[q] += Elem<TP>::ld(W + (4 + k) * hd + c); }
+  }
   for (long bt = (long)blockIdx.x * 4 + wave; bt < nbt; bt += (long)gridDim.x * 4) {
     const long b = bt / Tn; const int t = (int)(bt - b * Tn);
     for (int h = 0; h < H; ++h) {
       float sa = 0.f, sb = 0.f;
-      for (int c = lane; c < hd; c += 64) {
-        const float xv = Elem<T>::ld(x + bt * D + h * hd + c);
-        float wa = 0.f, wb = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { wa += Elem<TP>::ld(W + k * hd + c); wb += Elem<TP>::ld(W + (4 + k) * hd + c); }
-        sa += xv * wa; sb += xv * wb;
+      for (int q = 0; q < GATE_NC; ++q) {
+        const int c = lane + 64 * q;
+        if (c < hd) {
+          const float xv = Elem<T>::ld(x + bt * D + h * hd + c);
+          sa = fmaf(xv, wa[q], sa); sb = fmaf(xv, wb[q], sb);
+        }
       }
       sa = wave_sum(sa) + ba; sb = wave_sum(sb) + bb;
       const float ga = 1.f / (1.f + __expf(-sa)), gb = 1.f / (1.f + __expf(-sb));
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ x, 
   }
 }
 
-#define GATE_BLOCKS 256
+#define GATE_BLOCKS 512
 // partial layout per block: [2*hd (dWa, dWb)] [2 (dba, dbb)] [H (da)]
 template <typename T, typename TP>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dgate, const T* __restrict__ x,
@@ -263,10 +274,15 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   const long nbt = (long)B * Tn;
   const int D = H * hd;
   const int PW = 2 * hd + 2 + H;
-  float* mine = sm + wave * PW;
-  for (int i = lane; i < PW; i += 64) mine[i] = 0.f;
-  // per-wave accumulators live in LDS (hd may exceed 64); each lane owns channels lane, lane+64, ...
-  float dba = 0.f, dbb = 0.f;
+  float wa[GATE_NC], wb[GATE_NC], dwa[GATE_NC], dwb[GATE_NC];
+#pragma unroll
+  for (int q = 0; q < GATE_NC; ++q) {
+    const int c = lane + 64 * q;
+    wa[q] = 0.f; wb[q] = 0.f; dwa[q] = 0.f; dwb[q] = 0.f;
+    if (c < hd)
+      for (int k = 0; k < 4; ++k) { wa[q] += Elem<TP>::ld(W + k * hd + c); wb[q] += Elem<TP>::ld(W + (4 + k) * hd + c); }
+  }
+  float dba = 0.f, dbb = 0.f, da = 0.f;  // da: lane h accumulates head h (H <= 64)
   for (long bt = (long)blockIdx.x * 4 + wave; bt < nbt; bt += (long)gridDim.x * 4) {
     const long b = bt / Tn; const int t = (int)(bt - b * Tn);
     for (int h = 0; h < H; ++h) {
@@ -275,36 +291,54 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       const float a = Elem<TP>::ld(grep_a + h);
       const float dsa = dg * (gb * a - 1.f) * ga * (1.f - ga);
       const float dsb = dg * ga * a * gb * (1.f - gb);
-      if (lane == 0) mine[2 * hd + 2 + h] += dg * ga * gb;
+      if (lane == h) da += dg * ga * gb;
       dba += dsa; dbb += dsb;
-      for (int c = lane; c < hd; c += 64) {
-        const float xv = Elem<T>::ld(x + bt * D + h * hd + c);
-        float wa = 0.f, wb = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { wa += Elem<TP>::ld(W + k * hd + c); wb += Elem<TP>::ld(W + (4 + k) * hd + c); }
-        Elem<T>::st(dx + bt * D + h * hd + c, dsa * wa + dsb * wb);
-        mine[c] += dsa * xv;
-        mine[hd + c] += dsb * xv;
+      for (int q = 0; q < GATE_NC; ++q) {
+        const int c = lane + 64 * q;
+        if (c < hd) {
+          const float xv = Elem<T>::ld(x + bt * D + h * hd + c);
+          Elem<T>::st(dx + bt * D + h * hd + c, dsa * wa[q] + dsb * wb[q]);
+          dwa[q] = fmaf(dsa, xv, dwa[q]);
+          dwb[q] = fmaf(dsb, xv, dwb[q]);
+        }
       }
     }
   }
+  float* mine = sm + wave * PW;
+#pragma unroll
+  for (int q = 0; q < GATE_NC; ++q) {
+    const int c = lane + 64 * q;
+    if (c < hd) { mine[c] = dwa[q]; mine[hd + c] = dwb[q]; }
+  }
   if (lane == 0) { mine[2 * hd] = dba; mine[2 * hd + 1] = dbb; }
+  if (lane < H) mine[2 * hd + 2 + lane] = da;
   __syncthreads();
   float* out = part + (long)blockIdx.x * PW;
   for (int i = threadIdx.x; i < PW; i += 256) out[i] = sm[i] + sm[PW + i] + sm[2 * PW + i] + sm[3 * PW + i];
 }
-// dW[8][hd], dbias[8], dgrep_a[H] from the block partials
-__global__ __launch_bounds__(256) void gate_bwd_finish_kernel(const float* __restrict__ part, int nblk, int H, int hd,
+// dW[8][hd], dbias[8], dgrep_a[H] from the block partials (256 outputs x 4 slices per pass)
+__global__ __launch_bounds__(1024) void gate_bwd_finish_kernel(const float* __restrict__ part, int nblk, int H, int hd,
     void* dW, void* dbias, void* da, int pdt) {
+  __shared__ float red[4][256];
   const int PW = 2 * hd + 2 + H;
-  for (int i = threadIdx.x; i < PW; i += 256) {
+  const int col = threadIdx.x & 255, slice = threadIdx.x >> 8;
+  for (int i0 = 0; i0 < PW; i0 += 256) {
+    const int i = i0 + col;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * PW + i];
-    if (i < hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)k * hd + i, pdt, s); }
-    else if (i < 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)(4 + k) * hd + (i - hd), pdt, s); }
-    else if (i == 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dbias, k, pdt, s); }
-    else if (i == 2 * hd + 1) { for (int k = 0; k < 4; ++k) st_elem(dbias, 4 + k, pdt, s); }
-    else st_elem(da, i - (2 * hd + 2), pdt, s);
+    if (i < PW)
+      for (int b = slice; b < nblk; b += 4) s += part[(long)b * PW + i];
+    red[slice][col] = s;
+    __syncthreads();
+    if (slice == 0 && i < PW) {
+      s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+      if (i < hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)k * hd + i, pdt, s); }
+      else if (i < 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)(4 + k) * hd + (i - hd), pdt, s); }
+      else if (i == 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dbias, k, pdt, s); }
+      else if (i == 2 * hd + 1) { for (int k = 0; k < 4; ++k) st_elem(dbias, 4 + k, pdt, s); }
+      else st_elem(da, i - (2 * hd + 2), pdt, s);
+    }
+    __syncthreads();
   }
 }
 
@@ -377,7 +411,7 @@ int wavlm_relpos_scatter(const float* dtab, const int32_t* bucket, void* demb, i
 
 int wavlm_gate_fwd(const void* x, const void* W, const void* bias, const void* grep_a, float* gate, float* ga, float* gb,
                    int32_t B, int32_t T, int32_t H, int32_t hd, int32_t dtype, int32_t param_dtype, void* stream) {
-  if (!x || !W || !bias || !grep_a || !gate || !ga || !gb || B <= 0 || T <= 0 || H <= 0 || hd <= 0) return WL_EINVAL;
+  if (!x || !W || !bias || !grep_a || !gate || !ga || !gb || B <= 0 || T <= 0 || H <= 0 || hd <= 0 || hd > 64 * GATE_NC) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   long grid = ((long)B * T + 3) / 4; if (grid > 8192) grid = 8192;
 #define GF(TT, TP) WL_LAUNCH((gate_fwd_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), 0, st, (const TT*)x, \
@@ -398,7 +432,7 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
                    const float* gb, void* dx, void* dW, void* dbias, void* dgrep_a, int32_t B, int32_t T, int32_t H,
                    int32_t hd, int32_t dtype, int32_t param_dtype, void* workspace, uint64_t ws_bytes, void* stream) {
   if (!dgate || !x || !W || !grep_a || !ga || !gb || !dx || !dW || !dbias || !dgrep_a || !workspace) return WL_EINVAL;
-  if (B <= 0 || T <= 0 || H <= 0 || hd <= 0 || ws_bytes < wavlm_gate_bwd_workspace_bytes(H, hd)) return WL_EINVAL;
+  if (B <= 0 || T <= 0 || H <= 0 || H > 64 || hd <= 0 || hd > 64 * GATE_NC || ws_bytes < wavlm_gate_bwd_workspace_bytes(H, hd)) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   long grid = ((long)B * T + 3) / 4; if (grid > GATE_BLOCKS) grid = GATE_BLOCKS;
   const size_t smem = 4 * (2 * (size_t)hd + 2 + H) * sizeof(float);
@@ -411,7 +445,7 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
 #undef GB
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  WL_LAUNCH(gate_bwd_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)grid, (int)H,
+  WL_LAUNCH(gate_bwd_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace, (int)grid, (int)H,
                      (int)hd, dW, dbias, dgrep_a, (int)param_dtype);
   return wl_check_launch();
 }

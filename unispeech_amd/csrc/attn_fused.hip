@@ -34,7 +34,7 @@ __device__ __forceinline__ bool fa_keep(unsigned s0, unsigned s1, unsigned idx, 
   return x >= thresh;
 }
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return pack_bf16x2(a, b); }
 
 // A-operand fragment for a contraction over the tile's 64 "k" positions stored along LDS rows ([rows][64 k]):
 // k-slot (hi, e) of k-step (f, s) <-> position 32f + 16s + 4hi + (e&3) + 8(e>>2)
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(FaP p) {
 
 // ------------------------------------------------------------------------------- backward 1/2: dQ, dgate, drel
 // Same decomposition as the forward (lane owns a query row).  Also writes delta[i] = <dO_i, O_i> for kernel 2/2.
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(FaP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per stage: K [kv][hd] 8 KB | V [kv][hd] 8 KB | K^T [hd][kv] 8 KB
   auto kbuf = [&](int st) { return smem + st * 24576; };
@@ -269,20 +269,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(FaP p) {
       glds_tile64(base + 2 * D, D3, j0 + FA_BKV, T, vbuf(cur ^ 1), wave_u);
       load_ks<64>(base + D + (long)(j0 + FA_BKV) * D3, D3, 64, T - j0 - FA_BKV, kr);
     }
-    f32x16_t s[2], dp[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
+      // one 32-key block at a time keeps only one (S, dP) accumulator pair live
+      U4 dsf[2];
+      f32x16_t s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[f][r] = 0.f; dp[f][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s[f], 0, 0, 0);
-        dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(vbuf(cur), 32 * f + ql, kk, hi), dof[kk].b, dp[f], 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(vbuf(cur), 32 * f + ql, kk, hi), dof[kk].b, dp, 0, 0, 0);
       }
-    }
-    U4 dsf[2][2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         float dv[2];
@@ -291,28 +289,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(FaP p) {
           const int rr = r + e;
           const int j = j0 + 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
           const float tv = tabs[j - ic + T - 1];
-          const float x = s[f][rr] * p.scale + g * tv + kb[j];
+          const float x = s[rr] * p.scale + g * tv + kb[j];
           const float pe = __expf(x - lse_i);  // 0 for masked keys (x = -inf) and for rows past T (lse = +inf)
-          float dpe = dp[f][rr];
+          float dpe = dp[rr];
           if (p.th) dpe = fa_keep(p.s0, p.s1, (unsigned)(((long)bh * T + ic) * T + j), p.th) ? dpe * p.sc : 0.f;
           const float ds = pe * (dpe - dl);
           dv[e] = ds;
-          if (p.tab && ds != 0.f) {
-            dg += ds * tv;
-            atomicAdd(&diag[j - ic + T - 1], g * ds);
+          if (p.tab) {
+            dg = fmaf(ds, tv, dg);
+            if (ds != 0.f) atomicAdd(&diag[j - ic + T - 1], g * ds);
           }
         }
-        dsf[f][r >> 3].u[(r & 7) >> 1] = pack_bf16(dv[0], dv[1]);
+        dsf[r >> 3].u[(r & 7) >> 1] = pack_bf16(dv[0], dv[1]);
       }
-    // dQ^T += K^T dS^T
+      // dQ^T += K^T dS^T (this 32-key block)
 #pragma unroll
-    for (int f2 = 0; f2 < 2; ++f2)
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int f2 = 0; f2 < 2; ++f2)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
-          dq[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_perm(ktbuf(cur), 32 * f2 + ql, f, s2, hi), dsf[f][s2].b,
+          dq[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_perm(ktbuf(cur), 32 * f2 + ql, f, s2, hi), dsf[s2].b,
                                                            dq[f2], 0, 0, 0);
+    }
     if (more) store_ks<64>(ktbuf(cur ^ 1), kr);
     __syncthreads();
     cur ^= 1;
@@ -343,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(FaP p) {
 // ------------------------------------------------------------------------------------ backward 2/2: dK, dV
 // Lane owns a KEY column; scores are in the untransposed layout S[q][kv] so that the query contraction of
 // dV^T = dO^T P and dK^T = Q^T dS finds its k-slots in the lane's registers.
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(FaP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per stage: Q [q][hd] | dO [q][hd] | Q^T [hd][q] | dO^T [hd][q], 8 KB each
   auto qbuf = [&](int st) { return smem + st * 32768; };
@@ -415,20 +412,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(FaP p) {
     }
     const float* rv = rowv + cur * 192;
     // S = Q K^T, dP = dO V^T  (rows = queries of the tile, col = this lane's key)
-    f32x16_t s[2], dp[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
+      U4 pf[2], dsf[2];
+      f32x16_t s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[f][r] = 0.f; dp[f][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(qbuf(cur), 32 * f + kl, kk, hi), kf[kk].b, s[f], 0, 0, 0);
-        dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(dobuf(cur), 32 * f + kl, kk, hi), vf[kk].b, dp[f], 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(qbuf(cur), 32 * f + kl, kk, hi), kf[kk].b, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(dobuf(cur), 32 * f + kl, kk, hi), vf[kk].b, dp, 0, 0, 0);
       }
-    }
-    U4 pf[2][2], dsf[2][2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         float pv[2], dsv[2];
@@ -437,9 +431,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(FaP p) {
           const int rr = r + e;
           const int il = 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;  // query row within the tile
           int ii = iq0 + il; if (ii > T - 1) ii = T - 1;
-          const float x = s[f][rr] * p.scale + rv[128 + il] * tabs[jc - ii + T - 1];
+          const float x = s[rr] * p.scale + rv[128 + il] * tabs[jc - ii + T - 1];
           float pe = key_ok ? __expf(x - rv[il]) : 0.f;  // rows past T: lse = +inf -> 0
-          float dpe = dp[f][rr];
+          float dpe = dp[rr];
           float pd = pe;
           if (p.th) {
             const bool kp = fa_keep(p.s0, p.s1, (unsigned)(((long)bh * T + ii) * T + jc), p.th);
@@ -449,21 +443,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(FaP p) {
           pv[e] = pd;
           dsv[e] = pe * (dpe - rv[64 + il]);
         }
-        pf[f][r >> 3].u[(r & 7) >> 1] = pack_bf16(pv[0], pv[1]);
-        dsf[f][r >> 3].u[(r & 7) >> 1] = pack_bf16(dsv[0], dsv[1]);
+        pf[r >> 3].u[(r & 7) >> 1] = pack_bf16(pv[0], pv[1]);
+        dsf[r >> 3].u[(r & 7) >> 1] = pack_bf16(dsv[0], dsv[1]);
       }
-    // dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the tile's queries)
+      // dV^T += dO^T P ; dK^T += Q^T dS   (contraction over this 32-query block)
 #pragma unroll
-    for (int f2 = 0; f2 < 2; ++f2)
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int f2 = 0; f2 < 2; ++f2)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          dv[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_perm(dotbuf(cur), 32 * f2 + kl, f, s2, hi), pf[f][s2].b,
+          dv[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_perm(dotbuf(cur), 32 * f2 + kl, f, s2, hi), pf[s2].b,
                                                            dv[f2], 0, 0, 0);
-          dk[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_perm(qtbuf(cur), 32 * f2 + kl, f, s2, hi), dsf[f][s2].b,
+          dk[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_perm(qtbuf(cur), 32 * f2 + kl, f, s2, hi), dsf[s2].b,
                                                            dk[f2], 0, 0, 0);
         }
+    }
     if (more) {
       store_ks<64>(qtbuf(cur ^ 1), qr);
       store_ks<64>(dotbuf(cur ^ 1), dor);

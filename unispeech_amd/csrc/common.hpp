@@ -17,12 +17,17 @@ typedef unsigned short bf16_t;  // raw bf16 bits
 __device__ __forceinline__ float bf2f(bf16_t v) {
   return __uint_as_float(((unsigned)v) << 16);
 }
-// round-to-nearest-even, NaN preserved (quiet)
+// fp32 -> bf16, round-to-nearest-even: gfx950 has v_cvt_pk_bf16_f32; a C++ conversion to __bf16 selects it
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+// two fp32 -> packed bf16x2 (a in the low half): one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 // typed scalar access by runtime dtype (0 = f32, 1 = bf16)

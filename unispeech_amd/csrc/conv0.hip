@@ -36,8 +36,8 @@ template <> __device__ __forceinline__ void V8<bf16_t>::ld(const bf16_t* p, floa
 }
 template <> __device__ __forceinline__ void V8<bf16_t>::st(bf16_t* p, const float (&v)[8]) {
   uint4 o;
-  o.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-  o.z = f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); o.w = f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+  o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+  o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
   *reinterpret_cast<uint4*>(p) = o;
 }
 

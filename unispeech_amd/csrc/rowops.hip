@@ -25,8 +25,8 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
   uint4 o;
-  o.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-  o.z = f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16); o.w = f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+  o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+  o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
   *reinterpret_cast<uint4*>(p) = o;
 }
 // 8 keep-bits for elements idx .. idx+7 (idx % 8 == 0): two Philox calls
@@ -211,20 +211,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// out[c] (+)= sum_b part[b * stride + c].  Block = 64 columns x 4 row slices (coalesced 256-B reads per slice),
-// slices combined through LDS; grid = ceil(n / 64).
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nblk, long stride, int n,
-                                                             void* out, int out_dtype, int accumulate) {
-  __shared__ float red[4][64];
+// out[c] (+)= sum_b part[b * stride + c].  Block = 64 columns x 16 row slices (coalesced 256-B reads per slice, short
+// dependent-load chains), slices combined through LDS; grid = ceil(n / 64).
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int nblk, long stride, int n,
+                                                              void* out, int out_dtype, int accumulate) {
+  __shared__ float red[16][64];
   const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + col;
   float s = 0.f;
   if (c < n)
-    for (int b = slice; b < nblk; b += 4) s += part[(long)b * stride + c];
+    for (int b = slice; b < nblk; b += 16) s += part[(long)b * stride + c];
   red[slice][col] = s;
   __syncthreads();
   if (slice == 0 && c < n) {
-    s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][col];
     if (accumulate) s += ld_elem(out, c, out_dtype);
     st_elem(out, c, out_dtype, s);
   }
@@ -430,9 +432,9 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   const unsigned g2 = (unsigned)((D + 63) / 64);
-  WL_LAUNCH(colsum_finish_kernel, dim3(g2), dim3(256), 0, st, part, (int)grid, (long)(2 * D), (int)D, dgamma,
+  WL_LAUNCH(colsum_finish_kernel, dim3(g2), dim3(1024), 0, st, part, (int)grid, (long)(2 * D), (int)D, dgamma,
                      (int)param_dtype, (int)accumulate_params);
-  WL_LAUNCH(colsum_finish_kernel, dim3(g2), dim3(256), 0, st, part + D, (int)grid, (long)(2 * D), (int)D, dbeta,
+  WL_LAUNCH(colsum_finish_kernel, dim3(g2), dim3(1024), 0, st, part + D, (int)grid, (long)(2 * D), (int)D, dbeta,
                      (int)param_dtype, (int)accumulate_params);
   return wl_check_launch();
 }
@@ -456,7 +458,7 @@ int wavlm_colsum(const void* x, int64_t rows, int32_t N, int64_t ld, int32_t dty
   else return WL_EINVAL;
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, part, (int)grid, (long)N,
+  WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, part, (int)grid, (long)N,
                      (int)N, out, (int)out_dtype, (int)accumulate);
   return wl_check_launch();
 }
