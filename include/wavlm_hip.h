@@ -207,6 +207,8 @@ int wavlm_adam_step(float* p, float* m, float* v, const void* grad, int32_t grad
  * Measurement aid (bench.py roofline leg): HIP events around every wavlm_gemm launch while enabled.
  * ------------------------------------------------------------------------------------------ */
 void wavlm_prof_enable(int on);
+/* 0: automatic tile choice, 1: force the 128x128 tile (A/B measurements only) */
+void wavlm_gemm_set_variant(int v);
 int wavlm_prof_collect(int dtype, double* total_ms, double* total_flops);
 
 #ifdef __cplusplus

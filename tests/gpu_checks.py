@@ -49,6 +49,29 @@ def q(t, dtype):
 # ------------------------------------------------------------------------------------------------------ GEMM
 def check_gemm():
     out = []
+    # the 256x128 / 8-wave tile, forced, on ragged sizes in all four layouts (+ split-K)
+    ops.gemm_set_variant(2)
+    try:
+        dtype, tol = torch.bfloat16, TOLBF
+        for (M, N, K, tA, tB) in [(700, 200, 264, 0, 0), (513, 136, 749, 0, 1), (300, 260, 200, 1, 0), (258, 130, 333, 1, 1)]:
+            Kp, Mp, Np = (K + 7) // 8 * 8, (M + 7) // 8 * 8, (N + 7) // 8 * 8
+            A, B = q(gen(M, K, seed=21), dtype), q(gen(N, K, seed=22), dtype)
+            ref = A.double() @ B.double().t()
+            if tA:
+                Ad = torch.zeros(K, Mp); Ad[:, :M] = A.t(); lda = Mp
+            else:
+                Ad = torch.full((M, Kp), float("nan")); Ad[:, :K] = A; lda = Kp
+            if tB:
+                Bd = torch.zeros(K, Np); Bd[:, :N] = B.t(); ldb = Np
+            else:
+                Bd = torch.full((N, Kp), float("nan")); Bd[:, :K] = B; ldb = Kp
+            Ad, Bd = Ad.to(dtype).to(DEV), Bd.to(dtype).to(DEV)
+            for split in (1, 3):
+                C = torch.full((M, Np), float("nan"), dtype=dtype, device=DEV)
+                ops.gemm(Ad, Bd, C, M, N, K, lda=lda, ldb=ldb, ldc=Np, transA=tA, transB=tB, split_k=split)
+                out.append((f"gemm256[{dtype}] {M}x{N}x{K} tA={tA} tB={tB} split={split}", err(C[:, :N], ref), tol))
+    finally:
+        ops.gemm_set_variant(0)
     for dtype in (torch.float32, torch.bfloat16):
         tol = tol_for(dtype)
         for (M, N, K, tA, tB) in [(200, 136, 72, 0, 0), (129, 64, 264, 0, 1), (260, 130, 200, 1, 0), (77, 48, 333, 1, 1),

@@ -85,4 +85,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    for v in (1, 0):
+        print("==== tile variant", "128x128 forced" if v == 1 else "auto (256x128 on large problems)")
+        ops.gemm_set_variant(v)
+        main()

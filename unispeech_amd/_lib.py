@@ -93,6 +93,7 @@ SIGNATURES = {
     "wavlm_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
                                 c_i64, c_f32, c_vp, c_vp, c_f32, c_vp]),
     "wavlm_prof_enable": (None, [c_i32]),
+    "wavlm_gemm_set_variant": (None, [c_i32]),
     "wavlm_prof_collect": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

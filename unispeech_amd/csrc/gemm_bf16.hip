@@ -20,11 +20,12 @@
 #include "tile_loaders.hpp"
 
 template <bool TA, bool TB, int BM, int BN, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmP p) {
   constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
-  static_assert(WM * WN == 4 && FM >= 1 && FN >= 1, "4 waves");
+  constexpr int NT = WM * WN * 64;
+  static_assert((WM * WN == 4 || WM * WN == 8) && FM >= 1 && FN >= 1, "4 or 8 waves");
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 * (A_BYTES + B_BYTES)
 
   // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (private L2 per XCD); remap so each XCD walks
   // a contiguous range of tiles (neighbours share the A row panel and all of B).  Pure speed, any placement is valid.
@@ -56,8 +57,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Operand<TA, BM> oa;
-  Operand<TB, BN> ob;
+  Operand<TA, BM, NT> oa;
+  Operand<TB, BN, NT> ob;
   oa.init(Ab + (TA ? (long)m0 : (long)m0 * p.lda), p.lda, p.M - m0);
   ob.init(Bb + (TB ? (long)n0 : (long)n0 * p.ldb), p.ldb, p.N - n0);
   auto issue = [&](int t, unsigned char* buf) {
@@ -179,14 +180,34 @@ static int launch_cfg(GemmP& p, int nbatch, bool vec, hipStream_t st) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)nbatch, (unsigned)p.split_k);
-  if (vec) WL_LAUNCH((gemm_bf16_kernel<TA, TB, BM, BN, WM, WN, true>), grid, dim3(256), 0, st, p);
-  else WL_LAUNCH((gemm_bf16_kernel<TA, TB, BM, BN, WM, WN, false>), grid, dim3(256), 0, st, p);
+  constexpr size_t smem = 2 * (size_t)(BM + BN) * 128;
+  constexpr int nt = WM * WN * 64;
+  if (smem > 65536) {  // opt in to > 64 KiB of dynamic LDS once per instantiation
+    static bool done_v = false, done_s = false;
+    bool& done = vec ? done_v : done_s;
+    if (!done) {
+      const void* fn = vec ? (const void*)gemm_bf16_kernel<TA, TB, BM, BN, WM, WN, true>
+                           : (const void*)gemm_bf16_kernel<TA, TB, BM, BN, WM, WN, false>;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return WL_ELAUNCH;
+      done = true;
+    }
+  }
+  if (vec) WL_LAUNCH((gemm_bf16_kernel<TA, TB, BM, BN, WM, WN, true>), grid, dim3(nt), smem, st, p);
+  else WL_LAUNCH((gemm_bf16_kernel<TA, TB, BM, BN, WM, WN, false>), grid, dim3(nt), smem, st, p);
   return wl_check_launch();
 }
+
+static int g_gemm_variant = 0;  // 0: auto, 1: force 128x128, 2: force 256x128 (tests, tools/gemm_bench.py A/B)
+extern "C" void wavlm_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 template <bool TA, bool TB>
 static int launch_t(GemmP& p, int nbatch, bool vec, hipStream_t st) {
   if (p.N <= 64) return launch_cfg<TA, TB, 128, 64, 2, 2>(p, nbatch, vec, st);
+  // large problems: 256 x 128 tile, 8 waves (4 x 2), 96 KiB of LDS, one block per CU -- 2/3 of the operand bytes per
+  // flop of the 128 x 128 tile and twice the MFMA work between barriers
+  if (g_gemm_variant == 2 ||
+      (g_gemm_variant == 0 && p.M >= 2048 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * nbatch * p.split_k >= 192))
+    return launch_cfg<TA, TB, 256, 128, 4, 2>(p, nbatch, vec, st);
   return launch_cfg<TA, TB, 128, 128, 2, 2>(p, nbatch, vec, st);
 }
 

@@ -16,14 +16,14 @@ __device__ __forceinline__ unsigned lds_off(int row, int chunk) {
 }
 
 // ---- K-contiguous operand: tile [ROWS][64], global row stride ld --------------------------------
-template <int ROWS>
+template <int ROWS, int NT = 256>
 __device__ __forceinline__ void load_kc(const bf16_t* __restrict__ base, long ld, int rows_valid, int k_valid,
-                                        uint4 (&r)[ROWS / 32]) {
+                                        uint4 (&r)[ROWS / (NT / 8)]) {
   const int t = threadIdx.x;
   const int row = t >> 3, kk = (t & 7) * 8;
 #pragma unroll
-  for (int ps = 0; ps < ROWS / 32; ++ps) {
-    const int rr = row + ps * 32;
+  for (int ps = 0; ps < ROWS / (NT / 8); ++ps) {
+    const int rr = row + ps * (NT / 8);
     uint4 v = make_uint4(0, 0, 0, 0);
     if (rr < rows_valid) {
       const bf16_t* src = base + (long)rr * ld + kk;
@@ -40,22 +40,22 @@ __device__ __forceinline__ void load_kc(const bf16_t* __restrict__ base, long ld
     r[ps] = v;
   }
 }
-template <int ROWS>
-__device__ __forceinline__ void store_kc(unsigned char* lds, const uint4 (&r)[ROWS / 32]) {
+template <int ROWS, int NT = 256>
+__device__ __forceinline__ void store_kc(unsigned char* lds, const uint4 (&r)[ROWS / (NT / 8)]) {
   const int t = threadIdx.x;
   const int row = t >> 3, ch = t & 7;
 #pragma unroll
-  for (int ps = 0; ps < ROWS / 32; ++ps) {
-    const int rr = row + ps * 32;
+  for (int ps = 0; ps < ROWS / (NT / 8); ++ps) {
+    const int rr = row + ps * (NT / 8);
     *reinterpret_cast<uint4*>(lds + lds_off(rr, ch)) = r[ps];
   }
 }
 
 // ---- K-strided operand: global tile [64 k][ROWS] (rows contiguous), stride ld between k ---------
-template <int ROWS>
+template <int ROWS, int NT = 256>
 __device__ __forceinline__ void load_ks(const bf16_t* __restrict__ base, long ld, int rows_valid, int k_valid,
                                         uint4 (&r)[4]) {
-  static_assert(ROWS <= 128, "one pass covers at most 128 rows");
+  static_assert(ROWS <= NT / 2, "one pass covers at most NT/2 rows");
   const int t = threadIdx.x;
   const int kb4 = t & 15, nb = (t >> 6) * 4 + ((t >> 4) & 3);
   const int n = nb * 8;
@@ -78,7 +78,7 @@ __device__ __forceinline__ void load_ks(const bf16_t* __restrict__ base, long ld
     r[i] = v;
   }
 }
-template <int ROWS>
+template <int ROWS, int NT = 256>
 __device__ __forceinline__ void store_ks(unsigned char* lds, const uint4 (&r)[4]) {
   const int t = threadIdx.x;
   const int kb4 = t & 15, nb = (t >> 6) * 4 + ((t >> 4) & 3);
@@ -114,8 +114,9 @@ typedef __attribute__((address_space(3))) void* las_ptr;
 //       address); rows past the edge are clamped to the last valid row (they only feed outputs never stored).
 //   K-contiguous, K-tail tile         : register path with zero fill beyond K.
 //   K-strided                         : 4 x 16-B loads -> in-register 4x8 transpose -> ds_write_b64.
-template <bool TR, int ROWS> struct Operand {
-  static constexpr int NP = TR ? 4 : ROWS / 32;
+template <bool TR, int ROWS, int NT = 256> struct Operand {
+  static constexpr int RP = NT / 8;  // rows per K-contiguous pass
+  static constexpr int NP = TR ? 4 : ROWS / RP;
   const bf16_t* gp[NP];
   const bf16_t* base;
   long ld;
@@ -130,7 +131,7 @@ template <bool TR, int ROWS> struct Operand {
       const int row = t >> 3, pc = t & 7;
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps) {
-        const int rr = row + ps * 32;
+        const int rr = row + ps * RP;
         const int rc = rr < rows_valid ? rr : rows_valid - 1;
         gp[ps] = tile_base + (long)rc * ld + ((pc ^ ((rr >> 1) & 7)) << 3);
       }
@@ -152,25 +153,25 @@ template <bool TR, int ROWS> struct Operand {
       if (k_valid >= GEMM_BK) {
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps)
-          __builtin_amdgcn_global_load_lds((gas_ptr)(gp[ps] + koff), (las_ptr)(lds_tile + (ps * 32 + wave_u * 8) * 128),
+          __builtin_amdgcn_global_load_lds((gas_ptr)(gp[ps] + koff), (las_ptr)(lds_tile + (ps * RP + wave_u * 8) * 128),
                                            16, 0, 0);
       } else {
-        load_kc<ROWS>(base + koff, ld, rows_valid, k_valid, r);
+        load_kc<ROWS, NT>(base + koff, ld, rows_valid, k_valid, r);
       }
     } else {
       if (k_valid >= GEMM_BK && mode == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(gp[i] + koff);
       } else if (mode != 0) {
-        load_ks<ROWS>(base + koff, ld, rows_valid, k_valid, r);
+        load_ks<ROWS, NT>(base + koff, ld, rows_valid, k_valid, r);
       }
     }
   }
   __device__ __forceinline__ void commit(int k_valid, unsigned char* lds_tile) {
     if constexpr (!TR) {
-      if (k_valid < GEMM_BK) store_kc<ROWS>(lds_tile, r);
+      if (k_valid < GEMM_BK) store_kc<ROWS, NT>(lds_tile, r);
     } else {
-      store_ks<ROWS>(lds_tile, r);
+      store_ks<ROWS, NT>(lds_tile, r);
     }
   }
 };

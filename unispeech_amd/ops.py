@@ -434,6 +434,11 @@ def adam_step(p32, m, v, grad, p_lowp, *, lr, beta1, beta2, eps, weight_decay, s
                                      ptr(grad_mult_dev), ptr(gnorm_sq), float(max_norm), stream()), "wavlm_adam_step")
 
 
+def gemm_set_variant(v):
+    """0 auto | 1 force the 128x128 tile | 2 force the 256x128 tile (tests / A-B measurements)"""
+    _lib.lib().wavlm_gemm_set_variant(int(v))
+
+
 def prof_enable(on):
     _lib.lib().wavlm_prof_enable(1 if on else 0)
 
