@@ -145,6 +145,69 @@ def check_gemm():
     return out
 
 
+def check_gemm_pp():
+    """256x256 ping-pong kernel (variant 3): all four operand layouts, ragged M/N edges, K tails (zero-page path),
+    K batches with a tail in every batch, split-K, and the fused epilogues."""
+    out = []
+    dtype, tol = torch.bfloat16, TOLBF
+    ops.gemm_set_variant(3)
+    try:
+        cases = [  # M, N, K, tA, tB, KB, split
+            (600, 520, 256, 0, 0, 1, 1), (600, 520, 200, 0, 0, 1, 1), (1000, 296, 1000, 0, 1, 1, 1),
+            (512, 256, 777, 1, 1, 1, 1), (264, 392, 333, 1, 0, 1, 1), (520, 264, 150, 1, 1, 3, 1),
+            (768, 512, 1400, 1, 1, 2, 3), (300, 260, 128, 0, 0, 1, 2), (2000, 768, 64, 0, 0, 1, 1),
+            (256, 128, 64, 0, 1, 1, 1), (776, 1032, 520, 0, 0, 2, 1),
+        ]
+        for (M, N, K, tA, tB, KB, split) in cases:
+            A = q(gen(KB, M, K, seed=31), dtype)
+            B = q(gen(KB, N, K, seed=32), dtype)
+            ref = torch.einsum("kmc,knc->mn", A.double(), B.double())
+            Kp, Mp, Np = (K + 7) // 8 * 8 + 8, (M + 7) // 8 * 8, (N + 7) // 8 * 8
+            if tA:
+                Ad = torch.full((KB, K, Mp), float("nan")); Ad[:, :, :M] = A.transpose(1, 2); lda, sa = Mp, K * Mp
+            else:
+                Ad = torch.full((KB, M, Kp), float("nan")); Ad[:, :, :K] = A; lda, sa = Kp, M * Kp
+            if tB:
+                Bd = torch.full((KB, K, Np), float("nan")); Bd[:, :, :N] = B.transpose(1, 2); ldb, sb = Np, K * Np
+            else:
+                Bd = torch.full((KB, N, Kp), float("nan")); Bd[:, :, :K] = B; ldb, sb = Kp, N * Kp
+            Ad, Bd = Ad.to(dtype).to(DEV), Bd.to(dtype).to(DEV)
+            C = torch.full((M, Np), float("nan"), dtype=dtype, device=DEV)
+            ops.gemm(Ad, Bd, C, M, N, K, lda=lda, ldb=ldb, ldc=Np, transA=tA, transB=tB, KB=KB, sA_kb=sa, sB_kb=sb,
+                     split_k=split)
+            out.append((f"gemm_pp {M}x{N}x{K} tA={tA} tB={tB} KB={KB} split={split}", err(C[:, :N], ref), tol))
+        # batched + bias + gelu + aux + residual through the ping-pong kernel
+        Bo, Bi, M, N, K = 2, 2, 300, 264, 192
+        A = q(gen(Bo, Bi, M, K, seed=33), dtype)
+        B = q(gen(Bo, Bi, N, K, seed=34), dtype)
+        bias = q(gen(Bi, N, seed=35), dtype)
+        res = q(gen(Bo, Bi, M, N, seed=36), dtype)
+        pre = torch.einsum("oimc,oinc->oimn", A.double(), B.double()) * 0.5 + bias.double()[None, :, None, :]
+        ref = TF.gelu(pre) + res.double()
+        C = torch.empty(Bo, Bi, M, N, dtype=dtype, device=DEV)
+        aux = torch.empty(Bo, Bi, M, N, dtype=dtype, device=DEV)
+        ops.gemm(A.to(dtype).to(DEV), B.to(dtype).to(DEV), C, M, N, K, lda=K, ldb=K, ldc=N, batch=(Bo, Bi),
+                 sA=(Bi * M * K, M * K), sB=(Bi * N * K, N * K), sC=(Bi * M * N, M * N), alpha=0.5,
+                 bias=bias.to(dtype).to(DEV), sBias=(0, N), epi=1, aux=aux, ld_aux=N, sAux=(Bi * M * N, M * N),
+                 res=res.to(dtype).to(DEV), ld_res=N, sRes=(Bi * M * N, M * N))
+        out.append(("gemm_pp batched+bias+gelu+res", err(C, ref), tol))
+        out.append(("gemm_pp aux(pre-activation)", err(aux, pre), tol))
+        # overlapping rows (strided conv) through the ping-pong kernel
+        Bb, Tin, Cin, Cout, k, s = 2, 701, 64, 256, 3, 2
+        x = q(gen(Bb, Tin, Cin, seed=37), dtype)
+        w = q(gen(Cout, Cin, k, seed=38, scale=0.2), dtype)
+        refc = TF.conv1d(x.double().transpose(1, 2), w.double(), stride=s).transpose(1, 2)
+        Tout = refc.shape[1]
+        Wf = w.permute(0, 2, 1).reshape(Cout, k * Cin).contiguous()
+        y = torch.empty(Bb, Tout, Cout, dtype=dtype, device=DEV)
+        ops.gemm(x.to(dtype).to(DEV), Wf.to(dtype).to(DEV), y, Tout, Cout, k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout,
+                 batch=(Bb, 1), sA=(Tin * Cin, 0), sC=(Tout * Cout, 0))
+        out.append(("gemm_pp overlapping-row conv1d k3 s2", err(y, refc), tol))
+    finally:
+        ops.gemm_set_variant(0)
+    return out
+
+
 # --------------------------------------------------------------------------------------------------- row ops
 def check_layernorm():
     out = []
@@ -555,7 +618,7 @@ def check_adam():
 
 
 GROUPS = {
-    "gemm": check_gemm, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
+    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
     "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv,
     "linear_ffn": check_linear_ffn, "loss": check_loss, "adam": check_adam,
 }

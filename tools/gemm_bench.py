@@ -85,7 +85,7 @@ def main():
 
 
 if __name__ == "__main__":
-    for v in (1, 0):
-        print("==== tile variant", "128x128 forced" if v == 1 else "auto (256x128 on large problems)")
+    for v in [int(a) for a in sys.argv[1:]] or [1, 0, 3]:
+        print("==== tile variant", {1: "128x128 forced", 0: "auto", 2: "256x128 forced", 3: "256x256 ping-pong"}[v])
         ops.gemm_set_variant(v)
         main()

@@ -197,7 +197,7 @@ static int launch_cfg(GemmP& p, int nbatch, bool vec, hipStream_t st) {
   return wl_check_launch();
 }
 
-static int g_gemm_variant = 0;  // 0: auto, 1: force 128x128, 2: force 256x128 (tests, tools/gemm_bench.py A/B)
+static int g_gemm_variant = 0;  // 0: auto, 1: force 128x128, 2: force 256x128, 3: 256x256 ping-pong where it applies
 extern "C" void wavlm_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 template <bool TA, bool TB>
@@ -225,6 +225,8 @@ static bool vec_epilogue_ok(const wavlm_gemm_desc* d) {
 }
 
 int gemm_f32_launch(const wavlm_gemm_desc* d, hipStream_t st);  // gemm_f32.hip
+bool gemm_pp_ok(const wavlm_gemm_desc* d);                       // gemm_pp.hip
+int gemm_pp_launch(GemmP& p, int nbatch, bool transA, bool transB, bool vec, hipStream_t st);
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -304,7 +306,8 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   const int pi = prof_begin(d, st);
   int rc;
   const bool vec = vec_epilogue_ok(d);
-  if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, vec, st);
+  if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) rc = gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, vec, st);
+  else if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, vec, st);
   else if (!d->transA && d->transB) rc = launch_t<false, true>(p, nbatch, vec, st);
   else if (d->transA && !d->transB) rc = launch_t<true, false>(p, nbatch, vec, st);
   else rc = launch_t<true, true>(p, nbatch, vec, st);

@@ -1,0 +1,351 @@
+// bf16 MFMA GEMM for gfx950, large-problem path: 256 x 256 x 64 block tile, 8 waves, "ping-pong" schedule.
+//
+// Why a second kernel: at 128 x 128 the operand traffic L2 -> LDS (32 KiB per 2.1 MFLOP) saturates the per-CU load
+// path near ~40 % of the MFMA peak; 256 x 256 halves the bytes per flop, and each wave's 128 x 64 accumulator
+// tile needs 0.75 ds_read_b128 per MFMA instead of 1.0.  What makes the big tile pay is the schedule:
+//
+//   * Operands move HBM/L2 -> LDS only by LDS-DMA (global_load_lds_dwordx4), never through VGPRs, for BOTH operand
+//     layouts.  K-contiguous operands ([rows][K]) land as [row][64 k] (128-B rows, 16-B chunks XOR-swizzled by
+//     (row >> 1) & 7, fragments by ds_read_b128).  K-strided operands ([K][rows]: weight-gradient and
+//     activation-gradient forms) land untransposed as [k][128 rows] (256-B rows, 32-B granules XOR-swizzled by
+//     2 * (k & 3)) and are read with the transposing ds_read_b64_tr_b16, which hands each lane the four k of its
+//     row -- the transposition costs no instruction.  The swizzles are applied on the SOURCE address (the DMA writes
+//     lane l at base + 16 l).
+//   * A block tile is staged as four half-tiles per K step: A-top / A-bottom (each wave-row's first / second 64
+//     rows), B-left / B-right (each wave-column's first / second 32 columns), two stages = 128 KiB.  A K step is
+//     four phases, one 64 x 32 accumulator quadrant each (8 MFMA 32x32x16):
+//         P1 reads A-top + B-left, P2 reads B-right, P3 reads A-bottom, P4 reads nothing
+//     so a half-tile buffer is free again after its single read phase and is refilled 5 phases before its next
+//     use; every phase issues one half-tile of DMA (2 instructions per lane).  s_waitcnt vmcnt is counted (4 = two
+//     half-tiles stay in flight) and happens once per K step, in P4.
+//   * Waves 0-3 (rows 0-127) and waves 4-7 (rows 128-255) run the same phase sequence one barrier apart: while one
+//     group issues its ds_reads / DMA, the other owns the MFMA pipe (s_setprio 1).  Each SIMD hosts one wave of
+//     each group, so its MFMA pipe always has a wave in an MFMA section.
+//
+// Hazards (LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier):
+//   RAW  the P4 wait retires every half-tile of step t+1; group 0 waits before barrier b, group 1 before b+1, the
+//        first read of step t+1 (group 0, P1) follows barrier b+1.
+//   WAR  buffer X is read in phase q by group 0 (interval J) and group 1 (J+1, complete before barrier J+2 via the
+//        lgkmcnt(0) that precedes its MFMA section); it is refilled from phase q+2 (group 0: interval J+4).
+// K tails and M/N edges stay on the DMA path: rows past the edge are clamped (they feed outputs never stored), K
+// positions past the end are fetched from a zero page.
+#include "gemm_common.hpp"
+
+#include "tile_loaders.hpp"
+
+#define PP_HB 16384     // bytes per half-tile buffer
+#define PP_STAGE 65536  // bytes per stage: [A-top][A-bot][B-left][B-right]
+
+__device__ __attribute__((aligned(256))) unsigned char g_pp_zero[256];
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
+
+struct PPCursor {  // position of one half-tile stream in the flattened (K-batch, K-tile) sequence; all uniform
+  long off;        // element offset of the current K tile from the operand tile base
+  int kt;          // K-tile index inside the current K batch
+};
+
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 * PP_STAGE
+
+  int tile;
+  {
+    const int nt = p.tiles_m * p.tiles_n, bid = blockIdx.x;
+    const int q = nt >> 3, rem = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+  const int z = blockIdx.y, split = blockIdx.z;
+  const int zo = z / p.batch_i, zi = z % p.batch_i;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const char* Ab = (const char*)((const bf16_t*)p.A + (long)zo * p.sA_o + (long)zi * p.sA_i + (TA ? (long)m0 : (long)m0 * p.lda));
+  const char* Bb = (const char*)((const bf16_t*)p.B + (long)zo * p.sB_o + (long)zi * p.sB_i + (TB ? (long)n0 : (long)n0 * p.ldb));
+  const int kt_per = (p.K + 63) >> 6;
+  const int kv_last = p.K - (kt_per - 1) * 64;
+  int t0, t1;
+  gemm_split_range(p.KB * kt_per, p.split_k, split, t0, t1);
+  const int nt = t1 - t0;
+
+  // ---- DMA side: per-lane byte offsets of the two pieces (j) this lane fetches of each half-tile ------------------
+  // piece (wave, j) of a half-tile buffer: K-contiguous -> buffer rows 16 w + 8 j .. +8 (lane: row + (l >> 3), physical
+  // chunk l & 7); K-strided -> k rows 8 w + 4 j .. +4 (lane: k row + (l >> 4), physical 16-B chunk l & 15)
+  unsigned voff[4][2];
+  int kidx[2][2];  // [operand][j]: first k position this lane's 16 bytes cover (K-contiguous) / its k row (K-strided)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      const bool TR = op ? TB : TA;
+      const long ld = op ? p.ldb : p.lda;
+      const int rows_valid = op ? p.N - n0 : p.M - m0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned v;
+        if (!TR) {
+          const int R = wave * 16 + j * 8 + (lane >> 3);
+          const int c = (lane & 7) ^ ((R >> 1) & 7);
+          int r = op ? ((R >> 5) * 64 + h * 32 + (R & 31)) : ((R >> 6) * 128 + h * 64 + (R & 63));
+          if (r >= rows_valid) r = rows_valid - 1;
+          v = (unsigned)(((long)r * ld + c * 8) * 2);
+          kidx[op][j] = c * 8;
+        } else {
+          const int kr = wave * 8 + j * 4 + (lane >> 4);
+          const int pc = lane & 15;
+          const int R = (((pc >> 1) ^ (2 * (kr & 3))) << 4) + ((pc & 1) << 3);  // buffer row of the first of 8
+          int r = op ? ((R >> 5) * 64 + h * 32 + (R & 31)) : ((R >> 6) * 128 + h * 64 + (R & 63));
+          if (r + 8 > rows_valid) r = rows_valid - 8;
+          v = (unsigned)(((long)kr * ld + r) * 2);
+          kidx[op][j] = kr;
+        }
+        voff[op * 2 + h][j] = v;
+      }
+    }
+  }
+  const long stepA = TA ? 64 * p.lda : 64, stepB = TB ? 64 * p.ldb : 64;
+  const long jumpA = p.sA_kb - (long)kt_per * stepA, jumpB = p.sB_kb - (long)kt_per * stepB;
+  PPCursor cur[4];
+  {
+    const int kb0 = t0 / kt_per, kt0 = t0 - kb0 * kt_per;
+    cur[0].off = cur[1].off = (long)kb0 * p.sA_kb + (long)kt0 * stepA;
+    cur[2].off = cur[3].off = (long)kb0 * p.sB_kb + (long)kt0 * stepB;
+    cur[0].kt = cur[1].kt = cur[2].kt = cur[3].kt = kt0;
+  }
+  // issue half-tile `which` (0 A-top, 1 A-bot, 2 B-left, 3 B-right) of the stream's current K tile into `stage`,
+  // then advance the stream by one K tile
+  auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) {
+    constexpr int W = decltype(which_c)::value;
+    constexpr int OP = W >> 1;
+    PPCursor& c = cur[W];
+    const char* src = (OP ? Bb : Ab) + c.off * 2;
+    const int kv = (c.kt == kt_per - 1) ? kv_last : 64;
+    unsigned char* dst = smem + stage * PP_STAGE + W * PP_HB + wave * 2048;
+    if (kv >= 64) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((gas_ptr)(src + voff[W][j]), (las_ptr)(dst + j * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* s = (kidx[OP][j] < kv) ? src + voff[W][j] : (const char*)g_pp_zero;
+        __builtin_amdgcn_global_load_lds((gas_ptr)s, (las_ptr)(dst + j * 1024), 16, 0, 0);
+      }
+    }
+    c.off += OP ? stepB : stepA;
+    if (++c.kt == kt_per) { c.kt = 0; c.off += OP ? jumpB : jumpA; }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // ---- fragment side ---------------------------------------------------------------------------------------------
+  // K-contiguous image: lane -> row (l & 31), chunk 2 s + (l >> 5), swizzle ((l >> 1) & 7)
+  unsigned kc_a[4], kc_b[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const unsigned lo = (unsigned)((lane & 31) * 128 + (((2 * s + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
+    kc_a[s] = lo + wm * 8192;
+    kc_b[s] = lo + wn * 4096;
+  }
+  // K-strided image: 16-lane group g reads the [4 k][16 rows] block of k octet (l >> 5), rows 16 (g & 1) + ..;
+  // lane i of the group supplies the address of k row (i >> 2), rows 4 (i & 3) .. +4
+  unsigned tr_a[2], tr_b;
+  {
+    const int i = lane & 15, g1 = (lane >> 4) & 1;
+    const unsigned kpart = (unsigned)((8 * (lane >> 5) + (i >> 2)) * 256 + (i & 3) * 8);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) tr_a[f] = kpart + (unsigned)(((wm * 4 + f * 2 + g1) ^ (2 * (i >> 2))) << 5);
+    tr_b = kpart + (unsigned)(((wn * 2 + g1) ^ (2 * (i >> 2))) << 5);
+  }
+  auto rd_a = [&](int base, int f, int s) __attribute__((always_inline)) -> bf16x8_t {  // base: byte offset of the half-tile buffer
+    if constexpr (!TA) {
+      return *reinterpret_cast<const bf16x8_t*>(smem + base + f * 4096 + kc_a[s]);
+    } else {
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 4096 + tr_a[f]));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 4096 + 1024 + tr_a[f]));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto rd_b = [&](int base, int s) __attribute__((always_inline)) -> bf16x8_t {
+    if constexpr (!TB) {
+      return *reinterpret_cast<const bf16x8_t*>(smem + base + kc_b[s]);
+    } else {
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 4096 + tr_b));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 4096 + 1024 + tr_b));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8_t at[2][4], ab[2][4], bl[4], br[4];
+
+#define PP_MFMA_SECTION(FA, I0_, BF, J_)                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  __builtin_amdgcn_s_barrier();                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  __builtin_amdgcn_s_setprio(1);                                                                    \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
+    acc[I0_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][s], BF[s], acc[I0_][J_], 0, 0, 0);  \
+    acc[I0_ + 1][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][s], BF[s], acc[I0_ + 1][J_], 0, 0, 0); \
+  }                                                                                                 \
+  __builtin_amdgcn_s_setprio(0);                                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  __builtin_amdgcn_s_barrier();                                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto k_step = [&](auto stage_c, int t) __attribute__((always_inline)) {
+    constexpr int ST = decltype(stage_c)::value;
+    constexpr int SB = ST * PP_STAGE;
+    const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+    // ---- P1: A-top, B-left -> quadrant (0,0)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bl[s] = rd_b(SB + 2 * PP_HB, s);
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) at[f][s] = rd_a(SB, f, s);
+    if (more1) issue(I3{}, ST ^ 1);
+    PP_MFMA_SECTION(at, 0, bl, 0)
+    // ---- P2: B-right -> quadrant (0,1)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) br[s] = rd_b(SB + 3 * PP_HB, s);
+    if (more1) issue(I1{}, ST ^ 1);
+    PP_MFMA_SECTION(at, 0, br, 1)
+    // ---- P3: A-bottom -> quadrant (1,1)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ab[f][s] = rd_a(SB + PP_HB, f, s);
+    if (more2) issue(I0{}, ST);
+    PP_MFMA_SECTION(ab, 2, br, 1)
+    // ---- P4: quadrant (1,0); retire every half-tile of step t+1
+    if (more2) {
+      issue(I2{}, ST);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PP_MFMA_SECTION(ab, 2, bl, 0)
+  };
+
+  if (nt > 0) {
+    issue(I0{}, 0); issue(I2{}, 0); issue(I3{}, 0); issue(I1{}, 0);
+    if (nt > 1) {
+      issue(I0{}, 1); issue(I2{}, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+    for (int t = 0; t < nt; t += 2) {
+      k_step(I0{}, t);
+      if (t + 1 < nt) k_step(I1{}, t + 1);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+  }
+#undef PP_MFMA_SECTION
+  __syncthreads();
+
+  // ---- epilogue (same as the 128-wide kernel: per-wave LDS staging -> 16-byte row vectors) -------------------------
+  const int mw = m0 + wm * 128, nw = n0 + wn * 64;  // wave tile origin; fragment i -> rows 32 i, j -> cols 32 j
+  if constexpr (!VEC) {
+    auto store_block = [&](const f32x16_t (&a)[2], int i) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nn = nw + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mm = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (mm < p.M && nn < p.N) gemm_store(p, z, split, mm, nn, a[j][r]);
+        }
+      }
+    };
+    store_block(acc[0], 0); store_block(acc[1], 1); store_block(acc[2], 2); store_block(acc[3], 3);
+  } else {
+    constexpr int EP_LD = 64 + 4;
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    auto stage_block = [&](const f32x16_t (&a)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] = a[j][r];
+    };
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      // constant accumulator indices in every arm: the (large) store code below is emitted once, the accumulators
+      // stay in registers
+      switch (i) {
+        case 0: stage_block(acc[0]); break;
+        case 1: stage_block(acc[1]); break;
+        case 2: stage_block(acc[2]); break;
+        default: stage_block(acc[3]); break;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int id = lane + 64 * q;
+        const int rl = id >> 3, ch = id & 7;
+        const int mm = mw + i * 32 + rl;
+        const int nn = nw + ch * 8;
+        if (mm < p.M && nn < p.N) {
+          const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          gemm_store8(p, zo, zi, z, split, mm, nn, v);
+        }
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+static int pp_launch_t(GemmP& p, int nbatch, bool vec, hipStream_t st) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)nbatch, (unsigned)p.split_k);
+  constexpr int smem = 2 * PP_STAGE;
+  static bool done[2] = {false, false};
+  if (!done[vec]) {
+    const void* fn = vec ? (const void*)gemm_pp_kernel<TA, TB, true> : (const void*)gemm_pp_kernel<TA, TB, false>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return WL_ELAUNCH;
+    done[vec] = true;
+  }
+  if (vec) WL_LAUNCH((gemm_pp_kernel<TA, TB, true>), grid, dim3(512), smem, st, p);
+  else WL_LAUNCH((gemm_pp_kernel<TA, TB, false>), grid, dim3(512), smem, st, p);
+  return wl_check_launch();
+}
+
+// Shapes the ping-pong kernel takes: everything stays on 16-byte DMA pieces (K % 8 for K-contiguous operands, M / N
+// % 8 for K-strided ones), offsets fit 32 bits, and the tile is worth filling.
+bool gemm_pp_ok(const wavlm_gemm_desc* d) {
+  if (d->M < 256 || d->N < 128 || d->K < 64) return false;
+  if (!d->transA && d->K % 8) return false;
+  if (!d->transB && d->K % 8) return false;
+  if (d->transA && d->M % 8) return false;
+  if (d->transB && d->N % 8) return false;
+  const int64_t ra = d->transA ? 64 : 256, rb = d->transB ? 64 : 256;
+  if (ra * d->lda * 2 >= (1ll << 31) || rb * d->ldb * 2 >= (1ll << 31)) return false;
+  return true;
+}
+
+int gemm_pp_launch(GemmP& p, int nbatch, bool transA, bool transB, bool vec, hipStream_t st) {
+  if (!transA && !transB) return pp_launch_t<false, false>(p, nbatch, vec, st);
+  if (!transA && transB) return pp_launch_t<false, true>(p, nbatch, vec, st);
+  if (transA && !transB) return pp_launch_t<true, false>(p, nbatch, vec, st);
+  return pp_launch_t<true, true>(p, nbatch, vec, st);
+}

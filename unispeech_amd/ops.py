@@ -98,7 +98,13 @@ def gemm(A, B, Cc, M, N, K, *, lda, ldb, ldc, transA=False, transB=False, KB=1, 
 
 
 def pick_split(M, N, ktiles, nbatch=1, target_blocks=768):
-    """split-K factor so that a small-output / long-reduction GEMM still fills 256 CUs"""
+    """split-K factor so that a small-output / long-reduction GEMM still fills 256 CUs.  Problems the 256 x 256
+    ping-pong kernel takes (one block per CU) aim at one full round of 256 blocks; the 128-wide kernel (two to three
+    blocks per CU) at `target_blocks`."""
+    if M >= 256 and N >= 256:
+        tiles = ((M + 255) // 256) * ((N + 255) // 256) * nbatch
+        s = max(1, 256 // tiles)
+        return max(1, min(s, ktiles // 8, 64))
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * nbatch
     s = max(1, min(ktiles, (target_blocks + tiles - 1) // tiles))
     return min(s, 64)
