@@ -1,0 +1,40 @@
+"""Times the fused attention forward / backward at the WavLM-Base step shape (B=32, T=749, H=12, hd=64) with the
+gated relative-position bias and attention dropout on.  For per-kernel numbers run under
+`rocprofv3 --kernel-trace --stats`."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from unispeech_amd import ops  # noqa: E402
+
+dev = "cuda"
+B, T, H, hd = 32, 749, 12, 64
+D = H * hd
+p = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
+qkv = (0.5 * torch.randn(B, T, 3 * D, device=dev)).to(torch.bfloat16)
+gate = 1 + 0.5 * torch.rand(B, H, T, device=dev)
+tab = 0.5 * torch.randn(H, 2 * T - 1, device=dev)
+dO = torch.randn(B, T, D, device=dev).to(torch.bfloat16)
+
+
+def timeit(fn, name, flops):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print("%-28s %8.3f ms  %7.1f TF/s" % (name, ms, flops / ms / 1e9), flush=True)
+
+
+fl = 4.0 * B * H * T * T * hd
+O, lse = ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234)
+timeit(lambda: ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234), "attention fwd (p=%.2f)" % p, fl)
+timeit(lambda: ops.attn_fused_bwd(qkv, O, dO, lse, gate, tab, None, H, hd ** -0.5, p, 1234), "attention bwd (dq+dkv+red)", 2.5 * fl)
+timeit(lambda: ops.attn_fused_fwd(qkv, None, None, None, H, hd ** -0.5, 0.0, 0), "fwd, no bias, no dropout", fl)

@@ -20,19 +20,38 @@
 #include "tile_loaders.hpp"
 #include "../../include/wavlm_hip.h"
 
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
+
 #define FA_HD 64
 #define FA_BQ 128   // query rows per block (forward, dQ kernel): 4 waves x 32
 #define FA_BKV 64   // keys per iteration
 #define FA_BK1 128  // key rows per block (dK/dV kernel): 4 waves x 32
 #define FA_BQ1 64   // query rows per iteration (dK/dV kernel)
 
-__device__ __forceinline__ bool fa_keep(unsigned s0, unsigned s1, unsigned idx, unsigned thresh) {
-  unsigned x = (idx ^ s0) * 0x9E3779B1u;
-  x ^= x >> 15; x = (x + s1) * 0x85EBCA77u;
+// Dropout mask: stateless, identical in all three kernels whichever lane holds element (i, j).
+//   word(i, j >> 1) = mix(row_word(b, h, i) + col_word(j >> 1));  keep(i, j) = 16-bit half (j & 1) of it >= th16
+// row_word / col_word are strong multiplicative hashes (3 x v_mul_lo_u32 each, quarter rate) evaluated once per
+// query row / key pair; the per-element work is only the multiply-free mix (xor-shift / shift-add, full rate) --
+// the previous per-element multiplicative hash was ~1/3 of the forward kernel's VALU time.
+__device__ __forceinline__ unsigned fa_hash32(unsigned x) {
+  x *= 0x9E3779B1u;
+  x ^= x >> 15; x *= 0x85EBCA77u;
   x ^= x >> 13; x *= 0xC2B2AE3Du;
   x ^= x >> 16;
-  return x >= thresh;
+  return x;
 }
+__device__ __forceinline__ unsigned fa_row_word(unsigned s0, unsigned grow) { return fa_hash32(grow ^ s0); }
+__device__ __forceinline__ unsigned fa_col_word(unsigned s1, unsigned jpair) { return fa_hash32((jpair ^ s1) + 0x68E31DA4u); }
+__device__ __forceinline__ unsigned fa_mix(unsigned x) {
+  x ^= x >> 16; x += x << 3;
+  x ^= x >> 11; x += x << 7;
+  x ^= x >> 13;
+  return x;
+}
+#define FA_LOG2E 1.4426950408889634f
+#define FA_LN2 0.6931471805599453f
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) { return pack_bf16x2(a, b); }
 
@@ -49,6 +68,22 @@ __device__ __forceinline__ bf16x8_t frag_perm(const unsigned char* lds, int row,
 __device__ __forceinline__ bf16x8_t frag_plain(const unsigned char* lds, int row, int kk, int hi) {
   U4 u; u.v = *reinterpret_cast<const uint4*>(lds + lds_off(row, 2 * kk + hi));
   return u.b;
+}
+
+// Transposed A-operand fragment straight from a K-contiguous [64 keys][64 hd] tile (no separately staged transpose):
+// rows = head-dim 32 f2 + (l & 31), k-slot (hi, e) of k-step (f, s) <-> key 32f + 16s + 4hi + (e&3) + 8(e>>2), the
+// order in which a lane holds P / dS.  ds_read_b64_tr_b16: lane i of a 16-lane group supplies the address of key
+// (i >> 2), head-dim columns 4 (i & 3) .. +4 and receives column i of the 4 x 16 block.  `tr_base` is the per-lane
+// part of the (swizzled) address, fa_tr_base(); everything else is an immediate.
+__device__ __forceinline__ unsigned fa_tr_base(int lane) {
+  const int hi = lane >> 5, li = lane & 15, g1 = (lane >> 4) & 1;
+  return (unsigned)((4 * hi + (li >> 2)) * 128 + ((((g1 ^ hi) << 1) | (((li >> 1) & 1) ^ (li >> 3))) << 4) + (li & 1) * 8);
+}
+__device__ __forceinline__ bf16x8_t frag_tr(const unsigned char* tile, unsigned tr_base, int f2, int f, int s) {
+  const unsigned char* kt = tile + tr_base + (32 * f + 16 * s) * 128;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(kt + (f2 << 6)));
+  const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(kt + 8 * 128 + ((f2 ^ 1) << 6)));
+  return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // K-contiguous [64 rows][64] tile -> LDS through LDS-DMA; rows past `nrows` are clamped (results unused/masked)
@@ -68,17 +103,19 @@ struct FaP {
   const bf16_t* qkv; bf16_t* O; float* lse;
   const float* gate; const float* tab; const unsigned char* kpm;
   const bf16_t* dO; bf16_t* dqkv; float* delta; float* dgate; float* dtab_part;
-  int B, H, T; float scale; unsigned th; float sc; unsigned s0, s1;
+  int B, H, T; float scale; float sc2; unsigned th; float sc; unsigned s0, s1;  // th: 16-bit keep threshold (0 = no dropout)
   int Ltab, Tkb;  // LDS extents: rel table (zero padded) and key bias
 };
 
 // ------------------------------------------------------------------------------------------------- forward
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(FaP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   auto kbuf = [&](int st) { return smem + st * 16384; };
   auto vbuf = [&](int st) { return smem + st * 16384 + 8192; };
   float* tabs = reinterpret_cast<float*>(smem + 32768);
   float* kb = tabs + p.Ltab;
+  unsigned* colw = reinterpret_cast<unsigned*>(kb + p.Tkb);  // [Tkb / 2] dropout column words
   const int T = p.T, H = p.H;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -96,7 +133,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(FaP p) {
   for (int d = threadIdx.x; d < p.Ltab; d += 256) tabs[d] = (p.tab && d < L) ? p.tab[(long)h * L + d] : 0.f;
   for (int j = threadIdx.x; j < p.Tkb; j += 256)
     kb[j] = (j < T && !(p.kpm && p.kpm[(long)b * T + j])) ? 0.f : -INFINITY;
-  const float g = p.gate ? p.gate[(long)bh * T + ic] : 0.f;
+  if constexpr (DROP)
+    for (int jp = threadIdx.x; jp < (p.Tkb >> 1); jp += 256) colw[jp] = fa_col_word(p.s1, (unsigned)jp);
+  // everything below lives in the log2 domain: x2 = log2(e) * (scale * s + gate * rel), p = 2^(x2 - m2)
+  const float g2 = p.gate ? p.gate[(long)bh * T + ic] * FA_LOG2E : 0.f;
+  const unsigned roww = fa_row_word(p.s0, (unsigned)(bh * T + ic));
+  const float* trow = tabs + (T - 1 - ic);  // trow[j] = rel[h, j - i]
 
   f32x16_t o[2];
 #pragma unroll
@@ -105,11 +147,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(FaP p) {
     for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
   float m = -INFINITY, l = 0.f;
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
-  uint4 vr[4];
+  const unsigned vtr = fa_tr_base(lane);
 
   glds_tile64(base + FA_HD * H, D3, 0, T, kbuf(0), wave_u);
-  load_ks<64>(base + 2 * FA_HD * H, D3, 64, T, vr);
-  store_ks<64>(vbuf(0), vr);
+  glds_tile64(base + 2 * FA_HD * H, D3, 0, T, vbuf(0), wave_u);
   __syncthreads();
 
   int cur = 0;
@@ -118,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(FaP p) {
     const bool more = jt + 1 < nkv;
     if (more) {
       glds_tile64(base + FA_HD * H, D3, j0 + FA_BKV, T, kbuf(cur ^ 1), wave_u);
-      load_ks<64>(base + 2 * FA_HD * H + (long)(j0 + FA_BKV) * D3, D3, 64, T - j0 - FA_BKV, vr);
+      glds_tile64(base + 2 * FA_HD * H, D3, j0 + FA_BKV, T, vbuf(cur ^ 1), wave_u);
     }
     // S^T = K Q^T
     f32x16_t s[2];
@@ -130,47 +171,61 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(FaP p) {
       for (int kk = 0; kk < 4; ++kk)
         s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s[f], 0, 0, 0);
     }
+    // scores -> log2 domain with the Toeplitz bias; key padding / keys past T only on edge tiles
     float tmax = -INFINITY;
+    const bool edge = (p.kpm != nullptr) || (j0 + FA_BKV > T);
+    if (!edge) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+      for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float x = s[f][r] * p.scale + g * tabs[j - ic + T - 1] + kb[j];
-        s[f][r] = x;
-        tmax = fmaxf(tmax, x);
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float x = fmaf(s[f][r], p.sc2, g2 * trow[j]);
+          s[f][r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float x = fmaf(s[f][r], p.sc2, g2 * trow[j]) + kb[j];
+          s[f][r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+    }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m, tmax);
     const bool dead = (m_new == -INFINITY);
-    const float alpha = dead ? 1.f : __expf(m - m_new);
+    const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
+    const float msub = dead ? 0.f : m_new;  // dead rows: every x is -inf -> 2^(-inf) = 0
     float rs = 0.f;
     U4 pf[2][2];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        float pv[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int rr = r + e;
-          float pe = dead ? 0.f : __expf(s[f][rr] - m_new);
-          rs += pe;
-          if (p.th) {
-            const int j = j0 + 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-            pe = fa_keep(p.s0, p.s1, (unsigned)(((long)bh * T + ic) * T + j), p.th) ? pe * p.sc : 0.f;
-          }
-          pv[e] = pe;
+        float p0 = __builtin_amdgcn_exp2f(s[f][r] - msub);
+        float p1 = __builtin_amdgcn_exp2f(s[f][r + 1] - msub);
+        rs += p0 + p1;
+        if constexpr (DROP) {
+          const int jp = (j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi) >> 1;
+          const unsigned w = fa_mix(roww + colw[jp]);
+          p0 = (w & 0xffffu) >= p.th ? p0 * p.sc : 0.f;
+          p1 = (w >> 16) >= p.th ? p1 * p.sc : 0.f;
         }
-        pf[f][r >> 3].u[(r & 7) >> 1] = pack_bf16(pv[0], pv[1]);
+        pf[f][r >> 3].u[(r & 7) >> 1] = pack_bf16(p0, p1);
       }
     rs += __shfl_xor(rs, 32, 64);
     l = l * alpha + rs;
     m = m_new;
+    if (__any(alpha != 1.f)) {  // the running maximum settles after the first tiles: skip the rescale then
 #pragma unroll
-    for (int f2 = 0; f2 < 2; ++f2)
+      for (int f2 = 0; f2 < 2; ++f2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[f2][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[f2][r] *= alpha;
+    }
     // O^T += V^T P^T
 #pragma unroll
     for (int f2 = 0; f2 < 2; ++f2)
@@ -178,9 +233,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(FaP p) {
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
-          o[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_perm(vbuf(cur), 32 * f2 + ql, f, s2, hi), pf[f][s2].b,
-                                                          o[f2], 0, 0, 0);
-    if (more) store_ks<64>(vbuf(cur ^ 1), vr);
+          o[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vbuf(cur), vtr, f2, f, s2), pf[f][s2].b, o[f2], 0, 0, 0);
     __syncthreads();
     cur ^= 1;
   }
@@ -196,20 +249,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(FaP p) {
         w.y = pack_bf16(o[f2][4 * q4 + 2] * inv, o[f2][4 * q4 + 3] * inv);
         *reinterpret_cast<uint2*>(dst + 32 * f2 + 8 * q4 + 4 * hi) = w;
       }
-    if (hi == 0) p.lse[(long)bh * T + i] = m + __logf(l);
+    if (hi == 0) p.lse[(long)bh * T + i] = (m + __log2f(l)) * FA_LN2;
   }
 }
 
 // ------------------------------------------------------------------------------- backward 1/2: dQ, dgate, drel
 // Same decomposition as the forward (lane owns a query row).  Also writes delta[i] = <dO_i, O_i> for kernel 2/2.
+//
+// drel[h, d] = sum_i gate_i dS[i, i + d - (T-1)] is a sum along diagonals.  Per key tile a wave holds U = gate * dS
+// for 32 query rows x 64 keys, one row per lane, i.e. the diagonals run ACROSS lanes.  The skew is done by the LDS
+// write address, the reduction by the matrix core:
+//   * lane (row rho) stores element (rho, dd) as bf16 at Sk[c][rho], c = dd - rho + 31 in [0, 95): every (c, rho) has
+//     one writer, the two corner triangles are never written and stay zero from the one-time clear;
+//   * column sums of Sk over rho = ones[16 x 32] . Sk^T: six v_mfma_f32_16x16x32_bf16 (one per 16 diagonals) with the
+//     32 rows as the K dimension -- every output row holds the sums, lane l reads diagonal 16 cb + (l & 15);
+//   * the window slides 64 diagonals per tile: blocks 0-3 are final after a tile (one coalesced 256-B store to the
+//     wave's private partial row), blocks 4-5 are fed back as the C operand of blocks 0-1 of the next tile.
+// (History: LDS float atomics cost ~550 cycles per wave-instruction; a register sliding window pulled with
+// ds_bpermute cost ~22 VALU ops per element.  This form costs 1.5 LDS ops per element and no VALU.)
+// K^T for dQ = dS K is not staged separately: the A operand is read from the K tile itself with the transposing
+// ds_read_b64_tr_b16 (lane i of a 16-lane group addresses key (i >> 2), head-dim columns 4 (i & 3) .. +4).
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // per stage: K [kv][hd] 8 KB | V [kv][hd] 8 KB | K^T [hd][kv] 8 KB
-  auto kbuf = [&](int st) { return smem + st * 24576; };
-  auto vbuf = [&](int st) { return smem + st * 24576 + 8192; };
-  auto ktbuf = [&](int st) { return smem + st * 24576 + 16384; };
-  float* tabs = reinterpret_cast<float*>(smem + 49152);
+  // per stage: K [kv][hd] 8 KB | V [kv][hd] 8 KB;  then the four waves' skew buffers (96 x 64 B each)
+  auto kbuf = [&](int st) { return smem + st * 16384; };
+  auto vbuf = [&](int st) { return smem + st * 16384 + 8192; };
+  float* tabs = reinterpret_cast<float*>(smem + 32768 + 4 * 6144);
   float* kb = tabs + p.Ltab;
+  unsigned* colw = reinterpret_cast<unsigned*>(kb + p.Tkb);
   const int T = p.T, H = p.H;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -218,17 +286,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   const int i = blockIdx.x * FA_BQ + 32 * wave + ql;
   const int ic = i < T ? i : T - 1;
   const bool valid_i = i < T;
-  // drel accumulation without atomics (LDS float atomics measured ~550 cycles per wave-instruction here):
-  // d = j - i + T - 1 is Toeplitz, so while the wave walks the key tiles its 32 rows touch a window of 95
-  // consecutive d that slides by 64 per tile.  The window lives in registers, one circular 128-entry buffer
-  // per wave: entry e = d & 127 is owned by lane e & 63, register e >> 6.  Each owner PULLS its contributions
-  // with ds_bpermute (for a fixed element slot the 32 source rows map to 32 consecutive entries, so a lane has
-  // exactly one source or none); after a tile the 64 entries that can no longer be touched go to the wave's
-  // private row of the partial buffer with a plain store.
+  unsigned char* skew = smem + 32768 + wave_u * 6144;
   const int ib = blockIdx.x * FA_BQ + 32 * wave_u;
-  const int dlo0 = -ib - 31 + T - 1;               // first d of tile 0 (may be negative for rows past the table)
-  const int r0 = (lane - dlo0) & 127;              // window-relative position of entry `lane` at tile 0
-  float W0 = 0.f, W1 = 0.f;
+  const int dlo0 = -ib - 31 + T - 1;  // diagonal of skew row 0 at tile 0 (negative for rows past the table)
   float* wpart = p.tab ? p.dtab_part + (((long)bh * gridDim.x + blockIdx.x) * 4 + wave_u) * (2 * T - 1) : nullptr;
   const long D3 = 3L * H * FA_HD, D = (long)H * FA_HD;
   const bf16_t* base = p.qkv + (long)b * T * D3 + h * FA_HD;
@@ -252,22 +312,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   for (int d = threadIdx.x; d < p.Ltab; d += 256) tabs[d] = (p.tab && d < L) ? p.tab[(long)h * L + d] : 0.f;
   for (int j = threadIdx.x; j < p.Tkb; j += 256)
     kb[j] = (j < T && !(p.kpm && p.kpm[(long)b * T + j])) ? 0.f : -INFINITY;
+  if constexpr (DROP)
+    for (int jp = threadIdx.x; jp < (p.Tkb >> 1); jp += 256) colw[jp] = fa_col_word(p.s1, (unsigned)jp);
+  for (int q = threadIdx.x; q < 4 * 6144 / 16; q += 256) reinterpret_cast<uint4*>(smem + 32768)[q] = make_uint4(0, 0, 0, 0);
   const float g = p.gate ? p.gate[(long)bh * T + ic] : 0.f;
-  const float lse_i = valid_i ? p.lse[(long)bh * T + ic] : INFINITY;
+  const float g2 = g * FA_LOG2E;
+  const float lse2 = valid_i ? p.lse[(long)bh * T + ic] * FA_LOG2E : INFINITY;
+  const unsigned roww = fa_row_word(p.s0, (unsigned)(bh * T + ic));
+  const float* trow = tabs + (T - 1 - ic);
+  // skew write base of this lane: row (31 - rho + 4 hi), column rho (bf16)
+  unsigned short* sk_w = reinterpret_cast<unsigned short*>(skew + (31 - ql + 4 * hi) * 64 + 2 * ql);
+  // B-operand read of diagonal block cb: row 16 cb + (l & 15), 16 bytes at (l >> 4) * 16
+  const unsigned char* sk_r = skew + (lane & 15) * 64 + (lane >> 4) * 16;
+  // transposed A-operand read base into a K tile (see the header comment)
+  const unsigned ktr = fa_tr_base(lane);
 
   f32x16_t dq[2];
 #pragma unroll
   for (int f = 0; f < 2; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[f][r] = 0.f;
+  f32x4_t dacc[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) dacc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  U4 ones; ones.v = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
   float dg = 0.f;
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
-  uint4 kr[4];
 
   glds_tile64(base + D, D3, 0, T, kbuf(0), wave_u);
   glds_tile64(base + 2 * D, D3, 0, T, vbuf(0), wave_u);
-  load_ks<64>(base + D, D3, 64, T, kr);
-  store_ks<64>(ktbuf(0), kr);
   __syncthreads();
 
   int cur = 0;
@@ -277,10 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
     if (more) {
       glds_tile64(base + D, D3, j0 + FA_BKV, T, kbuf(cur ^ 1), wave_u);
       glds_tile64(base + 2 * D, D3, j0 + FA_BKV, T, vbuf(cur ^ 1), wave_u);
-      load_ks<64>(base + D + (long)(j0 + FA_BKV) * D3, D3, 64, T - j0 - FA_BKV, kr);
     }
-    const int rel0 = r0 ^ ((jt & 1) << 6);         // window position of entry `lane` (W0); W1 is rel0 ^ 64
-    const int A0 = 31 - rel0, A1 = 31 - (rel0 ^ 64);
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       // one 32-key block at a time keeps only one (S, dP) accumulator pair live
@@ -293,63 +363,69 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(vbuf(cur), 32 * f + ql, kk, hi), dof[kk].b, dp, 0, 0, 0);
       }
+      auto elem_pass = [&](auto edge_c) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_c)::value;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        float dv[2];
+        for (int r = 0; r < 16; r += 2) {
+          float dv[2];
+          unsigned w = 0;
+          if constexpr (DROP) w = fa_mix(roww + colw[(j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi) >> 1]);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int rr = r + e;
-          const int j = j0 + 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-          const float tv = tabs[j - ic + T - 1];
-          const float x = s[rr] * p.scale + g * tv + kb[j];
-          const float pe = __expf(x - lse_i);  // 0 for masked keys (x = -inf) and for rows past T (lse = +inf)
-          float dpe = dp[rr];
-          if (p.th) dpe = fa_keep(p.s0, p.s1, (unsigned)(((long)bh * T + ic) * T + j), p.th) ? dpe * p.sc : 0.f;
-          const float ds = pe * (dpe - dl);
-          dv[e] = ds;
-          if (p.tab) {
+          for (int e = 0; e < 2; ++e) {
+            const int rr = r + e;
+            const int j = j0 + 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+            const float tv = trow[j];
+            float x = fmaf(s[rr], p.sc2, g2 * tv);
+            if constexpr (EDGE) x += kb[j];
+            const float pe = __builtin_amdgcn_exp2f(x - lse2);  // 0 for masked keys (-inf) and rows past T (lse = +inf)
+            float dpe = dp[rr];
+            if constexpr (DROP) dpe = (e ? (w >> 16) : (w & 0xffffu)) >= p.th ? dpe * p.sc : 0.f;
+            const float ds = pe * (dpe - dl);
+            dv[e] = ds;
             dg = fmaf(ds, tv, dg);
-            const float u = g * ds;
-            // element slot offset within the tile; the source row for window position rel is 31 + dd - rel
-#pragma unroll
-            for (int hs = 0; hs < 2; ++hs) {
-              const int dd = 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hs;
-              const int q0 = A0 + dd, q1 = A1 + dd;
-              const bool v0 = (unsigned)q0 < 32u, v1 = (unsigned)q1 < 32u;
-              const int src = (v0 ? q0 : q1) + 32 * hs;
-              const float got = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(u)));
-              W0 += v0 ? got : 0.f;
-              W1 += v1 ? got : 0.f;
-            }
+          }
+          dsf[r >> 3].u[(r & 7) >> 1] = pack_bf16(dv[0], dv[1]);
+          if (p.tab) {
+            const unsigned u2 = pack_bf16(g * dv[0], g * dv[1]);
+            const int dd = 32 * f + (r & 3) + 8 * (r >> 2);  // + 4 hi is in sk_w
+            sk_w[dd * 32] = (unsigned short)u2;
+            sk_w[(dd + 1) * 32] = (unsigned short)(u2 >> 16);
           }
         }
-        dsf[r >> 3].u[(r & 7) >> 1] = pack_bf16(dv[0], dv[1]);
-      }
-      // dQ^T += K^T dS^T (this 32-key block)
+      };
+      if ((p.kpm != nullptr) || (j0 + FA_BKV > T)) elem_pass(std::true_type{}); else elem_pass(std::false_type{});
+      // dQ^T += K^T dS^T (this 32-key block); K^T fragments by transposing reads of the K tile
 #pragma unroll
       for (int f2 = 0; f2 < 2; ++f2)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-          dq[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_perm(ktbuf(cur), 32 * f2 + ql, f, s2, hi), dsf[s2].b,
-                                                           dq[f2], 0, 0, 0);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          dq[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kbuf(cur), ktr, f2, f, s2), dsf[s2].b, dq[f2], 0, 0, 0);
+        }
     }
     if (p.tab) {
-      // entries at window positions [0, 64) are final: d = dlo + rel
-      const bool first = rel0 < 64;
-      const int d = dlo0 + 64 * jt + (first ? rel0 : (rel0 ^ 64));
-      if (d >= 0 && d < L) wpart[d] = first ? W0 : W1;
-      if (first) W0 = 0.f; else W1 = 0.f;
+      // diagonal sums of this tile; blocks 4, 5 of the previous tile carry into blocks 0, 1
+      f32x4_t nacc[6];
+#pragma unroll
+      for (int cb = 0; cb < 6; ++cb) {
+        U4 bfr; bfr.v = *reinterpret_cast<const uint4*>(sk_r + cb * 1024);
+        const f32x4_t cin = cb < 2 ? dacc[cb + 4] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        nacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.b, bfr.b, cin, 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 6; ++cb) dacc[cb] = nacc[cb];
+      const int gsel = lane >> 4;
+      const float v = gsel == 0 ? dacc[0][0] : gsel == 1 ? dacc[1][0] : gsel == 2 ? dacc[2][0] : dacc[3][0];
+      const int d = dlo0 + j0 + lane;
+      if (d >= 0 && d < L) wpart[d] = v;
     }
-    if (more) store_ks<64>(ktbuf(cur ^ 1), kr);
     __syncthreads();
     cur ^= 1;
   }
-  if (p.tab) {
-    // what is left sits at window positions [0, 64) of the tile after the last one
-    const int relN = r0 ^ ((nkv & 1) << 6);
-    const bool first = relN < 64;
-    const int d = dlo0 + 64 * nkv + (first ? relN : (relN ^ 64));
-    if (d >= 0 && d < L) wpart[d] = first ? W0 : W1;
+  if (p.tab && lane < 32) {
+    // the 31 diagonals past the last tile's first 64 (blocks 4, 5)
+    const float v = lane < 16 ? dacc[4][0] : dacc[5][0];
+    const int d = dlo0 + 64 * nkv + lane;
+    if (d >= 0 && d < L) wpart[d] = v;
   }
   dg += __shfl_xor(dg, 32, 64);
   if (valid_i) {
@@ -373,15 +449,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
 // ------------------------------------------------------------------------------------ backward 2/2: dK, dV
 // Lane owns a KEY column; scores are in the untransposed layout S[q][kv] so that the query contraction of
 // dV^T = dO^T P and dK^T = Q^T dS finds its k-slots in the lane's registers.
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // per stage: Q [q][hd] | dO [q][hd] | Q^T [hd][q] | dO^T [hd][q], 8 KB each
-  auto qbuf = [&](int st) { return smem + st * 32768; };
-  auto dobuf = [&](int st) { return smem + st * 32768 + 8192; };
-  auto qtbuf = [&](int st) { return smem + st * 32768 + 16384; };
-  auto dotbuf = [&](int st) { return smem + st * 32768 + 24576; };
-  float* tabs = reinterpret_cast<float*>(smem + 65536);
-  float* rowv = tabs + p.Ltab;  // [2 stages][3][64]: lse, delta, gate of the query tile
+  // per stage: Q [q][hd] | dO [q][hd], 8 KB each; the transposed operands of the query contraction are read from
+  // the same tiles with ds_read_b64_tr_b16 (frag_tr)
+  auto qbuf = [&](int st) { return smem + st * 16384; };
+  auto dobuf = [&](int st) { return smem + st * 16384 + 8192; };
+  float* tabs = reinterpret_cast<float*>(smem + 32768);
+  float* rowv = tabs + p.Ltab;  // [2 stages][4][64]: lse * log2e, delta, gate * log2e, dropout row word of the query tile
   const int T = p.T, H = p.H;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -402,6 +478,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   }
   for (int d = threadIdx.x; d < p.Ltab; d += 256) tabs[d] = (p.tab && d < L) ? p.tab[(long)h * L + d] : 0.f;
   const bool key_ok = j < T && !(p.kpm && p.kpm[(long)b * T + jc]);
+  const unsigned cw = fa_col_word(p.s1, (unsigned)(jc >> 1));
+  const unsigned csh = (jc & 1) << 4;
+  const float* tcol = tabs + (jc + T - 1);  // tcol[-i] = rel[h, j - i]
 
   f32x16_t dk[2], dv[2];
 #pragma unroll
@@ -409,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[f][r] = 0.f; dv[f][r] = 0.f; }
   const int nq = (T + FA_BQ1 - 1) / FA_BQ1;
-  uint4 qr[4], dor[4];
+  const unsigned qtr = fa_tr_base(lane);
 
   auto stage_rows = [&](int it, int st) {
     const int t = threadIdx.x;
@@ -417,18 +496,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
       const int ii = it * FA_BQ1 + t;
       const bool ok = ii < T;
       const long o = (long)bh * T + (ok ? ii : T - 1);
-      rowv[st * 192 + t] = ok ? p.lse[o] : INFINITY;
-      rowv[st * 192 + 64 + t] = p.delta[o];
-      rowv[st * 192 + 128 + t] = p.gate ? p.gate[o] : 0.f;
+      rowv[st * 256 + t] = ok ? p.lse[o] * FA_LOG2E : INFINITY;
+      rowv[st * 256 + 64 + t] = p.delta[o];
+      rowv[st * 256 + 128 + t] = p.gate ? p.gate[o] * FA_LOG2E : 0.f;
+      rowv[st * 256 + 192 + t] = __uint_as_float(fa_row_word(p.s0, (unsigned)o));
     }
   };
 
   glds_tile64(base, D3, 0, T, qbuf(0), wave_u);
   glds_tile64(dobase, D, 0, T, dobuf(0), wave_u);
-  load_ks<64>(base, D3, 64, T, qr);
-  load_ks<64>(dobase, D, 64, T, dor);
-  store_ks<64>(qtbuf(0), qr);
-  store_ks<64>(dotbuf(0), dor);
   stage_rows(0, 0);
   __syncthreads();
 
@@ -439,11 +515,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
     if (more) {
       glds_tile64(base, D3, iq0 + FA_BQ1, T, qbuf(cur ^ 1), wave_u);
       glds_tile64(dobase, D, iq0 + FA_BQ1, T, dobuf(cur ^ 1), wave_u);
-      load_ks<64>(base + (long)(iq0 + FA_BQ1) * D3, D3, 64, T - iq0 - FA_BQ1, qr);
-      load_ks<64>(dobase + (long)(iq0 + FA_BQ1) * D, D, 64, T - iq0 - FA_BQ1, dor);
       stage_rows(it + 1, cur ^ 1);
     }
-    const float* rv = rowv + cur * 192;
+    const float* rv = rowv + cur * 256;
     // S = Q K^T, dP = dO V^T  (rows = queries of the tile, col = this lane's key)
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -464,12 +538,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
           const int rr = r + e;
           const int il = 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;  // query row within the tile
           int ii = iq0 + il; if (ii > T - 1) ii = T - 1;
-          const float x = s[rr] * p.scale + rv[128 + il] * tabs[jc - ii + T - 1];
-          float pe = key_ok ? __expf(x - rv[il]) : 0.f;  // rows past T: lse = +inf -> 0
+          const float x = fmaf(s[rr], p.sc2, rv[128 + il] * tcol[-ii]);
+          float pe = key_ok ? __builtin_amdgcn_exp2f(x - rv[il]) : 0.f;  // rows past T: lse = +inf -> 0
           float dpe = dp[rr];
           float pd = pe;
-          if (p.th) {
-            const bool kp = fa_keep(p.s0, p.s1, (unsigned)(((long)bh * T + ii) * T + jc), p.th);
+          if constexpr (DROP) {
+            const unsigned w = fa_mix(__float_as_uint(rv[192 + il]) + cw);
+            const bool kp = ((w >> csh) & 0xffffu) >= p.th;
             pd = kp ? pe * p.sc : 0.f;
             dpe = kp ? dpe * p.sc : 0.f;
           }
@@ -484,15 +559,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
       for (int f2 = 0; f2 < 2; ++f2)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          dv[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_perm(dotbuf(cur), 32 * f2 + kl, f, s2, hi), pf[s2].b,
-                                                           dv[f2], 0, 0, 0);
-          dk[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_perm(qtbuf(cur), 32 * f2 + kl, f, s2, hi), dsf[s2].b,
-                                                           dk[f2], 0, 0, 0);
+          dv[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dobuf(cur), qtr, f2, f, s2), pf[s2].b, dv[f2], 0, 0, 0);
+          dk[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qbuf(cur), qtr, f2, f, s2), dsf[s2].b, dk[f2], 0, 0, 0);
         }
-    }
-    if (more) {
-      store_ks<64>(qtbuf(cur ^ 1), qr);
-      store_ks<64>(dotbuf(cur ^ 1), dor);
     }
     __syncthreads();
     cur ^= 1;
@@ -540,9 +609,11 @@ __global__ __launch_bounds__(1024) void fa_dtab_reduce_kernel(const float* __res
 static FaP fa_params(int B, int H, int T, float scale, float p_drop, uint64_t seed) {
   FaP p;
   p.B = B; p.H = H; p.T = T; p.scale = scale;
-  double tt = (double)p_drop * 4294967296.0; if (tt > 4294967295.0) tt = 4294967295.0;
+  p.sc2 = scale * FA_LOG2E;
+  double tt = (double)p_drop * 65536.0 + 0.5; if (tt > 65535.0) tt = 65535.0;
   p.th = p_drop > 0.f ? (unsigned)tt : 0u;
-  p.sc = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  if (p_drop > 0.f && p.th == 0u) p.th = 1u;
+  p.sc = p.th ? (float)(1.0 / (1.0 - (double)p.th / 65536.0)) : 1.f;  // unbiased for the quantised probability
   p.s0 = (unsigned)seed; p.s1 = (unsigned)(seed >> 32);
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
   p.Tkb = nkv * FA_BKV;
@@ -568,10 +639,15 @@ int wavlm_attn_fused_fwd(const void* qkv, void* O, float* lse, const float* gate
   if ((gate == nullptr) != (tab == nullptr)) return WL_EINVAL;
   FaP p = fa_params(B, H, T, scale, p_drop, seed);
   p.qkv = (const bf16_t*)qkv; p.O = (bf16_t*)O; p.lse = lse; p.gate = gate; p.tab = tab; p.kpm = kpm;
-  const size_t smem = 32768 + (size_t)(p.Ltab + p.Tkb) * sizeof(float);
-  if (fa_set_smem(attn_fwd_kernel, smem) != WL_OK) return WL_ELAUNCH;
-  WL_LAUNCH(attn_fwd_kernel, dim3((unsigned)((T + FA_BQ - 1) / FA_BQ), (unsigned)(B * H)), dim3(256), smem,
-            (hipStream_t)stream, p);
+  const size_t smem = 32768 + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float);
+  const dim3 grid((unsigned)((T + FA_BQ - 1) / FA_BQ), (unsigned)(B * H));
+  if (p.th) {
+    if (fa_set_smem(attn_fwd_kernel<true>, smem) != WL_OK) return WL_ELAUNCH;
+    WL_LAUNCH(attn_fwd_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, p);
+  } else {
+    if (fa_set_smem(attn_fwd_kernel<false>, smem) != WL_OK) return WL_ELAUNCH;
+    WL_LAUNCH(attn_fwd_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, p);
+  }
   return wl_check_launch();
 }
 
@@ -600,12 +676,23 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
   p.delta = p.dtab_part + (long)B * H * nqt * 4 * L;
   // each wave stores every d of its own window range exactly once; everything else must read as zero
   if (tab && hipMemsetAsync(p.dtab_part, 0, (size_t)B * H * nqt * 4 * L * sizeof(float), st) != hipSuccess) return WL_ELAUNCH;
-  const size_t smem1 = 49152 + (size_t)(p.Ltab + p.Tkb) * sizeof(float);
-  if (fa_set_smem(attn_bwd_dq_kernel, smem1) != WL_OK) return WL_ELAUNCH;
-  WL_LAUNCH(attn_bwd_dq_kernel, dim3((unsigned)nqt, (unsigned)(B * H)), dim3(256), smem1, st, p);
-  const size_t smem2 = 65536 + (size_t)(p.Ltab + 2 * 192) * sizeof(float);
-  if (fa_set_smem(attn_bwd_dkv_kernel, smem2) != WL_OK) return WL_ELAUNCH;
-  WL_LAUNCH(attn_bwd_dkv_kernel, dim3((unsigned)((T + FA_BK1 - 1) / FA_BK1), (unsigned)(B * H)), dim3(256), smem2, st, p);
+  const size_t smem1 = 32768 + 4 * 6144 + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float);
+  if (p.th) {
+    if (fa_set_smem(attn_bwd_dq_kernel<true>, smem1) != WL_OK) return WL_ELAUNCH;
+    WL_LAUNCH(attn_bwd_dq_kernel<true>, dim3((unsigned)nqt, (unsigned)(B * H)), dim3(256), smem1, st, p);
+  } else {
+    if (fa_set_smem(attn_bwd_dq_kernel<false>, smem1) != WL_OK) return WL_ELAUNCH;
+    WL_LAUNCH(attn_bwd_dq_kernel<false>, dim3((unsigned)nqt, (unsigned)(B * H)), dim3(256), smem1, st, p);
+  }
+  const size_t smem2 = 32768 + (size_t)(p.Ltab + 2 * 256) * sizeof(float);
+  const dim3 grid2((unsigned)((T + FA_BK1 - 1) / FA_BK1), (unsigned)(B * H));
+  if (p.th) {
+    if (fa_set_smem(attn_bwd_dkv_kernel<true>, smem2) != WL_OK) return WL_ELAUNCH;
+    WL_LAUNCH(attn_bwd_dkv_kernel<true>, grid2, dim3(256), smem2, st, p);
+  } else {
+    if (fa_set_smem(attn_bwd_dkv_kernel<false>, smem2) != WL_OK) return WL_ELAUNCH;
+    WL_LAUNCH(attn_bwd_dkv_kernel<false>, grid2, dim3(256), smem2, st, p);
+  }
   if (tab)
     WL_LAUNCH(fa_dtab_reduce_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)H), dim3(1024), 0, st,
               (const float*)p.dtab_part, dtab, (int)B, (int)H, nqt * 4, L);
