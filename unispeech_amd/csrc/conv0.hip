@@ -159,14 +159,27 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const TW* __restrict__
   }
 }
 
-// backward pass 1: A[b,c] = sum_t dz, Bq[b,c] = sum_t dz * xhat   (dz = g * gelu'(z)) -> chunk partials
+// Backward in ONE pass over the incoming gradient (1.57 GB at cfg2 -- this stage is HBM-bound on reading it):
+//   dz   = g * gscale * gelu'(z),  xhat = (conv - mean) * rstd,  z = xhat * gamma + beta
+//   dconv = rstd * gamma * (dz - A/T0 - xhat * Bq/T0),   A = sum_t dz,  Bq = sum_t dz * xhat      (GroupNorm backward)
+//   dW[c][k] = sum_{b,t} dconv[b,t,c] * x[b, 5t+k]
+//            = sum_b rstd * gamma * ( P[b,c,k] - A/T0 * Q[b,k] - Bq/T0 * R[b,c,k] )
+//   with P = sum_t dz * x_k            (the only term that needs g: accumulated in the same pass as A and Bq)
+//        Q = sum_t x_k                 (waveform only)
+//        R = sum_t xhat * x_k = rstd * ( sum_j w[c][j] * XX[b][j][k] - mean * Q[b,k] ),  XX = sum_t x_j x_k  (waveform only)
+// so the second sweep over g (and the second recomputation of conv + gelu') of a two-pass GroupNorm backward is
+// replaced by a 10 x 10 waveform Gram matrix per batch row.
+// part[(b * nchunk + chunk)][12][C]: A, Bq, P[0..9];  partx[(b * nchunk + chunk)][112]: Q[10], XX[10][10]
+#define C0_NQ (2 + C0_KW)
+#define C0_NX 112
 template <typename TW, typename TP, typename TO>
-__global__ __launch_bounds__(256) void conv0_bwd_stats_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
+__global__ __launch_bounds__(256) void conv0_bwd_fused_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
     const TP* __restrict__ gamma, const TP* __restrict__ beta, const float* __restrict__ stats,
-    const TO* __restrict__ g, float* __restrict__ part, long T, int T0, int C, int stride, float gscale) {
+    const TO* __restrict__ g, float* __restrict__ part, float* __restrict__ partx, long T, int T0, int C, int stride,
+    float gscale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* seg = sm;
-  float* red = sm + ((C0_TCH_BWD - 1) * stride + C0_KW + 3) / 4 * 4;
+  float* red = sm + ((C0_TCH_BWD - 1) * stride + C0_KW + 3) / 4 * 4;  // [4 waves][512]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH_BWD;
   const int nt = min(C0_TCH_BWD, T0 - t0);
@@ -181,51 +194,108 @@ __global__ __launch_bounds__(256) void conv0_bwd_stats_kernel(const TW* __restri
     gm[e] = Elem<TP>::ld(gamma + c); bt[e] = Elem<TP>::ld(beta + c);
   }
   __syncthreads();
-  float a1[8], a2[8];
+  // waveform-only sums of this chunk: Q[k] and XX[j][k]
+  if (threadIdx.x < C0_KW + C0_KW * C0_KW) {
+    const int idx = threadIdx.x;
+    float acc = 0.f;
+    if (idx < C0_KW) {
+      for (int tt = 0; tt < nt; ++tt) acc += seg[tt * stride + idx];
+    } else {
+      const int j = (idx - C0_KW) / C0_KW, k = (idx - C0_KW) % C0_KW;
+      for (int tt = 0; tt < nt; ++tt) acc = fmaf(seg[tt * stride + j], seg[tt * stride + k], acc);
+    }
+    partx[((long)b * gridDim.x + blockIdx.x) * C0_NX + idx] = acc;
+  }
+  float a1[8], a2[8], pw[8][C0_KW];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) {
+    a1[e] = 0.f; a2[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) pw[e][k] = 0.f;
+  }
   if (lane * 8 < C) {
     for (int tt = wave; tt < nt; tt += 4) {
-      float y[8], gv[8];
-      conv_at(seg, tt, stride, w, y);
+      float xw[C0_KW], y[8], gv[8];
+#pragma unroll
+      for (int k = 0; k < C0_KW; ++k) xw[k] = seg[tt * stride + k];
       V8<TO>::ld(g + ((long)b * T0 + t0 + tt) * C + lane * 8, gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < C0_KW; ++k) a = fmaf(xw[k], w[e][k], a);
+        y[e] = a;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float xh = (y[e] - mean[e]) * rstd[e];
         const float dz = gv[e] * gscale * gelu_grad_f(fmaf(xh, gm[e], bt[e]));
         a1[e] += dz; a2[e] = fmaf(dz, xh, a2[e]);
+#pragma unroll
+        for (int k = 0; k < C0_KW; ++k) pw[e][k] = fmaf(dz, xw[k], pw[e][k]);
       }
     }
   }
+  float* out = part + ((long)b * gridDim.x + blockIdx.x) * (long)C0_NQ * C;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { red[(wave * 2 + 0) * 512 + lane * 8 + e] = a1[e]; red[(wave * 2 + 1) * 512 + lane * 8 + e] = a2[e]; }
-  __syncthreads();
-  float* out = part + ((long)b * gridDim.x + blockIdx.x) * 2 * C;
-  for (int i = threadIdx.x; i < 2 * 512; i += 256) {
-    const int which = i >> 9, c = i & 511;
-    if (c < C) out[which * C + c] = red[(0 * 2 + which) * 512 + c] + red[(1 * 2 + which) * 512 + c] +
-                                     red[(2 * 2 + which) * 512 + c] + red[(3 * 2 + which) * 512 + c];
+  for (int q = 0; q < C0_NQ; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave * 512 + lane * 8 + e] = q == 0 ? a1[e] : q == 1 ? a2[e] : pw[e][q >= 2 ? q - 2 : 0];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) out[(long)q * C + c] = red[c] + red[512 + c] + red[1024 + c] + red[1536 + c];
   }
 }
-// ab[b][c] = (A, Bq) per batch row: block = 64 channels x 4 chunk slices of one batch row
-__global__ __launch_bounds__(256) void conv0_bwd_stats_finish_kernel(const float* __restrict__ part,
-    float* __restrict__ ab, int nchunk, int C) {
-  __shared__ double red[4][2][64];
+
+// Per (b, c): reduce the chunk partials (double), form this batch row's dW contribution, and (A, Bq) for dgamma/dbeta.
+// grid (ceil(C / 64), B), 256 threads = 64 channels x 4 chunk slices.
+template <typename TP>
+__global__ __launch_bounds__(256) void conv0_bwd_combine_kernel(const float* __restrict__ part, const float* __restrict__ partx,
+    const float* __restrict__ stats, const TP* __restrict__ W, const TP* __restrict__ gamma, float* __restrict__ ab,
+    float* __restrict__ dwb, int nchunk, int C, int T0) {
+  __shared__ double red[4][C0_NQ][64];
+  __shared__ double xs[C0_NX];
   const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + col, b = blockIdx.y;
-  double s1 = 0.0, s2 = 0.0;
+  if (threadIdx.x < C0_KW + C0_KW * C0_KW) {
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += partx[((long)b * nchunk + k) * C0_NX + threadIdx.x];
+    xs[threadIdx.x] = s;
+  }
+  double acc[C0_NQ];
+#pragma unroll
+  for (int q = 0; q < C0_NQ; ++q) acc[q] = 0.0;
   if (c < C)
     for (int k = slice; k < nchunk; k += 4) {
-      const float* p = part + ((long)b * nchunk + k) * 2 * C;
-      s1 += p[c]; s2 += p[C + c];
+      const float* pp = part + ((long)b * nchunk + k) * (long)C0_NQ * C + c;
+#pragma unroll
+      for (int q = 0; q < C0_NQ; ++q) acc[q] += pp[(long)q * C];
     }
-  red[slice][0][col] = s1; red[slice][1][col] = s2;
+#pragma unroll
+  for (int q = 0; q < C0_NQ; ++q) red[slice][q][col] = acc[q];
   __syncthreads();
   if (slice == 0 && c < C) {
-    ab[((long)b * C + c) * 2] = (float)(red[0][0][col] + red[1][0][col] + red[2][0][col] + red[3][0][col]);
-    ab[((long)b * C + c) * 2 + 1] = (float)(red[0][1][col] + red[1][1][col] + red[2][1][col] + red[3][1][col]);
+#pragma unroll
+    for (int q = 0; q < C0_NQ; ++q) acc[q] = red[0][q][col] + red[1][q][col] + red[2][q][col] + red[3][q][col];
+    const double mean = stats[((long)b * C + c) * 2], rstd = stats[((long)b * C + c) * 2 + 1];
+    const double gm = Elem<TP>::ld(gamma + c);
+    const double am = acc[0] / T0, bm = acc[1] / T0;
+    double wv[C0_KW];
+#pragma unroll
+    for (int j = 0; j < C0_KW; ++j) wv[j] = Elem<TP>::ld(W + (long)c * C0_KW + j);
+    ab[((long)b * C + c) * 2] = (float)acc[0];
+    ab[((long)b * C + c) * 2 + 1] = (float)acc[1];
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) {
+      double r = -mean * xs[k];
+#pragma unroll
+      for (int j = 0; j < C0_KW; ++j) r += wv[j] * xs[C0_KW + j * C0_KW + k];
+      r *= rstd;
+      dwb[((long)b * C + c) * C0_KW + k] = (float)(rstd * gm * (acc[2 + k] - am * xs[k] - bm * r));
+    }
   }
 }
+
 // dgamma[c] = sum_b Bq[b][c], dbeta[c] = sum_b A[b][c]
 __global__ __launch_bounds__(256) void conv0_bwd_affine_kernel(const float* __restrict__ ab, void* dgamma, void* dbeta,
                                                                int pdt, int B, int C) {
@@ -237,64 +307,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_affine_kernel(const float* __re
   st_elem(dgamma, c, pdt, (float)tb);
 }
 
-// backward pass 2: dconv = rstd*gamma*(dz - A/T0 - xhat*Bq/T0); dW[c][k] = sum dconv * x[5t + k] -> block partials
-template <typename TW, typename TP, typename TO>
-__global__ __launch_bounds__(256) void conv0_bwd_w_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
-    const TP* __restrict__ gamma, const TP* __restrict__ beta, const float* __restrict__ stats,
-    const float* __restrict__ ab, const TO* __restrict__ g, float* __restrict__ part, long T, int T0, int C, int stride,
-    float gscale) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* seg = sm;
-  float* red = sm + ((C0_TCH_BWD - 1) * stride + C0_KW + 3) / 4 * 4;  // [4][512]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH_BWD;
-  const int nt = min(C0_TCH_BWD, T0 - t0);
-  stage_wave(wav, T, b, t0, nt, stride, seg);
-  float w[8][C0_KW];
-  load_w(W, lane, C, w);
-  float mean[8], rstd[8], gm[8], bt[8], am[8], bm[8];
-  const float invT = 1.f / (float)T0;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = min(lane * 8 + e, C - 1);
-    mean[e] = stats[((long)b * C + c) * 2]; rstd[e] = stats[((long)b * C + c) * 2 + 1];
-    gm[e] = Elem<TP>::ld(gamma + c); bt[e] = Elem<TP>::ld(beta + c);
-    am[e] = ab[((long)b * C + c) * 2] * invT; bm[e] = ab[((long)b * C + c) * 2 + 1] * invT;
-  }
-  __syncthreads();
-  float dw[8][C0_KW];
-#pragma unroll
-  for (int e = 0; e < 8; ++e)
-#pragma unroll
-    for (int k = 0; k < C0_KW; ++k) dw[e][k] = 0.f;
-  if (lane * 8 < C) {
-    for (int tt = wave; tt < nt; tt += 4) {
-      float y[8], gv[8], xw[C0_KW];
-      conv_at(seg, tt, stride, w, y);
-#pragma unroll
-      for (int k = 0; k < C0_KW; ++k) xw[k] = seg[tt * stride + k];
-      V8<TO>::ld(g + ((long)b * T0 + t0 + tt) * C + lane * 8, gv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float xh = (y[e] - mean[e]) * rstd[e];
-        const float dz = gv[e] * gscale * gelu_grad_f(fmaf(xh, gm[e], bt[e]));
-        const float dc = rstd[e] * gm[e] * (dz - am[e] - xh * bm[e]);
-#pragma unroll
-        for (int k = 0; k < C0_KW; ++k) dw[e][k] = fmaf(dc, xw[k], dw[e][k]);
-      }
-    }
-  }
-  float* out = part + ((long)b * gridDim.x + blockIdx.x) * (long)C * C0_KW;
-#pragma unroll
-  for (int k = 0; k < C0_KW; ++k) {
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[wave * 512 + lane * 8 + e] = dw[e][k];
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256)
-      out[(long)c * C0_KW + k] = red[c] + red[512 + c] + red[1024 + c] + red[1536 + c];
-  }
-}
+// dW[i] = sum over nblk partial rows (double)
 __global__ __launch_bounds__(256) void conv0_bwd_w_finish_kernel(const float* __restrict__ part, int nblk, int n,
                                                                  void* dW, int pdt) {
   __shared__ double red[4][64];
@@ -359,8 +372,8 @@ int wavlm_conv0_gn_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
 uint64_t wavlm_conv0_gn_bwd_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride) {
   const long T0 = (T - C0_KW) / stride + 1;
   const uint64_t nchunk = (uint64_t)((T0 + C0_TCH_BWD - 1) / C0_TCH_BWD);
-  // chunk partials (2C) + per-block dW partials (C*KW) + ab[B][C][2]
-  return ((uint64_t)B * nchunk * (2 * (uint64_t)C + (uint64_t)C * C0_KW) + (uint64_t)B * C * 2) * sizeof(float);
+  // chunk partials [12][C] + waveform partials [112] + per-batch-row dW [C][KW] + ab[B][C][2]
+  return ((uint64_t)B * nchunk * ((uint64_t)C0_NQ * C + C0_NX) + (uint64_t)B * C * C0_KW + (uint64_t)B * C * 2) * sizeof(float);
 }
 
 // backward: dW[C, kw], dgamma[C], dbeta[C] (param dtype); g = dL/dy0 [B, T0, C]; gscale = feature_grad_mult
@@ -375,38 +388,34 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   const int T0 = (int)((T - kw) / stride + 1);
   const int nchunk = (T0 + C0_TCH_BWD - 1) / C0_TCH_BWD;
   const dim3 grid((unsigned)nchunk, (unsigned)B);
-  float* part1 = (float*)workspace;
-  float* part2 = part1 + (long)B * nchunk * 2 * C;
-  float* ab = part2 + (long)B * nchunk * C * C0_KW;
-  const size_t sm1 = (seg_floats(C0_TCH_BWD, stride) + 4 * 2 * 512) * sizeof(float);
-  const size_t sm2 = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float);
-#define B1(TW, TP, TO) WL_LAUNCH((conv0_bwd_stats_kernel<TW, TP, TO>), grid, dim3(256), sm1, st, (const TW*)wav, \
-    (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (const TO*)g, part1, (long)T, T0, (int)C, (int)stride, gscale)
-#define B2(TW, TP, TO) WL_LAUNCH((conv0_bwd_w_kernel<TW, TP, TO>), grid, dim3(256), sm2, st, (const TW*)wav, \
-    (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, ab, (const TO*)g, part2, (long)T, T0, (int)C, (int)stride, gscale)
+  float* part = (float*)workspace;
+  float* partx = part + (long)B * nchunk * C0_NQ * C;
+  float* dwb = partx + (long)B * nchunk * C0_NX;
+  float* ab = dwb + (long)B * C * C0_KW;
+  const size_t sm1 = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float);
+#define B1(TW, TP, TO) WL_LAUNCH((conv0_bwd_fused_kernel<TW, TP, TO>), grid, dim3(256), sm1, st, (const TW*)wav, \
+    (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (const TO*)g, part, partx, (long)T, T0, (int)C, (int)stride, gscale)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
   if (key == 0) B1(float, float, float);
   else if (key == 111) B1(bf16_t, bf16_t, bf16_t);
   else if (key == 11) B1(float, bf16_t, bf16_t);
   else if (key == 1) B1(float, float, bf16_t);
   else return WL_EINVAL;
+#undef B1
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  WL_LAUNCH(conv0_bwd_stats_finish_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0, st, part1, ab,
-            nchunk, (int)C);
+  const dim3 g2((unsigned)((C + 63) / 64), (unsigned)B);
+  if (param_dtype == WL_F32)
+    WL_LAUNCH((conv0_bwd_combine_kernel<float>), g2, dim3(256), 0, st, part, partx, stats, (const float*)W,
+              (const float*)gamma, ab, dwb, nchunk, (int)C, T0);
+  else
+    WL_LAUNCH((conv0_bwd_combine_kernel<bf16_t>), g2, dim3(256), 0, st, part, partx, stats, (const bf16_t*)W,
+              (const bf16_t*)gamma, ab, dwb, nchunk, (int)C, T0);
   WL_LAUNCH(conv0_bwd_affine_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, ab, dgamma, dbeta,
             (int)param_dtype, (int)B, (int)C);
-  if (key == 0) B2(float, float, float);
-  else if (key == 111) B2(bf16_t, bf16_t, bf16_t);
-  else if (key == 11) B2(float, bf16_t, bf16_t);
-  else B2(float, float, bf16_t);
-#undef B1
-#undef B2
-  rc = wl_check_launch();
-  if (rc != WL_OK) return rc;
   const int n = C * C0_KW;
-  WL_LAUNCH(conv0_bwd_w_finish_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part2, B * nchunk, n,
-                     dW, (int)param_dtype);
+  WL_LAUNCH(conv0_bwd_w_finish_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, dwb, (int)B, n, dW,
+            (int)param_dtype);
   return wl_check_launch();
 }
 
