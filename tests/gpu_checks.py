@@ -460,9 +460,11 @@ def check_attention():
     fd = (Lp - Lm) / (2 * eps)
     out.append(("attn[fused] dropout fwd/bwd mask consistency (finite difference)", abs(fd - lin) / max(abs(fd), 1e-6), 0.2))
     # gate
-    for dtype in (torch.float32, torch.bfloat16):
+    # (3, 64): 16-byte fast path with idle lanes, even row count; (12, 64) x 67 rows: Base geometry, odd row count (half
+    # step at the end); (2, 32): generic kernel
+    for dtype, (B, T, H, hd) in [(dt_, g_) for dt_ in (torch.float32, torch.bfloat16)
+                                 for g_ in ((2, 33, 3, 64), (1, 67, 12, 64), (2, 19, 2, 32))]:
         tol = tol_for(dtype)
-        B, T, H, hd = 2, 33, 3, 64
         x = q(gen(B, T, H * hd, seed=1), dtype)
         W, b = q(0.2 * gen(8, hd, seed=2), dtype), q(0.1 * gen(8, seed=3), dtype)
         a = q(1 + 0.1 * gen(1, H, 1, 1, seed=4), dtype)
@@ -475,7 +477,7 @@ def check_attention():
         xd, Wd, bd, ad = [t.to(dtype).to(DEV).requires_grad_(True) for t in (x, W, b, a)]
         gdv = F.GateFn.apply(xd, Wd, bd, ad, H)
         gdv.backward(dg.to(DEV))
-        tag = f"gate[{dtype}]"
+        tag = f"gate[{dtype}] H={H} hd={hd} rows={B * T}"
         out.append((tag + " gate", err(gdv, gr), tol))
         out.append((tag + " dx", err(xd.grad, xr.grad), tol * 2))
         out.append((tag + " dW", err(Wd.grad, Wr.grad), tol * 2))
