@@ -37,21 +37,9 @@ typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
 // the previous per-element multiplicative hash was ~1/3 of the forward kernel's VALU time.  The 1/(1-p) factor is
 // never applied per element: forward folds it into the final 1/l, backward into the exponent (lse - log2 sc) and
 // into delta / sc.
-__device__ __forceinline__ unsigned fa_hash32(unsigned x) {
-  x *= 0x9E3779B1u;
-  x ^= x >> 15; x *= 0x85EBCA77u;
-  x ^= x >> 13; x *= 0xC2B2AE3Du;
-  x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ unsigned fa_row_word(unsigned s0, unsigned grow) { return fa_hash32(grow ^ s0); }
-__device__ __forceinline__ unsigned fa_col_word(unsigned s1, unsigned jpair) { return fa_hash32((jpair ^ s1) + 0x68E31DA4u); }
-__device__ __forceinline__ unsigned fa_mix(unsigned x) {
-  // one xor-shift + one shift-add: enough to break the additive structure of (row word + column word) -- measured
-  // 4-point correlation of the keep decisions 0.002 +- 0.0014 (0.068 without it), pair correlation < 1e-3
-  x ^= x >> 16; x += x << 5;
-  return x;
-}
+__device__ __forceinline__ unsigned fa_row_word(unsigned s0, unsigned grow) { return hash32(grow ^ s0); }
+__device__ __forceinline__ unsigned fa_col_word(unsigned s1, unsigned jpair) { return hash32((jpair ^ s1) + 0x68E31DA4u); }
+__device__ __forceinline__ unsigned fa_mix(unsigned x) { return drop_mix(x); }
 #define FA_LOG2E 1.4426950408889634f
 #define FA_LN2 0.6931471805599453f
 

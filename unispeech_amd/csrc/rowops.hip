@@ -44,6 +44,32 @@ static inline unsigned drop_thresh(float p) {
 
 #define LN_MAXC 4  // 64 lanes x 4 chunks x 8 = rows up to 2048 channels
 
+// LayerNorm dropout masks (input-side and output-side): row word per (seed, row), four column words per 8-channel
+// chunk (shared by both masks; they depend on both seeds), see common.hpp.  Forward and backward evaluate the same
+// function, nothing is stored.
+__device__ __forceinline__ void ln_drop_cols(unsigned long long seed_in, unsigned long long seed_out, int lane, int nch,
+                                             unsigned (&cw)[LN_MAXC][4]) {
+  const unsigned k = (unsigned)seed_in * 0x2545F491u + (unsigned)seed_out + 0x7F4A7C15u;
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int ch = lane + 64 * c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cw[c][j] = ch < nch ? hash32(k ^ (unsigned)(ch * 4 + j)) : 0u;
+  }
+}
+__device__ __forceinline__ unsigned ln_drop_row(unsigned long long seed, long row) {
+  return hash32((unsigned)(seed >> 32) + (unsigned)row * 0x27D4EB2Fu + ((unsigned)seed ^ 0x165667B1u));
+}
+// v[0..7] -> dropout(v) for one chunk: element 2j / 2j+1 <- low / high half of word j
+__device__ __forceinline__ void ln_drop_apply(float (&v)[8], unsigned rw, const unsigned (&cw)[4], unsigned th, float sc) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned w = drop_mix(rw + cw[j]);
+    v[2 * j] = (w & 0xffffu) >= th ? v[2 * j] * sc : 0.f;
+    v[2 * j + 1] = (w >> 16) >= th ? v[2 * j + 1] * sc : 0.f;
+  }
+}
+
 // y = dropout_out( act( LN( x + dropout_in(r) ) ) ); optionally stores s = x + dropout_in(r), mean, rstd
 template <typename T, typename TP>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ y,
@@ -52,9 +78,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     unsigned long long seed_in, unsigned th_out, float sc_out, unsigned long long seed_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 3;
+  unsigned cw[LN_MAXC][4];
+  if (th_in | th_out) ln_drop_cols(seed_in, seed_out, lane, nch, cw);
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
     float v[LN_MAXC][8];
     float sum = 0.f;
+    const unsigned rw_in = th_in ? ln_drop_row(seed_in, row) : 0u, rw_out = th_out ? ln_drop_row(seed_out, row) : 0u;
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c) {
       const int ch = lane + 64 * c;
@@ -64,11 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         if (r) {
           float rv[8];
           load8(r + off, rv);
-          if (th_in) {
-            const unsigned k = keep8(seed_in, (unsigned long long)off, th_in);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) rv[e] = ((k >> e) & 1u) ? rv[e] * sc_in : 0.f;
-          }
+          if (th_in) ln_drop_apply(rv, rw_in, cw[c], th_in, sc_in);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[c][e] += rv[e];
           // statistics are taken on the sum as it is stored (bf16-rounded in bf16 mode): that is the
@@ -109,11 +134,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
           if (act) z = gelu_f(z);
           o[e] = z;
         }
-        if (th_out) {
-          const unsigned k = keep8(seed_out, (unsigned long long)off, th_out);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = ((k >> e) & 1u) ? o[e] * sc_out : 0.f;
-        }
+        if (th_out) ln_drop_apply(o, rw_out, cw[c], th_out, sc_out);
         store8(y + off, o);
       }
     }
@@ -139,8 +160,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; gm[c][e] = 0.f; bt[c][e] = 0.f; }
     if (ch < nch) { load8(gamma + ch * 8, gm[c]); if (act) load8(beta + ch * 8, bt[c]); }
   }
+  unsigned cw[LN_MAXC][4];
+  if (th_in | th_out) ln_drop_cols(seed_in, seed_out, lane, nch, cw);
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
     const float mean = mean_i[row], rstd = rstd_i[row];
+    const unsigned rw_in = th_in ? ln_drop_row(seed_in, row) : 0u, rw_out = th_out ? ln_drop_row(seed_out, row) : 0u;
     float h[LN_MAXC][8], xh[LN_MAXC][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -151,11 +175,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         float g[8], sv[8];
         load8(dy + off, g);
         load8(s + off, sv);
-        if (th_out) {
-          const unsigned k = keep8(seed_out, (unsigned long long)off, th_out);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) g[e] = ((k >> e) & 1u) ? g[e] * sc_out : 0.f;
-        }
+        if (th_out) ln_drop_apply(g, rw_out, cw[c], th_out, sc_out);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float xhat = (sv[e] - mean) * rstd;
@@ -181,11 +201,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int e = 0; e < 8; ++e) o[e] = grad_scale * rstd * (h[c][e] - s1 - xh[c][e] * s2);  // grad_scale: input gradient only, not dgamma/dbeta
         store8(dx + off, o);
         if (dr) {
-          if (th_in) {
-            const unsigned k = keep8(seed_in, (unsigned long long)off, th_in);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = ((k >> e) & 1u) ? o[e] * sc_in : 0.f;
-          }
+          if (th_in) ln_drop_apply(o, rw_in, cw[c], th_in, sc_in);
           store8(dr + off, o);
         }
       }
@@ -391,9 +407,9 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   if (!x || !y || !gamma || !beta || rows < 0 || D <= 0 || (D & 7) || D > LN_MAXC * 512) return WL_EINVAL;
   if (rows == 0) return WL_OK;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned ti = drop_thresh(p_in), to = drop_thresh(p_out);
-  const float si = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, so = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
-  const unsigned grid = grid_for(rows, 4, 8192);
+  const unsigned ti = drop_thresh16(p_in), to = drop_thresh16(p_out);
+  const float si = drop_scale16(ti), so = drop_scale16(to);
+  const unsigned grid = grid_for(rows, 4, (ti | to) ? 1024 : 8192);  // with dropout: several rows per wave amortise the column words
 #define LN_FWD(T, TP) WL_LAUNCH((layernorm_fwd_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)x, \
     (const T*)r, (T*)y, (T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (long)rows, (int)D, eps, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out)
@@ -417,8 +433,8 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   if (act && !beta) return WL_EINVAL;
   if (ws_bytes < wavlm_layernorm_bwd_workspace_bytes(D)) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned ti = drop_thresh(p_in), to = drop_thresh(p_out);
-  const float si = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, so = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+  const unsigned ti = drop_thresh16(p_in), to = drop_thresh16(p_out);
+  const float si = drop_scale16(ti), so = drop_scale16(to);
   const unsigned grid = grid_for(rows, 4, LN_BWD_BLOCKS);
   float* part = (float*)workspace;
 #define LN_BWD(T, TP) WL_LAUNCH((layernorm_bwd_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
