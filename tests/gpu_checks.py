@@ -145,12 +145,12 @@ def check_gemm():
     return out
 
 
-def check_gemm_pp():
-    """256x256 ping-pong kernel (variant 3): all four operand layouts, ragged M/N edges, K tails (zero-page path),
-    K batches with a tail in every batch, split-K, and the fused epilogues."""
+def check_gemm_pp(variant=3, name="gemm_pp"):
+    """256x256 (variant 3) / 192x384 (variant 4) ping-pong kernels: all four operand layouts, ragged M/N edges, K tails
+    (zero-page path), K batches with a tail in every batch, split-K, and the fused epilogues."""
     out = []
     dtype, tol = torch.bfloat16, TOLBF
-    ops.gemm_set_variant(3)
+    ops.gemm_set_variant(variant)
     try:
         cases = [  # M, N, K, tA, tB, KB, split
             (600, 520, 256, 0, 0, 1, 1), (600, 520, 200, 0, 0, 1, 1), (1000, 296, 1000, 0, 1, 1, 1),
@@ -175,7 +175,7 @@ def check_gemm_pp():
             C = torch.full((M, Np), float("nan"), dtype=dtype, device=DEV)
             ops.gemm(Ad, Bd, C, M, N, K, lda=lda, ldb=ldb, ldc=Np, transA=tA, transB=tB, KB=KB, sA_kb=sa, sB_kb=sb,
                      split_k=split)
-            out.append((f"gemm_pp {M}x{N}x{K} tA={tA} tB={tB} KB={KB} split={split}", err(C[:, :N], ref), tol))
+            out.append((f"{name} {M}x{N}x{K} tA={tA} tB={tB} KB={KB} split={split}", err(C[:, :N], ref), tol))
         # batched + bias + gelu + aux + residual through the ping-pong kernel
         Bo, Bi, M, N, K = 2, 2, 300, 264, 192
         A = q(gen(Bo, Bi, M, K, seed=33), dtype)
@@ -190,8 +190,8 @@ def check_gemm_pp():
                  sA=(Bi * M * K, M * K), sB=(Bi * N * K, N * K), sC=(Bi * M * N, M * N), alpha=0.5,
                  bias=bias.to(dtype).to(DEV), sBias=(0, N), epi=1, aux=aux, ld_aux=N, sAux=(Bi * M * N, M * N),
                  res=res.to(dtype).to(DEV), ld_res=N, sRes=(Bi * M * N, M * N))
-        out.append(("gemm_pp batched+bias+gelu+res", err(C, ref), tol))
-        out.append(("gemm_pp aux(pre-activation)", err(aux, pre), tol))
+        out.append((f"{name} batched+bias+gelu+res", err(C, ref), tol))
+        out.append((f"{name} aux(pre-activation)", err(aux, pre), tol))
         # overlapping rows (strided conv) through the ping-pong kernel
         Bb, Tin, Cin, Cout, k, s = 2, 701, 64, 256, 3, 2
         x = q(gen(Bb, Tin, Cin, seed=37), dtype)
@@ -202,10 +202,14 @@ def check_gemm_pp():
         y = torch.empty(Bb, Tout, Cout, dtype=dtype, device=DEV)
         ops.gemm(x.to(dtype).to(DEV), Wf.to(dtype).to(DEV), y, Tout, Cout, k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout,
                  batch=(Bb, 1), sA=(Tin * Cin, 0), sC=(Tout * Cout, 0))
-        out.append(("gemm_pp overlapping-row conv1d k3 s2", err(y, refc), tol))
+        out.append((f"{name} overlapping-row conv1d k3 s2", err(y, refc), tol))
     finally:
         ops.gemm_set_variant(0)
     return out
+
+
+def check_gemm_pp3():
+    return check_gemm_pp(4, "gemm_pp3")
 
 
 # --------------------------------------------------------------------------------------------------- row ops
@@ -620,7 +624,7 @@ def check_adam():
 
 
 GROUPS = {
-    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
+    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
     "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv,
     "linear_ffn": check_linear_ffn, "loss": check_loss, "adam": check_adam,
 }

@@ -197,7 +197,7 @@ static int launch_cfg(GemmP& p, int nbatch, bool vec, hipStream_t st) {
   return wl_check_launch();
 }
 
-static int g_gemm_variant = 0;  // 0: auto, 1: force 128x128, 2: force 256x128, 3: 256x256 ping-pong where it applies
+static int g_gemm_variant = 0;  // 0: auto, 1: force 128x128, 2: force 256x128, 3 / 4: force the 256x256 / 192x384 ping-pong kernel where it applies
 extern "C" void wavlm_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 template <bool TA, bool TB>
@@ -227,6 +227,16 @@ static bool vec_epilogue_ok(const wavlm_gemm_desc* d) {
 int gemm_f32_launch(const wavlm_gemm_desc* d, hipStream_t st);  // gemm_f32.hip
 bool gemm_pp_ok(const wavlm_gemm_desc* d);                       // gemm_pp.hip
 int gemm_pp_launch(GemmP& p, int nbatch, bool transA, bool transB, bool vec, hipStream_t st);
+bool gemm_pp3_ok(const wavlm_gemm_desc* d);                      // gemm_pp3.hip
+int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, bool vec, hipStream_t st);
+
+// fraction of a CU-round's MFMA work that is useful for a BM x BN tiling on 256 CUs (edge waste x round quantisation)
+static double tile_efficiency(const wavlm_gemm_desc* d, int nbatch, int BM, int BN) {
+  const long tm = (d->M + BM - 1) / BM, tn = (d->N + BN - 1) / BN;
+  const long tiles = tm * tn * nbatch * (d->split_k < 1 ? 1 : d->split_k);
+  const double useful = ((double)d->M * d->N) / ((double)tm * BM * tn * BN);
+  return useful * (double)tiles / (256.0 * (double)((tiles + 255) / 256));
+}
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -306,7 +316,11 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   const int pi = prof_begin(d, st);
   int rc;
   const bool vec = vec_epilogue_ok(d);
-  if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) rc = gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, vec, st);
+  if ((g_gemm_variant == 4 && gemm_pp3_ok(d)) ||
+      (g_gemm_variant == 0 && d->N >= 384 && gemm_pp3_ok(d) && gemm_pp_ok(d) &&
+       tile_efficiency(d, nbatch, 192, 384) > 1.25 * tile_efficiency(d, nbatch, 256, 256)))  // six shorter phases per K step cost ~10 %: only where the 256 x 256 tiling quantises badly (N = 768 at 24 k rows)
+    rc = gemm_pp3_launch(p, nbatch, d->transA != 0, d->transB != 0, vec, st);
+  else if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) rc = gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, vec, st);
   else if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, vec, st);
   else if (!d->transA && d->transB) rc = launch_t<false, true>(p, nbatch, vec, st);
   else if (d->transA && !d->transB) rc = launch_t<true, false>(p, nbatch, vec, st);

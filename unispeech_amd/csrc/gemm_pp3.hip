@@ -1,0 +1,359 @@
+// bf16 MFMA GEMM for gfx950, second large-problem tile: 192 x 384 x 64, 8 waves (2 x 4), 96 x 96 accumulators per
+// wave (3 x 3 v_mfma_f32_32x32x16_bf16 blocks), same ping-pong / LDS-DMA / counted-vmcnt machinery as gemm_pp.hip.
+//
+// Why a second shape: the transformer's token count (B = 32 x 749 = 23 968 rows) against N = 768 gives 94 x 3 = 282
+// tiles of 256 x 256 -- two rounds on 256 CUs with the second round 10 % full (55 % efficiency).  192 x 384 tiles
+// have the same area per flop-byte ratio (0.0078 B/flop) and give 125 x 2 = 250 tiles: one round, 98 % full.  For
+// N = 2304 / 3072 they give 750 / 1000 tiles (2.93 / 3.9 rounds) against 846 / 1128 (3.3 / 4.4 rounds).
+//
+// Staging units per K step: A_0, A_1, A_2 (the i-th 32-row block of both wave rows: 64 rows, 8 KiB) and B (384 rows,
+// 48 KiB); two stages = 144 KiB.  Nine accumulator blocks (144 VGPRs) leave room for the fragments of only two of the
+// four k-slices at a time, so a K step is SIX phases q = 3 kh + i (k half kh, accumulator row block i), 6 MFMA each:
+//     q = 0, 3 read B (k half) + A_0;   q = 1, 4 read A_1;   q = 2, 5 read A_2
+// A unit is free after its second read (B and A_0 after q = 3, A_1 after 4, A_2 after 5) and may be refilled two
+// phases later (WAR with the two wave groups one barrier apart, see gemm_pp.hip).  DMA pieces per wave (1 KiB each):
+//     q=0: B pieces 2,3 (t+1)   q=1: B pieces 4,5 (t+1)   q=2: A_0, A_1 (t+1)   q=3: A_2 (t+1)   q=4: -
+//     q=5: B pieces 0,1 (t+2), then s_waitcnt vmcnt(2): everything of step t+1 has landed (RAW: first read of step
+//     t+1 follows the barrier after both groups' waits).
+// K-strided operands: A units are [64 k][64 rows] (128-B k rows, 32-B granule ^ 2*((k>>1)&1)), B is
+// [64 k][384 rows] (768-B k rows, granule ^ 2*(k&3) inside aligned groups of 8), both read with ds_read_b64_tr_b16.
+#include "gemm_common.hpp"
+
+#include "tile_loaders.hpp"
+
+#define P3_AU 8192
+#define P3_BB 49152
+#define P3_STAGE (3 * P3_AU + P3_BB)  // 73728
+
+__device__ __attribute__((aligned(256))) unsigned char g_pp3_zero[256];  // zero page for K positions past the end
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
+
+struct P3Cursor { long off; int kt; };
+
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 * P3_STAGE
+
+  int tile;
+  {
+    const int nt = p.tiles_m * p.tiles_n, bid = blockIdx.x;
+    const int q = nt >> 3, rem = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+  const int z = blockIdx.y, split = blockIdx.z;
+  const int zo = z / p.batch_i, zi = z % p.batch_i;
+  const int m0 = tm * 192, n0 = tn * 384;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const char* Ab = (const char*)((const bf16_t*)p.A + (long)zo * p.sA_o + (long)zi * p.sA_i + (TA ? (long)m0 : (long)m0 * p.lda));
+  const char* Bb = (const char*)((const bf16_t*)p.B + (long)zo * p.sB_o + (long)zi * p.sB_i + (TB ? (long)n0 : (long)n0 * p.ldb));
+  const int kt_per = (p.K + 63) >> 6;
+  const int kv_last = p.K - (kt_per - 1) * 64;
+  int t0, t1;
+  gemm_split_range(p.KB * kt_per, p.split_k, split, t0, t1);
+  const int nt = t1 - t0;
+
+  // ---- DMA side -------------------------------------------------------------------------------------------------
+  // A unit i, piece = wave: K-contiguous -> buffer rows 8 w .. +8 (lane: row + (l >> 3), physical chunk l & 7);
+  //                         K-strided   -> k rows 8 w .. +8 (lane: k row + (l >> 3), physical 16-B chunk l & 7 of 8)
+  // B piece p = 6 w + j:    K-contiguous -> buffer rows 8 p .. +8;  K-strided -> bytes 1024 p .. of the [64][768 B] image
+  // buffer row R of A unit i <-> tile row (R >> 5) * 96 + 32 i + (R & 31);  B buffer row = tile column
+  unsigned voffA[3], voffB[6];
+  {
+    const int rows_valid = p.M - m0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (!TA) {
+        const int R = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        int r = (R >> 5) * 96 + i * 32 + (R & 31);
+        if (r >= rows_valid) r = rows_valid - 1;
+        voffA[i] = (unsigned)(((long)r * p.lda + c * 8) * 2);
+      } else {
+        const int kr = wave * 8 + (lane >> 3);
+        const int pc = lane & 7;
+        const int R = (((pc >> 1) ^ (2 * ((kr >> 1) & 1))) << 4) + ((pc & 1) << 3);
+        int r = (R >> 5) * 96 + i * 32 + (R & 31);
+        if (r + 8 > rows_valid) r = rows_valid - 8;
+        voffA[i] = (unsigned)(((long)kr * p.lda + r) * 2);
+      }
+    }
+    const int cols_valid = p.N - n0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int pi = wave * 6 + j;
+      if (!TB) {
+        const int R = pi * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        int r = R;
+        if (r >= cols_valid) r = cols_valid - 1;
+        voffB[j] = (unsigned)(((long)r * p.ldb + c * 8) * 2);
+      } else {
+        const int o = pi * 1024 + lane * 16;
+        const int kr = o / 768, pc = (o % 768) >> 4;
+        const int pg = pc >> 1;
+        const int g = (pg & ~7) | ((pg & 7) ^ (2 * (kr & 3)));
+        int r = g * 16 + ((pc & 1) << 3);
+        if (r + 8 > cols_valid) r = cols_valid - 8;
+        voffB[j] = (unsigned)(((long)kr * p.ldb + r) * 2);
+      }
+    }
+  }
+  const long stepA = TA ? 64 * p.lda : 64, stepB = TB ? 64 * p.ldb : 64;
+  const long jumpA = p.sA_kb - (long)kt_per * stepA, jumpB = p.sB_kb - (long)kt_per * stepB;
+  // streams: 0..2 = A_0..A_2, 3..5 = B pieces {0,1}, {2,3}, {4,5}
+  P3Cursor cur[6];
+  {
+    const int kb0 = t0 / kt_per, kt0 = t0 - kb0 * kt_per;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      cur[q].off = q < 3 ? (long)kb0 * p.sA_kb + (long)kt0 * stepA : (long)kb0 * p.sB_kb + (long)kt0 * stepB;
+      cur[q].kt = kt0;
+    }
+  }
+  // first k position (K-contiguous) / k row (K-strided) this lane's 16 bytes of a piece cover -- only needed on K tails
+  auto kidx_a = [&]() __attribute__((always_inline)) -> int {
+    if (!TA) { const int R = wave * 8 + (lane >> 3); return ((lane & 7) ^ ((R >> 1) & 7)) * 8; }
+    return wave * 8 + (lane >> 3);
+  };
+  auto kidx_b = [&](int j) __attribute__((always_inline)) -> int {
+    const int pi = wave * 6 + j;
+    if (!TB) { const int R = pi * 8 + (lane >> 3); return ((lane & 7) ^ ((R >> 1) & 7)) * 8; }
+    return (pi * 1024 + lane * 16) / 768;
+  };
+  auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) {
+    constexpr int W = decltype(which_c)::value;
+    P3Cursor& c = cur[W];
+    const int kv = (c.kt == kt_per - 1) ? kv_last : 64;
+    if constexpr (W < 3) {
+      const char* src = Ab + c.off * 2 + voffA[W];
+      if (kv < 64 && !(kidx_a() < kv)) src = (const char*)g_pp3_zero;
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(smem + stage * P3_STAGE + W * P3_AU + wave * 1024), 16, 0, 0);
+      c.off += stepA;
+      if (++c.kt == kt_per) { c.kt = 0; c.off += jumpA; }
+    } else {
+      constexpr int J0 = 2 * (W - 3);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* src = Bb + c.off * 2 + voffB[J0 + j];
+        if (kv < 64 && !(kidx_b(J0 + j) < kv)) src = (const char*)g_pp3_zero;
+        __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(smem + stage * P3_STAGE + 3 * P3_AU + (wave * 6 + J0 + j) * 1024),
+                                         16, 0, 0);
+      }
+      c.off += stepB;
+      if (++c.kt == kt_per) { c.kt = 0; c.off += jumpB; }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+  using I5 = std::integral_constant<int, 5>;
+
+  // ---- fragment side ---------------------------------------------------------------------------------------------
+  unsigned kc_a[4], kc_b[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const unsigned lo = (unsigned)((lane & 31) * 128 + (((2 * s + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
+    kc_a[s] = lo + wm * 4096;
+    kc_b[s] = lo + wn * 12288;
+  }
+  unsigned tr_a, tr_b[3];
+  {
+    const int i = lane & 15, g1 = (lane >> 4) & 1, o = lane >> 5;
+    tr_a = (unsigned)((8 * o + (i >> 2)) * 128 + (((wm * 2 + g1) ^ (2 * ((i >> 3) & 1))) << 5) + (i & 3) * 8);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int gB = wn * 6 + j * 2 + g1;
+      tr_b[j] = (unsigned)((8 * o + (i >> 2)) * 768 + (((gB & ~7) | ((gB & 7) ^ (2 * (i >> 2)))) << 5) + (i & 3) * 8);
+    }
+  }
+  auto rd_a = [&](int base, int s) __attribute__((always_inline)) -> bf16x8_t {  // base: byte offset of the A unit
+    if constexpr (!TA) {
+      return *reinterpret_cast<const bf16x8_t*>(smem + base + kc_a[s]);
+    } else {
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 2048 + tr_a));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 2048 + 512 + tr_a));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto rd_b = [&](int base, int j, int s) __attribute__((always_inline)) -> bf16x8_t {  // base: byte offset of B
+    if constexpr (!TB) {
+      return *reinterpret_cast<const bf16x8_t*>(smem + base + j * 4096 + kc_b[s]);
+    } else {
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 12288 + tr_b[j]));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 12288 + 3072 + tr_b[j]));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+
+  f32x16_t acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8_t bf[3][2], af[2];
+
+#define P3_MFMA_SECTION(I_)                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  __builtin_amdgcn_s_barrier();                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  __builtin_amdgcn_s_setprio(1);                                                                    \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                   \
+      acc[I_][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bf[j][s], acc[I_][j], 0, 0, 0);    \
+  }                                                                                                 \
+  __builtin_amdgcn_s_setprio(0);                                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  __builtin_amdgcn_s_barrier();                                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto k_step = [&](auto stage_c, int t) __attribute__((always_inline)) {
+    constexpr int ST = decltype(stage_c)::value;
+    constexpr int SB = ST * P3_STAGE;
+    const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      // ---- q = 3 kh: B (this k half), A_0
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bf[j][s] = rd_b(SB + 3 * P3_AU, j, 2 * kh + s);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) af[s] = rd_a(SB, 2 * kh + s);
+      if (more1) { if (kh == 0) issue(I4{}, ST ^ 1); else issue(I2{}, ST ^ 1); }
+      P3_MFMA_SECTION(0)
+      // ---- q = 3 kh + 1: A_1
+#pragma unroll
+      for (int s = 0; s < 2; ++s) af[s] = rd_a(SB + P3_AU, 2 * kh + s);
+      if (more1 && kh == 0) issue(I5{}, ST ^ 1);
+      P3_MFMA_SECTION(1)
+      // ---- q = 3 kh + 2: A_2
+#pragma unroll
+      for (int s = 0; s < 2; ++s) af[s] = rd_a(SB + 2 * P3_AU, 2 * kh + s);
+      if (kh == 0) {
+        if (more1) { issue(I0{}, ST ^ 1); issue(I1{}, ST ^ 1); }
+      } else {
+        if (more2) {
+          issue(I3{}, ST);
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      P3_MFMA_SECTION(2)
+    }
+  };
+
+  if (nt > 0) {
+    issue(I3{}, 0); issue(I4{}, 0); issue(I5{}, 0); issue(I0{}, 0); issue(I1{}, 0); issue(I2{}, 0);
+    if (nt > 1) {
+      issue(I3{}, 1);
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+    for (int t = 0; t < nt; t += 2) {
+      k_step(I0{}, t);
+      if (t + 1 < nt) k_step(I1{}, t + 1);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+  }
+#undef P3_MFMA_SECTION
+  __syncthreads();
+
+  // ---- epilogue ----------------------------------------------------------------------------------------------------
+  const int mw = m0 + wm * 96, nw = n0 + wn * 96;  // wave tile origin; block i -> rows 32 i, j -> cols 32 j
+  if constexpr (!VEC) {
+    auto store_block = [&](const f32x16_t (&a)[3], int i) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int nn = nw + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mm = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (mm < p.M && nn < p.N) gemm_store(p, z, split, mm, nn, a[j][r]);
+        }
+      }
+    };
+    store_block(acc[0], 0); store_block(acc[1], 1); store_block(acc[2], 2);
+  } else {
+    constexpr int EP_LD = 96 + 4;
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    auto stage_block = [&](const f32x16_t (&a)[3]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] = a[j][r];
+    };
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+      switch (i) {
+        case 0: stage_block(acc[0]); break;
+        case 1: stage_block(acc[1]); break;
+        default: stage_block(acc[2]); break;
+      }
+#pragma unroll 1
+      for (int q = 0; q < 6; ++q) {  // not unrolled: with 144 accumulator registers live the store code must stay small
+        const int id = lane + 64 * q;   // 32 rows x 12 chunks
+        const int rl = id / 12, ch = id - rl * 12;
+        const int mm = mw + i * 32 + rl;
+        const int nn = nw + ch * 8;
+        if (mm < p.M && nn < p.N) {
+          const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          gemm_store8(p, zo, zi, z, split, mm, nn, v);
+        }
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+static int pp3_launch_t(GemmP& p, int nbatch, bool vec, hipStream_t st) {
+  p.tiles_m = (p.M + 191) / 192;
+  p.tiles_n = (p.N + 383) / 384;
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)nbatch, (unsigned)p.split_k);
+  constexpr int smem = 2 * P3_STAGE;
+  static bool done[2] = {false, false};
+  if (!done[vec]) {
+    const void* fn = vec ? (const void*)gemm_pp3_kernel<TA, TB, true> : (const void*)gemm_pp3_kernel<TA, TB, false>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return WL_ELAUNCH;
+    done[vec] = true;
+  }
+  if (vec) WL_LAUNCH((gemm_pp3_kernel<TA, TB, true>), grid, dim3(512), smem, st, p);
+  else WL_LAUNCH((gemm_pp3_kernel<TA, TB, false>), grid, dim3(512), smem, st, p);
+  return wl_check_launch();
+}
+
+bool gemm_pp3_ok(const wavlm_gemm_desc* d) {
+  if (d->M < 192 || d->N < 192 || d->K < 64) return false;
+  if (!d->transA && d->K % 8) return false;
+  if (!d->transB && d->K % 8) return false;
+  if (d->transA && d->M % 8) return false;
+  if (d->transB && d->N % 8) return false;
+  const int64_t ra = d->transA ? 64 : 192, rb = d->transB ? 64 : 384;
+  if (ra * d->lda * 2 >= (1ll << 31) || rb * d->ldb * 2 >= (1ll << 31)) return false;
+  return true;
+}
+
+int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, bool vec, hipStream_t st) {
+  if (!transA && !transB) return pp3_launch_t<false, false>(p, nbatch, vec, st);
+  if (!transA && transB) return pp3_launch_t<false, true>(p, nbatch, vec, st);
+  if (transA && !transB) return pp3_launch_t<true, false>(p, nbatch, vec, st);
+  return pp3_launch_t<true, true>(p, nbatch, vec, st);
+}

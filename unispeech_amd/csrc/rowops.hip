@@ -47,11 +47,12 @@ static inline unsigned drop_thresh(float p) {
 // LayerNorm dropout masks (input-side and output-side): row word per (seed, row), four column words per 8-channel
 // chunk (shared by both masks; they depend on both seeds), see common.hpp.  Forward and backward evaluate the same
 // function, nothing is stored.
+template <int NC>
 __device__ __forceinline__ void ln_drop_cols(unsigned long long seed_in, unsigned long long seed_out, int lane, int nch,
-                                             unsigned (&cw)[LN_MAXC][4]) {
+                                             unsigned (&cw)[NC][4]) {
   const unsigned k = (unsigned)seed_in * 0x2545F491u + (unsigned)seed_out + 0x7F4A7C15u;
 #pragma unroll
-  for (int c = 0; c < LN_MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     const int ch = lane + 64 * c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) cw[c][j] = ch < nch ? hash32(k ^ (unsigned)(ch * 4 + j)) : 0u;
@@ -71,21 +72,21 @@ __device__ __forceinline__ void ln_drop_apply(float (&v)[8], unsigned rw, const 
 }
 
 // y = dropout_out( act( LN( x + dropout_in(r) ) ) ); optionally stores s = x + dropout_in(r), mean, rstd
-template <typename T, typename TP>
+template <typename T, typename TP, int NC>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ y,
     T* __restrict__ s, float* __restrict__ mean_o, float* __restrict__ rstd_o, const TP* __restrict__ gamma,
     const TP* __restrict__ beta, long rows, int D, float eps, int act, unsigned th_in, float sc_in,
     unsigned long long seed_in, unsigned th_out, float sc_out, unsigned long long seed_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 3;
-  unsigned cw[LN_MAXC][4];
-  if (th_in | th_out) ln_drop_cols(seed_in, seed_out, lane, nch, cw);
+  unsigned cw[NC][4];
+  if (th_in | th_out) ln_drop_cols<NC>(seed_in, seed_out, lane, nch, cw);
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
-    float v[LN_MAXC][8];
+    float v[NC][8];
     float sum = 0.f;
     const unsigned rw_in = th_in ? ln_drop_row(seed_in, row) : 0u, rw_out = th_out ? ln_drop_row(seed_out, row) : 0u;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int ch = lane + 64 * c;
       if (ch < nch) {
         const long off = row * D + ch * 8;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int ch = lane + 64 * c;
       if (ch < nch) {
 #pragma unroll
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
     if (lane == 0) { if (mean_o) mean_o[row] = mean; if (rstd_o) rstd_o[row] = rstd; }
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int ch = lane + 64 * c;
       if (ch < nch) {
         const long off = row * D + ch * 8;
@@ -143,32 +144,32 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 
 // backward of the above.  dx -> gradient of x (and of the un-dropped residual path); dr (optional) ->
 // gradient of r (= dx with the input-dropout mask).  dgamma/dbeta partials: part[block][2][D].
-template <typename T, typename TP>
+template <typename T, typename TP, int NC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
     const float* __restrict__ mean_i, const float* __restrict__ rstd_i, const TP* __restrict__ gamma,
     const TP* __restrict__ beta, T* __restrict__ dx, T* __restrict__ dr, float* __restrict__ part, long rows, int D,
     int act, unsigned th_in, float sc_in, unsigned long long seed_in, unsigned th_out, float sc_out,
     unsigned long long seed_out, float grad_scale) {
-  __shared__ float red[4][2][64 * LN_MAXC * 8 / 4];  // cross-wave reduce, processed in 4 column quarters
+  __shared__ float red[4][2][512];  // cross-wave reduce of one chunk slot (64 lanes x 8 columns) at a time
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 3;
-  float ag[LN_MAXC][8], ab[LN_MAXC][8], gm[LN_MAXC][8], bt[LN_MAXC][8];
+  float ag[NC][8], ab[NC][8], gm[NC][8], bt[NC][8];
 #pragma unroll
-  for (int c = 0; c < LN_MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     const int ch = lane + 64 * c;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; gm[c][e] = 0.f; bt[c][e] = 0.f; }
     if (ch < nch) { load8(gamma + ch * 8, gm[c]); if (act) load8(beta + ch * 8, bt[c]); }
   }
-  unsigned cw[LN_MAXC][4];
-  if (th_in | th_out) ln_drop_cols(seed_in, seed_out, lane, nch, cw);
+  unsigned cw[NC][4];
+  if (th_in | th_out) ln_drop_cols<NC>(seed_in, seed_out, lane, nch, cw);
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
     const float mean = mean_i[row], rstd = rstd_i[row];
     const unsigned rw_in = th_in ? ln_drop_row(seed_in, row) : 0u, rw_out = th_out ? ln_drop_row(seed_out, row) : 0u;
-    float h[LN_MAXC][8], xh[LN_MAXC][8];
+    float h[NC][8], xh[NC][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int ch = lane + 64 * c;
       if (ch < nch) {
         const long off = row * D + ch * 8;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int ch = lane + 64 * c;
       if (ch < nch) {
         const long off = row * D + ch * 8;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   // cross-wave reduction of the column accumulators, one chunk-slot at a time
   float* pg = part + (long)blockIdx.x * 2 * D;
 #pragma unroll
-  for (int c = 0; c < LN_MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[wave][0][lane * 8 + e] = ag[c][e]; red[wave][1][lane * 8 + e] = ab[c][e]; }
@@ -229,11 +230,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 
 // out[c] (+)= sum_b part[b * stride + c].  Block = 64 columns x 16 row slices (coalesced 256-B reads per slice, short
 // dependent-load chains), slices combined through LDS; grid = ceil(n / 64).
+// blockIdx.y selects one of two interleaved partial arrays / outputs (LayerNorm's dgamma, dbeta in one launch)
 __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int nblk, long stride, int n,
-                                                              void* out, int out_dtype, int accumulate) {
+                                                              void* out, int out_dtype, int accumulate, long part_y, void* out_y) {
   __shared__ float red[16][64];
   const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + col;
+  if (blockIdx.y) { part += part_y; out = out_y; }
   float s = 0.f;
   if (c < n)
     for (int b = slice; b < nblk; b += 16) s += part[(long)b * stride + c];
@@ -394,7 +397,7 @@ static inline unsigned grid_for(long work_items, int per_block, unsigned cap) {
   return (unsigned)g;
 }
 
-#define LN_BWD_BLOCKS 512
+#define LN_BWD_BLOCKS 1024
 #define CS_BLOCKS 512
 
 extern "C" {
@@ -410,14 +413,17 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   const unsigned ti = drop_thresh16(p_in), to = drop_thresh16(p_out);
   const float si = drop_scale16(ti), so = drop_scale16(to);
   const unsigned grid = grid_for(rows, 4, (ti | to) ? 1024 : 8192);  // with dropout: several rows per wave amortise the column words
-#define LN_FWD(T, TP) WL_LAUNCH((layernorm_fwd_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)x, \
+  // chunk slots per lane are a template parameter: registers (and occupancy) follow the actual row width
+#define LN_FWD_N(T, TP, NCS) WL_LAUNCH((layernorm_fwd_kernel<T, TP, NCS>), dim3(grid), dim3(256), 0, st, (const T*)x, \
     (const T*)r, (T*)y, (T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (long)rows, (int)D, eps, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out)
+#define LN_FWD(T, TP) do { if (D <= 512) LN_FWD_N(T, TP, 1); else if (D <= 1024) LN_FWD_N(T, TP, 2); else LN_FWD_N(T, TP, 4); } while (0)
   if (dtype == WL_F32 && param_dtype == WL_F32) LN_FWD(float, float);
   else if (dtype == WL_BF16 && param_dtype == WL_BF16) LN_FWD(bf16_t, bf16_t);
   else if (dtype == WL_BF16 && param_dtype == WL_F32) LN_FWD(bf16_t, float);
   else return WL_EINVAL;
 #undef LN_FWD
+#undef LN_FWD_N
   return wl_check_launch();
 }
 
@@ -437,21 +443,21 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   const float si = drop_scale16(ti), so = drop_scale16(to);
   const unsigned grid = grid_for(rows, 4, LN_BWD_BLOCKS);
   float* part = (float*)workspace;
-#define LN_BWD(T, TP) WL_LAUNCH((layernorm_bwd_kernel<T, TP>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
+#define LN_BWD_N(T, TP, NCS) WL_LAUNCH((layernorm_bwd_kernel<T, TP, NCS>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
     (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, part, (long)rows, (int)D, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale)
+#define LN_BWD(T, TP) do { if (D <= 512) LN_BWD_N(T, TP, 1); else if (D <= 1024) LN_BWD_N(T, TP, 2); else LN_BWD_N(T, TP, 4); } while (0)
   if (dtype == WL_F32 && param_dtype == WL_F32) LN_BWD(float, float);
   else if (dtype == WL_BF16 && param_dtype == WL_BF16) LN_BWD(bf16_t, bf16_t);
   else if (dtype == WL_BF16 && param_dtype == WL_F32) LN_BWD(bf16_t, float);
   else return WL_EINVAL;
 #undef LN_BWD
+#undef LN_BWD_N
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   const unsigned g2 = (unsigned)((D + 63) / 64);
-  WL_LAUNCH(colsum_finish_kernel, dim3(g2), dim3(1024), 0, st, part, (int)grid, (long)(2 * D), (int)D, dgamma,
-                     (int)param_dtype, (int)accumulate_params);
-  WL_LAUNCH(colsum_finish_kernel, dim3(g2), dim3(1024), 0, st, part + D, (int)grid, (long)(2 * D), (int)D, dbeta,
-                     (int)param_dtype, (int)accumulate_params);
+  WL_LAUNCH(colsum_finish_kernel, dim3(g2, 2), dim3(1024), 0, st, part, (int)grid, (long)(2 * D), (int)D, dgamma,
+                     (int)param_dtype, (int)accumulate_params, (long)D, dbeta);
   return wl_check_launch();
 }
 
@@ -475,7 +481,7 @@ int wavlm_colsum(const void* x, int64_t rows, int32_t N, int64_t ld, int32_t dty
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, part, (int)grid, (long)N,
-                     (int)N, out, (int)out_dtype, (int)accumulate);
+                     (int)N, out, (int)out_dtype, (int)accumulate, 0L, (void*)nullptr);
   return wl_check_launch();
 }
 
