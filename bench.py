@@ -123,7 +123,7 @@ def main():
     cfg = base_cfg(True)
     torch.manual_seed(0)
     model = WavLMPretrainModel(cfg, None, [range(V)]).to(dev).to(torch.bfloat16).train()
-    opt = FusedAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=10.0)
+    opt = FusedAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=10.0, model=model)
     net = DataParallelWavLM(model, opt) if world > 1 else model
     crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0], defer_logging=True)
 

@@ -210,3 +210,38 @@ def test_bf16_mode_tracks_fp32_mode():
         x16, _ = m16.extract_features(wav.to(torch.bfloat16))
     assert x16.dtype == torch.bfloat16
     assert rel_err(x16.float(), x32) < 5e-2
+
+
+def test_gradient_sink_matches_autograd_accumulation():
+    """FusedAdam re-homes parameters / gradients into flat arenas, packs q|k|v and lets the backward kernels accumulate
+    straight into the gradient arena.  Same model, same batch: every gradient must equal the one autograd accumulates
+    without the optimizer (bf16, 2 layers, Base width), and a second backward must add on top (accumulation steps)."""
+    from unispeech_amd.optim import FusedAdam
+    B, T = 2, 32000
+    g = torch.Generator().manual_seed(7)
+    wav = torch.randn(B, T, generator=g).cuda().to(torch.bfloat16)
+    target = torch.randint(4, 504, (B, 100), generator=g).cuda()
+    sample = {"id": torch.arange(B), "net_input": {"source": wav, "padding_mask": torch.zeros(B, T, dtype=torch.bool).cuda()},
+              "target_list": [target]}
+    grads = []
+    for use_opt in (False, True):
+        model, _sd, _cfg, crit = _base_models(2)
+        model = model.cuda().to(torch.bfloat16).train()
+        opt = FusedAdam(model.parameters(), model=model) if use_opt else None
+        if opt is not None:
+            opt.zero_grad()
+            att = [m for m in model.modules() if hasattr(m, "packed_param_groups")]
+            assert att and all(m._packed is not None for m in att), "q|k|v were not bound to packed arena views"
+        for rep in range(2):
+            np.random.seed(11)
+            torch.manual_seed(5)
+            import unispeech_amd.functional as F
+            F._SEED_CTR[0] = 0  # identical dropout seeds in both runs and both repetitions
+            loss, _, _ = crit(model, sample)
+            loss.backward()
+        grads.append({n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+    a, b = grads
+    assert a.keys() == b.keys()
+    for n in a:
+        scale = a[n].abs().max().clamp_min(1e-6)
+        assert ((a[n] - b[n]).abs().max() / scale).item() < 2e-2, n

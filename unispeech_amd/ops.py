@@ -132,40 +132,44 @@ def layernorm_fwd(x, r, gamma, beta, eps, *, act=0, p_in=0.0, seed_in=0, p_out=0
 
 
 def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0,
-                  grad_scale=1.0, need_dr=False):
-    """returns (dx, dr, dgamma, dbeta)"""
+                  grad_scale=1.0, need_dr=False, dgamma=None, dbeta=None):
+    """returns (dx, dr, dgamma, dbeta); given dgamma / dbeta tensors are accumulated into (+=)"""
     dev = _dev(dy)
     _contig(dy); _contig(s)
     D = dy.shape[-1]
     rows = dy.numel() // D
     dx = torch.empty_like(dy)
     dr = torch.empty_like(dy) if need_dr else None
-    dgamma = torch.empty_like(gamma)
-    dbeta = torch.empty_like(beta)
+    acc = dgamma is not None and dbeta is not None
+    if not acc:
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
     L = _lib.lib()
     need = L.wavlm_layernorm_bwd_workspace_bytes(D)
     ws = workspace(dev, need)
     check(L.wavlm_layernorm_bwd(ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dr),
                                 ptr(dgamma), ptr(dbeta), rows, D, dt(dy), dt(gamma), int(act), float(p_in),
-                                int(seed_in), float(p_out), int(seed_out), float(grad_scale), 0, ptr(ws), need,
+                                int(seed_in), float(p_out), int(seed_out), float(grad_scale), int(acc), ptr(ws), need,
                                 stream()), "wavlm_layernorm_bwd")
     return dx, dr, dgamma, dbeta
 
 
-def colsum(x2d, out_dtype, *, include=None, exclude=None, rows=None, N=None, ld=None):
-    """column sums of a [rows, N] matrix (row stride ld) -> [N] tensor of out_dtype"""
+def colsum(x2d, out_dtype, *, include=None, exclude=None, rows=None, N=None, ld=None, out=None, accumulate=False):
+    """column sums of a [rows, N] matrix (row stride ld) -> [N] tensor of out_dtype (or (+)= into `out`)"""
     dev = _dev(x2d)
     if rows is None:
         N = x2d.shape[-1]
         rows = x2d.numel() // N
         ld = N
         _contig(x2d)
-    out = torch.empty(N, dtype=out_dtype, device=dev)
+    if out is None:
+        out = torch.empty(N, dtype=out_dtype, device=dev)
+        accumulate = False
     L = _lib.lib()
     need = L.wavlm_colsum_workspace_bytes(N)
     ws = workspace(dev, need)
-    check(L.wavlm_colsum(ptr(x2d), rows, N, ld, dt(x2d), ptr(include), ptr(exclude), ptr(out), dt(out), 0, ptr(ws),
-                         need, stream()), "wavlm_colsum")
+    check(L.wavlm_colsum(ptr(x2d), rows, N, ld, dt(x2d), ptr(include), ptr(exclude), ptr(out), dt(out),
+                         int(bool(accumulate)), ptr(ws), need, stream()), "wavlm_colsum")
     return out
 
 

@@ -16,7 +16,13 @@ _ALIGN = 64  # elements; keeps every parameter 128-byte aligned in bf16 (16-byte
 
 
 class FusedAdam:
-    def __init__(self, params, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=0.0):
+    """`model` (optional): modules exposing `packed_param_groups()` -> [(params, bind)] get those parameters laid
+    out back to back in the arenas and `bind(param_view, grad_view)` called with flat views over the group (the
+    attention block's q|k|v projections become one [3D, D] weight without a per-step torch.cat, and its gradient is
+    written packed).  Every parameter is marked as a gradient sink (functional._sink): backward kernels accumulate
+    into the arena directly."""
+
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=0.0, model=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no parameters")
@@ -25,11 +31,37 @@ class FusedAdam:
             if p.device != dev or p.dtype != dtype:
                 raise ValueError("all parameters must share device and dtype")
         self.lr, self.betas, self.eps, self.weight_decay, self.clip_norm = lr, betas, eps, weight_decay, clip_norm
-        self.offsets = []
-        off = 0
+        groups = []
+        if model is not None:
+            for m in model.modules():
+                if hasattr(m, "packed_param_groups"):
+                    groups.extend(m.packed_param_groups())
+        member = {}
+        for gi, (gp, _bind) in enumerate(groups):
+            if all(any(q is p for p in self.params) for q in gp) and all(q.numel() % 8 == 0 for q in gp):
+                for q in gp:
+                    member[id(q)] = gi
+        # arena order: registration order, except that a packed group is placed whole at its first member
+        order, placed = [], set()
         for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            gi = member.get(id(p))
+            if gi is None:
+                order.append([p])
+            elif gi not in placed:
+                placed.add(gi)
+                order.append(list(groups[gi][0]))
+        off_of = {}
+        off = 0
+        self._group_span = {}
+        for blk in order:
+            start = off
+            for p in blk:
+                off_of[id(p)] = off
+                off += p.numel()
+            if len(blk) > 1:
+                self._group_span[member[id(blk[0])]] = (start, off)
+            off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.offsets = [off_of[id(p)] for p in self.params]
         self.numel = off
         self.flat_param = torch.zeros(off, dtype=dtype, device=dev)
         self.flat_grad = torch.zeros(off, dtype=dtype, device=dev)
@@ -39,6 +71,9 @@ class FusedAdam:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+                p._wl_sink = True
+        for gi, (lo, hi) in self._group_span.items():
+            groups[gi][1](self.flat_param[lo:hi], self.flat_grad[lo:hi])
         self.lowp = dtype != torch.float32
         self.master = self.flat_param.float() if self.lowp else self.flat_param
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)

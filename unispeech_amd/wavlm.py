@@ -161,6 +161,7 @@ class MultiheadAttention(nn.Module):
         self.v_proj = nn.Linear(embed_dim, embed_dim, bias=True)
         self.q_proj = nn.Linear(embed_dim, embed_dim, bias=True)
         self.out_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+        self._packed = None  # (W[3D, D], dW sink, b[3D], db sink): set by a flat-arena optimizer, see packed_param_groups
         self.gru_rel_pos = gru_rel_pos
         if gru_rel_pos:
             self.grep_linear = nn.Linear(self.head_dim, 8)
@@ -176,6 +177,25 @@ class MultiheadAttention(nn.Module):
         nn.init.constant_(self.out_proj.bias, 0.0)
         if self.has_relative_attention_bias:
             nn.init.xavier_normal_(self.relative_attention_bias.weight)
+
+    def packed_param_groups(self):
+        """parameter groups a flat-arena optimizer should lay out contiguously, with the binder for the packed views"""
+        D = self.embed_dim
+
+        def bind_w(pv, gv):
+            self._packed_w = (pv.view(3 * D, D), gv.view(3 * D, D))
+            self._refresh_packed()
+
+        def bind_b(pv, gv):
+            self._packed_b = (pv.view(3 * D), gv.view(3 * D))
+            self._refresh_packed()
+
+        return [([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], bind_w),
+                ([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], bind_b)]
+
+    def _refresh_packed(self):
+        w, b = getattr(self, "_packed_w", None), getattr(self, "_packed_b", None)
+        self._packed = (w[0], w[1], b[0], b[1]) if (w is not None and b is not None) else None
 
     def position_table(self, T, device):
         """[H, 2T-1] fp32 Toeplitz generator of compute_bias(T, T) (modules.py:444-455)"""
@@ -193,9 +213,15 @@ class MultiheadAttention(nn.Module):
                 gate = F.GateFn.apply(x, self.grep_linear.weight, self.grep_linear.bias, self.grep_a, self.num_heads)
             else:
                 gate = torch.ones((B, self.num_heads, T), dtype=torch.float32, device=x.device)
-        w = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
-        b = torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0)
-        qkv = F.LinearFn.apply(x, w, b)
+        pk = self._packed
+        if (pk is not None and torch.is_grad_enabled() and pk[0].data_ptr() == self.q_proj.weight.data_ptr()
+                and pk[2].data_ptr() == self.q_proj.bias.data_ptr() and pk[0].dtype == x.dtype):
+            # optimizer-bound packed views of q|k|v (no concatenation; the gradient lands packed in the arena)
+            qkv = F.LinearFn.apply(x, pk[0], pk[2], pk[1], pk[3])
+        else:
+            w = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
+            b = torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0)
+            qkv = F.LinearFn.apply(x, w, b)
         p = self.dropout_module.p if self.training else 0.0
         o = F.AttnCoreFn.apply(qkv, gate, position_table, key_padding_u8, self.num_heads, self.scaling, p,
                                F.next_seed() if p > 0 else 0)
