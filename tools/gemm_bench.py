@@ -86,6 +86,8 @@ def main():
 
 if __name__ == "__main__":
     for v in [int(a) for a in sys.argv[1:]] or [1, 0, 3]:
-        print("==== tile variant", {1: "128x128 forced", 0: "auto", 2: "256x128 forced", 3: "256x256 ping-pong", 4: "192x384 ping-pong"}[v])
+        print("==== tile variant", {1: "128x128 forced", 0: "auto", 2: "256x128 forced", 3: "256x256 ping-pong",
+                                   4: "192x384 ping-pong"}[v & 15], "| pp launch mode", {0: "default", 1: "block per tile", 2: "persistent",
+                                                                                         3: "persistent + skew"}[v >> 4])
         ops.gemm_set_variant(v)
         main()

@@ -198,7 +198,9 @@ static int launch_cfg(GemmP& p, int nbatch, bool vec, hipStream_t st) {
 }
 
 static int g_gemm_variant = 0;  // 0: auto, 1: force 128x128, 2: force 256x128, 3 / 4: force the 256x256 / 192x384 ping-pong kernel where it applies
-extern "C" void wavlm_gemm_set_variant(int v) { g_gemm_variant = v; }
+extern int g_pp_mode;  // gemm_pp.hip
+// low 4 bits: tile variant; bits 4-5 (+1): launch mode of the 256x256 ping-pong kernel (tools A/B); 0 keeps the default
+extern "C" void wavlm_gemm_set_variant(int v) { g_gemm_variant = v & 15; if (v >> 4) g_pp_mode = (v >> 4) - 1; }
 
 template <bool TA, bool TB>
 static int launch_t(GemmP& p, int nbatch, bool vec, hipStream_t st) {
