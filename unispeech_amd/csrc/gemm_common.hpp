@@ -17,6 +17,7 @@ struct GemmP {
   int split_k; float* ws;
   int tiles_m, tiles_n;
   int vtotal, nbatch, skew;  // persistent launch (ping-pong kernels): virtual block count, batch count, start skew
+  int patch_m;               // split-K work order: tile-row patch height (0: tiles only, split outermost)
 };
 
 static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
@@ -33,7 +34,7 @@ static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
   p.accumulate = d->accumulate;
   p.split_k = d->split_k < 1 ? 1 : d->split_k;
   p.ws = (float*)d->workspace;
-  p.tiles_m = 0; p.tiles_n = 0; p.vtotal = 0; p.nbatch = 1; p.skew = 0;
+  p.tiles_m = 0; p.tiles_n = 0; p.vtotal = 0; p.nbatch = 1; p.skew = 0; p.patch_m = 0;
   return p;
 }
 

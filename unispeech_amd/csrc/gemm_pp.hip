@@ -58,14 +58,33 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     for (int i = (int)(blockIdx.x & 3) * p.skew; i > 0; --i) __builtin_amdgcn_s_sleep(127);
   }
   for (int vid = blockIdx.x; vid < p.vtotal; vid += gridDim.x) {
-  int tile;
-  {
+  int tm, tn, z, split;
+  if (p.patch_m == 0) {
+    // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (private L2 per XCD); each XCD walks a contiguous
+    // run of tiles (neighbours share the A row panel and all of B).  Batch and split are the outer dimensions.
     const int nt = ntile, bid = vid % ntile;
     const int q = nt >> 3, rem = nt & 7, xcd = bid & 7, idx = bid >> 3;
-    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    tn = tile % p.tiles_n; tm = tile / p.tiles_n;
+    z = (vid / ntile) % p.nbatch; split = vid / (ntile * p.nbatch);
+  } else {
+    // Split-K (weight-gradient) order.  Blocks that share operand panels are the tiles of ONE split: they must sit on
+    // one XCD at the same time or every XCD re-reads the panels from HBM (measured 630 MB per fc1 dW launch against
+    // 184 MB algorithmic -- the launch was HBM-bound).  Work items are ordered (patch of patch_m tile rows x all tile
+    // columns, split, tile in patch) and each XCD takes a contiguous run of that order.
+    const int nv = p.vtotal;
+    const int q = nv >> 3, rem = nv & 7, xcd = vid & 7, idx = vid >> 3;
+    const int item = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    const int full = p.patch_m * p.tiles_n * p.split_k;           // items of a full patch
+    const int npatch = (p.tiles_m + p.patch_m - 1) / p.patch_m;
+    int pi = item / full; if (pi > npatch - 1) pi = npatch - 1;
+    const int r = item - pi * full;
+    const int h = min(p.patch_m, p.tiles_m - pi * p.patch_m);
+    split = r / (h * p.tiles_n);
+    const int qq = r - split * h * p.tiles_n;
+    tm = pi * p.patch_m + qq / p.tiles_n; tn = qq % p.tiles_n;
+    z = 0;
   }
-  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-  const int z = (vid / ntile) % p.nbatch, split = vid / (ntile * p.nbatch);
   const int zo = z / p.batch_i, zi = z % p.batch_i;
   const int m0 = tm * 256, n0 = tn * 256;
   const int lane = threadIdx.x & 63;
@@ -331,6 +350,10 @@ static int pp_launch_t(GemmP& p, int nbatch, bool vec, hipStream_t st) {
   p.tiles_n = (p.N + 255) / 256;
   p.nbatch = nbatch;
   p.vtotal = p.tiles_m * p.tiles_n * nbatch * p.split_k;
+  p.patch_m = 0;
+  if (p.split_k > 1 && nbatch == 1 && g_pp_mode != 0) {
+    p.patch_m = 16 / p.tiles_n; if (p.patch_m < 1) p.patch_m = 1; if (p.patch_m > p.tiles_m) p.patch_m = p.tiles_m;
+  }
   const int kt = ((p.K + 63) / 64) * p.KB / p.split_k;
   p.skew = (g_pp_mode == 2 && p.vtotal >= 768) ? (kt * 11 / 100 > 0 ? kt * 11 / 100 : 1) : 0;  // s_sleep(127) ~ 3.9 us; one step ~ a quarter of a tile's main loop (1.72 us per K step)
   // persistent launch pays on the transformer GEMMs (4-5 rounds: +5-10 %); the long conv GEMMs (24 rounds) measured
