@@ -109,11 +109,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # WAVLM_SHARED_GPU=1 + WAVLM_DIST_BACKEND=gloo: functional test of the N > 1 path on a single-GPU box (all ranks on
+    # cuda:0, gradients reduced through gloo); the real thing is one rank per GPU over RCCL ("nccl")
+    if os.environ.get("WAVLM_SHARED_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("WAVLM_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from unispeech_amd import ops
     from unispeech_amd.dp import DataParallelWavLM
@@ -179,9 +187,22 @@ def main():
         ops.prof_enable(False)
         if ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all instantiations, every dense contraction of the step)",
+            # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x 2 on
+            # gfx950 + WRITE_SIZE, tools/pmc_traffic.py); counters cannot be read from inside the run
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "r01", "gemm_hbm_traffic.json")
+            if os.path.exists(tj):
+                try:
+                    traffic = round(json.load(open(tj))["gemm_hbm_bytes_per_launch"])
+                except Exception:
+                    traffic = None
+            roof = {"bound": "mfma",
+                    "kernel": "bf16 MFMA GEMM family (gemm_pp_kernel 256x256, gemm_pp3_kernel 192x384, gemm_bf16_kernel "
+                              "128-wide): every dense contraction of the step",
                     "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (avg over the step's GEMM launches, PMC)",
+                    "algorithmic_bytes_per_launch": None,
                     "launches_per_step": n_l // 2, "gemm_ms_per_step": round(ms / 2, 3),
                     "gemm_algorithmic_tflop_per_step": round(fl / 2 / 1e12, 3),
                     "avg_launch_us": round(ms / max(n_l, 1) * 1e3, 2)}
