@@ -37,6 +37,8 @@ int wavlm_abi_version(void);
  * (WavLM/WavLM.py:514-527), torch.bmm inside F.multi_head_attention_forward, the cosine-logit
  * product (src/fairseq/models/wavlm/wavlm.py:431) and all their autograd backward contractions.
  * epi: 0 none | 1 gelu (pre-activation stored to aux if aux != NULL) | 2 multiply by gelu'(aux)
+ *      | 3 gelu (gelu'(pre-activation) stored to aux if aux != NULL) | 4 multiply by aux
+ *      (3 / 4 are the training pair: forward pays three extra VALU ops per element, backward saves an erf + exp)
  * then: + res (if res != NULL), + old C (if accumulate).
  * split_k > 1: the KB range is cut into split_k slabs written to `workspace` (f32) and summed by a
  * second kernel (deterministic, no atomics).  workspace bytes >= wavlm_gemm_workspace_bytes().
@@ -176,7 +178,7 @@ int wavlm_posconv_weight_bwd(const float* dWf, const void* v, const void* g, con
                              void* stream);
 /* x[B,T,D] (optionally * gelu'(aux)) -> group-major, time-padded out[B,G,Tp,D/G]; nat_out optional natural copy */
 int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* nat_out, int32_t B, int32_t T, int32_t D,
-                              int32_t G, int32_t left_pad, int32_t Tp, int32_t dtype, void* stream);
+                              int32_t G, int32_t left_pad, int32_t Tp, int32_t dtype, int32_t aux_is_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Masked-prediction loss (src/fairseq/models/wavlm/wavlm.py:426-438; criterions/wavlm_criterion.py:52-138)

@@ -84,7 +84,7 @@ SIGNATURES = {
     "wavlm_posconv_weight_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_u64,
                                          c_vp]),
     "wavlm_posconv_group_major": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                          c_vp]),
+                                          c_i32, c_vp]),
     "wavlm_l2norm_fwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_f32, c_vp]),
     "wavlm_l2norm_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "wavlm_ce_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),

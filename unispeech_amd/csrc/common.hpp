@@ -88,6 +88,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, e));
   return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
+// value and derivative from one erf / exp evaluation (forward epilogues that store gelu'(pre-activation) for backward)
+__device__ __forceinline__ float gelu_both_f(float x, float& grad) {
+  float e;
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, e));
+  grad = fmaf(x * 0.39894228040143267794f, e, cdf);
+  return x * cdf;
+}
 
 // ---- cheap stateless dropout masks -------------------------------------------------------------------------------
 // word(row, col) = drop_mix(row_word + col_word): the two words are strong multiplicative hashes (3 x v_mul_lo_u32,

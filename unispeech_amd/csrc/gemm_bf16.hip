@@ -228,9 +228,9 @@ static bool vec_epilogue_ok(const wavlm_gemm_desc* d) {
 
 int gemm_f32_launch(const wavlm_gemm_desc* d, hipStream_t st);  // gemm_f32.hip
 bool gemm_pp_ok(const wavlm_gemm_desc* d);                       // gemm_pp.hip
-int gemm_pp_launch(GemmP& p, int nbatch, bool transA, bool transB, bool vec, hipStream_t st);
+int gemm_pp_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);
 bool gemm_pp3_ok(const wavlm_gemm_desc* d);                      // gemm_pp3.hip
-int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, bool vec, hipStream_t st);
+int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);
 
 // fraction of a CU-round's MFMA work that is useful for a BM x BN tiling on 256 CUs (edge waste x round quantisation)
 static double tile_efficiency(const wavlm_gemm_desc* d, int nbatch, int BM, int BN) {
@@ -299,7 +299,8 @@ extern "C" uint64_t wavlm_gemm_workspace_bytes(const wavlm_gemm_desc* d) {
 extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return WL_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return WL_EINVAL;
-  if (d->epi == 2 && !d->aux) return WL_EINVAL;
+  if ((d->epi == 2 || d->epi == 4) && !d->aux) return WL_EINVAL;
+  if (d->epi < 0 || d->epi > 4) return WL_EINVAL;
   if (d->split_k > 1 && (!d->workspace || d->ws_bytes < wavlm_gemm_workspace_bytes(d))) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == WL_F32) {
@@ -321,8 +322,8 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   if ((g_gemm_variant == 4 && gemm_pp3_ok(d)) ||
       (g_gemm_variant == 0 && d->N >= 384 && gemm_pp3_ok(d) && gemm_pp_ok(d) &&
        tile_efficiency(d, nbatch, 192, 384) > 1.25 * tile_efficiency(d, nbatch, 256, 256)))  // six shorter phases per K step cost ~10 %: only where the 256 x 256 tiling quantises badly (N = 768 at 24 k rows)
-    rc = gemm_pp3_launch(p, nbatch, d->transA != 0, d->transB != 0, vec, st);
-  else if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) rc = gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, vec, st);
+    rc = gemm_pp3_launch(p, nbatch, d->transA != 0, d->transB != 0, gemm_epilogue_class(d, vec), st);
+  else if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) rc = gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, gemm_epilogue_class(d, vec), st);
   else if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, vec, st);
   else if (!d->transA && d->transB) rc = launch_t<false, true>(p, nbatch, vec, st);
   else if (d->transA && !d->transB) rc = launch_t<true, false>(p, nbatch, vec, st);

@@ -48,6 +48,12 @@ __device__ __forceinline__ void gemm_epi_final(const GemmP& p, int zo, int zi, i
   } else if (p.epi == 2) {
     const float u = ld_elem(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, p.aux_dtype);
     v *= gelu_grad_f(u);
+  } else if (p.epi == 3) {
+    float gr;
+    v = gelu_both_f(v, gr);
+    if (p.aux) st_elem(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, p.aux_dtype, gr);
+  } else if (p.epi == 4) {
+    v *= ld_elem(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, p.aux_dtype);
   }
   if (p.res) v += ld_elem(p.res, (long)zo * p.sRes_o + (long)zi * p.sRes_i + (long)m * p.ld_res + n, p.res_dtype);
   const long ci = (long)zo * p.sC_o + (long)zi * p.sC_i + (long)m * p.ldc + n;
@@ -122,6 +128,16 @@ __device__ __forceinline__ void gemm_store8(const GemmP& p, int zo, int zi, int 
     ld8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, p.aux_dtype, u);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(u[e]);
+  } else if (p.epi == 3) {
+    float gr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_both_f(v[e], gr[e]);
+    if (p.aux) st8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, p.aux_dtype, gr);
+  } else if (p.epi == 4) {
+    float u[8];
+    ld8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, p.aux_dtype, u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= u[e];
   }
   if (p.res) {
     float r[8];
@@ -137,6 +153,47 @@ __device__ __forceinline__ void gemm_store8(const GemmP& p, int zo, int zi, int 
     for (int e = 0; e < 8; ++e) v[e] += c[e];
   }
   st8_dt(p.C, ci, p.c_dtype, v);
+}
+
+// Specialised 8-wide store for the cases that carry the step (bf16 C, bf16 bias / aux, no residual, no accumulate, no
+// split-K): KIND 0 = alpha * acc (+ bias); 3 = + GELU with GELU'(pre-activation) stored to aux; 4 = * aux.
+// The generic gemm_store8 decides all of that per 8-element chunk at run time; with one block per CU the epilogue is
+// exposed, and the probe in tools/gemm_epi_probe.py showed it bound by the CU's own instruction stream (7.5 us per tile
+// even with 8 CUs active), not by the HBM write burst.
+template <int KIND>
+__device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi, int m, int n, const float (&acc)[8]) {
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = p.alpha * acc[e];
+  if (p.bias) {
+    float b[8];
+    ld8_dt(p.bias, (long)zo * p.sBias_o + (long)zi * p.sBias_i + n, WL_BF16, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += b[e];
+  }
+  if constexpr (KIND == 3) {
+    float gr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_both_f(v[e], gr[e]);
+    if (p.aux) st8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, WL_BF16, gr);
+  } else if constexpr (KIND == 4) {
+    float u[8];
+    ld8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, WL_BF16, u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= u[e];
+  }
+  st8_dt(p.C, (long)zo * p.sC_o + (long)zi * p.sC_i + (long)m * p.ldc + n, WL_BF16, v);
+}
+
+// epilogue class of a launch: 0 scalar stores, 1 generic row vectors, 2 / 3 / 4 specialised for epi 0 / 3 / 4
+static inline int gemm_epilogue_class(const wavlm_gemm_desc* d, bool vec) {
+  if (!vec) return 0;
+  const bool fast = d->split_k <= 1 && !d->res && !d->accumulate && d->c_dtype == WL_BF16 && d->N % 8 == 0 &&
+                    (!d->bias || d->bias_dtype == WL_BF16) &&
+                    (d->epi == 0 || (d->epi == 3 && (!d->aux || d->aux_dtype == WL_BF16)) ||
+                     (d->epi == 4 && d->aux && d->aux_dtype == WL_BF16));
+  if (!fast) return 1;
+  return d->epi == 0 ? 2 : d->epi == 3 ? 3 : 4;
 }
 
 // flattened reduction-tile range [t0, t1) owned by split `s` (tiles = KB * ceil(K / BK))

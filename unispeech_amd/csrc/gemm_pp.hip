@@ -46,7 +46,7 @@ struct PPCursor {  // position of one half-tile stream in the flattened (K-batch
   int kt;          // K-tile index inside the current K batch
 };
 
-template <bool TA, bool TB, bool VEC>
+template <bool TA, bool TB, int EP>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 * PP_STAGE
 
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 
   // ---- epilogue (same as the 128-wide kernel: per-wave LDS staging -> 16-byte row vectors) -------------------------
   const int mw = m0 + wm * 128, nw = n0 + wn * 64;  // wave tile origin; fragment i -> rows 32 i, j -> cols 32 j
-  if constexpr (!VEC) {
+  if constexpr (EP == 0) {
     auto store_block = [&](const f32x16_t (&a)[2], int i) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -333,7 +333,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
           const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
           const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          gemm_store8(p, zo, zi, z, split, mm, nn, v);
+          if constexpr (EP == 1) gemm_store8(p, zo, zi, z, split, mm, nn, v);
+          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(p, zo, zi, mm, nn, v);
         }
       }
     }
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 int g_pp_mode = 1;  // 0: one block per tile, 1: persistent (256 blocks), 2: persistent with start skew
 
 template <bool TA, bool TB>
-static int pp_launch_t(GemmP& p, int nbatch, bool vec, hipStream_t st) {
+static int pp_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   p.nbatch = nbatch;
@@ -360,14 +361,15 @@ static int pp_launch_t(GemmP& p, int nbatch, bool vec, hipStream_t st) {
   // 1 % better with one block per tile
   dim3 grid((unsigned)(g_pp_mode == 0 || p.vtotal < 256 || p.vtotal > 2048 ? p.vtotal : 256), 1, 1);
   constexpr int smem = 2 * PP_STAGE;
-  static bool done[2] = {false, false};
-  if (!done[vec]) {
-    const void* fn = vec ? (const void*)gemm_pp_kernel<TA, TB, true> : (const void*)gemm_pp_kernel<TA, TB, false>;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return WL_ELAUNCH;
-    done[vec] = true;
-  }
-  if (vec) WL_LAUNCH((gemm_pp_kernel<TA, TB, true>), grid, dim3(512), smem, st, p);
-  else WL_LAUNCH((gemm_pp_kernel<TA, TB, false>), grid, dim3(512), smem, st, p);
+  static bool done[5] = {false, false, false, false, false};
+#define PP_CASE(E) case E: { \
+    if (!done[E]) { \
+      if (hipFuncSetAttribute((const void*)gemm_pp_kernel<TA, TB, E>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return WL_ELAUNCH; \
+      done[E] = true; \
+    } \
+    WL_LAUNCH((gemm_pp_kernel<TA, TB, E>), grid, dim3(512), smem, st, p); } break;
+  switch (ep) { PP_CASE(0) PP_CASE(1) PP_CASE(2) PP_CASE(3) default: PP_CASE(4) }
+#undef PP_CASE
   return wl_check_launch();
 }
 
@@ -384,9 +386,9 @@ bool gemm_pp_ok(const wavlm_gemm_desc* d) {
   return true;
 }
 
-int gemm_pp_launch(GemmP& p, int nbatch, bool transA, bool transB, bool vec, hipStream_t st) {
-  if (!transA && !transB) return pp_launch_t<false, false>(p, nbatch, vec, st);
-  if (!transA && transB) return pp_launch_t<false, true>(p, nbatch, vec, st);
-  if (transA && !transB) return pp_launch_t<true, false>(p, nbatch, vec, st);
-  return pp_launch_t<true, true>(p, nbatch, vec, st);
+int gemm_pp_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st) {
+  if (!transA && !transB) return pp_launch_t<false, false>(p, nbatch, ep, st);
+  if (!transA && transB) return pp_launch_t<false, true>(p, nbatch, ep, st);
+  if (transA && !transB) return pp_launch_t<true, false>(p, nbatch, ep, st);
+  return pp_launch_t<true, true>(p, nbatch, ep, st);
 }

@@ -32,7 +32,7 @@ typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
 
 struct P3Cursor { long off; int kt; };
 
-template <bool TA, bool TB, bool VEC>
+template <bool TA, bool TB, int EP>
 __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 * P3_STAGE
 
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------
   const int mw = m0 + wm * 96, nw = n0 + wn * 96;  // wave tile origin; block i -> rows 32 i, j -> cols 32 j
-  if constexpr (!VEC) {
+  if constexpr (EP == 0) {
     auto store_block = [&](const f32x16_t (&a)[3], int i) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
           const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
           const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          gemm_store8(p, zo, zi, z, split, mm, nn, v);
+          if constexpr (EP == 1) gemm_store8(p, zo, zi, z, split, mm, nn, v);
+          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(p, zo, zi, mm, nn, v);
         }
       }
     }
@@ -324,19 +325,20 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
 }
 
 template <bool TA, bool TB>
-static int pp3_launch_t(GemmP& p, int nbatch, bool vec, hipStream_t st) {
+static int pp3_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
   p.tiles_m = (p.M + 191) / 192;
   p.tiles_n = (p.N + 383) / 384;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)nbatch, (unsigned)p.split_k);
   constexpr int smem = 2 * P3_STAGE;
-  static bool done[2] = {false, false};
-  if (!done[vec]) {
-    const void* fn = vec ? (const void*)gemm_pp3_kernel<TA, TB, true> : (const void*)gemm_pp3_kernel<TA, TB, false>;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return WL_ELAUNCH;
-    done[vec] = true;
-  }
-  if (vec) WL_LAUNCH((gemm_pp3_kernel<TA, TB, true>), grid, dim3(512), smem, st, p);
-  else WL_LAUNCH((gemm_pp3_kernel<TA, TB, false>), grid, dim3(512), smem, st, p);
+  static bool done[5] = {false, false, false, false, false};
+#define PP_CASE(E) case E: { \
+    if (!done[E]) { \
+      if (hipFuncSetAttribute((const void*)gemm_pp3_kernel<TA, TB, E>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return WL_ELAUNCH; \
+      done[E] = true; \
+    } \
+    WL_LAUNCH((gemm_pp3_kernel<TA, TB, E>), grid, dim3(512), smem, st, p); } break;
+  switch (ep) { PP_CASE(0) PP_CASE(1) PP_CASE(2) PP_CASE(3) default: PP_CASE(4) }
+#undef PP_CASE
   return wl_check_launch();
 }
 
@@ -351,9 +353,9 @@ bool gemm_pp3_ok(const wavlm_gemm_desc* d) {
   return true;
 }
 
-int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, bool vec, hipStream_t st) {
-  if (!transA && !transB) return pp3_launch_t<false, false>(p, nbatch, vec, st);
-  if (!transA && transB) return pp3_launch_t<false, true>(p, nbatch, vec, st);
-  if (transA && !transB) return pp3_launch_t<true, false>(p, nbatch, vec, st);
-  return pp3_launch_t<true, true>(p, nbatch, vec, st);
+int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st) {
+  if (!transA && !transB) return pp3_launch_t<false, false>(p, nbatch, ep, st);
+  if (!transA && transB) return pp3_launch_t<false, true>(p, nbatch, ep, st);
+  if (transA && !transB) return pp3_launch_t<true, false>(p, nbatch, ep, st);
+  return pp3_launch_t<true, true>(p, nbatch, ep, st);
 }

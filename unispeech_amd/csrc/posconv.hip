@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void pc_weight_bwd_kernel(const float* __restr
 // outside [left_pad, left_pad + T).  nat (optional) receives the same values in the natural [B,T,D] layout.
 template <typename T>
 __global__ __launch_bounds__(256) void pc_group_major_kernel(const T* __restrict__ x, const T* __restrict__ aux,
-    T* __restrict__ out, T* __restrict__ nat, int B, int Tn, int D, int G, int left_pad, int Tp) {
+    T* __restrict__ out, T* __restrict__ nat, int B, int Tn, int D, int G, int left_pad, int Tp, int aux_is_grad) {
   const int Cg = D / G, c8n = Cg >> 3;
   const long total = (long)B * G * Tp * c8n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256) void pc_group_major_kernel(const T* __restrict
       for (int e = 0; e < 8; ++e) v[e] = Elem<T>::ld(x + src + e);
       if (aux) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(Elem<T>::ld(aux + src + e));
+        for (int e = 0; e < 8; ++e) {
+          const float a = Elem<T>::ld(aux + src + e);
+          v[e] *= aux_is_grad ? a : gelu_grad_f(a);  // aux holds gelu'(u) (GEMM epi 3) or the pre-activation u (epi 1)
+        }
       }
       if (nat) {
 #pragma unroll
@@ -186,7 +189,7 @@ int wavlm_posconv_weight_bwd(const float* dWf, const void* v, const void* g, con
 }
 
 int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* nat_out, int32_t B, int32_t T, int32_t D,
-                              int32_t G, int32_t left_pad, int32_t Tp, int32_t dtype, void* stream) {
+                              int32_t G, int32_t left_pad, int32_t Tp, int32_t dtype, int32_t aux_is_grad, void* stream) {
   if (!x || !out || B <= 0 || T <= 0 || D <= 0 || G <= 0 || D % G || ((D / G) & 7) || left_pad < 0 || Tp < left_pad + T)
     return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -194,11 +197,11 @@ int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* n
   long grid = (total + 255) / 256; if (grid > 8192) grid = 8192;
   if (dtype == WL_F32)
     WL_LAUNCH((pc_group_major_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)x,
-                       (const float*)aux, (float*)out, (float*)nat_out, (int)B, (int)T, (int)D, (int)G, (int)left_pad, (int)Tp);
+                       (const float*)aux, (float*)out, (float*)nat_out, (int)B, (int)T, (int)D, (int)G, (int)left_pad, (int)Tp, (int)aux_is_grad);
   else if (dtype == WL_BF16)
     WL_LAUNCH((pc_group_major_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)x,
                        (const bf16_t*)aux, (bf16_t*)out, (bf16_t*)nat_out, (int)B, (int)T, (int)D, (int)G, (int)left_pad,
-                       (int)Tp);
+                       (int)Tp, (int)aux_is_grad);
   else return WL_EINVAL;
   return wl_check_launch();
 }

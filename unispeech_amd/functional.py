@@ -123,7 +123,9 @@ class FFNFn(torch.autograd.Function):
         n = x2d.shape[0]
         F = W1.shape[0]
         u = torch.empty((n, F), dtype=x2d.dtype, device=x2d.device)
-        h = _linear_fwd(x2d, W1, b1, epi=1, aux=u)
+        # without activation dropout the auxiliary tensor holds gelu'(pre-activation) (epi 3): backward multiplies
+        # by it (epi 4) instead of re-evaluating erf / exp; with dropout it holds the pre-activation itself
+        h = _linear_fwd(x2d, W1, b1, epi=3 if p_act <= 0 else 1, aux=u)
         hd = ops.dropout(h, p_act, seed) if p_act > 0 else h
         y = _linear_fwd(hd, W2, b2)
         ctx.save_for_backward(x2d, W1, W2, u, hd, b1, b2)
@@ -144,7 +146,7 @@ class FFNFn(torch.autograd.Function):
             du, _ = ops.group_major(dh.view(1, n, F), u.view(1, n, F), 1, 0, n)
             du = du.view(n, F)
         else:
-            du = _linear_bwd_x(dy2d, W2, epi=2, aux=u)
+            du = _linear_bwd_x(dy2d, W2, epi=4, aux=u)
         dW1, db1 = _param_grads(du, x2d, W1, b1, b1 is not None, True, True)
         dx = _linear_bwd_x(du, W1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         return dx, dW1, db1, dW2, db2, None, None
@@ -240,7 +242,7 @@ class ConvStackFn(torch.autograd.Function):
             y = torch.empty((B, T_out, Cout), dtype=cur.dtype, device=cur.device)
             u = torch.empty_like(y)
             ops.gemm(cur, Wf, y, T_out, Cout, k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout, batch=(B, 1),
-                     sA=(T_in * Cin, 0), sC=(T_out * Cout, 0), epi=1, aux=u, ld_aux=Cout, sAux=(T_out * Cout, 0))
+                     sA=(T_in * Cin, 0), sC=(T_out * Cout, 0), epi=3, aux=u, ld_aux=Cout, sAux=(T_out * Cout, 0))
             xs.append(cur); us.append(u); wfs.append(Wf)
             cur = y
         ctx.specs = specs
@@ -260,7 +262,7 @@ class ConvStackFn(torch.autograd.Function):
         k, s = specs[-1]
         T_out, J, fp, bp = _conv_geometry(xs[-1].shape[1], k, s)
         Cout = weights[-1].shape[0]
-        P, _ = ops.group_major(dy.contiguous(), us[-1], 1, fp, fp + T_out + bp)
+        P, _ = ops.group_major(dy.contiguous(), us[-1], 1, fp, fp + T_out + bp, aux_is_grad=True)
         P = P.view(B, fp + T_out + bp, Cout)
         for i in range(nl - 1, -1, -1):
             k, s = specs[i]
@@ -304,7 +306,7 @@ class ConvStackFn(torch.autograd.Function):
                 Mr = (T_in - r + s - 1) // s
                 ops.gemm(P, Wb, nxt, Mr, Cin, Jr * Cout, lda=Cout, ldb=Jr * Cout, ldc=s * Cin, batch=(B, 1),
                          a_off=(fp - Jr + 1) * Cout, sA=(Tp * Cout, 0), c_off=(fpp + r) * Cin, sC=(Tpp * Cin, 0),
-                         epi=2 if aux is not None else 0, aux=aux, aux_off=r * Cin, ld_aux=s * Cin,
+                         epi=4 if aux is not None else 0, aux=aux, aux_off=r * Cin, ld_aux=s * Cin,
                          sAux=(T_in * Cin, 0))
             P = nxt
         dx = P if ctx.needs_input_grad[0] else None

@@ -392,14 +392,15 @@ def posconv_weight_bwd(dWf, v, g, norm):
     return dv, dg
 
 
-def group_major(x, aux, G, left_pad, Tp, want_nat=False):
-    """x[B,T,D] (* gelu'(aux)) -> [B,G,Tp,D/G] with zero rows outside [left_pad, left_pad+T)"""
+def group_major(x, aux, G, left_pad, Tp, want_nat=False, aux_is_grad=False):
+    """x[B,T,D] (* gelu'(aux), or * aux if it already holds the derivative) -> [B,G,Tp,D/G], zero rows outside
+    [left_pad, left_pad+T)"""
     dev = _dev(x); _contig(x); _contig(aux)
     B, T, D = x.shape
     out = torch.empty((B, G, Tp, D // G), dtype=x.dtype, device=dev)
     nat = torch.empty_like(x) if want_nat else None
     check(_lib.lib().wavlm_posconv_group_major(ptr(x), ptr(aux), ptr(out), ptr(nat), B, T, D, G, left_pad, Tp, dt(x),
-                                               stream()), "wavlm_posconv_group_major")
+                                               int(bool(aux_is_grad)), stream()), "wavlm_posconv_group_major")
     return out, nat
 
 
