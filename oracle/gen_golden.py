@@ -133,6 +133,39 @@ def gen_tiny_wavlm():
     np.savez_compressed(os.path.join(OUT, "tiny_wavlm.npz"), **out)
 
 
+def gen_tiny_large():
+    """WavLM-Large structure at tiny size: extractor_mode 'layer_norm' (LayerNorm + GELU after every conv block) and
+    layer_norm_first=True (pre-LN encoder layers + final encoder LayerNorm).  Forward outputs and, through a scalar
+    probe loss, every parameter gradient of the standalone reference (WavLM/WavLM.py with the out-of-place x + x_conv
+    patch of ref_shim)."""
+    ref, _ = ref_shim.standalone(differentiable=True)
+    d = dict(TINY)
+    d.update(extractor_mode="layer_norm", layer_norm_first=True, normalize=True)
+    cfg = ref.WavLMConfig(d)
+    torch.manual_seed(0)
+    model = ref.WavLM(cfg)
+    model.eval()
+    out = sd_to_np(model.state_dict())
+    g = torch.Generator().manual_seed(4321)
+    wav = torch.randn(2, 16000, generator=g)
+    probe = torch.randn(2, 49, 64, generator=g)
+    out["in/source"] = wav.numpy()
+    out["in/probe"] = probe.numpy()
+    with torch.no_grad():
+        out["out/conv_features"] = model.feature_extractor(wav).numpy()
+        (x, lr), _ = model.extract_features(wav.clone(), ret_layer_results=True)
+        out["out/x"] = x.numpy()
+        out["out/n_layer_results"] = np.int64(len(lr))
+        for i, r in enumerate(lr):
+            out["out/layer_results%d" % i] = r[0].numpy()
+    model.zero_grad()
+    x, _ = model.extract_features(wav.clone())
+    (x * probe).sum().backward()
+    for n, p in model.named_parameters():
+        out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_large.npz"), **out)
+
+
 class _Dict:
     def __init__(self, n):
         self.n = n
@@ -202,5 +235,6 @@ if __name__ == "__main__":
     gen_buckets()
     gen_tiny_wavlm()
     gen_tiny_pretrain()
+    gen_tiny_large()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

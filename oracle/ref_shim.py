@@ -66,11 +66,27 @@ def install():
             sys.path.insert(0, p)
 
 
-def standalone():
-    """(WavLM module of the reference, its `modules` module)"""
+def _patch_oop(ref):
+    """the reference's `x += x_conv` (wavlm.py:713, WavLM.py:579) breaks autograd on torch >= 2; value-identical
+    out-of-place form, applied in the harness only"""
+    if not getattr(ref.TransformerEncoder, "_oop_patched", False):
+        import inspect
+        import textwrap
+        src = inspect.getsource(ref.TransformerEncoder.extract_features)
+        assert "x += x_conv" in src
+        ns = {}
+        exec(compile(textwrap.dedent(src.replace("x += x_conv", "x = x + x_conv")), "<patched>", "exec"), vars(ref), ns)
+        ref.TransformerEncoder.extract_features = ns["extract_features"]
+        ref.TransformerEncoder._oop_patched = True
+
+
+def standalone(differentiable=False):
+    """(WavLM module of the reference, its `modules` module); differentiable=True applies the out-of-place patch"""
     install()
     import WavLM as ref_wavlm  # noqa
     import modules as ref_modules  # noqa
+    if differentiable:
+        _patch_oop(ref_wavlm)
     return ref_wavlm, ref_modules
 
 
@@ -82,15 +98,5 @@ def fairseq_wavlm():
     from fairseq.data.data_utils import compute_mask_indices
     from fairseq.models.wavlm import wavlm as ref
 
-    # the reference's `x += x_conv` (wavlm.py:713) breaks autograd on torch >= 2; value-identical out-of-place form
-    if not getattr(ref.TransformerEncoder, "_oop_patched", False):
-        import inspect
-        src = inspect.getsource(ref.TransformerEncoder.extract_features)
-        assert "x += x_conv" in src
-        import textwrap
-        ns = {}
-        exec(compile(textwrap.dedent(src.replace("x += x_conv", "x = x + x_conv")), "<patched>", "exec"),
-             vars(ref), ns)
-        ref.TransformerEncoder.extract_features = ns["extract_features"]
-        ref.TransformerEncoder._oop_patched = True
+    _patch_oop(ref)
     return ref.WavLMModel, ref.WavLMConfig, WavLMCriterion, ref.TransformerEncoder, compute_mask_indices

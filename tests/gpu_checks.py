@@ -325,6 +325,18 @@ def check_conv0():
             out.append((tag + " dW", err(Wd.grad, Wr.grad), tol * 3))
             out.append((tag + " dgamma", err(gd.grad, gr.grad), tol * 3))
             out.append((tag + " dbeta", err(bd.grad, br.grad), tol * 3))
+            # extractor_mode "layer_norm": conv0 -> LayerNorm over channels -> GELU
+            Wr2, gr2, br2 = W.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y2 = TF.gelu(TF.layer_norm(TF.conv1d(wav.unsqueeze(1), Wr2, stride=5).transpose(1, 2), (C,), gr2, br2, 1e-5))
+            (y2 * dy).sum().backward()
+            Wd, gd, bd = [t.to(dtype).to(DEV).requires_grad_(True) for t in (W, g, b)]
+            yd = F.Conv0LNFn.apply(wav.to(dtype).to(DEV), Wd, gd, bd, 5, 1e-5, dtype)
+            yd.backward(dy.to(dtype).to(DEV))
+            tag = f"conv0+LN[{dtype}] B={B} T={T} C={C}"
+            out.append((tag + " y", err(yd, y2), tol))
+            out.append((tag + " dW", err(Wd.grad, Wr2.grad), tol * 3))
+            out.append((tag + " dgamma", err(gd.grad, gr2.grad), tol * 3))
+            out.append((tag + " dbeta", err(bd.grad, br2.grad), tol * 3))
     return out
 
 
@@ -346,7 +358,7 @@ def check_convstack():
         (yr * dy).sum().backward()
         xd = x.to(dtype).to(DEV).requires_grad_(True)
         Wd = [w.to(dtype).to(DEV).requires_grad_(True) for w in Ws]
-        yd = F.ConvStackFn.apply(xd, specs, *Wd)
+        yd = F.ConvStackFn.apply(xd, specs, True, *Wd)
         yd.backward(dy.to(dtype).to(DEV))
         tag = f"convstack[{dtype}]"
         out.append((tag + " y", err(yd, yr), tol))

@@ -245,3 +245,29 @@ def test_gradient_sink_matches_autograd_accumulation():
     for n in a:
         scale = a[n].abs().max().clamp_min(1e-6)
         assert ((a[n] - b[n]).abs().max() / scale).item() < 2e-2, n
+
+
+def test_large_structure_vs_reference_golden():
+    """WavLM-Large structure at tiny size (extractor_mode 'layer_norm' on every conv block, pre-LN encoder layers;
+    BASELINE.json configs[3]) on the HIP path against the reference-generated golden: conv features, encoder output,
+    and every parameter gradient of a scalar probe loss."""
+    from unispeech_amd.wavlm import WavLM, WavLMConfig
+    z = load_golden("tiny_large.npz")
+    d = dict(TINY)
+    d.update(extractor_mode="layer_norm", layer_norm_first=True, normalize=True)
+    m = WavLM(WavLMConfig(d))
+    m.load_state_dict(golden_state_dict(z))
+    m = m.to("cuda").eval()
+    wav = torch.from_numpy(z["in/source"]).cuda()
+    with torch.no_grad():
+        conv = m.feature_extractor(wav)
+        assert rel_err(conv.transpose(1, 2), z["out/conv_features"]) < RTOL
+    x, _ = m.extract_features(wav)
+    assert rel_err(x, z["out/x"]) < RTOL
+    (x * torch.from_numpy(z["in/probe"]).cuda()).sum().backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+    for n, p in m.named_parameters():
+        ref = torch.from_numpy(z["grad/" + n])
+        g = p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(ref)
+        tol = GTOL * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8
+        assert (g - ref).abs().max().item() <= tol, (n, (g - ref).abs().max().item(), tol)

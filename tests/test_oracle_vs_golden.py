@@ -144,3 +144,31 @@ def test_oracle_pretrain_loss_and_grads(tiny_cfg):
         scale = ref.abs().max().item()
         # k_proj.bias has an analytically zero gradient (softmax is invariant to a key bias): absolute floor
         assert (g - ref).abs().max().item() <= 5e-4 * scale + 1e-8, k
+
+
+def test_oracle_large_structure():
+    """extractor_mode 'layer_norm' + layer_norm_first (WavLM-Large structure, BASELINE.json configs[3]) against the
+    reference-generated golden: forward and every parameter gradient of a scalar probe loss."""
+    from conftest import Cfg, TINY
+    z = load_golden("tiny_large.npz")
+    d = dict(TINY)
+    d.update(extractor_mode="layer_norm", layer_norm_first=True, normalize=True)
+    cfg = Cfg(**d)
+    sd = golden_state_dict(z, as_param=True)
+    wav = torch.from_numpy(z["in/source"])
+    with torch.no_grad():
+        conv = O.conv_feature_extractor(sd, cfg, wav)
+        assert rel_err(conv, z["out/conv_features"]) < RTOL
+    r = O.extract_features(sd, cfg, wav)
+    assert rel_err(r["x"].detach(), z["out/x"]) < RTOL
+    (r["x"] * torch.from_numpy(z["in/probe"])).sum().backward()
+    # the standalone reference has feature_grad_mult applied inside extract_features (WavLM.py:339-345)
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+    for k, p in sd.items():
+        if not p.is_floating_point() or ("grad/" + k) not in z.files:
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        ref = torch.from_numpy(z["grad/" + k])
+        if k.startswith("feature_extractor."):
+            g = g * cfg.feature_grad_mult
+        assert (g - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8, k

@@ -61,6 +61,11 @@ SIGNATURES = {
     "wavlm_conv0_gn_bwd_workspace_bytes": (c_u64, [c_i32, c_i64, c_i32, c_i32]),
     "wavlm_conv0_gn_gelu_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
                                         c_i32, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_u64, c_vp]),
+    "wavlm_conv0_ln_gelu_fwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32,
+                                        c_i32, c_f32, c_vp]),
+    "wavlm_conv0_ln_bwd_workspace_bytes": (c_u64, [c_i32, c_i64, c_i32, c_i32]),
+    "wavlm_conv0_ln_gelu_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64,
+                                        c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_u64, c_vp]),
     "wavlm_relpos_gather": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "wavlm_relpos_scatter": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "wavlm_gate_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,

@@ -321,6 +321,149 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_finish_kernel(const float* __
   if (slice == 0 && i < n) st_elem(dW, i, pdt, (float)(red[0][col] + red[1][col] + red[2][col] + red[3][col]));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// extractor_mode = "layer_norm" (WavLM-Large: WavLM/WavLM.py:403-418): conv0 -> LayerNorm over the C channels of
+// every frame -> GELU.  A frame's 512 channels are one wave (lane owns 8), so the LayerNorm statistics are two wave
+// reductions per frame and everything fuses into one pass; backward recomputes conv + statistics and needs two more
+// reductions per frame, again a single pass over the incoming gradient.
+template <typename TW, typename TP, typename TO>
+__global__ __launch_bounds__(256) void conv0_ln_fwd_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
+    const TP* __restrict__ gamma, const TP* __restrict__ beta, TO* __restrict__ out, long T, int T0, int C, int stride,
+    float eps) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* seg = sm;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH;
+  const int nt = min(C0_TCH, T0 - t0);
+  stage_wave(wav, T, b, t0, nt, stride, seg);
+  float w[8][C0_KW];
+  load_w(W, lane, C, w);
+  float gm[8], bt[8];
+  const bool act = lane * 8 < C;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = min(lane * 8 + e, C - 1);
+    gm[e] = Elem<TP>::ld(gamma + c); bt[e] = Elem<TP>::ld(beta + c);
+  }
+  __syncthreads();
+  const float invC = 1.f / (float)C;
+  for (int tt = wave; tt < nt; tt += 4) {
+    float y[8];
+    conv_at(seg, tt, stride, w, y);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += act ? y[e] : 0.f;
+    const float mean = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = y[e] - mean; q += act ? d * d : 0.f; }
+    const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = gelu_f(fmaf((y[e] - mean) * rstd, gm[e], bt[e]));
+      V8<TO>::st(out + ((long)b * T0 + t0 + tt) * C + lane * 8, y);
+    }
+  }
+}
+
+// part[(b * nchunk + chunk)][12][C]: dbeta, dgamma, dW[.][0..9]
+template <typename TW, typename TP, typename TO>
+__global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
+    const TP* __restrict__ gamma, const TP* __restrict__ beta, const TO* __restrict__ g, float* __restrict__ part, long T,
+    int T0, int C, int stride, float eps, float gscale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* seg = sm;
+  float* red = sm + ((C0_TCH_BWD - 1) * stride + C0_KW + 3) / 4 * 4;  // [4 waves][512]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH_BWD;
+  const int nt = min(C0_TCH_BWD, T0 - t0);
+  stage_wave(wav, T, b, t0, nt, stride, seg);
+  float w[8][C0_KW];
+  load_w(W, lane, C, w);
+  float gm[8], bt[8];
+  const bool act = lane * 8 < C;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = min(lane * 8 + e, C - 1);
+    gm[e] = Elem<TP>::ld(gamma + c); bt[e] = Elem<TP>::ld(beta + c);
+  }
+  __syncthreads();
+  float a1[8], a2[8], pw[8][C0_KW];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a1[e] = 0.f; a2[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) pw[e][k] = 0.f;
+  }
+  const float invC = 1.f / (float)C;
+  for (int tt = wave; tt < nt; tt += 4) {
+    float xw[C0_KW], y[8], gv[8];
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) xw[k] = seg[tt * stride + k];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gv[e] = 0.f;
+    if (act) V8<TO>::ld(g + ((long)b * T0 + t0 + tt) * C + lane * 8, gv);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < C0_KW; ++k) a = fmaf(xw[k], w[e][k], a);
+      y[e] = a; s += act ? a : 0.f;
+    }
+    const float mean = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = y[e] - mean; q += act ? d * d : 0.f; }
+    const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+    float h[8], xh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xh[e] = (y[e] - mean) * rstd;
+      const float dz = act ? gv[e] * gscale * gelu_grad_f(fmaf(xh[e], gm[e], bt[e])) : 0.f;
+      a1[e] += dz; a2[e] = fmaf(dz, xh[e], a2[e]);
+      h[e] = dz * gm[e];
+      s1 += h[e]; s2 = fmaf(h[e], xh[e], s2);
+    }
+    s1 = wave_sum(s1) * invC; s2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float dc = act ? rstd * (h[e] - s1 - xh[e] * s2) : 0.f;
+#pragma unroll
+      for (int k = 0; k < C0_KW; ++k) pw[e][k] = fmaf(dc, xw[k], pw[e][k]);
+    }
+  }
+  float* out = part + ((long)b * gridDim.x + blockIdx.x) * (long)C0_NQ * C;
+#pragma unroll
+  for (int q = 0; q < C0_NQ; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave * 512 + lane * 8 + e] = q == 0 ? a1[e] : q == 1 ? a2[e] : pw[e][q >= 2 ? q - 2 : 0];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) out[(long)q * C + c] = red[c] + red[512 + c] + red[1024 + c] + red[1536 + c];
+  }
+}
+
+// sums the [nblk][12][C] partials: row 0 -> dbeta, row 1 -> dgamma, rows 2.. -> dW[c][k]
+__global__ __launch_bounds__(256) void conv0_ln_bwd_finish_kernel(const float* __restrict__ part, int nblk, int C, void* dW,
+                                                                  void* dgamma, void* dbeta, int pdt) {
+  __shared__ double red[4][64];
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col, n = C0_NQ * C;
+  double s = 0.0;
+  if (i < n)
+    for (int b = slice; b < nblk; b += 4) s += part[(long)b * n + i];
+  red[slice][col] = s;
+  __syncthreads();
+  if (slice == 0 && i < n) {
+    const float v = (float)(red[0][col] + red[1][col] + red[2][col] + red[3][col]);
+    const int q = i / C, c = i - q * C;
+    if (q == 0) st_elem(dbeta, c, pdt, v);
+    else if (q == 1) st_elem(dgamma, c, pdt, v);
+    else st_elem(dW, (long)c * C0_KW + (q - 2), pdt, v);
+  }
+}
+
 static inline size_t seg_floats(int tch, int stride) { return (size_t)(((tch - 1) * stride + C0_KW + 3) / 4 * 4); }
 
 extern "C" {
@@ -416,6 +559,65 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   const int n = C * C0_KW;
   WL_LAUNCH(conv0_bwd_w_finish_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, dwb, (int)B, n, dW,
             (int)param_dtype);
+  return wl_check_launch();
+}
+
+uint64_t wavlm_conv0_ln_bwd_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride) {
+  const long T0 = (T - C0_KW) / stride + 1;
+  const uint64_t nchunk = (uint64_t)((T0 + C0_TCH_BWD - 1) / C0_TCH_BWD);
+  return (uint64_t)B * nchunk * C0_NQ * C * sizeof(float);
+}
+
+// extractor_mode "layer_norm", block 0: out[B, T0, C] = gelu(LayerNorm_C(conv0(wav)))  (WavLM/WavLM.py:403-418)
+int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, const void* gamma, const void* beta,
+                            int32_t param_dtype, void* out, int32_t out_dtype, int32_t B, int64_t T, int32_t C, int32_t kw,
+                            int32_t stride, float eps, void* stream) {
+  if (!wav || !W || !gamma || !beta || !out) return WL_EINVAL;
+  if (kw != C0_KW || stride < 1 || stride > 8 || C <= 0 || C > 512 || (C & 7) || B <= 0 || T < kw) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int T0 = (int)((T - kw) / stride + 1);
+  const dim3 grid((unsigned)((T0 + C0_TCH - 1) / C0_TCH), (unsigned)B);
+  const size_t smem = seg_floats(C0_TCH, stride) * sizeof(float);
+#define FW(TW, TP, TO) WL_LAUNCH((conv0_ln_fwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
+    (const TP*)W, (const TP*)gamma, (const TP*)beta, (TO*)out, (long)T, T0, (int)C, (int)stride, eps)
+  const int key = wav_dtype * 100 + param_dtype * 10 + out_dtype;
+  if (key == 0) FW(float, float, float);
+  else if (key == 111) FW(bf16_t, bf16_t, bf16_t);
+  else if (key == 11) FW(float, bf16_t, bf16_t);
+  else if (key == 1) FW(float, float, bf16_t);
+  else return WL_EINVAL;
+#undef FW
+  return wl_check_launch();
+}
+
+// backward of the above: dW[C, kw], dgamma[C], dbeta[C] (param dtype) from g = dL/dout; conv0 has no input gradient
+int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, const void* gamma, const void* beta,
+                            int32_t param_dtype, const void* g, int32_t g_dtype, void* dW, void* dgamma, void* dbeta,
+                            int32_t B, int64_t T, int32_t C, int32_t kw, int32_t stride, float eps, float gscale,
+                            void* workspace, uint64_t ws_bytes, void* stream) {
+  if (!wav || !W || !gamma || !beta || !g || !dW || !dgamma || !dbeta || !workspace) return WL_EINVAL;
+  if (kw != C0_KW || stride < 1 || stride > 8 || C <= 0 || C > 512 || (C & 7) || B <= 0 || T < kw) return WL_EINVAL;
+  if (ws_bytes < wavlm_conv0_ln_bwd_workspace_bytes(B, T, C, stride)) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int T0 = (int)((T - kw) / stride + 1);
+  const int nchunk = (T0 + C0_TCH_BWD - 1) / C0_TCH_BWD;
+  const dim3 grid((unsigned)nchunk, (unsigned)B);
+  float* part = (float*)workspace;
+  const size_t smem = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float);
+#define BW(TW, TP, TO) WL_LAUNCH((conv0_ln_bwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
+    (const TP*)W, (const TP*)gamma, (const TP*)beta, (const TO*)g, part, (long)T, T0, (int)C, (int)stride, eps, gscale)
+  const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
+  if (key == 0) BW(float, float, float);
+  else if (key == 111) BW(bf16_t, bf16_t, bf16_t);
+  else if (key == 11) BW(float, bf16_t, bf16_t);
+  else if (key == 1) BW(float, float, bf16_t);
+  else return WL_EINVAL;
+#undef BW
+  int rc = wl_check_launch();
+  if (rc != WL_OK) return rc;
+  const int n = C0_NQ * C;
+  WL_LAUNCH(conv0_ln_bwd_finish_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, (int)(B * nchunk), (int)C, dW,
+            dgamma, dbeta, (int)param_dtype);
   return wl_check_launch();
 }
 

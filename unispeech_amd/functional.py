@@ -214,6 +214,25 @@ class Conv0Fn(torch.autograd.Function):
         return None, dW, dgamma, dbeta, None, None, None
 
 
+class Conv0LNFn(torch.autograd.Function):
+    """conv0 (k=10) + LayerNorm over channels + GELU -> [B, T0, C]: block 0 of extractor_mode 'layer_norm'
+    (WavLM-Large; WavLM/WavLM.py:403-418)"""
+
+    @staticmethod
+    def forward(ctx, wav, W, gamma, beta, stride, eps, out_dtype):
+        wav = wav.contiguous()
+        y = ops.conv0_ln_gelu_fwd(wav, W.contiguous(), gamma, beta, stride, eps, out_dtype)
+        ctx.save_for_backward(wav, W, gamma, beta)
+        ctx.stride, ctx.eps = stride, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        wav, W, gamma, beta = ctx.saved_tensors
+        dW, dgamma, dbeta = ops.conv0_ln_gelu_bwd(wav, W.contiguous(), gamma, beta, g.contiguous(), ctx.stride, ctx.eps)
+        return None, dW, dgamma, dbeta, None, None, None
+
+
 def _conv_geometry(T_in, k, s):
     T_out = (T_in - k) // s + 1
     J = [len(range(r, k, s)) for r in range(s)]
@@ -230,7 +249,9 @@ class ConvStackFn(torch.autograd.Function):
     du_{i-1} = dx * gelu'(u_{i-1}) straight into the zero-padded buffer the next (earlier) layer consumes."""
 
     @staticmethod
-    def forward(ctx, x, specs, *weights):
+    def forward(ctx, x, specs, act, *weights):
+        """act=True: GELU fused (default mode); act=False: plain convolution (layer_norm mode: the LayerNorm + GELU
+        that follows is a LayerNormFn)"""
         B = x.shape[0]
         xs, us, wfs = [], [], []
         cur = x.contiguous()
@@ -240,12 +261,14 @@ class ConvStackFn(torch.autograd.Function):
             T_out = (T_in - k) // s + 1
             Wf = W.permute(0, 2, 1).reshape(Cout, k * Cin).contiguous()
             y = torch.empty((B, T_out, Cout), dtype=cur.dtype, device=cur.device)
-            u = torch.empty_like(y)
+            u = torch.empty_like(y) if act else y.new_empty(0)
             ops.gemm(cur, Wf, y, T_out, Cout, k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout, batch=(B, 1),
-                     sA=(T_in * Cin, 0), sC=(T_out * Cout, 0), epi=3, aux=u, ld_aux=Cout, sAux=(T_out * Cout, 0))
+                     sA=(T_in * Cin, 0), sC=(T_out * Cout, 0), epi=3 if act else 0, aux=u if act else None, ld_aux=Cout,
+                     sAux=(T_out * Cout, 0))
             xs.append(cur); us.append(u); wfs.append(Wf)
             cur = y
         ctx.specs = specs
+        ctx.act = act
         ctx.nl = len(specs)
         ctx.save_for_backward(*xs, *us, *weights)
         return cur
@@ -262,7 +285,7 @@ class ConvStackFn(torch.autograd.Function):
         k, s = specs[-1]
         T_out, J, fp, bp = _conv_geometry(xs[-1].shape[1], k, s)
         Cout = weights[-1].shape[0]
-        P, _ = ops.group_major(dy.contiguous(), us[-1], 1, fp, fp + T_out + bp, aux_is_grad=True)
+        P, _ = ops.group_major(dy.contiguous(), us[-1] if ctx.act else None, 1, fp, fp + T_out + bp, aux_is_grad=True)
         P = P.view(B, fp + T_out + bp, Cout)
         for i in range(nl - 1, -1, -1):
             k, s = specs[i]
@@ -273,7 +296,7 @@ class ConvStackFn(torch.autograd.Function):
             T_out, J, fp, bp = _conv_geometry(T_in, k, s)
             Tp = fp + T_out + bp
             # ---- weight gradient: dWf[co, (kk, ci)] = sum_{b,t} du[b,t,co] * x[b, s*t + kk, ci]
-            if ctx.needs_input_grad[2 + i]:
+            if ctx.needs_input_grad[3 + i]:
                 dWf = torch.empty((Cout, k * Cin), dtype=W.dtype, device=dev)
                 split = ops.pick_split(Cout, k * Cin, B * ((T_out + 63) // 64))
                 ops.gemm(P, x, dWf, Cout, k * Cin, T_out, lda=Cout, ldb=s * Cin, ldc=k * Cin, transA=True, transB=True,
@@ -292,7 +315,7 @@ class ConvStackFn(torch.autograd.Function):
                     nxt[:, :fpp].zero_()
                 if bpp:
                     nxt[:, fpp + T_in:].zero_()
-                aux = us[i - 1]
+                aux = us[i - 1] if ctx.act else None
             else:
                 fpp, Tpp = 0, T_in
                 nxt = torch.empty((B, T_in, Cin), dtype=dy.dtype, device=dev)
@@ -310,7 +333,7 @@ class ConvStackFn(torch.autograd.Function):
                          sAux=(T_in * Cin, 0))
             P = nxt
         dx = P if ctx.needs_input_grad[0] else None
-        return (dx, None) + tuple(grads)
+        return (dx, None, None) + tuple(grads)
 
 
 # ---------------------------------------------------------------------------------------------- pos_conv

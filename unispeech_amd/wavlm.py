@@ -121,19 +121,28 @@ class ConvFeatureExtractionModel(nn.Module):
 
     def forward(self, x):
         """x: waveform [B, T] -> features [B, T', C] (channel-last; the reference returns [B, C, T'])"""
-        if self.mode != "default":
-            raise NotImplementedError("extractor_mode='layer_norm' is not wired to the HIP path yet")
         blk0 = self.conv_layers[0]
-        conv0, gn = blk0[0], blk0[2]
+        conv0 = blk0[0]
         if conv0.bias is not None:
             raise NotImplementedError("conv_bias=True is not supported by the HIP path")
         wdt = conv0.weight.dtype
         if x.dtype != wdt:
             x = x.to(wdt)
+        if self.mode == "layer_norm":
+            # every block: conv -> LayerNorm over channels -> GELU (WavLM/WavLM.py:403-418).  Block 0 is one fused
+            # kernel; blocks 1.. are an overlapping-row GEMM followed by the fused LayerNorm + GELU row kernel.
+            ln0 = blk0[2][1]
+            y = F.Conv0LNFn.apply(x, conv0.weight, ln0.weight, ln0.bias, self.specs[0][1], ln0.eps, wdt)
+            for blk, spec in zip(list(self.conv_layers)[1:], self.specs[1:]):
+                ln = blk[2][1]
+                v = F.ConvStackFn.apply(y, (spec,), False, blk[0].weight)
+                y, _ = F.layer_norm(v, ln.weight, ln.bias, ln.eps, act=1)
+            return y
+        gn = blk0[2]
         y = F.Conv0Fn.apply(x, conv0.weight, gn.weight, gn.bias, self.specs[0][1], gn.eps, wdt)
         weights = [blk[0].weight for blk in list(self.conv_layers)[1:]]
         if weights:
-            y = F.ConvStackFn.apply(y, tuple(self.specs[1:]), *weights)
+            y = F.ConvStackFn.apply(y, tuple(self.specs[1:]), True, *weights)
         return y
 
 
