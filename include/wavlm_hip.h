@@ -204,6 +204,20 @@ int wavlm_l2norm_bwd(const void* dy, const void* y, int32_t y_dtype, const float
 int wavlm_ce_rows(const float* logits, const int32_t* target, float* loss_rows, float* correct_rows, void* dlogits,
                   int32_t d_dtype, int64_t S, int32_t V, int64_t ld_logits, int64_t ld_dlogits, float weight,
                   void* stream);
+
+/* Sampled-instance cosine logits + BCE: the utterance-contrastive head of UniSpeech-SAT
+ * (src/fairseq/models/unispeech_sat/unispeech_sat.py:487-557 sample_instances / compute_nce, 701-737 compute_pred_spk;
+ * the same gathered-cosine shape as wav2vec 2.0's sample_negatives, models/wav2vec/wav2vec2.py:474-553).
+ * Y: L2-normalised rows [S_all, D]; idx[s, n]: row gathered for logit n of row s (the host draws the indices with the
+ * reference's torch.randint calls); out[s, n] = scale * <Y[s], Y[idx[s, n]]>.  rows_wsum is both halves of its backward:
+ * out[j] (+)= sum_{e in [off[j], off[j+1])} w[e] * Y[src[e]]. */
+int wavlm_gather_dot(const void* Y, int32_t dtype, const int32_t* idx, float* out, int64_t S, int32_t N, int32_t D,
+                     float scale, void* stream);
+int wavlm_rows_wsum(const void* Y, int32_t dtype, const int32_t* src, const float* w, const int32_t* off, void* out,
+                    int32_t out_dtype, int64_t rows, int32_t D, int32_t accumulate, void* stream);
+uint64_t wavlm_bce_workspace_bytes(void);
+int wavlm_bce_logits(const float* logits, const uint8_t* targets, float* dlogits, float* out, int64_t n, float gscale,
+                     void* workspace, uint64_t ws_bytes, void* stream);
 uint64_t wavlm_sum_workspace_bytes(void);
 int wavlm_sum_f32(const float* x, int64_t n, float* out, void* workspace, uint64_t ws_bytes, void* stream);
 

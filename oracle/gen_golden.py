@@ -227,6 +227,63 @@ def gen_tiny_pretrain():
     np.savez_compressed(os.path.join(OUT, "tiny_pretrain.npz"), **out)
 
 
+def gen_tiny_sat():
+    """UniSpeech-SAT at tiny size (fairseq UniSpeechSATModel, utterance_contrastive_loss with 2 in-utterance and 5
+    cross-utterance instances tapped after layer 1 of 2) + HubertCriterion with loss_weights [10, 5, 0]: loss, the
+    speaker logits statistics and every parameter gradient."""
+    ref_shim.fairseq_wavlm()  # installs stubs + patches nothing SAT-specific
+    from fairseq.criterions.hubert_criterion import HubertCriterion
+    from fairseq.models.unispeech_sat import unispeech_sat as us
+    ref_shim.patch_oop(us)
+    cfg = us.UniSpeechSATConfig()
+    for k, v in TINY.items():
+        if hasattr(cfg, k):
+            setattr(cfg, k, v)
+    cfg.relative_position_embedding = False
+    cfg.gru_rel_pos = False
+    cfg.label_rate = 50
+    cfg.final_dim = 32
+    cfg.utterance_contrastive_loss = True
+    cfg.utterance_contrastive_layer = 1
+    cfg.num_instances = 2
+    cfg.cross_sample_instances = 5
+    V = 23
+    torch.manual_seed(0)
+    model = us.UniSpeechSATModel(cfg, SimpleNamespace(sample_rate=16000), [_Dict(V)])
+    model.train()
+    crit = HubertCriterion(SimpleNamespace(), 1.0, 0.0, loss_weights=[10.0, 5.0, 0.0])
+    out = sd_to_np(model.state_dict())
+    g = torch.Generator().manual_seed(99)
+    wav = torch.randn(3, 16000, generator=g)
+    target = torch.randint(4, V, (3, 50), generator=g)
+    pm = torch.zeros(3, 16000, dtype=torch.bool)
+    sample = {"id": torch.arange(3), "net_input": {"source": wav, "padding_mask": pm}, "target_list": [target]}
+    np.random.seed(321)
+    torch.manual_seed(77)
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    np.random.seed(321)
+    torch.manual_seed(77)
+    net = model(target_list=[target], source=wav, padding_mask=pm)
+    out["in/source"] = wav.numpy()
+    out["in/target"] = target.numpy()
+    out["out/loss"] = np.float64(loss.item())
+    out["out/sample_size"] = np.int64(sample_size)
+    out["out/loss_spk_m"] = np.float64(net["loss_spk_m"].item())
+    out["out/mean_targets"] = np.float64(float(net["mean_targets"]))
+    out["out/contrastive_acc"] = np.float64(float(net["contrastive_acc"]))
+    out["out/x"] = net["x"].detach().numpy()
+    np.random.seed(321)
+    from fairseq.data.data_utils import compute_mask_indices
+    T = net["x"].shape[1]
+    m = compute_mask_indices((3, T), torch.zeros(3, T, dtype=torch.bool), cfg.mask_prob, cfg.mask_length,
+                             cfg.mask_selection, cfg.mask_other, min_masks=2, no_overlap=False, min_space=1)
+    out["out/mask_seed321"] = m
+    for n, p in model.named_parameters():
+        out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_sat.npz"), **out)
+
+
 if __name__ == "__main__":
     if not ref_shim.available():
         raise SystemExit("reference tree not found at %s" % ref_shim.REF_ROOT)
@@ -236,5 +293,6 @@ if __name__ == "__main__":
     gen_tiny_wavlm()
     gen_tiny_pretrain()
     gen_tiny_large()
+    gen_tiny_sat()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

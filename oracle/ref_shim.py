@@ -66,7 +66,7 @@ def install():
             sys.path.insert(0, p)
 
 
-def _patch_oop(ref):
+def patch_oop(ref):
     """the reference's `x += x_conv` (wavlm.py:713, WavLM.py:579) breaks autograd on torch >= 2; value-identical
     out-of-place form, applied in the harness only"""
     if not getattr(ref.TransformerEncoder, "_oop_patched", False):
@@ -86,7 +86,7 @@ def standalone(differentiable=False):
     import WavLM as ref_wavlm  # noqa
     import modules as ref_modules  # noqa
     if differentiable:
-        _patch_oop(ref_wavlm)
+        patch_oop(ref_wavlm)
     return ref_wavlm, ref_modules
 
 
@@ -98,5 +98,5 @@ def fairseq_wavlm():
     from fairseq.data.data_utils import compute_mask_indices
     from fairseq.models.wavlm import wavlm as ref
 
-    _patch_oop(ref)
+    patch_oop(ref)
     return ref.WavLMModel, ref.WavLMConfig, WavLMCriterion, ref.TransformerEncoder, compute_mask_indices

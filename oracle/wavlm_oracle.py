@@ -154,7 +154,7 @@ def pos_conv(sd, cfg, x, prefix="encoder."):
     return F.gelu(y).transpose(1, 2)
 
 
-def transformer_encoder(sd, cfg, x, padding_mask=None, tgt_layer=None, prefix="encoder."):
+def transformer_encoder(sd, cfg, x, padding_mask=None, tgt_layer=None, prefix="encoder.", extract_layer=None, taps=None):
     """TransformerEncoder.forward / extract_features, eval-equivalent (dropout, layerdrop = 0)
     (WavLM/WavLM.py:564-612).  x: [B, T, D].  Returns (x [B, T, D], layer_results [(x_l [T,B,D], None)],
     conv_sum [B, T, D])."""
@@ -178,6 +178,8 @@ def transformer_encoder(sd, cfg, x, padding_mask=None, tgt_layer=None, prefix="e
                                     first_layer_emb=emb if i == 0 else None)
         if tgt_layer is not None:
             layer_results.append((x, None))
+        if extract_layer is not None and i == extract_layer and taps is not None:
+            taps.append(x.transpose(0, 1))  # UniSpeech-SAT speaker tap (unispeech_sat.py:1243-1244)
         if i == tgt_layer:
             r = x
             break
@@ -248,7 +250,10 @@ def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, n
         padding_mask = forward_padding_mask(T, padding_mask)
     if mask_indices is not None:
         x = torch.where(mask_indices.unsqueeze(-1), sd["mask_emb"].view(1, 1, -1), x)
-    y, _, conv_sum = transformer_encoder(sd, cfg, x, padding_mask, None)
+    taps = []
+    utt = getattr(cfg, "utterance_contrastive_loss", False)
+    y, _, conv_sum = transformer_encoder(sd, cfg, x, padding_mask, None,
+                                         extract_layer=(cfg.utterance_contrastive_layer - 1) if utt else None, taps=taps)
     pad = padding_mask if padding_mask is not None else torch.zeros(y.shape[:2], dtype=torch.bool)
     label_embs_list = sd["label_embs_concat"].split(num_classes, 0)
 
@@ -263,8 +268,57 @@ def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, n
         return out
 
     m = mask_indices if mask_indices is not None else torch.zeros_like(pad)
-    return {"x": y, "features": conv_sum, "padding_mask": padding_mask, "features_pen": features_pen,
-            "logit_m_list": pred(torch.logical_and(~pad, m)), "logit_u_list": pred(torch.logical_and(~pad, ~m))}
+    out = {"x": y, "features": conv_sum, "padding_mask": padding_mask, "features_pen": features_pen,
+           "logit_m_list": pred(torch.logical_and(~pad, m)), "logit_u_list": pred(torch.logical_and(~pad, ~m))}
+    if utt:
+        out.update(utterance_contrastive(sd, cfg, taps[0], torch.logical_and(~pad, m)))
+    return out
+
+
+def sample_instances(bsz, tsz, num, n_instances, cross_sample_instances):
+    """UniSpeechSATModel.sample_instances index draws (unispeech_sat.py:487-537): same torch.randint calls, CPU RNG."""
+    high, cross_high = tsz, tsz * bsz
+    idxs = cross = None
+    if n_instances > 0:
+        tszs = torch.arange(num).unsqueeze(-1).expand(-1, n_instances).flatten()
+        idxs = torch.randint(low=0, high=high - 1, size=(bsz, n_instances * num))
+        idxs[idxs >= tszs] += 1
+    if cross_sample_instances > 0:
+        tszs = torch.arange(num).unsqueeze(-1).expand(-1, cross_sample_instances).flatten()
+        cross = torch.randint(low=0, high=cross_high - 1, size=(bsz, cross_sample_instances * num))
+        cross[cross >= tszs] += 1
+    if n_instances > 0:
+        for i in range(1, bsz):
+            idxs[i] += i * high
+    else:
+        idxs = cross
+    if cross_sample_instances > 0 and n_instances > 0:
+        idxs = torch.cat([idxs, cross], dim=1)
+    return idxs
+
+
+def utterance_contrastive(sd, cfg, spk_x, masked_indices):
+    """compute_pred_spk + compute_nce(replace_inf=False) (unispeech_sat.py:545-557, 701-737), no quantiser."""
+    B, _, D = spk_x.shape
+    N = cfg.num_instances + cfg.cross_sample_instances
+    spk_x_m = spk_x[masked_indices].view(B, -1, D)
+    proj = F.linear(spk_x_m, sd["spk_proj.weight"], sd["spk_proj.bias"])         # [B, num, C]
+    num = proj.size(1)
+    b_pos = torch.arange(B).unsqueeze(1).expand(B, num)
+    yflat = proj.reshape(-1, proj.size(-1))
+    idx = sample_instances(B, num, num, cfg.num_instances, cfg.cross_sample_instances)
+    samples = yflat[idx.view(-1)].view(B, N, num, -1).permute(1, 0, 2, 3)         # [N, B, num, C]
+    samples_b = b_pos.reshape(-1)[idx.view(-1)].view(B, N, num).permute(1, 0, 2)
+    x_b = b_pos[..., 0].unsqueeze(1).unsqueeze(0).expand_as(samples_b)
+    targets = torch.cat([torch.ones(1, B, num, dtype=torch.long), (samples_b == x_b).long()], dim=0)
+    px = proj.reshape(-1, proj.size(-1))
+    inst = samples.reshape(N, -1, px.size(-1))
+    tg = targets.reshape(N + 1, -1).transpose(0, 1)
+    cand = torch.cat([px.unsqueeze(0), inst], dim=0)
+    logits = (torch.cosine_similarity(px.float(), cand.float(), dim=-1) / cfg.logit_temp).transpose(0, 1)
+    loss = F.binary_cross_entropy_with_logits(logits, tg.type_as(logits), reduction="none").mean()
+    return {"loss_spk_m": loss, "mean_targets": tg.float().mean(), "contrastive_acc": ((logits >= 0.0) == tg).float().mean(),
+            "spk_logits": logits}
 
 
 def criterion(net_output, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_weights=None):
@@ -292,6 +346,11 @@ def criterion(net_output, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_w
         p = loss_weights[0] * net_output["features_pen"].float() * sample_size
         loss = loss + p
         log["loss_features_pen"] = p
+        if "loss_spk_m" in net_output:  # get_extra_losses order: features_pen, loss_spk_m, loss_spk_u (None)
+            w = loss_weights[1] if len(loss_weights) > 1 else loss_weights[0]
+            q = w * net_output["loss_spk_m"].float() * sample_size
+            loss = loss + q
+            log["loss_loss_spk_m"] = q
     for name, ls in (("m", lm), ("u", lu)):
         for i, l in enumerate(ls):
             if l.numel() == 0:

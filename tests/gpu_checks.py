@@ -606,6 +606,27 @@ def check_loss():
     (pen * 3.0).sum().backward()
     out.append(("features_pen", err(pen, f.pow(2).mean().reshape(1)), 1e-5))
     out.append(("features_pen grad", err(fd.grad, fr.grad), 1e-5))
+    # sampled-instance cosine logits + BCE (UniSpeech-SAT utterance-contrastive head): gathered rows, duplicates, the
+    # row itself as column 0
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        S, N, C = 301, 9, 256
+        y = q(gen(S, C, seed=41), dtype)
+        gi = torch.Generator().manual_seed(5)
+        idx = torch.cat([torch.arange(S).view(S, 1), torch.randint(0, S, (S, N), generator=gi)], dim=1)
+        tg = torch.cat([torch.ones(S, 1, dtype=torch.bool), torch.rand(S, N, generator=gi) < 0.3], dim=1)
+        yr = y.clone().double().requires_grad_(True)
+        cand = yr[idx.view(-1)].view(S, N + 1, C)
+        lg = torch.cosine_similarity(yr.unsqueeze(1), cand, dim=-1) / 0.1
+        lr_ = TF.binary_cross_entropy_with_logits(lg, tg.double(), reduction="none").mean()
+        lr_.backward()
+        yd = y.to(dtype).to(DEV).requires_grad_(True)
+        ld, acc = F.UttContrastiveLossFn.apply(yd, idx.to(torch.int32).to(DEV), tg.to(torch.uint8).to(DEV), 0.1)
+        ld.sum().backward()
+        tag = f"utt_contrastive[{dtype}]"
+        out.append((tag + " loss", abs(ld.item() - lr_.item()) / abs(lr_.item()), tol))
+        out.append((tag + " accuracy", abs(acc.item() - ((lg >= 0) == tg).double().mean().item()), 1e-6 if dtype == torch.float32 else 0.02))
+        out.append((tag + " dproj", err(yd.grad, yr.grad), tol * 3))
     return out
 
 

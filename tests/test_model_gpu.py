@@ -271,3 +271,43 @@ def test_large_structure_vs_reference_golden():
         g = p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(ref)
         tol = GTOL * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8
         assert (g - ref).abs().max().item() <= tol, (n, (g - ref).abs().max().item(), tol)
+
+
+def test_unispeech_sat_head_vs_reference_golden():
+    """UniSpeech-SAT utterance-contrastive head (speaker tap after layer 1, spk_proj, sampled
+    in-/cross-utterance instances, gathered cosine logits, BCE) on the HIP path against the reference-generated golden:
+    total criterion loss, speaker loss + statistics, and every parameter gradient."""
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
+    z = load_golden("tiny_sat.npz")
+    d = dict(TINY)
+    d.update(relative_position_embedding=False, gru_rel_pos=False, utterance_contrastive_loss=True,
+             utterance_contrastive_layer=1, num_instances=2, cross_sample_instances=5)
+    cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    m = WavLMPretrainModel(cfg, None, [range(23)])
+    missing = m.load_state_dict(golden_state_dict(z), strict=True)
+    m = m.to("cuda").train()
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0, 5.0, 0.0])
+    wav = torch.from_numpy(z["in/source"]).cuda()
+    target = torch.from_numpy(z["in/target"]).cuda()
+    pm = torch.zeros(3, 16000, dtype=torch.bool)
+    sample = {"id": torch.arange(3), "net_input": {"source": wav, "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+              "target_list": [target]}
+    np.random.seed(321)
+    torch.manual_seed(77)
+    net = m(**sample["net_input"], target_list=sample["target_list"])
+    assert rel_err(net["x"], z["out/x"]) < RTOL
+    assert abs(float(net["loss_spk_m"]) - float(z["out/loss_spk_m"])) < RTOL * abs(float(z["out/loss_spk_m"]))
+    assert abs(float(net["mean_targets"]) - float(z["out/mean_targets"])) < 1e-6
+    assert abs(float(net["contrastive_acc"]) - float(z["out/contrastive_acc"])) < 1e-6
+    np.random.seed(321)
+    torch.manual_seed(77)
+    loss, sample_size, _ = crit(m, sample)
+    assert sample_size == int(z["out/sample_size"])
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
+    loss.backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+    for n, p in m.named_parameters():
+        ref = torch.from_numpy(z["grad/" + n])
+        g = p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(ref)
+        tol = GTOL * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8
+        assert (g - ref).abs().max().item() <= tol, (n, (g - ref).abs().max().item(), tol)

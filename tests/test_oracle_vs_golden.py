@@ -172,3 +172,41 @@ def test_oracle_large_structure():
         if k.startswith("feature_extractor."):
             g = g * cfg.feature_grad_mult
         assert (g - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8, k
+
+
+def _sat_cfg():
+    from conftest import Cfg, TINY
+    d = dict(TINY)
+    d.update(relative_position_embedding=False, gru_rel_pos=False, utterance_contrastive_loss=True,
+             utterance_contrastive_layer=1, num_instances=2, cross_sample_instances=5)
+    return Cfg(**d)
+
+
+def test_oracle_unispeech_sat_head():
+    """UniSpeech-SAT utterance-contrastive head against the reference-generated golden: total loss,
+    speaker loss / statistics and every parameter gradient; instance indices come from the same torch.randint stream."""
+    z = load_golden("tiny_sat.npz")
+    cfg = _sat_cfg()
+    sd = golden_state_dict(z, as_param=True)
+    wav = torch.from_numpy(z["in/source"])
+    target = torch.from_numpy(z["in/target"])
+    m = torch.from_numpy(z["out/mask_seed321"])
+    torch.manual_seed(77)
+    net = O.pretrain_forward(sd, cfg, wav, [target], torch.zeros(3, 16000, dtype=torch.bool), m, [23])
+    assert rel_err(net["x"].detach(), z["out/x"]) < RTOL
+    assert abs(net["loss_spk_m"].item() - float(z["out/loss_spk_m"])) < RTOL * abs(float(z["out/loss_spk_m"]))
+    assert abs(float(net["mean_targets"]) - float(z["out/mean_targets"])) < 1e-6
+    assert abs(float(net["contrastive_acc"]) - float(z["out/contrastive_acc"])) < 1e-6
+    loss, ss, _ = O.criterion(net, 1.0, 0.0, [10.0, 5.0, 0.0])
+    assert ss == int(z["out/sample_size"])
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
+    loss.backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+    for k, p in sd.items():
+        if not p.is_floating_point() or ("grad/" + k) not in z.files:
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        ref = torch.from_numpy(z["grad/" + k])
+        if k.startswith("feature_extractor."):
+            g = g * cfg.feature_grad_mult
+        assert (g - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8, k

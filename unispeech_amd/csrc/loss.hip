@@ -86,6 +86,105 @@ __global__ void sum_finish_kernel(const double* part, int n, float* out) {
   }
 }
 
+
+// ---- sampled-instance cosine logits (UniSpeech-SAT utterance-contrastive head, models/unispeech_sat/unispeech_sat.py:
+// 487-557 + 701-737; the same shape as wav2vec 2.0's sampled negatives, models/wav2vec/wav2vec2.py:474-553) ----------
+// The reference gathers the sampled rows into [N, S, C] (1.4 GB fp32 at cfg2-like sizes) and calls
+// cosine_similarity; here rows are L2-normalised once and every logit is one gathered dot product.
+// out[s, n] = scale * <Y[s], Y[idx[s, n]]>     (one wave per s; lane l owns elements 4l .. 4l+3 of up to 4 chunks)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_dot_kernel(const T* __restrict__ Y, const int* __restrict__ idx,
+                                                          float* __restrict__ out, long S, int N, int D, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = D >> 2;  // float4 groups per row
+  for (long s = (long)blockIdx.x * 4 + wave; s < S; s += (long)gridDim.x * 4) {
+    float x[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[c][e] = (lane + 64 * c < nv) ? Elem<T>::ld(Y + s * D + (lane + 64 * c) * 4 + e) : 0.f;
+    for (int n = 0; n < N; ++n) {
+      const long j = idx[s * N + n];
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (lane + 64 * c < nv) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a = fmaf(x[c][e], Elem<T>::ld(Y + j * D + (lane + 64 * c) * 4 + e), a);
+        }
+      a = wave_sum(a);
+      if (lane == 0) out[s * N + n] = a * scale;
+    }
+  }
+}
+
+// out[j] (+)= sum_{e in [off[j], off[j+1])} w[e] * Y[src[e]]   -- both halves of the gathered dot product's backward
+// (direct: entries of row j in order; transposed: entries sorted by their gathered index)
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void rows_wsum_kernel(const T* __restrict__ Y, const int* __restrict__ src,
+    const float* __restrict__ w, const int* __restrict__ off, TO* __restrict__ out, long rows, int D, int accumulate) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = D >> 2;
+  for (long j = (long)blockIdx.x * 4 + wave; j < rows; j += (long)gridDim.x * 4) {
+    float acc[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[c][e] = 0.f;
+    const int e0 = off[j], e1 = off[j + 1];
+    for (int q = e0; q < e1; ++q) {
+      const long r = src[q];
+      const float ww = w[q];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (lane + 64 * c < nv) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[c][e] = fmaf(ww, Elem<T>::ld(Y + r * D + (lane + 64 * c) * 4 + e), acc[c][e]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (lane + 64 * c < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          TO* o = out + j * D + (lane + 64 * c) * 4 + e;
+          Elem<TO>::st(o, acc[c][e] + (accumulate ? Elem<TO>::ld(o) : 0.f));
+        }
+      }
+  }
+}
+
+// binary cross-entropy with logits (F.binary_cross_entropy_with_logits, reduction 'none' -> caller takes the mean):
+// part[block] = (sum loss, count of (logit >= 0) == target); dlogits = gscale * (sigmoid(l) - t)
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ tgt,
+                                                          float* __restrict__ dlogits, double* __restrict__ part, long n,
+                                                          float gscale) {
+  __shared__ double red[4][2];
+  double ls = 0.0, cs = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float l = logits[i], t = tgt[i] ? 1.f : 0.f;
+    const float sp = __logf(1.f + __expf(-fabsf(l)));
+    ls += (double)(fmaxf(l, 0.f) - l * t + sp);
+    cs += ((l >= 0.f) == (t > 0.5f)) ? 1.0 : 0.0;
+    if (dlogits) dlogits[i] = gscale * (1.f / (1.f + __expf(-l)) - t);
+  }
+  ls = wave_sum_d(ls); cs = wave_sum_d(cs);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = ls; red[threadIdx.x >> 6][1] = cs; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    part[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  }
+}
+__global__ void bce_finish_kernel(const double* part, int nblk, float* out, double inv_n) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < nblk; ++i) { a += part[2 * i]; b += part[2 * i + 1]; }
+    out[0] = (float)(a * inv_n);  // mean loss
+    out[1] = (float)(b * inv_n);  // accuracy
+  }
+}
+
 extern "C" {
 
 int wavlm_l2norm_fwd(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, float* inv_norm, int64_t rows,
@@ -146,6 +245,49 @@ int wavlm_sum_f32(const float* x, int64_t n, float* out, void* workspace, uint64
   long grid = (n + 256 * 8 - 1) / (256 * 8); if (grid < 1) grid = 1; if (grid > 1024) grid = 1024;
   WL_LAUNCH(sum_partial_f32_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, (long)n, (double*)workspace);
   WL_LAUNCH(sum_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)grid, out);
+  return wl_check_launch();
+}
+
+int wavlm_gather_dot(const void* Y, int32_t dtype, const int32_t* idx, float* out, int64_t S, int32_t N, int32_t D,
+                     float scale, void* stream) {
+  if (!Y || !idx || !out || S < 0 || N <= 0 || D <= 0 || (D & 3) || D > 1024) return WL_EINVAL;
+  if (S == 0) return WL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  long grid = (S + 3) / 4; if (grid > 8192) grid = 8192;
+  if (dtype == WL_F32) WL_LAUNCH((gather_dot_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)Y, idx, out, (long)S, (int)N, (int)D, scale);
+  else if (dtype == WL_BF16) WL_LAUNCH((gather_dot_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)Y, idx, out, (long)S, (int)N, (int)D, scale);
+  else return WL_EINVAL;
+  return wl_check_launch();
+}
+
+int wavlm_rows_wsum(const void* Y, int32_t dtype, const int32_t* src, const float* w, const int32_t* off, void* out,
+                    int32_t out_dtype, int64_t rows, int32_t D, int32_t accumulate, void* stream) {
+  if (!Y || !src || !w || !off || !out || rows < 0 || D <= 0 || (D & 3) || D > 1024) return WL_EINVAL;
+  if (rows == 0) return WL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  long grid = (rows + 3) / 4; if (grid > 8192) grid = 8192;
+  const int key = dtype * 10 + out_dtype;
+#define RW(T, TO) WL_LAUNCH((rows_wsum_kernel<T, TO>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Y, src, w, off, \
+                            (TO*)out, (long)rows, (int)D, (int)accumulate)
+  if (key == 0) RW(float, float);
+  else if (key == 11) RW(bf16_t, bf16_t);
+  else if (key == 10) RW(bf16_t, float);
+  else if (key == 1) RW(float, bf16_t);
+  else return WL_EINVAL;
+#undef RW
+  return wl_check_launch();
+}
+
+uint64_t wavlm_bce_workspace_bytes(void) { return 2 * 1024 * sizeof(double); }
+
+/* out[0] = mean BCE-with-logits, out[1] = fraction of (logit >= 0) == target; dlogits (optional) = gscale * dloss_sum/dlogit */
+int wavlm_bce_logits(const float* logits, const uint8_t* targets, float* dlogits, float* out, int64_t n, float gscale,
+                     void* workspace, uint64_t ws_bytes, void* stream) {
+  if (!logits || !targets || !out || !workspace || n <= 0 || ws_bytes < wavlm_bce_workspace_bytes()) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  long grid = (n + 256 * 8 - 1) / (256 * 8); if (grid > 1024) grid = 1024;
+  WL_LAUNCH(bce_logits_kernel, dim3((unsigned)grid), dim3(256), 0, st, logits, targets, dlogits, (double*)workspace, (long)n, gscale);
+  WL_LAUNCH(bce_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)grid, out, 1.0 / (double)n);
   return wl_check_launch();
 }
 

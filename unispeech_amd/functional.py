@@ -609,3 +609,43 @@ class FeaturesPenFn(torch.autograd.Function):
         ops.axpby_(d, fc, 2.0 * ctx.grad_scale / fc.numel(), 0.0)
         ops.scale_dev_(d, g.reshape(1).to(torch.float32))
         return d, None
+
+
+# ------------------------------------------------------------------------ utterance-contrastive head (UniSpeech-SAT)
+class UttContrastiveLossFn(torch.autograd.Function):
+    """mean BCE-with-logits of cos(y_s, y_{idx[s, n]}) / temp against same-utterance indicators: compute_pred_spk of
+    UniSpeech-SAT (src/fairseq/models/unispeech_sat/unispeech_sat.py:701-737) with compute_nce(replace_inf=False)
+    (545-557).  idx[:, 0] is the row itself (the reference's positive is the projection itself); the gathered
+    [N, S, C] instance tensor of the reference is never built.  Returns (loss[1], accuracy[1])."""
+
+    @staticmethod
+    def forward(ctx, proj, idx, targets_u8, temp):
+        S, N1 = idx.shape
+        yn, inv = ops.l2norm_fwd(proj.contiguous(), proj.dtype)
+        logits = ops.gather_dot(yn, idx, 1.0 / temp)
+        out, dl = ops.bce_logits(logits, targets_u8, 1.0 / (temp * S * N1), want_grad=True)
+        ctx.save_for_backward(yn, inv, dl, idx, proj)
+        loss, acc = out[0:1].clone(), out[1:2].clone()
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, dloss, _dacc):
+        yn, inv, dl, idx, proj = ctx.saved_tensors
+        S, N1 = idx.shape
+        dev = yn.device
+        w = (dl * dloss.reshape(1).to(torch.float32)).view(-1)      # d loss / d logits, already / temp / numel
+        flat = idx.view(-1)
+        # direct half: d yn[s] += sum_n w[s, n] * yn[idx[s, n]]
+        off = torch.arange(0, (S + 1) * N1, N1, dtype=torch.int32, device=dev)
+        dyn = ops.rows_wsum(yn, flat, w, off, S)
+        # transposed half: d yn[j] += sum_{(s, n): idx[s, n] = j} w[s, n] * yn[s]   (entries sorted by gathered row)
+        order = torch.argsort(flat.long(), stable=True)
+        src_t = torch.div(order, N1, rounding_mode="floor").to(torch.int32)
+        w_t = w.index_select(0, order)
+        counts = torch.bincount(flat.long(), minlength=S)
+        off_t = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+        off_t[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        ops.rows_wsum(yn, src_t, w_t, off_t, S, out=dyn, accumulate=True)
+        dproj = ops.l2norm_bwd(dyn, yn, inv, proj.dtype)
+        return dproj, None, None, None

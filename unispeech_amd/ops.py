@@ -487,3 +487,39 @@ def prof_collect(dtype=-1):
     ms, fl = C.c_double(0.0), C.c_double(0.0)
     n = _lib.lib().wavlm_prof_collect(int(dtype), C.byref(ms), C.byref(fl))
     return n, ms.value, fl.value
+
+
+# ------------------------------------------------------------------------- sampled-instance cosine head
+def gather_dot(Y, idx, scale):
+    """out[s, n] = scale * <Y[s], Y[idx[s, n]]>  (Y: [S_all, D] rows, idx: int32 [S, N])"""
+    dev = _dev(Y); _contig(Y); _contig(idx)
+    S, N = idx.shape
+    out = torch.empty((S, N), dtype=torch.float32, device=dev)
+    check(_lib.lib().wavlm_gather_dot(ptr(Y), dt(Y), ptr(idx), ptr(out), S, N, Y.shape[1], float(scale), stream()),
+          "wavlm_gather_dot")
+    return out
+
+
+def rows_wsum(Y, src, w, off, rows, out=None, accumulate=False):
+    """out[j] (+)= sum_{e in [off[j], off[j+1])} w[e] * Y[src[e]]; out has Y's dtype"""
+    dev = _dev(Y); _contig(Y); _contig(src); _contig(w); _contig(off)
+    if out is None:
+        out = torch.empty((rows, Y.shape[1]), dtype=Y.dtype, device=dev)
+        accumulate = False
+    check(_lib.lib().wavlm_rows_wsum(ptr(Y), dt(Y), ptr(src), ptr(w), ptr(off), ptr(out), dt(out), rows, Y.shape[1],
+                                     int(bool(accumulate)), stream()), "wavlm_rows_wsum")
+    return out
+
+
+def bce_logits(logits, targets_u8, gscale, want_grad=True):
+    """(out[2] = (mean BCE-with-logits, accuracy of logit >= 0), dlogits = gscale * (sigmoid - target) or None)"""
+    dev = _dev(logits); _contig(logits); _contig(targets_u8)
+    n = logits.numel()
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    dl = torch.empty_like(logits) if want_grad else None
+    L = _lib.lib()
+    need = L.wavlm_bce_workspace_bytes()
+    ws = workspace(dev, need)
+    check(L.wavlm_bce_logits(ptr(logits), ptr(targets_u8), ptr(dl), ptr(out), n, float(gscale), ptr(ws), need, stream()),
+          "wavlm_bce_logits")
+    return out, dl

@@ -71,6 +71,12 @@ class WavLMPretrainConfig:
     max_distance: int = 1280
     gru_rel_pos: bool = False
     expand_attention_head_size: int = -1
+    # UniSpeech-SAT utterance-contrastive head (models/unispeech_sat/unispeech_sat.py:236-262)
+    utterance_contrastive_loss: bool = False
+    utterance_contrastive_layer: int = 6
+    num_instances: int = 0
+    cross_sample_instances: int = 100
+    quantize_targets: bool = False
 
 
 @dataclass
@@ -109,6 +115,17 @@ class WavLMPretrainModel(WavLM):
             self.num_classes = [len(d) for d in dictionaries]
             self.label_embs_concat = nn.Parameter(torch.FloatTensor(sum(self.num_classes), final_dim))
             nn.init.uniform_(self.label_embs_concat)
+        # speaker-aware head of UniSpeech-SAT (unispeech_sat.py:382-406): parameters in the reference's creation order
+        self.utterance_contrastive_loss = getattr(cfg, "utterance_contrastive_loss", False)
+        self.utterance_contrastive_layer = None
+        if self.utterance_contrastive_loss:
+            if getattr(cfg, "quantize_targets", False):
+                raise NotImplementedError("quantize_targets (Gumbel quantiser) is not supported by the HIP path")
+            self.utterance_contrastive_layer = cfg.utterance_contrastive_layer
+            self.n_instances = cfg.num_instances
+            self.cross_sample_instances = cfg.cross_sample_instances
+            self.project_q = nn.Linear(cfg.encoder_embed_dim, final_dim)  # unused without the quantiser; state-dict parity
+            self.spk_proj = nn.Linear(cfg.encoder_embed_dim, final_dim)
 
     @classmethod
     def build_model(cls, cfg, task):
@@ -190,8 +207,14 @@ class WavLMPretrainModel(WavLM):
         if sel is not None or kpm is not None:
             x = F.SelectRowsFn.apply(x, sel, self.mask_emb if sel is not None else None, kpm)
         layer = None if output_layer is None else output_layer - 1
-        x, layer_results, conv_sum = self.encoder(x, padding_mask=padding_mask, layer=layer,
-                                                  fairseq_layer_results=True, prezeroed=True)
+        spk_x = None
+        if self.utterance_contrastive_layer is not None:
+            x, layer_results, conv_sum, spk_x = self.encoder(x, padding_mask=padding_mask, layer=layer,
+                                                             fairseq_layer_results=True, prezeroed=True,
+                                                             extract_layer=self.utterance_contrastive_layer - 1)
+        else:
+            x, layer_results, conv_sum = self.encoder(x, padding_mask=padding_mask, layer=layer,
+                                                      fairseq_layer_results=True, prezeroed=True)
         result = {"x": x, "padding_mask": padding_mask, "features": conv_sum, "layer_results": layer_results}
         if features_only:
             return result
@@ -228,7 +251,63 @@ class WavLMPretrainModel(WavLM):
         result["logit_m_list"] = None  # materialised lazily by get_logits()
         result["logit_u_list"] = None
         result["features_pen"] = features_pen
+        if self.utterance_contrastive_loss:
+            if self.skip_masked or spk_x is None:
+                result.update(loss_spk_m=None, mean_targets=None, contrastive_acc=None, loss_spk_u=None)
+            else:
+                loss_spk, mean_t, acc = self._utterance_contrastive(spk_x, np.logical_and(~pad_np, m_np))
+                result.update(loss_spk_m=loss_spk, mean_targets=mean_t, contrastive_acc=acc, loss_spk_u=None)
         return result
+
+    def _sample_instances(self, bsz, tsz, num):
+        """Row indices into the flattened [bsz * tsz] projections, [bsz, (n_instances + cross) * num], drawn with the
+        reference's torch.randint calls (unispeech_sat.py:487-543) so the host RNG stream stays aligned."""
+        n_in, n_cr = self.n_instances, self.cross_sample_instances
+        high, cross_high = tsz, tsz * bsz
+        assert high > 1
+        idxs = cross = None
+        if n_in > 0:
+            tszs = torch.arange(num).unsqueeze(-1).expand(-1, n_in).flatten()
+            idxs = torch.randint(low=0, high=high - 1, size=(bsz, n_in * num))
+            idxs[idxs >= tszs] += 1
+        if n_cr > 0:
+            tszs = torch.arange(num).unsqueeze(-1).expand(-1, n_cr).flatten()
+            cross = torch.randint(low=0, high=cross_high - 1, size=(bsz, n_cr * num))
+            cross[cross >= tszs] += 1
+        if n_in > 0:
+            for i in range(1, bsz):
+                idxs[i] += i * high
+        else:
+            idxs = cross
+        if n_cr > 0 and n_in > 0:
+            idxs = torch.cat([idxs, cross], dim=1)
+        return idxs
+
+    def _utterance_contrastive(self, spk_x, masked_np):
+        """compute_pred_spk (unispeech_sat.py:701-737): project the masked frames of the tapped layer, score each against
+        itself + sampled instances, BCE against "same utterance".  Returns (loss, mean_targets, accuracy)."""
+        B, T, D = spk_x.shape
+        dev = spk_x.device
+        idx_np = np.flatnonzero(masked_np.reshape(-1)).astype(np.int32)
+        S = int(idx_np.size)
+        num = S // B                                    # equal number of masked frames per row (mask subsampling)
+        assert num * B == S and num > 1
+        inv_np = np.full(B * T, -1, dtype=np.int32)
+        inv_np[idx_np] = np.arange(S, dtype=np.int32)
+        rows = F.GatherRowsFn.apply(spk_x.reshape(B * T, D), torch.from_numpy(idx_np).to(dev),
+                                    torch.from_numpy(inv_np).to(dev))
+        proj = F.LinearFn.apply(rows, self.spk_proj.weight, self.spk_proj.bias)         # [S, final_dim], row = b * num + t
+        N = self.n_instances + self.cross_sample_instances
+        samples_idx = self._sample_instances(B, num, num)                               # [B, N * num], CPU int64
+        # instance n of frame (b, t) is samples_idx[b, n * num + t]; its utterance = index // num
+        si = samples_idx.view(B, N, num).permute(0, 2, 1).reshape(S, N)                 # [S, N]
+        own = torch.arange(S).view(S, 1)
+        idx_full = torch.cat([own, si], dim=1).to(torch.int32)                          # column 0: the frame itself
+        b_of = torch.arange(B).view(B, 1).expand(B, num).reshape(S, 1)
+        targets = torch.cat([torch.ones(S, 1, dtype=torch.bool), torch.div(si, num, rounding_mode="floor") == b_of], dim=1)
+        mean_targets = float(targets.float().mean())
+        loss, acc = F.UttContrastiveLossFn.apply(proj, idx_full.to(dev), targets.to(torch.uint8).to(dev), self.logit_temp)
+        return loss, mean_targets, acc
 
     # gradient through the unmasked head is only needed when pred_nomask_weight > 0 (criterion sets this)
     training_nomask_grad = False
@@ -274,11 +353,20 @@ class WavLMPretrainModel(WavLM):
         if "features_pen" in net_output:
             extra_losses.append(net_output["features_pen"])
             names.append("features_pen")
+        if "loss_spk_m" in net_output:
+            extra_losses.append(net_output["loss_spk_m"])
+            names.append("loss_spk_m")
+        if "loss_spk_u" in net_output:
+            extra_losses.append(net_output["loss_spk_u"])
+            names.append("loss_spk_u")
         return extra_losses, names
 
     def remove_pretraining_modules(self):
         self.final_proj = None
         self.label_embs_concat = None
+        if self.utterance_contrastive_loss:
+            self.project_q = None
+            self.spk_proj = None
 
 
 class WavLMCriterion(nn.Module):

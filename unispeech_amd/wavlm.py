@@ -208,7 +208,17 @@ class MultiheadAttention(nn.Module):
 
     def position_table(self, T, device):
         """[H, 2T-1] fp32 Toeplitz generator of compute_bias(T, T) (modules.py:444-455)"""
-        bucket = relative_position_buckets(T, self.num_buckets, self.max_distance).to(device)
+        # the bucket line depends only on (T, num_buckets, max_distance): computed on the host exactly as the reference
+        # does (bit-exact) once per sequence length and kept on the device (the reference rebuilds the [T, T] index
+        # matrix on the CPU and uploads it every step, modules.py:179-190)
+        key = (int(T), str(device))
+        cache = self.__dict__.setdefault("_bucket_cache", {})
+        bucket = cache.get(key)
+        if bucket is None:
+            if len(cache) > 64:
+                cache.clear()
+            bucket = relative_position_buckets(T, self.num_buckets, self.max_distance).to(device)
+            cache[key] = bucket
         return F.RelPosTableFn.apply(self.relative_attention_bias.weight, bucket)
 
     def forward(self, x, key_padding_u8=None, position_table=None):
@@ -340,13 +350,28 @@ class TransformerEncoder(nn.Module):
         self.layerdrop = args.encoder_layerdrop
         self.apply(init_bert_params)
 
-    def forward(self, x, padding_mask=None, layer=None, fairseq_layer_results=False, prezeroed=False):
-        x, layer_results, pre_ln = self.extract_features(x, padding_mask, layer, fairseq_layer_results, prezeroed)
+    def forward(self, x, padding_mask=None, layer=None, fairseq_layer_results=False, prezeroed=False, extract_layer=None):
+        """extract_layer (0-based): also return that layer's output [B, T, D] (UniSpeech-SAT's speaker tap,
+        models/unispeech_sat/unispeech_sat.py:1202-1255) as a 4th value"""
+        x, layer_results, pre_ln = self.extract_features(x, padding_mask, layer, fairseq_layer_results, prezeroed,
+                                                         extract_layer=extract_layer)
         if self.layer_norm_first and layer is None:
             x, _ = F.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
-        return x, layer_results, pre_ln
+        if extract_layer is None:
+            return x, layer_results, pre_ln
+        er = self._extract_result
+        self._extract_result = None
+        if er is not None and self.layer_norm_first and layer is None:
+            ln = getattr(self, "layer_norm_for_extract", None)
+            if ln is None:
+                raise NotImplementedError("pre-LN encoder with a speaker tap needs layer_norm_for_extract parameters")
+            er, _ = F.layer_norm(er, ln.weight, ln.bias, ln.eps)
+        return x, layer_results, pre_ln, er
 
-    def extract_features(self, x, padding_mask=None, tgt_layer=None, fairseq_layer_results=False, prezeroed=False):
+    _extract_result = None
+
+    def extract_features(self, x, padding_mask=None, tgt_layer=None, fairseq_layer_results=False, prezeroed=False,
+                         extract_layer=None):
         """x [B, T, D].  Returns (x, layer_results, conv_sum) where conv_sum = x + pos_conv(x): the tensor the
         reference's in-place `x += x_conv` leaves behind in `features` (WavLM/WavLM.py:579)."""
         kpm = None
@@ -374,6 +399,8 @@ class TransformerEncoder(nn.Module):
                 x, z, table = layer(x, kpm, table)
             else:
                 z = None
+            if extract_layer is not None and i == extract_layer:
+                self._extract_result = x
             if fairseq_layer_results:
                 if isinstance(tgt_layer, list) and i + 1 in tgt_layer:
                     layer_results.append((x.transpose(0, 1), z))
