@@ -284,6 +284,54 @@ def gen_tiny_sat():
     np.savez_compressed(os.path.join(OUT, "tiny_sat.npz"), **out)
 
 
+def gen_tiny_ils():
+    """ILS-HuBERT at tiny size (fairseq ILSHubertModel, predict_layers [1, 2], shared final_proj / label embeddings) +
+    HubertCriterion: loss, logits of both layers and every parameter gradient."""
+    ref_shim.fairseq_wavlm()
+    from fairseq.criterions.hubert_criterion import HubertCriterion
+    from fairseq.models.hubert import ils_hubert as ih
+    cfg = ih.ILSHubertConfig()
+    for k, v in TINY.items():
+        if hasattr(cfg, k):
+            setattr(cfg, k, v)
+    cfg.label_rate = 50
+    cfg.final_dim = 32
+    cfg.predict_layers = "[1,2]"
+    V = 23
+    torch.manual_seed(0)
+    model = ih.ILSHubertModel(cfg, SimpleNamespace(sample_rate=16000), [_Dict(V)])
+    model.train()
+    crit = HubertCriterion(SimpleNamespace(), 1.0, 0.0, loss_weights=[10.0])
+    out = sd_to_np(model.state_dict())
+    g = torch.Generator().manual_seed(555)
+    wav = torch.randn(2, 16000, generator=g)
+    target = torch.randint(4, V, (2, 50), generator=g)
+    pm = torch.zeros(2, 16000, dtype=torch.bool)
+    sample = {"id": torch.arange(2), "net_input": {"source": wav, "padding_mask": pm}, "target_list": [target]}
+    np.random.seed(222)
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    np.random.seed(222)
+    net = model(target_list=[target], source=wav, padding_mask=pm)
+    out["in/source"] = wav.numpy()
+    out["in/target"] = target.numpy()
+    out["out/loss"] = np.float64(loss.item())
+    out["out/sample_size"] = np.int64(sample_size)
+    out["out/n_logit_m"] = np.int64(len(net["logit_m_list"]))
+    for i, l in enumerate(net["logit_m_list"]):
+        out["out/logit_m%d" % i] = l.detach().float().numpy()
+    out["out/x"] = net["x"].detach().numpy()
+    np.random.seed(222)
+    from fairseq.data.data_utils import compute_mask_indices
+    T = net["x"].shape[1]
+    m = compute_mask_indices((2, T), torch.zeros(2, T, dtype=torch.bool), cfg.mask_prob, cfg.mask_length,
+                             cfg.mask_selection, cfg.mask_other, min_masks=2, no_overlap=False, min_space=1)
+    out["out/mask_seed222"] = m
+    for n, p in model.named_parameters():
+        out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_ils.npz"), **out)
+
+
 if __name__ == "__main__":
     if not ref_shim.available():
         raise SystemExit("reference tree not found at %s" % ref_shim.REF_ROOT)
@@ -294,5 +342,6 @@ if __name__ == "__main__":
     gen_tiny_pretrain()
     gen_tiny_large()
     gen_tiny_sat()
+    gen_tiny_ils()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

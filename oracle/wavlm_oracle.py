@@ -154,7 +154,8 @@ def pos_conv(sd, cfg, x, prefix="encoder."):
     return F.gelu(y).transpose(1, 2)
 
 
-def transformer_encoder(sd, cfg, x, padding_mask=None, tgt_layer=None, prefix="encoder.", extract_layer=None, taps=None):
+def transformer_encoder(sd, cfg, x, padding_mask=None, tgt_layer=None, prefix="encoder.", extract_layer=None, taps=None,
+                        collect=None, collected=None):
     """TransformerEncoder.forward / extract_features, eval-equivalent (dropout, layerdrop = 0)
     (WavLM/WavLM.py:564-612).  x: [B, T, D].  Returns (x [B, T, D], layer_results [(x_l [T,B,D], None)],
     conv_sum [B, T, D])."""
@@ -180,6 +181,8 @@ def transformer_encoder(sd, cfg, x, padding_mask=None, tgt_layer=None, prefix="e
             layer_results.append((x, None))
         if extract_layer is not None and i == extract_layer and taps is not None:
             taps.append(x.transpose(0, 1))  # UniSpeech-SAT speaker tap (unispeech_sat.py:1243-1244)
+        if collect is not None and (i + 1) in collect:
+            collected.append(x.transpose(0, 1))  # ILS: `isinstance(tgt_layer, list) and i+1 in tgt_layer` (wavlm.py:731)
         if i == tgt_layer:
             r = x
             break
@@ -252,19 +255,26 @@ def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, n
         x = torch.where(mask_indices.unsqueeze(-1), sd["mask_emb"].view(1, 1, -1), x)
     taps = []
     utt = getattr(cfg, "utterance_contrastive_loss", False)
+    pl = getattr(cfg, "predict_layers", "")
+    pl = eval(pl) if pl else None
+    collected = []
     y, _, conv_sum = transformer_encoder(sd, cfg, x, padding_mask, None,
-                                         extract_layer=(cfg.utterance_contrastive_layer - 1) if utt else None, taps=taps)
+                                         extract_layer=(cfg.utterance_contrastive_layer - 1) if utt else None, taps=taps,
+                                         collect=pl, collected=collected)
     pad = padding_mask if padding_mask is not None else torch.zeros(y.shape[:2], dtype=torch.bool)
-    label_embs_list = sd["label_embs_concat"].split(num_classes, 0)
+    lec = sd["label_embs_concat"]
+    label_embs_list = (lec[0] if lec.dim() == 3 else lec).split(num_classes, 0)
+    sources = collected if pl is not None else [y]  # ILS-SSL (ils_hubert.py:180-250): same head on every collected layer
 
     def pred(sel):
-        proj = F.linear(y[sel], sd["final_proj.weight"], sd["final_proj.bias"])
         out = []
-        for i, t in enumerate(target_list):
-            emb = label_embs_list[i]
-            pos = torch.index_select(emb, 0, t[sel].long())
-            negs = emb.unsqueeze(1).expand(-1, proj.size(0), -1)
-            out.append(compute_nce(proj, pos, negs, cfg.logit_temp))
+        for src in sources:
+            proj = F.linear(src[sel], sd["final_proj.weight"], sd["final_proj.bias"])
+            for i, t in enumerate(target_list):
+                emb = label_embs_list[i]
+                pos = torch.index_select(emb, 0, t[sel].long())
+                negs = emb.unsqueeze(1).expand(-1, proj.size(0), -1)
+                out.append(compute_nce(proj, pos, negs, cfg.logit_temp))
         return out
 
     m = mask_indices if mask_indices is not None else torch.zeros_like(pad)

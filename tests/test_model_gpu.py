@@ -311,3 +311,32 @@ def test_unispeech_sat_head_vs_reference_golden():
         g = p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(ref)
         tol = GTOL * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8
         assert (g - ref).abs().max().item() <= tol, (n, (g - ref).abs().max().item(), tol)
+
+
+def test_ils_hubert_vs_reference_golden():
+    """ILS-SSL on the HIP path against the golden generated from the reference's ILSHubertModel:
+    criterion loss and every parameter gradient with the head on layers [1, 2]."""
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
+    z = load_golden("tiny_ils.npz")
+    d = dict(TINY)
+    d.update(predict_layers="[1,2]", gru_rel_pos=False)  # HuBERT config: relative position bias without the gate
+    cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    m = WavLMPretrainModel(cfg, None, [range(23)])
+    m.load_state_dict(golden_state_dict(z), strict=True)
+    m = m.to("cuda").train()
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0])
+    pm = torch.zeros(2, 16000, dtype=torch.bool)
+    sample = {"id": torch.arange(2),
+              "net_input": {"source": torch.from_numpy(z["in/source"]).cuda(), "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+              "target_list": [torch.from_numpy(z["in/target"]).cuda()]}
+    np.random.seed(222)
+    loss, sample_size, _ = crit(m, sample)
+    assert sample_size == int(z["out/sample_size"])
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
+    loss.backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+    for n, p in m.named_parameters():
+        ref = torch.from_numpy(z["grad/" + n])
+        g = p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(ref)
+        tol = GTOL * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8
+        assert (g - ref).abs().max().item() <= tol, (n, (g - ref).abs().max().item(), tol)

@@ -210,3 +210,37 @@ def test_oracle_unispeech_sat_head():
         if k.startswith("feature_extractor."):
             g = g * cfg.feature_grad_mult
         assert (g - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8, k
+
+
+def test_oracle_ils_hubert():
+    """ILS-SSL: the masked-prediction head on the outputs of layers [1, 2] against the golden
+    generated from the reference's ILSHubertModel + HubertCriterion: logits of both layers, loss, gradients."""
+    from conftest import Cfg, TINY
+    z = load_golden("tiny_ils.npz")
+    d = dict(TINY)
+    d.update(predict_layers="[1,2]", gru_rel_pos=False)  # HuBERT config: relative position bias without the gate
+    cfg = Cfg(**d)
+    sd = golden_state_dict(z, as_param=True)
+    wav = torch.from_numpy(z["in/source"])
+    target = torch.from_numpy(z["in/target"])
+    m = torch.from_numpy(z["out/mask_seed222"])
+    net = O.pretrain_forward(sd, cfg, wav, [target], torch.zeros(2, 16000, dtype=torch.bool), m, [23])
+    assert len(net["logit_m_list"]) == int(z["out/n_logit_m"]) == 2
+    for i, l in enumerate(net["logit_m_list"]):
+        ref = torch.from_numpy(z["out/logit_m%d" % i])
+        fin = torch.isfinite(ref)
+        assert torch.equal(torch.isfinite(l.detach()), fin)
+        assert rel_err(l.detach()[fin], ref[fin]) < RTOL
+    loss, ss, _ = O.criterion(net, 1.0, 0.0, [10.0])
+    assert ss == int(z["out/sample_size"])
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
+    loss.backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+    for k, p in sd.items():
+        if not p.is_floating_point() or ("grad/" + k) not in z.files:
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        ref = torch.from_numpy(z["grad/" + k])
+        if k.startswith("feature_extractor."):
+            g = g * cfg.feature_grad_mult
+        assert (g - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8, k

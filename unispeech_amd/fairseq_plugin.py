@@ -9,6 +9,7 @@ built-ins in fairseq's registries instead, for drop-in use of unmodified recipes
 
 Registered:
   models     wavlm_mi355x  (WavLMPretrainModel  <- src/fairseq/models/wavlm/wavlm.py:255  @register_model("wavlm"))
+             unispeech_sat_mi355x, ils_hubert_mi355x  (same class; heads selected by config fields)
   criterions wavlm_mi355x, hubert_mi355x  (WavLMCriterion  <- criterions/wavlm_criterion.py:38, hubert_criterion.py:39)
 Tasks (`hubert_pretraining`, `utterance_mixing_pretraining`) are the reference's own: they are the *caller* of this
 path; the sample dict they collate is consumed unchanged.
@@ -70,6 +71,11 @@ def register(override: bool = False):
             CRITERION_DATACLASS_REGISTRY[name] = CritCfg
     else:
         register_model("wavlm_mi355x", dataclass=ModelCfg)(Model)
+        # the same class carries UniSpeech-SAT's utterance-contrastive head (utterance_contrastive_loss=True; reference
+        # "unispeech_sat", models/unispeech_sat/unispeech_sat.py:283) and ILS-SSL (predict_layers="[4,12]"; reference
+        # "ils_hubert", models/hubert/ils_hubert.py:60): registered under their own names for recipes that select by arch
+        register_model("unispeech_sat_mi355x", dataclass=ModelCfg)(type("UniSpeechSATMI355X", (Model,), {}))
+        register_model("ils_hubert_mi355x", dataclass=ModelCfg)(type("ILSHubertMI355X", (Model,), {}))
         register_criterion("wavlm_mi355x", dataclass=CritCfg)(Criterion)
         register_criterion("hubert_mi355x", dataclass=CritCfg)(type("HubertCriterionMI355X", (Criterion,), {}))
     _REGISTERED = True

@@ -77,6 +77,11 @@ class WavLMPretrainConfig:
     num_instances: int = 0
     cross_sample_instances: int = 100
     quantize_targets: bool = False
+    # ILS-SSL (models/hubert/ils_hubert.py:44-58): the masked-prediction loss on several layers' outputs
+    predict_layers: str = ""
+    separate_label_embeds: bool = False
+    separate_layer_targets: bool = False
+    weighted_sum: bool = False
 
 
 @dataclass
@@ -115,6 +120,20 @@ class WavLMPretrainModel(WavLM):
             self.num_classes = [len(d) for d in dictionaries]
             self.label_embs_concat = nn.Parameter(torch.FloatTensor(sum(self.num_classes), final_dim))
             nn.init.uniform_(self.label_embs_concat)
+        # ILS-SSL (ils_hubert.py:60-107): same head on the outputs of `predict_layers` (1-based); the reference model
+        # re-creates final_proj and a 3-D label_embs_concat [1, V, F] after the base constructor
+        pl = getattr(cfg, "predict_layers", "")
+        self.predict_layers = eval(pl) if pl else None
+        if self.predict_layers is not None:
+            if getattr(cfg, "separate_label_embeds", False) or getattr(cfg, "separate_layer_targets", False) \
+                    or getattr(cfg, "weighted_sum", False) or cfg.layer_norm_first:
+                raise NotImplementedError("ILS options separate_label_embeds / separate_layer_targets / weighted_sum / "
+                                          "pre-LN are not supported by the HIP path")
+            self.final_proj = nn.Linear(cfg.encoder_embed_dim,
+                                        final_dim * (len(dictionaries) if self.untie_final_proj else 1))
+            if self.num_classes is not None:
+                self.label_embs_concat = nn.Parameter(torch.FloatTensor(1, sum(self.num_classes), final_dim))
+                nn.init.uniform_(self.label_embs_concat)
         # speaker-aware head of UniSpeech-SAT (unispeech_sat.py:382-406): parameters in the reference's creation order
         self.utterance_contrastive_loss = getattr(cfg, "utterance_contrastive_loss", False)
         self.utterance_contrastive_layer = None
@@ -207,6 +226,8 @@ class WavLMPretrainModel(WavLM):
         if sel is not None or kpm is not None:
             x = F.SelectRowsFn.apply(x, sel, self.mask_emb if sel is not None else None, kpm)
         layer = None if output_layer is None else output_layer - 1
+        if self.predict_layers is not None and not features_only:
+            layer = list(self.predict_layers)
         spk_x = None
         if self.utterance_contrastive_layer is not None:
             x, layer_results, conv_sum, spk_x = self.encoder(x, padding_mask=padding_mask, layer=layer,
@@ -221,11 +242,22 @@ class WavLMPretrainModel(WavLM):
 
         pad_np = pad_cpu.numpy() if pad_cpu is not None else np.zeros((B, T), dtype=bool)
         m_np = mask_np if mask_np is not None else np.zeros((B, T), dtype=bool)
-        label_embs_list = self.label_embs_concat.split(self.num_classes, 0)
-        x2d = x.reshape(B * T, -1)
+        lec = self.label_embs_concat[0] if self.label_embs_concat.dim() == 3 else self.label_embs_concat
+        label_embs_list = lec.split(self.num_classes, 0)
         n = B * T
+        if self.predict_layers is not None:
+            # ILS: the head runs on every collected layer output ([T, B, C] views -> [B, T, C])
+            sources = [lx.transpose(0, 1).reshape(B * T, -1) for lx, _ in layer_results]
+        else:
+            sources = [x.reshape(B * T, -1)]
 
         def head(frame_sel_np, need_grad):
+            out = []
+            for x2d in sources:
+                out.extend(head_one(x2d, frame_sel_np, need_grad))
+            return out
+
+        def head_one(x2d, frame_sel_np, need_grad):
             idx_np = np.flatnonzero(frame_sel_np.reshape(-1)).astype(np.int32)
             S = int(idx_np.size)
             inv_np = np.full(n, -1, dtype=np.int32)
