@@ -208,11 +208,12 @@ int wavlm_ce_rows(const float* logits, const int32_t* target, float* loss_rows, 
 /* Sampled-instance cosine logits + BCE: the utterance-contrastive head of UniSpeech-SAT
  * (src/fairseq/models/unispeech_sat/unispeech_sat.py:487-557 sample_instances / compute_nce, 701-737 compute_pred_spk;
  * the same gathered-cosine shape as wav2vec 2.0's sample_negatives, models/wav2vec/wav2vec2.py:474-553).
- * Y: L2-normalised rows [S_all, D]; idx[s, n]: row gathered for logit n of row s (the host draws the indices with the
- * reference's torch.randint calls); out[s, n] = scale * <Y[s], Y[idx[s, n]]>.  rows_wsum is both halves of its backward:
+ * X, Y: L2-normalised rows (X = Y for UniSpeech-SAT); idx[s, n]: row of Y gathered for logit n of row s (the host draws
+ * the indices with the reference's torch.randint calls); out[s, n] = scale * <X[s], Y[idx[s, n]]>; mask_equal: logits
+ * n >= 1 whose gathered row equals the row of column 0 become -inf (wav2vec 2.0's neg_is_pos, wav2vec2.py:535-551).  rows_wsum is both halves of its backward:
  * out[j] (+)= sum_{e in [off[j], off[j+1])} w[e] * Y[src[e]]. */
-int wavlm_gather_dot(const void* Y, int32_t dtype, const int32_t* idx, float* out, int64_t S, int32_t N, int32_t D,
-                     float scale, void* stream);
+int wavlm_gather_dot(const void* X, const void* Y, int32_t dtype, const int32_t* idx, float* out, int64_t S, int32_t N,
+                     int32_t D, float scale, int32_t mask_equal, void* stream);
 int wavlm_rows_wsum(const void* Y, int32_t dtype, const int32_t* src, const float* w, const int32_t* off, void* out,
                     int32_t out_dtype, int64_t rows, int32_t D, int32_t accumulate, void* stream);
 uint64_t wavlm_bce_workspace_bytes(void);

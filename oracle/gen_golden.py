@@ -332,6 +332,31 @@ def gen_tiny_ils():
     np.savez_compressed(os.path.join(OUT, "tiny_ils.npz"), **out)
 
 
+def gen_sampled_negatives():
+    """wav2vec 2.0 head at function level: the reference's Wav2Vec2Model.sample_negatives and
+    compute_preds called as unbound functions (they only read n_negatives / cross_sample_negatives / logit_temp), then the
+    criterion's cross_entropy(sum).  y contains repeated rows (as quantised targets do) so neg_is_pos masking triggers."""
+    ref_shim.fairseq_wavlm()
+    from fairseq.models.wav2vec.wav2vec2 import Wav2Vec2Model
+    ns = SimpleNamespace(n_negatives=7, cross_sample_negatives=3, logit_temp=0.1)
+    g = torch.Generator().manual_seed(2024)
+    B, T, C = 3, 40, 32
+    code = torch.randn(12, C, generator=g)
+    y = code[torch.randint(0, 12, (B, T), generator=g)].clone().requires_grad_(True)     # 12 distinct target vectors
+    x = torch.randn(B, T, C, generator=g).requires_grad_(True)
+    torch.manual_seed(31)
+    negs, idxs = Wav2Vec2Model.sample_negatives(ns, y, T)
+    logits = Wav2Vec2Model.compute_preds(ns, x, y, negs)
+    l2 = logits.transpose(0, 2).reshape(-1, logits.size(0)).float()
+    loss = torch.nn.functional.cross_entropy(l2, l2.new_zeros(l2.size(0), dtype=torch.long), reduction="sum")
+    loss.backward()
+    out = {"in/x": x.detach().numpy(), "in/y": y.detach().numpy(), "out/neg_idxs": idxs.numpy(),
+           "out/logits": logits.detach().numpy(), "out/loss": np.float64(loss.item()),
+           "out/n_masked": np.int64(torch.isinf(logits).sum().item()),
+           "grad/x": x.grad.numpy(), "grad/y": y.grad.numpy()}
+    np.savez_compressed(os.path.join(OUT, "sampled_negatives.npz"), **out)
+
+
 if __name__ == "__main__":
     if not ref_shim.available():
         raise SystemExit("reference tree not found at %s" % ref_shim.REF_ROOT)
@@ -343,5 +368,6 @@ if __name__ == "__main__":
     gen_tiny_large()
     gen_tiny_sat()
     gen_tiny_ils()
+    gen_sampled_negatives()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -331,6 +331,26 @@ def utterance_contrastive(sd, cfg, spk_x, masked_indices):
             "spk_logits": logits}
 
 
+def sampled_negatives_logits(x, y, neg_idxs, n_neg, logit_temp):
+    """Wav2Vec2Model.sample_negatives' gather + compute_preds (models/wav2vec/wav2vec2.py:521-553): x, y [B, T, C];
+    neg_idxs int64 [B, T * N] indexing the flattened [B * T] rows of y.  Returns logits [N + 1, B, T]."""
+    B, T, C = y.shape
+    negs = y.reshape(-1, C)[neg_idxs.view(-1)].view(B, T, n_neg, C).permute(2, 0, 1, 3)
+    neg_is_pos = (y == negs).all(-1)
+    targets = torch.cat([y.unsqueeze(0), negs], dim=0)
+    logits = torch.cosine_similarity(x.float(), targets.float(), dim=-1).type_as(x) / logit_temp
+    if neg_is_pos.any():
+        logits[1:] = logits[1:].masked_fill(neg_is_pos, float("-inf"))
+    return logits
+
+
+def infonce_loss(logits):
+    """Wav2vecCriterion (criterions/wav2vec_criterion.py:44-64) with infonce: logits [N+1, B, T] -> get_logits' [T*B, N+1]
+    (wav2vec2.py:738-741), cross_entropy against class 0, sum"""
+    l2 = logits.transpose(0, 2).reshape(-1, logits.size(0)).float()
+    return F.cross_entropy(l2, l2.new_zeros(l2.size(0), dtype=torch.long), reduction="sum"), l2
+
+
 def criterion(net_output, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_weights=None):
     """WavLMCriterion.get_loss (src/fairseq/criterions/wavlm_criterion.py:52-138), sum reduction."""
     loss = 0.0

@@ -340,3 +340,28 @@ def test_ils_hubert_vs_reference_golden():
         g = p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(ref)
         tol = GTOL * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8
         assert (g - ref).abs().max().item() <= tol, (n, (g - ref).abs().max().item(), tol)
+
+
+def test_sampled_negatives_loss_vs_reference_golden():
+    """wav2vec 2.0's InfoNCE over sampled negatives on the HIP path (gathered cosine logits with
+    neg_is_pos masking + cross entropy) against the golden produced by the reference's sample_negatives / compute_preds."""
+    from unispeech_amd import functional as F
+    z = load_golden("sampled_negatives.npz")
+    B, T, C = z["in/y"].shape
+    N = 10
+    torch.manual_seed(31)
+    idx = F.sample_negatives_indices(B, T, T, 7, 3)
+    assert torch.equal(idx, torch.from_numpy(z["out/neg_idxs"]))
+    S = B * T
+    idx_full = torch.cat([torch.arange(S).view(S, 1), idx.view(B, T, N).reshape(S, N)], dim=1).to(torch.int32).cuda()
+    x = torch.from_numpy(z["in/x"]).reshape(S, C).cuda().requires_grad_(True)
+    y = torch.from_numpy(z["in/y"]).reshape(S, C).cuda().requires_grad_(True)
+    loss, ncorrect = F.SampledNegativesLossFn.apply(x, y, idx_full, 0.1)
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
+    ref = torch.from_numpy(z["out/logits"]).permute(1, 2, 0).reshape(S, N + 1)
+    mx = ref.argmax(-1) == 0
+    mn = ref.argmin(-1) == 0
+    assert abs(ncorrect.item() - float(mx.sum() - (mx & mn).sum())) <= 1
+    loss.sum().backward()
+    assert rel_err(x.grad.reshape(B, T, C), z["grad/x"]) < GTOL
+    assert rel_err(y.grad.reshape(B, T, C), z["grad/y"]) < GTOL

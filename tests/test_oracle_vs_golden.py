@@ -244,3 +244,27 @@ def test_oracle_ils_hubert():
         if k.startswith("feature_extractor."):
             g = g * cfg.feature_grad_mult
         assert (g - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8, k
+
+
+def test_sampled_negatives_oracle_and_index_stream():
+    """wav2vec 2.0 sampled negatives: the host index draws are bit-exact with the reference's
+    sample_negatives under the same torch seed; the oracle's logits (incl. -inf masking of negatives equal to the
+    positive), loss and gradients match the golden produced by the reference functions."""
+    from unispeech_amd.functional import sample_negatives_indices
+    z = load_golden("sampled_negatives.npz")
+    B, T, C = z["in/y"].shape
+    torch.manual_seed(31)
+    idx = sample_negatives_indices(B, T, T, 7, 3)
+    assert torch.equal(idx, torch.from_numpy(z["out/neg_idxs"]))
+    x = torch.from_numpy(z["in/x"]).requires_grad_(True)
+    y = torch.from_numpy(z["in/y"]).requires_grad_(True)
+    logits = O.sampled_negatives_logits(x, y, idx, 10, 0.1)
+    ref = torch.from_numpy(z["out/logits"])
+    fin = torch.isfinite(ref)
+    assert int((~fin).sum()) == int(z["out/n_masked"]) > 0
+    assert torch.equal(torch.isfinite(logits.detach()), fin)
+    assert rel_err(logits.detach()[fin], ref[fin]) < RTOL
+    loss, _ = O.infonce_loss(logits)
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
+    loss.backward()
+    assert rel_err(x.grad, z["grad/x"]) < 5e-4 and rel_err(y.grad, z["grad/y"]) < 5e-4

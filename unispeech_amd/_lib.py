@@ -93,7 +93,7 @@ SIGNATURES = {
     "wavlm_l2norm_fwd": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_f32, c_vp]),
     "wavlm_l2norm_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "wavlm_ce_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),
-    "wavlm_gather_dot": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_vp]),
+    "wavlm_gather_dot": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "wavlm_rows_wsum": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "wavlm_bce_workspace_bytes": (c_u64, []),
     "wavlm_bce_logits": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_u64, c_vp]),

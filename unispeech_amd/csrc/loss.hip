@@ -91,29 +91,42 @@ __global__ void sum_finish_kernel(const double* part, int n, float* out) {
 // 487-557 + 701-737; the same shape as wav2vec 2.0's sampled negatives, models/wav2vec/wav2vec2.py:474-553) ----------
 // The reference gathers the sampled rows into [N, S, C] (1.4 GB fp32 at cfg2-like sizes) and calls
 // cosine_similarity; here rows are L2-normalised once and every logit is one gathered dot product.
-// out[s, n] = scale * <Y[s], Y[idx[s, n]]>     (one wave per s; lane l owns elements 4l .. 4l+3 of up to 4 chunks)
+// out[s, n] = scale * <X[s], Y[idx[s, n]]>     (one wave per s; lane l owns elements 4l .. 4l+3 of up to 4 chunks)
+// mask_equal: columns n >= 1 whose gathered row equals the row of column 0 (the positive) get -inf -- wav2vec 2.0's
+// `neg_is_pos` rule (models/wav2vec/wav2vec2.py:535-551) for quantised targets that repeat
 template <typename T>
-__global__ __launch_bounds__(256) void gather_dot_kernel(const T* __restrict__ Y, const int* __restrict__ idx,
-                                                          float* __restrict__ out, long S, int N, int D, float scale) {
+__global__ __launch_bounds__(256) void gather_dot_kernel(const T* __restrict__ X, const T* __restrict__ Y,
+    const int* __restrict__ idx, float* __restrict__ out, long S, int N, int D, float scale, int mask_equal) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = D >> 2;  // float4 groups per row
   for (long s = (long)blockIdx.x * 4 + wave; s < S; s += (long)gridDim.x * 4) {
-    float x[4][4];
+    float x[4][4], pz[4][4];
+    const long j0 = idx[s * N];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) x[c][e] = (lane + 64 * c < nv) ? Elem<T>::ld(Y + s * D + (lane + 64 * c) * 4 + e) : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const bool in = lane + 64 * c < nv;
+        x[c][e] = in ? Elem<T>::ld(X + s * D + (lane + 64 * c) * 4 + e) : 0.f;
+        pz[c][e] = (in && mask_equal) ? Elem<T>::ld(Y + j0 * D + (lane + 64 * c) * 4 + e) : 0.f;
+      }
     for (int n = 0; n < N; ++n) {
       const long j = idx[s * N + n];
       float a = 0.f;
+      bool same = true;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (lane + 64 * c < nv) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a = fmaf(x[c][e], Elem<T>::ld(Y + j * D + (lane + 64 * c) * 4 + e), a);
+          for (int e = 0; e < 4; ++e) {
+            const float yv = Elem<T>::ld(Y + j * D + (lane + 64 * c) * 4 + e);
+            a = fmaf(x[c][e], yv, a);
+            same = same && (yv == pz[c][e]);
+          }
         }
       a = wave_sum(a);
-      if (lane == 0) out[s * N + n] = a * scale;
+      const bool all_same = mask_equal && n > 0 && __all(same);
+      if (lane == 0) out[s * N + n] = all_same ? -INFINITY : a * scale;
     }
   }
 }
@@ -248,14 +261,14 @@ int wavlm_sum_f32(const float* x, int64_t n, float* out, void* workspace, uint64
   return wl_check_launch();
 }
 
-int wavlm_gather_dot(const void* Y, int32_t dtype, const int32_t* idx, float* out, int64_t S, int32_t N, int32_t D,
-                     float scale, void* stream) {
-  if (!Y || !idx || !out || S < 0 || N <= 0 || D <= 0 || (D & 3) || D > 1024) return WL_EINVAL;
+int wavlm_gather_dot(const void* X, const void* Y, int32_t dtype, const int32_t* idx, float* out, int64_t S, int32_t N,
+                     int32_t D, float scale, int32_t mask_equal, void* stream) {
+  if (!X || !Y || !idx || !out || S < 0 || N <= 0 || D <= 0 || (D & 3) || D > 1024) return WL_EINVAL;
   if (S == 0) return WL_OK;
   hipStream_t st = (hipStream_t)stream;
   long grid = (S + 3) / 4; if (grid > 8192) grid = 8192;
-  if (dtype == WL_F32) WL_LAUNCH((gather_dot_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)Y, idx, out, (long)S, (int)N, (int)D, scale);
-  else if (dtype == WL_BF16) WL_LAUNCH((gather_dot_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)Y, idx, out, (long)S, (int)N, (int)D, scale);
+  if (dtype == WL_F32) WL_LAUNCH((gather_dot_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)X, (const float*)Y, idx, out, (long)S, (int)N, (int)D, scale, (int)mask_equal);
+  else if (dtype == WL_BF16) WL_LAUNCH((gather_dot_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Y, idx, out, (long)S, (int)N, (int)D, scale, (int)mask_equal);
   else return WL_EINVAL;
   return wl_check_launch();
 }

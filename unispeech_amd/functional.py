@@ -622,7 +622,7 @@ class UttContrastiveLossFn(torch.autograd.Function):
     def forward(ctx, proj, idx, targets_u8, temp):
         S, N1 = idx.shape
         yn, inv = ops.l2norm_fwd(proj.contiguous(), proj.dtype)
-        logits = ops.gather_dot(yn, idx, 1.0 / temp)
+        logits = ops.gather_dot(yn, yn, idx, 1.0 / temp)
         out, dl = ops.bce_logits(logits, targets_u8, 1.0 / (temp * S * N1), want_grad=True)
         ctx.save_for_backward(yn, inv, dl, idx, proj)
         loss, acc = out[0:1].clone(), out[1:2].clone()
@@ -649,3 +649,72 @@ class UttContrastiveLossFn(torch.autograd.Function):
         ops.rows_wsum(yn, src_t, w_t, off_t, S, out=dyn, accumulate=True)
         dproj = ops.l2norm_bwd(dyn, yn, inv, proj.dtype)
         return dproj, None, None, None
+
+
+def _csr_by_target(flat_idx, n_rows, per_row):
+    """entries of a [S, per_row] index matrix grouped by the row they point to: (source row of each entry, order, offsets)"""
+    order = torch.argsort(flat_idx.long(), stable=True)
+    src_t = torch.div(order, per_row, rounding_mode="floor").to(torch.int32)
+    off_t = torch.zeros(n_rows + 1, dtype=torch.int32, device=flat_idx.device)
+    off_t[1:] = torch.cumsum(torch.bincount(flat_idx.long(), minlength=n_rows), 0).to(torch.int32)
+    return src_t, order, off_t
+
+
+class SampledNegativesLossFn(torch.autograd.Function):
+    """InfoNCE over sampled negatives (wav2vec 2.0 / UniSpeech: Wav2Vec2Model.compute_preds, models/wav2vec/wav2vec2.py:
+    533-553, + Wav2vecCriterion's cross_entropy(logits, 0, 'sum'), criterions/wav2vec_criterion.py:44-64).
+    x [S, C]: context projections; y [S, C]: targets; idx [S, 1 + N] int32 rows of y (column 0 = the positive, i.e. s
+    itself, then the sampled negatives); negatives equal to the positive are masked to -inf.  Returns
+    (loss_sum[1], n_correct[1])."""
+
+    @staticmethod
+    def forward(ctx, x, y, idx, temp):
+        S, N1 = idx.shape
+        xn, inv_x = ops.l2norm_fwd(x.contiguous(), x.dtype)
+        yn, inv_y = ops.l2norm_fwd(y.contiguous(), y.dtype)
+        logits = ops.gather_dot(xn, yn, idx, 1.0 / temp, mask_equal=True)
+        target = torch.zeros(S, dtype=torch.int32, device=x.device)
+        dlog = torch.empty((S, N1), dtype=torch.float32, device=x.device)
+        loss_rows, correct_rows = ops.ce_rows(logits, target, N1, N1, dlog, N1, 1.0)
+        loss, ncorrect = ops.sum_f32(loss_rows), ops.sum_f32(correct_rows)
+        ctx.save_for_backward(xn, yn, inv_x, inv_y, dlog, idx, x, y)
+        ctx.temp = temp
+        ctx.mark_non_differentiable(ncorrect)
+        return loss, ncorrect
+
+    @staticmethod
+    def backward(ctx, dloss, _dc):
+        xn, yn, inv_x, inv_y, dlog, idx, x, y = ctx.saved_tensors
+        S, N1 = idx.shape
+        dev = xn.device
+        w = (dlog * (dloss.reshape(1).to(torch.float32) / ctx.temp)).view(-1)
+        flat = idx.view(-1)
+        off = torch.arange(0, (S + 1) * N1, N1, dtype=torch.int32, device=dev)
+        dxn = ops.rows_wsum(yn, flat, w, off, S)                                   # d xn[s] = sum_n w[s,n] yn[idx[s,n]]
+        src_t, order, off_t = _csr_by_target(flat, y.shape[0], N1)
+        dyn = ops.rows_wsum(xn, src_t, w.index_select(0, order), off_t, y.shape[0])  # d yn[j] = sum_{idx=j} w xn[s]
+        return ops.l2norm_bwd(dxn, xn, inv_x, x.dtype), ops.l2norm_bwd(dyn, yn, inv_y, y.dtype), None, None
+
+
+def sample_negatives_indices(bsz, tsz, num, n_negatives, cross_sample_negatives, padding_count=None):
+    """Index draws of Wav2Vec2Model.sample_negatives (wav2vec2.py:474-531): same torch.randint calls on the CPU RNG.
+    Returns int64 [bsz, num * N]: negative n of frame t of utterance b is [b, t * N + n], indexing the [bsz * tsz] rows."""
+    high, cross_high = tsz - (padding_count or 0), tsz * bsz
+    assert high > 1
+    neg = cross = None
+    if n_negatives > 0:
+        tszs = torch.arange(num).unsqueeze(-1).expand(-1, n_negatives).flatten()
+        neg = torch.randint(low=0, high=high - 1, size=(bsz, n_negatives * num))
+        neg[neg >= tszs] += 1
+    if cross_sample_negatives > 0:
+        tszs = torch.arange(num).unsqueeze(-1).expand(-1, cross_sample_negatives).flatten()
+        cross = torch.randint(low=0, high=cross_high - 1, size=(bsz, cross_sample_negatives * num))
+        cross[cross >= tszs] += 1
+    if n_negatives > 0:
+        for i in range(1, bsz):
+            neg[i] += i * high
+    else:
+        neg = cross
+    if cross_sample_negatives > 0 and n_negatives > 0:
+        neg = torch.cat([neg, cross], dim=1)
+    return neg

@@ -490,13 +490,14 @@ def prof_collect(dtype=-1):
 
 
 # ------------------------------------------------------------------------- sampled-instance cosine head
-def gather_dot(Y, idx, scale):
-    """out[s, n] = scale * <Y[s], Y[idx[s, n]]>  (Y: [S_all, D] rows, idx: int32 [S, N])"""
-    dev = _dev(Y); _contig(Y); _contig(idx)
+def gather_dot(X, Y, idx, scale, mask_equal=False):
+    """out[s, n] = scale * <X[s], Y[idx[s, n]]>  (rows [., D], idx: int32 [S, N]); mask_equal: columns n >= 1 whose
+    gathered row equals the row of column 0 become -inf"""
+    dev = _dev(Y); _contig(X); _contig(Y); _contig(idx)
     S, N = idx.shape
     out = torch.empty((S, N), dtype=torch.float32, device=dev)
-    check(_lib.lib().wavlm_gather_dot(ptr(Y), dt(Y), ptr(idx), ptr(out), S, N, Y.shape[1], float(scale), stream()),
-          "wavlm_gather_dot")
+    check(_lib.lib().wavlm_gather_dot(ptr(X), ptr(Y), dt(Y), ptr(idx), ptr(out), S, N, Y.shape[1], float(scale),
+                                      int(bool(mask_equal)), stream()), "wavlm_gather_dot")
     return out
 
 
