@@ -49,20 +49,47 @@ class GradReducer:
             self.buckets.append(cur)
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._seen = [False] * len(self.params)
         self._works = []
+        # arena element offsets (sorted) for sink notifications: backward kernels that accumulate straight into the
+        # arena (functional._sink) report the slice they wrote; a packed q|k|v slice covers three parameters
+        self._offsets = list(offsets)
+        self._order = sorted(range(len(self.params)), key=lambda i: self._offsets[i])
+        self._sorted_off = [self._offsets[i] for i in self._order]
         if self.enabled:
             for idx, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(idx))
+            from . import functional
+            functional.SINK_LISTENERS.append(self._sink_written)
+
+    def _mark(self, idx):
+        """parameter idx has its gradient of this backward in the arena (autograd hook or sink notification; idempotent)"""
+        if not (self.enabled and self.sync) or self._seen[idx]:
+            return
+        self._seen[idx] = True
+        b = self.bucket_of[idx]
+        self._ready[b] += 1
+        if self._ready[b] == self.buckets[b]["n"] and not self._launched[b]:
+            self._launch(b)
 
     def _make_hook(self, idx):
         def hook(_p):
-            if not (self.enabled and self.sync):
-                return
-            b = self.bucket_of[idx]
-            self._ready[b] += 1
-            if self._ready[b] == self.buckets[b]["n"] and not self._launched[b]:
-                self._launch(b)
+            self._mark(idx)
         return hook
+
+    def _sink_written(self, t):
+        if not (self.enabled and self.sync):
+            return
+        base, esize = self.flat_grad.data_ptr(), self.flat_grad.element_size()
+        lo = (t.data_ptr() - base) // esize
+        if lo < 0 or lo >= self.flat_grad.numel():
+            return
+        hi = lo + t.numel()
+        import bisect
+        k = bisect.bisect_left(self._sorted_off, lo)
+        while k < len(self._sorted_off) and self._sorted_off[k] < hi:
+            self._mark(self._order[k])
+            k += 1
 
     def _launch(self, b):
         bk = self.buckets[b]
@@ -102,6 +129,7 @@ class GradReducer:
         self._works = []
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._seen = [False] * len(self.params)
 
     @property
     def scale(self):

@@ -24,6 +24,40 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
+SINK_LISTENERS = []  # callables(tensor): told which arena slice a backward kernel has just accumulated into (dp.GradReducer)
+
+
+_SINK_USES = {}      # arena slice (data_ptr) -> forward uses not yet matched by a backward accumulation
+
+
+def reset_sink_uses():
+    """called by the optimizer's zero_grad(): forwards whose backward never ran must not leave counts behind"""
+    _SINK_USES.clear()
+
+
+def _sink_use(p, explicit=None):
+    """forward side: this parameter (or explicit sink view) will receive one more accumulation in backward"""
+    t = explicit if explicit is not None else _sink(p)
+    if t is not None and SINK_LISTENERS:
+        k = t.data_ptr()
+        _SINK_USES[k] = _SINK_USES.get(k, 0) + 1
+
+
+def _sink_written(t):
+    """backward side: one accumulation into slice t is enqueued; listeners hear about the slice once its LAST pending
+    accumulation of this backward is in (a parameter used twice -- ILS heads, tied projections -- must not be reduced early)"""
+    if not SINK_LISTENERS:
+        return
+    k = t.data_ptr()
+    left = _SINK_USES.get(k, 1) - 1
+    if left > 0:
+        _SINK_USES[k] = left
+        return
+    _SINK_USES.pop(k, None)
+    for cb in SINK_LISTENERS:
+        cb(t)
+
+
 def _sink(p):
     """Gradient sink of a parameter: FusedAdam points `p.grad` at its slice of the flat gradient arena (zeroed every
     step) and marks the parameter.  Backward kernels then accumulate straight into the arena and the Function returns
@@ -70,12 +104,14 @@ def _param_grads(dy2d, x2d, W, b, has_bias, need_w, need_b, sink_w=None, sink_b=
     sw = sink_w if sink_w is not None else _sink(W)
     if sw is not None:
         _linear_bwd_w(dy2d, x2d, W.dtype, out=sw.view(W.shape))
+        _sink_written(sw)
     elif need_w:
         dW = _linear_bwd_w(dy2d, x2d, W.dtype)
     if has_bias:
         sb = sink_b if sink_b is not None else _sink(b)
         if sb is not None:
             ops.colsum(dy2d, W.dtype, out=sb.view(-1), accumulate=True)
+            _sink_written(sb)
         elif need_b:
             db = ops.colsum(dy2d, W.dtype)
     return dW, db
@@ -93,6 +129,9 @@ class LinearFn(torch.autograd.Function):
         y = _linear_fwd(x2d, W, b)
         ctx.save_for_backward(x2d, W, b)
         ctx.sinks = (sink_w, sink_b)
+        _sink_use(W, sink_w)
+        if b is not None:
+            _sink_use(b, sink_b)
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], W.shape[0])
 
@@ -129,6 +168,9 @@ class FFNFn(torch.autograd.Function):
         hd = ops.dropout(h, p_act, seed) if p_act > 0 else h
         y = _linear_fwd(hd, W2, b2)
         ctx.save_for_backward(x2d, W1, W2, u, hd, b1, b2)
+        for t in (W1, b1, W2, b2):
+            if t is not None:
+                _sink_use(t)
         ctx.p_act, ctx.seed, ctx.xshape = p_act, seed, x.shape
         return y.view(*x.shape[:-1], W2.shape[0])
 
@@ -165,6 +207,8 @@ class LayerNormFn(torch.autograd.Function):
                                              p_out=p_out, seed_out=seed_out, save=True)
         ctx.save_for_backward(s, mean, rstd, gamma, beta)
         ctx.cfg = (act, p_in, seed_in, p_out, seed_out, grad_scale, r is not None)
+        _sink_use(gamma)
+        _sink_use(beta)
         s_out = s.detach()
         ctx.mark_non_differentiable(s_out)
         return y, s_out
@@ -182,6 +226,7 @@ class LayerNormFn(torch.autograd.Function):
                                                   dgamma=sg, dbeta=sb)
         if sg is not None:
             dgamma = dbeta = None  # accumulated in place
+            _sink_written(sg); _sink_written(sb)
         if has_r and dr is None:
             dr = dx
         return dx, (dr if has_r else None), dgamma, dbeta, None, None, None, None, None, None, None

@@ -82,6 +82,8 @@ class FusedAdam:
         self.step_count = 0
 
     def zero_grad(self):
+        from . import functional
+        functional.reset_sink_uses()
         self.flat_grad.zero_()
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
