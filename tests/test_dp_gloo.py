@@ -66,7 +66,26 @@ def _worker(rank, world, port, q):
     net(x).pow(2).sum().backward()
     red.finish()
     ok2 = torch.allclose(flat, 2 * (refs[0] + refs[1]), atol=1e-5)
-    q.put((rank, ok1, ok_avg, local_only, ok2))
+    # 3) sink notifications (backward kernels that accumulate straight into the arena): a slice used twice in one
+    #    forward only counts as complete after its second accumulation; a slice spanning two parameters marks both
+    from unispeech_amd import functional as Fn
+    flat.zero_()
+    Fn.reset_sink_uses()
+    w0 = flat[offsets[0]:offsets[0] + params[0].numel()]
+    span = flat[offsets[2]:offsets[3] + params[3].numel()]  # second Linear's weight|bias as one packed slice
+    Fn._sink_use(None, w0)
+    Fn._sink_use(None, w0)
+    Fn._sink_use(None, span)
+    Fn._sink_written(w0)
+    first = red._seen[0]
+    Fn._sink_written(w0)
+    second = red._seen[0]
+    Fn._sink_written(span)
+    both = red._seen[2] and red._seen[3]
+    ok3 = (not first) and second and both
+    red.finish()
+    ok3 = ok3 and not any(red._seen)
+    q.put((rank, ok1, ok_avg, local_only, ok2, ok3))
     dist.destroy_process_group()
 
 
