@@ -26,10 +26,11 @@ def _build(seed):
     net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
     unused = torch.nn.Parameter(torch.randn(40))
     params = list(net.parameters()) + [unused]
-    offsets, off = [], 0
-    for p in params:
-        offsets.append(off)
-        off += (p.numel() + 7) // 8 * 8
+    # arena order differs from registration order (the optimizer packs q|k|v groups out of order)
+    offsets, off = [0] * len(params), 0
+    for i in (2, 0, 3, 1, 4):
+        offsets[i] = off
+        off += (params[i].numel() + 7) // 8 * 8
     flat = torch.zeros(off)
     for p, o in zip(params, offsets):
         p.grad = flat[o:o + p.numel()].view_as(p)
@@ -45,6 +46,9 @@ def _worker(rank, world, port, q):
     net, params, offsets, flat = _build(0)  # same weights on both ranks
     red = GradReducer(params, flat, offsets, bucket_bytes=1024)  # several buckets
     assert len(red.buckets) >= 2
+    spans = sorted((b["lo"], b["hi"]) for b in red.buckets)  # disjoint, covering the arena
+    assert spans[0][0] == 0 and spans[-1][1] == flat.numel()
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     x = torch.randn(4, 16, generator=torch.Generator().manual_seed(100 + rank))
     # local reference gradients of both ranks, computed independently
     refs = []
@@ -72,7 +76,7 @@ def _worker(rank, world, port, q):
     flat.zero_()
     Fn.reset_sink_uses()
     w0 = flat[offsets[0]:offsets[0] + params[0].numel()]
-    span = flat[offsets[2]:offsets[3] + params[3].numel()]  # second Linear's weight|bias as one packed slice
+    span = flat[offsets[3]:offsets[1] + params[1].numel()]  # parameters 3 and 1 are adjacent in the arena: one packed slice
     Fn._sink_use(None, w0)
     Fn._sink_use(None, w0)
     Fn._sink_use(None, span)
@@ -81,7 +85,7 @@ def _worker(rank, world, port, q):
     Fn._sink_written(w0)
     second = red._seen[0]
     Fn._sink_written(span)
-    both = red._seen[2] and red._seen[3]
+    both = red._seen[3] and red._seen[1]
     ok3 = (not first) and second and both
     red.finish()
     ok3 = ok3 and not any(red._seen)

@@ -29,24 +29,30 @@ class GradReducer:
         self.sync = True
         self.is_cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.is_cuda and self.enabled) else None
-        # buckets over contiguous arena ranges, built from the END of the arena (gradients of the last layers
-        # are produced first)
+        # buckets = disjoint contiguous arena ranges, cut walking the arena from its END (gradients of the last layers
+        # are produced first).  The walk is in arena-offset order, not parameter order: the optimizer lays packed
+        # groups (q|k|v) out of registration order, and ranges cut by parameter index could overlap there.
         esize = flat_grad.element_size()
-        self.buckets = []  # dict(lo, hi, nparams)
+        self.buckets = []  # dict(lo, hi, n)
         self.bucket_of = {}
         cur = None
-        for idx in range(len(self.params) - 1, -1, -1):
-            p, o = self.params[idx], offsets[idx]
+        top = flat_grad.numel()
+        for idx in sorted(range(len(self.params)), key=lambda i: -offsets[i]):
+            o = offsets[idx]
             if cur is None:
-                cur = {"lo": o, "hi": o + p.numel(), "n": 0}
-            cur["lo"] = min(cur["lo"], o)
+                cur = {"lo": o, "hi": top, "n": 0}
+            cur["lo"] = o
             cur["n"] += 1
             self.bucket_of[idx] = len(self.buckets)
             if (cur["hi"] - cur["lo"]) * esize >= bucket_bytes:
                 self.buckets.append(cur)
+                top = cur["lo"]
                 cur = None
         if cur is not None:
+            cur["lo"] = 0
             self.buckets.append(cur)
+        elif self.buckets:
+            self.buckets[-1]["lo"] = 0
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._seen = [False] * len(self.params)
