@@ -101,9 +101,10 @@ def test_dp_world2_sink_gradients_sum_over_ranks():
         p.join(timeout=60)
     for rank, err, early, nb, nz, tb in res:
         assert tb is None, tb
-        # bf16 gradients: the synced and the local backward are the same kernels on the same data, only the float
-        # atomics' order differs
-        assert err < 5e-3, (rank, err)
+        # bf16 arena: the reduced sum is rounded to bf16 (2^-9 relative) and the two backward passes differ by the order
+        # of their float atomics; measured 3.3e-3 of the largest gradient.  A bucket reduced twice or too early shows
+        # up as >= 5e-2.
+        assert err < 1e-2, (rank, err)
         assert nz > 0.5, "gradient arena mostly empty"
         assert early >= nb // 2, f"only {early} of {nb} buckets were launched during backward"
         print(f"rank {rank}: {early}/{nb} buckets in flight at the end of backward, rel err {err:.2e}")
