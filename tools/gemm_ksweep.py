@@ -28,3 +28,12 @@ for K in (64, 256, 768, 1536, 3072, 6144):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     print("M=%d N=%d K=%5d  %8.3f ms  %7.1f TF/s" % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9), flush=True)
+    if os.environ.get("PROBE_STAMPS"):  # PP_PROBE bit 6: phase stamps of one steady K step, waves 0 (group 0) and 4 (group 1)
+        st = y.view(torch.int64).flatten()[2048:2048 + 32].view(2, 16).cpu()
+        base = int(st.min())
+        for g in range(2):
+            print("      group %d: " % g + "  ".join("P%d[%s]" % (q + 1, " ".join("%5d" % (int(st[g, 4 * q + i]) - base) for i in range(4))) for q in range(4)))
+    if os.environ.get("PROBE_CLOCK"):  # probe build with PP_PROBE bit 4: per-CU (cycles, 100-MHz ticks) for kernel / K loops
+        c = y.view(torch.int64).flatten()[:1024].view(256, 4).double().cpu()
+        print("      shader clock: whole kernel %.0f MHz, inside K loops %.0f MHz; K loops are %.0f %% of the kernel; kernel %.1f us"
+              % ((c[:, 0] / c[:, 1]).mean() * 100, (c[:, 2] / c[:, 3]).mean() * 100, (c[:, 3] / c[:, 1]).mean() * 100, c[:, 1].mean() / 100))

@@ -1,0 +1,22 @@
+"""Timing probes of the ping-pong GEMM: rebuild libwavlm_hip with gemm_pp.hip compiled under -DPP_PROBE=<bits> into
+unispeech_amd/lib/libwavlm_hip_probe<bits>.so (bit 0: no LDS fragment reads, bit 1: no operand DMA, bit 2: one MFMA
+pair per section instead of four).  Results of probe builds are WRONG by construction; they only answer "what does
+the K loop cost without X".  Use: WAVLM_HIP_LIB=.../libwavlm_hip_probe3.so python tools/gemm_ksweep.py 3 2048"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from unispeech_amd import build as B  # noqa: E402
+
+B.build_library(verbose=False)
+# arguments: <bits> (PP_PROBE value) or <tag>:-DNAME=V[,-DNAME2=V2] (free-form defines, library suffix <tag>)
+for a in sys.argv[1:] or ["1", "2", "3", "4"]:
+    tag, defs = (a, ["-DPP_PROBE=%d" % int(a)]) if a.isdigit() else (a.split(":")[0], a.split(":")[1].split(","))
+    obj = os.path.join(B.OBJ_DIR, "gemm_pp_probe%s.o" % tag)
+    subprocess.check_call([B._hipcc()] + B.FLAGS + defs + ["-c", os.path.join(B.CSRC, "gemm_pp.hip"), "-o", obj])
+    objs = [os.path.join(B.OBJ_DIR, s.replace(".hip", ".o")) for s in B.SOURCES if s != "gemm_pp.hip"] + [obj]
+    out = os.path.join(B.LIB_DIR, "libwavlm_hip_probe%s.so" % tag)
+    subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", out] + objs)
+    print("built", out)

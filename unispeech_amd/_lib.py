@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwavlm_hip.so")
+LIB_PATH = os.environ.get("WAVLM_HIP_LIB") or os.path.join(_HERE, "lib", "libwavlm_hip.so")
 
 _lib = None
 

@@ -16,15 +16,16 @@
 //     four phases, one 64 x 32 accumulator quadrant each (8 MFMA 32x32x16):
 //         P1 reads A-top + B-left, P2 reads B-right, P3 reads A-bottom, P4 reads nothing
 //     so a half-tile buffer is free again after its single read phase and is refilled 5 phases before its next
-//     use; every phase issues one half-tile of DMA (2 instructions per lane).  s_waitcnt vmcnt is counted (4 = two
-//     half-tiles stay in flight) and happens once per K step, in P4.
+//     use; every phase issues one half-tile of DMA (2 instructions per lane).  s_waitcnt vmcnt is counted (8 = four
+//     half-tiles stay in flight) and sits one phase before the first read of the half-tile it covers (P4: A-top /
+//     B-left of t+1, P1: B-right, P2: A-bottom), so every request has a full K step to land.
 //   * Waves 0-3 (rows 0-127) and waves 4-7 (rows 128-255) run the same phase sequence one barrier apart: while one
 //     group issues its ds_reads / DMA, the other owns the MFMA pipe (s_setprio 1).  Each SIMD hosts one wave of
 //     each group, so its MFMA pipe always has a wave in an MFMA section.
 //
 // Hazards (LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier):
-//   RAW  the P4 wait retires every half-tile of step t+1; group 0 waits before barrier b, group 1 before b+1, the
-//        first read of step t+1 (group 0, P1) follows barrier b+1.
+//   RAW  a wait in phase q covers what phase q+1 reads; group 0 waits before barrier b, group 1 before b+1, the
+//        read (group 0, phase q+1) follows barrier b+1.
 //   WAR  buffer X is read in phase q by group 0 (interval J) and group 1 (J+1, complete before barrier J+2 via the
 //        lgkmcnt(0) that precedes its MFMA section); it is refilled from phase q+2 (group 0: interval J+4).
 // K tails and M/N edges stay on the DMA path: rows past the edge are clamped (they feed outputs never stored), K
@@ -33,6 +34,15 @@
 
 #include "tile_loaders.hpp"
 
+#ifndef PP_PROBE
+// 0 in the product build.  Timing probes (tools/probe/build_probe.py; results are wrong by construction): bit 0 drops the
+// LDS fragment reads, bit 1 the DMA, bit 2 three quarters of the MFMAs, bit 3 makes the DMA source hot and contiguous,
+// bit 4 reports clocks into C, bit 5 drops the steady-state DMA waits, bit 6 stamps the phases of one K step.
+#define PP_PROBE 0
+#endif
+#ifndef PP_DMA_IN_SECTION
+#define PP_DMA_IN_SECTION 1  // 1: steady-state DMA is issued between the MFMAs of the issuing wave's own section
+#endif
 #define PP_HB 16384     // bytes per half-tile buffer
 #define PP_STAGE 65536  // bytes per stage: [A-top][A-bot][B-left][B-right]
 
@@ -57,6 +67,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     // de-phase the CUs: without it every CU reaches its HBM-bound epilogue at the same time in every round
     for (int i = (int)(blockIdx.x & 3) * p.skew; i > 0; --i) __builtin_amdgcn_s_sleep(127);
   }
+#if PP_PROBE & 16
+  const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = wall_clock64();
+  unsigned long long pck = 0, prk = 0;
+#endif
   for (int vid = blockIdx.x; vid < p.vtotal; vid += gridDim.x) {
   int tm, tn, z, split;
   if (p.patch_m == 0) {
@@ -145,18 +159,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
   }
   // issue half-tile `which` (0 A-top, 1 A-bot, 2 B-left, 3 B-right) of the stream's current K tile into `stage`,
   // then advance the stream by one K tile
-  auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) {
+  auto issue_gen = [&](auto which_c, int stage) __attribute__((always_inline)) {
     constexpr int W = decltype(which_c)::value;
     constexpr int OP = W >> 1;
     PPCursor& c = cur[W];
     const char* src = (OP ? Bb : Ab) + c.off * 2;
     const int kv = (c.kt == kt_per - 1) ? kv_last : 64;
     unsigned char* dst = smem + stage * PP_STAGE + W * PP_HB + wave * 2048;
+#if PP_PROBE & 2
+    if (false) {
+#else
     if (kv >= 64) {
+#endif
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         __builtin_amdgcn_global_load_lds((gas_ptr)(src + voff[W][j]), (las_ptr)(dst + j * 1024), 16, 0, 0);
-    } else {
+    } else if (!(PP_PROBE & 2)) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const char* s = (kidx[OP][j] < kv) ? src + voff[W][j] : (const char*)g_pp_zero;
@@ -165,6 +183,36 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     }
     c.off += OP ? stepB : stepA;
     if (++c.kt == kt_per) { c.kt = 0; c.off += OP ? jumpB : jumpA; }
+  };
+  // Steady-state form: the tile is full and not the last of its K batch -- no tail select, no cursor wrap.  The phase in
+  // which a wave issues DMA is also the phase it must finish inside the other group's 8-MFMA window (256 cycles at one
+  // instruction per 4 cycles per wave), so the ~40 scalar / branch instructions of the general form per half-tile are
+  // what the K loop cannot afford; this form is 2 x (address add + DMA) + 4 scalar.
+  auto issue_fast = [&](auto which_c, int stage) __attribute__((always_inline)) {
+    constexpr int W = decltype(which_c)::value;
+    constexpr int OP = W >> 1;
+    PPCursor& c = cur[W];
+    const char* src = (OP ? Bb : Ab) + c.off * 2;
+    unsigned char* dst = smem + stage * PP_STAGE + W * PP_HB + wave * 2048;
+#if PP_PROBE & 8
+    src = Ab + W * 16384 + wave * 2048 - voff[W][0] + lane * 16;  // hot, contiguous window (j = 1 lands wherever)
+#endif
+#if !(PP_PROBE & 2)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gas_ptr)(src + voff[W][j]), (las_ptr)(dst + j * 1024), 16, 0, 0);
+#endif
+    c.off += OP ? stepB : stepA;
+    ++c.kt;
+  };
+  auto issue_one = [&](auto which_c, int stage, int j) __attribute__((always_inline)) {  // instruction j of issue_fast
+    constexpr int W = decltype(which_c)::value;
+    constexpr int OP = W >> 1;
+    PPCursor& c = cur[W];
+    const char* src = (OP ? Bb : Ab) + c.off * 2;
+    unsigned char* dst = smem + stage * PP_STAGE + W * PP_HB + wave * 2048;
+    __builtin_amdgcn_global_load_lds((gas_ptr)(src + voff[W][j]), (las_ptr)(dst + j * 1024), 16, 0, 0);
+    if (j == 1) { c.off += OP ? stepB : stepA; ++c.kt; }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -191,6 +239,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     tr_b = kpart + (unsigned)(((wn * 2 + g1) ^ (2 * (i >> 2))) << 5);
   }
   auto rd_a = [&](int base, int f, int s) __attribute__((always_inline)) -> bf16x8_t {  // base: byte offset of the half-tile buffer
+#if PP_PROBE & 1
+    bf16x8_t z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)(float)(base + f + s); return z;
+#endif
     if constexpr (!TA) {
       return *reinterpret_cast<const bf16x8_t*>(smem + base + f * 4096 + kc_a[s]);
     } else {
@@ -200,6 +251,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     }
   };
   auto rd_b = [&](int base, int s) __attribute__((always_inline)) -> bf16x8_t {
+#if PP_PROBE & 1
+    bf16x8_t z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)(float)(base + s); return z;
+#endif
     if constexpr (!TB) {
       return *reinterpret_cast<const bf16x8_t*>(smem + base + kc_b[s]);
     } else {
@@ -219,25 +273,72 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 
   bf16x8_t at[2][4], ab[2][4], bl[4], br[4];
 
-#define PP_MFMA_SECTION(FA, I0_, BF, J_)                                                            \
+#if PP_PROBE & 32
+#define PP_VMWAIT(N) if (!SD) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#else
+#define PP_VMWAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#endif
+#if PP_PROBE & 64  // s_memtime stamps of the last steady stage-0 K step (block 0, waves 0 and 4)
+  unsigned long long ts[16];
+#define PP_STAMP(K_) if constexpr (SD && ST == 0) asm volatile("s_memtime %0" : "=s"(ts[K_]))
+#else
+#define PP_STAMP(K_)
+#endif
+#define PP_MFMA_SECTION(FA, I0_, BF, J_) PP_MFMA_SECTION_H(FA, I0_, BF, J_, (void)0, (void)0)
+#define PP_MFMA_SECTION_H(FA, I0_, BF, J_, H0_, H1_)                                                \
   __builtin_amdgcn_sched_barrier(0);                                                                \
+  PP_STAMP(4 * (I0_ + (I0_ ? 1 - J_ : J_)) + 0);                                                     \
   __builtin_amdgcn_s_barrier();                                                                     \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+  PP_STAMP(4 * (I0_ + (I0_ ? 1 - J_ : J_)) + 1);                                                     \
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_setprio(1);                                                                    \
-  _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
+  _Pragma("unroll") for (int s = 0; s < ((PP_PROBE & 4) ? 1 : 4); ++s) {                            \
     acc[I0_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][s], BF[s], acc[I0_][J_], 0, 0, 0);  \
     acc[I0_ + 1][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][s], BF[s], acc[I0_ + 1][J_], 0, 0, 0); \
+    if (s == 0) { H0_; }                                                                            \
+    if (s == 2) { H1_; }                                                                            \
   }                                                                                                 \
+  PP_STAMP(4 * (I0_ + (I0_ ? 1 - J_ : J_)) + 2);                                                     \
   __builtin_amdgcn_s_setprio(0);                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_barrier();                                                                     \
+  PP_STAMP(4 * (I0_ + (I0_ ? 1 - J_ : J_)) + 3);                                                     \
   __builtin_amdgcn_sched_barrier(0);
 
-  auto k_step = [&](auto stage_c, int t) __attribute__((always_inline)) {
+  auto k_step = [&](auto stage_c, auto steady_c, int t) __attribute__((always_inline)) {
     constexpr int ST = decltype(stage_c)::value;
     constexpr int SB = ST * PP_STAGE;
-    const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+    constexpr bool SD = decltype(steady_c)::value;  // steady: tiles t+1 and t+2 exist, are full, and share the K batch
+    const bool more1 = SD || t + 1 < nt, more2 = SD || t + 2 < nt;
+    auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) {
+      if constexpr (SD) issue_fast(which_c, stage); else issue_gen(which_c, stage);
+    };
+    if constexpr (SD && PP_DMA_IN_SECTION) {
+      // same phases; the half-tile of a phase is issued by each wave inside its own MFMA section (after MFMA pairs 1 and
+      // 3), so the read interval is ds_reads only and a full vector-memory queue stalls behind running MFMAs.  The
+      // waits come before the phase's own issue: three younger half-tiles (6) instead of four.
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bl[s] = rd_b(SB + 2 * PP_HB, s);
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) at[f][s] = rd_a(SB, f, s);
+      PP_VMWAIT(6);
+      PP_MFMA_SECTION_H(at, 0, bl, 0, issue_one(I3{}, ST ^ 1, 0), issue_one(I3{}, ST ^ 1, 1))
+#pragma unroll
+      for (int s = 0; s < 4; ++s) br[s] = rd_b(SB + 3 * PP_HB, s);
+      PP_VMWAIT(6);
+      PP_MFMA_SECTION_H(at, 0, br, 1, issue_one(I1{}, ST ^ 1, 0), issue_one(I1{}, ST ^ 1, 1))
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ab[f][s] = rd_a(SB + PP_HB, f, s);
+      PP_MFMA_SECTION_H(ab, 2, br, 1, issue_one(I0{}, ST, 0), issue_one(I0{}, ST, 1))
+      PP_VMWAIT(6);
+      PP_MFMA_SECTION_H(ab, 2, bl, 0, issue_one(I2{}, ST, 0), issue_one(I2{}, ST, 1))
+      return;
+    }
     // ---- P1: A-top, B-left -> quadrant (0,0)
 #pragma unroll
     for (int s = 0; s < 4; ++s) bl[s] = rd_b(SB + 2 * PP_HB, s);
@@ -245,47 +346,74 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int s = 0; s < 4; ++s) at[f][s] = rd_a(SB, f, s);
-    if (more1) issue(I3{}, ST ^ 1);
+    if (more1) {
+      issue(I3{}, ST ^ 1);
+      PP_VMWAIT(8);  // B-right(t) landed; younger: A-bot(t), A-top/B-left/B-right(t+1)
+    } else {
+      PP_VMWAIT(2);  // younger: A-bot(t)
+    }
     PP_MFMA_SECTION(at, 0, bl, 0)
     // ---- P2: B-right -> quadrant (0,1)
 #pragma unroll
     for (int s = 0; s < 4; ++s) br[s] = rd_b(SB + 3 * PP_HB, s);
-    if (more1) issue(I1{}, ST ^ 1);
+    if (more1) {
+      issue(I1{}, ST ^ 1);
+      PP_VMWAIT(8);  // A-bot(t) landed; younger: the four half-tiles of t+1
+    } else {
+      PP_VMWAIT(0);
+    }
     PP_MFMA_SECTION(at, 0, br, 1)
-    // ---- P3: A-bottom -> quadrant (1,1)
+    // ---- P3: A-bottom -> quadrant (1,1); P4 reads nothing, so nothing to wait for
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int s = 0; s < 4; ++s) ab[f][s] = rd_a(SB + PP_HB, f, s);
     if (more2) issue(I0{}, ST);
     PP_MFMA_SECTION(ab, 2, br, 1)
-    // ---- P4: quadrant (1,0); retire every half-tile of step t+1
+    // ---- P4: quadrant (1,0); A-top / B-left of step t+1 must have landed before P1(t+1)
     if (more2) {
       issue(I2{}, ST);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_VMWAIT(8);  // younger: B-right/A-bot(t+1), A-top/B-left(t+2)
+    } else if (more1) {
+      PP_VMWAIT(4);  // younger: B-right/A-bot(t+1)
     }
     PP_MFMA_SECTION(ab, 2, bl, 0)
   };
 
+#if PP_PROBE & 16
+  const unsigned long long kc0 = __builtin_readcyclecounter(), kr0 = wall_clock64();
+#endif
   if (nt > 0) {
-    issue(I0{}, 0); issue(I2{}, 0); issue(I3{}, 0); issue(I1{}, 0);
+    issue_gen(I0{}, 0); issue_gen(I2{}, 0); issue_gen(I3{}, 0); issue_gen(I1{}, 0);
     if (nt > 1) {
-      issue(I0{}, 1); issue(I2{}, 1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      issue_gen(I0{}, 1); issue_gen(I2{}, 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A-top(0), B-left(0) landed
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
-    for (int t = 0; t < nt; t += 2) {
-      k_step(I0{}, t);
-      if (t + 1 < nt) k_step(I1{}, t + 1);
+    // steady steps: everything prefetched (up to tile t+2) is a full tile of the same K batch
+    const int has_tail = (kv_last < 64 && t1 == p.KB * kt_per) ? 1 : 0;
+    const int n_steady = (p.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
+    int t = 0;
+    for (; t < n_steady; t += 2) {
+      k_step(I0{}, std::true_type{}, t);
+      k_step(I1{}, std::true_type{}, t + 1);
+    }
+    for (; t < nt; t += 2) {
+      k_step(I0{}, std::false_type{}, t);
+      if (t + 1 < nt) k_step(I1{}, std::false_type{}, t + 1);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
   }
 #undef PP_MFMA_SECTION
+#undef PP_MFMA_SECTION_H
+#undef PP_VMWAIT
+#undef PP_STAMP
+#if PP_PROBE & 16
+  pck += __builtin_readcyclecounter() - kc0; prk += wall_clock64() - kr0;
+#endif
   __syncthreads();
 
   // ---- epilogue (same as the 128-wide kernel: per-wave LDS staging -> 16-byte row vectors) -------------------------
@@ -340,7 +468,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     }
   }
   __syncthreads();  // every wave has read its staging slice before the next tile's DMA lands in it
+#if PP_PROBE & 64
+  if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned long long* o = (unsigned long long*)p.C + 2048 + (threadIdx.x >> 8) * 16;
+    for (int i = 0; i < 16; ++i) o[i] = ts[i];
   }
+#endif
+  }
+#if PP_PROBE & 16
+  if (threadIdx.x == 0) {
+    unsigned long long* o = (unsigned long long*)p.C + blockIdx.x * 4;
+    o[0] = __builtin_readcyclecounter() - pc0; o[1] = wall_clock64() - pr0; o[2] = pck; o[3] = prk;
+  }
+#endif
 }
 
 int g_pp_mode = 1;  // 0: one block per tile, 1: persistent (256 blocks), 2: persistent with start skew

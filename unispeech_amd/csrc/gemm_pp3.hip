@@ -12,9 +12,9 @@
 //     q = 0, 3 read B (k half) + A_0;   q = 1, 4 read A_1;   q = 2, 5 read A_2
 // A unit is free after its second read (B and A_0 after q = 3, A_1 after 4, A_2 after 5) and may be refilled two
 // phases later (WAR with the two wave groups one barrier apart, see gemm_pp.hip).  DMA pieces per wave (1 KiB each):
-//     q=0: B pieces 2,3 (t+1)   q=1: B pieces 4,5 (t+1)   q=2: A_0, A_1 (t+1)   q=3: A_2 (t+1)   q=4: -
-//     q=5: B pieces 0,1 (t+2), then s_waitcnt vmcnt(2): everything of step t+1 has landed (RAW: first read of step
-//     t+1 follows the barrier after both groups' waits).
+//     q=0: B pieces 2,3 (t+1)   q=1: B pieces 4,5 + A_0 (t+1)   q=2: A_1, A_2 (t+1)   q=3, 4: -   q=5: B pieces 0,1 (t+2)
+// s_waitcnt vmcnt is counted and placed one phase before the FIRST read of a unit (q=5: B + A_0 of t+1, q=0: A_1,
+// q=1: A_2), so every request has >= 4 phases to land (RAW: the read follows the barrier after both groups' waits).
 // K-strided operands: A units are [64 k][64 rows] (128-B k rows, 32-B granule ^ 2*((k>>1)&1)), B is
 // [64 k][384 rows] (768-B k rows, granule ^ 2*(k&3) inside aligned groups of 8), both read with ds_read_b64_tr_b16.
 #include "gemm_common.hpp"
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
     if (!TB) { const int R = pi * 8 + (lane >> 3); return ((lane & 7) ^ ((R >> 1) & 7)) * 8; }
     return (pi * 1024 + lane * 16) / 768;
   };
-  auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) {
+  auto issue_gen = [&](auto which_c, int stage) __attribute__((always_inline)) {
     constexpr int W = decltype(which_c)::value;
     P3Cursor& c = cur[W];
     const int kv = (c.kt == kt_per - 1) ? kv_last : 64;
@@ -147,6 +147,22 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
       }
       c.off += stepB;
       if (++c.kt == kt_per) { c.kt = 0; c.off += jumpB; }
+    }
+  };
+  // Steady-state form (gemm_pp.hip): full tile inside one K batch, one instruction per call so that it can be placed
+  // between the MFMAs of the issuing wave's own section.
+  auto issue_one = [&](auto which_c, int stage, int j) __attribute__((always_inline)) {
+    constexpr int W = decltype(which_c)::value;
+    P3Cursor& c = cur[W];
+    if constexpr (W < 3) {
+      __builtin_amdgcn_global_load_lds((gas_ptr)(Ab + c.off * 2 + voffA[W]), (las_ptr)(smem + stage * P3_STAGE + W * P3_AU + wave * 1024), 16, 0, 0);
+      c.off += stepA;
+      ++c.kt;
+    } else {
+      constexpr int J0 = 2 * (W - 3);
+      __builtin_amdgcn_global_load_lds((gas_ptr)(Bb + c.off * 2 + voffB[J0 + j]),
+                                       (las_ptr)(smem + stage * P3_STAGE + 3 * P3_AU + (wave * 6 + J0 + j) * 1024), 16, 0, 0);
+      if (j == 1) { c.off += stepB; ++c.kt; }
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -203,7 +219,8 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
 
   bf16x8_t bf[3][2], af[2];
 
-#define P3_MFMA_SECTION(I_)                                                                          \
+#define P3_MFMA_SECTION(I_) P3_MFMA_SECTION_H(I_, (void)0, (void)0, (void)0)
+#define P3_MFMA_SECTION_H(I_, H0_, H1_, H2_)                                                          \
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_barrier();                                                                     \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
@@ -211,16 +228,60 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
   __builtin_amdgcn_s_setprio(1);                                                                    \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
     _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                   \
+    {                                                                                               \
       acc[I_][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bf[j][s], acc[I_][j], 0, 0, 0);    \
+      if (s == 0 && j == 1) { H0_; }                                                                \
+      if (s == 1 && j == 0) { H1_; }                                                                \
+      if (s == 1 && j == 1) { H2_; }                                                                \
+    }                                                                                               \
   }                                                                                                 \
   __builtin_amdgcn_s_setprio(0);                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_barrier();                                                                     \
   __builtin_amdgcn_sched_barrier(0);
 
-  auto k_step = [&](auto stage_c, int t) __attribute__((always_inline)) {
+  auto k_step = [&](auto stage_c, auto steady_c, int t) __attribute__((always_inline)) {
     constexpr int ST = decltype(stage_c)::value;
     constexpr int SB = ST * P3_STAGE;
+    constexpr bool SD = decltype(steady_c)::value;  // steady: tiles t+1, t+2 exist, are full, and share the K batch
+    auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) { issue_gen(which_c, stage); };
+    if constexpr (SD) {
+      // same units and order as below, each DMA instruction issued inside the wave's own MFMA section; the waits precede
+      // the phase's own issue (q=0: A_1(t), younger A_2(t) + B 0-1 (t+1) = 3; q=1: A_2(t), younger B 0-3 = 4;
+      // q=5: B + A_0 of t+1, younger A_1, A_2 (t+1) = 2)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) bf[j][s] = rd_b(SB + 3 * P3_AU, j, 2 * kh + s);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) af[s] = rd_a(SB, 2 * kh + s);
+        if (kh == 0) {
+          asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+          P3_MFMA_SECTION_H(0, issue_one(I4{}, ST ^ 1, 0), issue_one(I4{}, ST ^ 1, 1), (void)0)
+        } else {
+          P3_MFMA_SECTION(0)
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) af[s] = rd_a(SB + P3_AU, 2 * kh + s);
+        if (kh == 0) {
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          P3_MFMA_SECTION_H(1, issue_one(I5{}, ST ^ 1, 0), issue_one(I5{}, ST ^ 1, 1), issue_one(I0{}, ST ^ 1, 0))
+        } else {
+          P3_MFMA_SECTION(1)
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) af[s] = rd_a(SB + 2 * P3_AU, 2 * kh + s);
+        if (kh == 0) {
+          P3_MFMA_SECTION_H(2, issue_one(I1{}, ST ^ 1, 0), issue_one(I2{}, ST ^ 1, 0), (void)0)
+        } else {
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          P3_MFMA_SECTION_H(2, issue_one(I3{}, ST, 0), issue_one(I3{}, ST, 1), (void)0)
+        }
+      }
+      return;
+    }
     const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
@@ -231,24 +292,39 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
         for (int s = 0; s < 2; ++s) bf[j][s] = rd_b(SB + 3 * P3_AU, j, 2 * kh + s);
 #pragma unroll
       for (int s = 0; s < 2; ++s) af[s] = rd_a(SB, 2 * kh + s);
-      if (more1) { if (kh == 0) issue(I4{}, ST ^ 1); else issue(I2{}, ST ^ 1); }
+      if (kh == 0) {  // wait: A_1(t) landed; younger: A_2(t) [, B 0-3 of t+1]
+        if (more1) {
+          issue(I4{}, ST ^ 1);
+          asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        }
+      }
       P3_MFMA_SECTION(0)
       // ---- q = 3 kh + 1: A_1
 #pragma unroll
       for (int s = 0; s < 2; ++s) af[s] = rd_a(SB + P3_AU, 2 * kh + s);
-      if (more1 && kh == 0) issue(I5{}, ST ^ 1);
+      if (kh == 0) {  // wait: A_2(t) landed; younger: B (6 pieces) and A_0 of t+1
+        if (more1) {
+          issue(I5{}, ST ^ 1);
+          issue(I0{}, ST ^ 1);
+          asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
       P3_MFMA_SECTION(1)
       // ---- q = 3 kh + 2: A_2
 #pragma unroll
       for (int s = 0; s < 2; ++s) af[s] = rd_a(SB + 2 * P3_AU, 2 * kh + s);
       if (kh == 0) {
-        if (more1) { issue(I0{}, ST ^ 1); issue(I1{}, ST ^ 1); }
-      } else {
+        if (more1) { issue(I1{}, ST ^ 1); issue(I2{}, ST ^ 1); }
+      } else {  // wait: B and A_0 of t+1 landed (read by q = 0 of step t+1); younger: A_1, A_2 (t+1) [, B 0-1 of t+2]
         if (more2) {
           issue(I3{}, ST);
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if (more1) {
           asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
       P3_MFMA_SECTION(2)
@@ -256,22 +332,30 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
   };
 
   if (nt > 0) {
-    issue(I3{}, 0); issue(I4{}, 0); issue(I5{}, 0); issue(I0{}, 0); issue(I1{}, 0); issue(I2{}, 0);
+    issue_gen(I3{}, 0); issue_gen(I4{}, 0); issue_gen(I5{}, 0); issue_gen(I0{}, 0); issue_gen(I1{}, 0); issue_gen(I2{}, 0);
     if (nt > 1) {
-      issue(I3{}, 1);
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      issue_gen(I3{}, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // B(0), A_0(0) landed; younger: A_1, A_2 (0), B 0-1 (1)
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
-    for (int t = 0; t < nt; t += 2) {
-      k_step(I0{}, t);
-      if (t + 1 < nt) k_step(I1{}, t + 1);
+    const int has_tail = (kv_last < 64 && t1 == p.KB * kt_per) ? 1 : 0;
+    const int n_steady = (p.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
+    int t = 0;
+    for (; t < n_steady; t += 2) {
+      k_step(I0{}, std::true_type{}, t);
+      k_step(I1{}, std::true_type{}, t + 1);
+    }
+    for (; t < nt; t += 2) {
+      k_step(I0{}, std::false_type{}, t);
+      if (t + 1 < nt) k_step(I1{}, std::false_type{}, t + 1);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
   }
 #undef P3_MFMA_SECTION
+#undef P3_MFMA_SECTION_H
   __syncthreads();
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------
