@@ -20,8 +20,16 @@
 //     half-tiles stay in flight) and sits one phase before the first read of the half-tile it covers (P4: A-top /
 //     B-left of t+1, P1: B-right, P2: A-bottom), so every request has a full K step to land.
 //   * Waves 0-3 (rows 0-127) and waves 4-7 (rows 128-255) run the same phase sequence one barrier apart: while one
-//     group issues its ds_reads / DMA, the other owns the MFMA pipe (s_setprio 1).  Each SIMD hosts one wave of
-//     each group, so its MFMA pipe always has a wave in an MFMA section.
+//     group issues its ds_reads, the other owns the MFMA pipe (s_setprio 1).  Each SIMD hosts one wave of each
+//     group, so its MFMA pipe always has a wave in an MFMA section.
+//   * Steady state (all K steps but the last two, no K tail in flight): the two DMA instructions of a phase are
+//     issued by each wave INSIDE its own MFMA section (after MFMA pairs 1 and 3) and carry no tail select.  Measured
+//     with the probe builds (tools/probe): the K step costs 2160 cycles without DMA and cost 2900-3500 with the DMA
+//     in the read interval -- the vector-memory path is ~55 % busy (64 KiB per K step against 64 B/clk), so a wave
+//     that issues DMA behind its ds_reads blocks on a full queue for longer than the other group's MFMA window,
+//     and every barrier interval then takes max(read wave, MFMA wave).  In-section issue: ~2500 cycles, at which
+//     point the kernel is power-limited (shader clock 1.5-1.7 GHz under load; register-only MFMA peaks at 1.95
+//     PFLOP/s with random operands, 2.45 with zeros).
 //
 // Hazards (LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier):
 //   RAW  a wait in phase q covers what phase q+1 reads; group 0 waits before barrier b, group 1 before b+1, the
@@ -39,9 +47,6 @@
 // LDS fragment reads, bit 1 the DMA, bit 2 three quarters of the MFMAs, bit 3 makes the DMA source hot and contiguous,
 // bit 4 reports clocks into C, bit 5 drops the steady-state DMA waits, bit 6 stamps the phases of one K step.
 #define PP_PROBE 0
-#endif
-#ifndef PP_DMA_IN_SECTION
-#define PP_DMA_IN_SECTION 1  // 1: steady-state DMA is issued between the MFMAs of the issuing wave's own section
 #endif
 #define PP_HB 16384     // bytes per half-tile buffer
 #define PP_STAGE 65536  // bytes per stage: [A-top][A-bot][B-left][B-right]
@@ -184,35 +189,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     c.off += OP ? stepB : stepA;
     if (++c.kt == kt_per) { c.kt = 0; c.off += OP ? jumpB : jumpA; }
   };
-  // Steady-state form: the tile is full and not the last of its K batch -- no tail select, no cursor wrap.  The phase in
-  // which a wave issues DMA is also the phase it must finish inside the other group's 8-MFMA window (256 cycles at one
-  // instruction per 4 cycles per wave), so the ~40 scalar / branch instructions of the general form per half-tile are
-  // what the K loop cannot afford; this form is 2 x (address add + DMA) + 4 scalar.
-  auto issue_fast = [&](auto which_c, int stage) __attribute__((always_inline)) {
+  // Steady-state form: one DMA instruction of a full tile (no K-tail select).  In the general form the ~40 scalar /
+  // branch instructions per half-tile run in the phase in which the wave must finish inside the other group's 8-MFMA
+  // window (256 cycles at one instruction per 4 cycles per wave) -- the K loop cannot afford them; here the
+  // instruction and its scalar cursor work sit between the wave's own MFMAs.
+  auto issue_one = [&](auto which_c, int stage, int j) __attribute__((always_inline)) {
     constexpr int W = decltype(which_c)::value;
     constexpr int OP = W >> 1;
     PPCursor& c = cur[W];
     const char* src = (OP ? Bb : Ab) + c.off * 2;
     unsigned char* dst = smem + stage * PP_STAGE + W * PP_HB + wave * 2048;
 #if PP_PROBE & 8
-    src = Ab + W * 16384 + wave * 2048 - voff[W][0] + lane * 16;  // hot, contiguous window (j = 1 lands wherever)
+    src = Ab + W * 16384 + wave * 2048 + j * 1024 - voff[W][j] + lane * 16;  // hot, contiguous window
 #endif
 #if !(PP_PROBE & 2)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gas_ptr)(src + voff[W][j]), (las_ptr)(dst + j * 1024), 16, 0, 0);
-#endif
-    c.off += OP ? stepB : stepA;
-    ++c.kt;
-  };
-  auto issue_one = [&](auto which_c, int stage, int j) __attribute__((always_inline)) {  // instruction j of issue_fast
-    constexpr int W = decltype(which_c)::value;
-    constexpr int OP = W >> 1;
-    PPCursor& c = cur[W];
-    const char* src = (OP ? Bb : Ab) + c.off * 2;
-    unsigned char* dst = smem + stage * PP_STAGE + W * PP_HB + wave * 2048;
     __builtin_amdgcn_global_load_lds((gas_ptr)(src + voff[W][j]), (las_ptr)(dst + j * 1024), 16, 0, 0);
-    if (j == 1) { c.off += OP ? stepB : stepA; ++c.kt; }
+#endif
+    if (j == 1) {  // scalar cursor work hides behind the MFMAs around it
+      c.off += OP ? stepB : stepA;
+      if (++c.kt == kt_per) { c.kt = 0; c.off += OP ? jumpB : jumpA; }
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -311,10 +307,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     constexpr int SB = ST * PP_STAGE;
     constexpr bool SD = decltype(steady_c)::value;  // steady: tiles t+1 and t+2 exist, are full, and share the K batch
     const bool more1 = SD || t + 1 < nt, more2 = SD || t + 2 < nt;
-    auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) {
-      if constexpr (SD) issue_fast(which_c, stage); else issue_gen(which_c, stage);
-    };
-    if constexpr (SD && PP_DMA_IN_SECTION) {
+    auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) { issue_gen(which_c, stage); };
+    if constexpr (SD) {
       // same phases; the half-tile of a phase is issued by each wave inside its own MFMA section (after MFMA pairs 1 and
       // 3), so the read interval is ds_reads only and a full vector-memory queue stalls behind running MFMAs.  The
       // waits come before the phase's own issue: three younger half-tiles (6) instead of four.
@@ -395,7 +389,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
     // steady steps: everything prefetched (up to tile t+2) is a full tile of the same K batch
     const int has_tail = (kv_last < 64 && t1 == p.KB * kt_per) ? 1 : 0;
-    const int n_steady = (p.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
+    // (K batches without a K tail are steady too: the in-section issue carries the cursor wrap)
+    const int n_steady = (kv_last == 64 || p.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
     int t = 0;
     for (; t < n_steady; t += 2) {
       k_step(I0{}, std::true_type{}, t);

@@ -157,12 +157,15 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
     if constexpr (W < 3) {
       __builtin_amdgcn_global_load_lds((gas_ptr)(Ab + c.off * 2 + voffA[W]), (las_ptr)(smem + stage * P3_STAGE + W * P3_AU + wave * 1024), 16, 0, 0);
       c.off += stepA;
-      ++c.kt;
+      if (++c.kt == kt_per) { c.kt = 0; c.off += jumpA; }
     } else {
       constexpr int J0 = 2 * (W - 3);
       __builtin_amdgcn_global_load_lds((gas_ptr)(Bb + c.off * 2 + voffB[J0 + j]),
                                        (las_ptr)(smem + stage * P3_STAGE + 3 * P3_AU + (wave * 6 + J0 + j) * 1024), 16, 0, 0);
-      if (j == 1) { c.off += stepB; ++c.kt; }
+      if (j == 1) {
+        c.off += stepB;
+        if (++c.kt == kt_per) { c.kt = 0; c.off += jumpB; }
+      }
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -342,7 +345,8 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
     const int has_tail = (kv_last < 64 && t1 == p.KB * kt_per) ? 1 : 0;
-    const int n_steady = (p.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
+    // (K batches without a K tail are steady too: the in-section issue carries the cursor wrap)
+    const int n_steady = (kv_last == 64 || p.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
     int t = 0;
     for (; t < n_steady; t += 2) {
       k_step(I0{}, std::true_type{}, t);
