@@ -27,6 +27,17 @@ def _rup(x, m):
 SINK_LISTENERS = []  # callables(tensor): told which arena slice a backward kernel has just accumulated into (dp.GradReducer)
 
 
+def h2d(a, dev):
+    """host array / CPU tensor -> device without stalling the host: a pageable `.to(device)` synchronises the stream,
+    i.e. the host waits for every kernel enqueued so far and the GPU then idles until the host is ahead again (measured:
+    ~1 ms of launch gaps around the prediction head).  Staged through pinned memory and copied asynchronously."""
+    t = torch.from_numpy(a) if not torch.is_tensor(a) else a
+    dev = torch.device(dev)
+    if dev.type != "cuda" or t.device.type != "cpu" or t.numel() == 0:
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 _SINK_USES = {}      # arena slice (data_ptr) -> forward uses not yet matched by a backward accumulation
 
 

@@ -221,7 +221,7 @@ class WavLMPretrainModel(WavLM):
         mask_np = None
         if mask:
             mask_np = self._mask_numpy(B, T, pad_cpu, boundary if self.boundary_mask else None)
-        sel = torch.from_numpy(mask_np).to(dev).to(torch.uint8).view(-1) if mask_np is not None else None
+        sel = F.h2d(mask_np.astype(np.uint8), dev).view(-1) if mask_np is not None else None
         kpm = padding_mask.to(torch.uint8).contiguous().view(-1) if padding_mask is not None else None
         if sel is not None or kpm is not None:
             x = F.SelectRowsFn.apply(x, sel, self.mask_emb if sel is not None else None, kpm)
@@ -251,6 +251,13 @@ class WavLMPretrainModel(WavLM):
         else:
             sources = [x.reshape(B * T, -1)]
 
+        tinds = {}
+
+        def tinds_dev(d):  # label index of every kept frame, uploaded once per device
+            if d not in tinds:
+                tinds[d] = F.h2d(target_inds, d)
+            return tinds[d]
+
         def head(frame_sel_np, need_grad):
             out = []
             for x2d in sources:
@@ -262,15 +269,15 @@ class WavLMPretrainModel(WavLM):
             S = int(idx_np.size)
             inv_np = np.full(n, -1, dtype=np.int32)
             inv_np[idx_np] = np.arange(S, dtype=np.int32)
-            idx = torch.from_numpy(idx_np).to(dev)
-            inv = torch.from_numpy(inv_np).to(dev)
+            idx = F.h2d(idx_np, dev)
+            inv = F.h2d(inv_np, dev)
             rows = F.GatherRowsFn.apply(x2d, idx, inv)
             proj = F.LinearFn.apply(rows, self.final_proj.weight, self.final_proj.bias)
             projs = proj.chunk(len(target_list), dim=-1) if self.untie_final_proj else [proj] * len(target_list)
             out = []
             idx64 = idx.long()
             for i, (pj, t) in enumerate(zip(projs, target_list)):
-                tt = t[:, target_inds.to(t.device)].reshape(-1).index_select(0, idx64).to(torch.int32)
+                tt = t[:, tinds_dev(t.device)].reshape(-1).index_select(0, idx64).to(torch.int32)
                 loss, ncorrect = F.MaskedPredLossFn.apply(pj.contiguous(), label_embs_list[i], tt, self.logit_temp,
                                                           need_grad)
                 out.append({"loss": loss, "correct": ncorrect, "count": S, "proj": pj, "target": tt,
@@ -326,8 +333,7 @@ class WavLMPretrainModel(WavLM):
         assert num * B == S and num > 1
         inv_np = np.full(B * T, -1, dtype=np.int32)
         inv_np[idx_np] = np.arange(S, dtype=np.int32)
-        rows = F.GatherRowsFn.apply(spk_x.reshape(B * T, D), torch.from_numpy(idx_np).to(dev),
-                                    torch.from_numpy(inv_np).to(dev))
+        rows = F.GatherRowsFn.apply(spk_x.reshape(B * T, D), F.h2d(idx_np, dev), F.h2d(inv_np, dev))
         proj = F.LinearFn.apply(rows, self.spk_proj.weight, self.spk_proj.bias)         # [S, final_dim], row = b * num + t
         N = self.n_instances + self.cross_sample_instances
         samples_idx = self._sample_instances(B, num, num)                               # [B, N * num], CPU int64
@@ -338,7 +344,7 @@ class WavLMPretrainModel(WavLM):
         b_of = torch.arange(B).view(B, 1).expand(B, num).reshape(S, 1)
         targets = torch.cat([torch.ones(S, 1, dtype=torch.bool), torch.div(si, num, rounding_mode="floor") == b_of], dim=1)
         mean_targets = float(targets.float().mean())
-        loss, acc = F.UttContrastiveLossFn.apply(proj, idx_full.to(dev), targets.to(torch.uint8).to(dev), self.logit_temp)
+        loss, acc = F.UttContrastiveLossFn.apply(proj, F.h2d(idx_full, dev), F.h2d(targets.to(torch.uint8), dev), self.logit_temp)
         return loss, mean_targets, acc
 
     # gradient through the unmasked head is only needed when pred_nomask_weight > 0 (criterion sets this)

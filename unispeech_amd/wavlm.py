@@ -495,7 +495,7 @@ class WavLM(nn.Module):
         if mask:
             m = self.compute_mask(B, T, padding_mask)
             if m is not None:
-                sel = torch.from_numpy(m).to(x.device).to(torch.uint8).view(-1)
+                sel = F.h2d(np.asarray(m).astype(np.uint8), x.device).view(-1)
         kpm = padding_mask.to(torch.uint8).contiguous().view(-1) if padding_mask is not None else None
         if sel is not None or kpm is not None:
             x = F.SelectRowsFn.apply(x, sel, self.mask_emb if sel is not None else None, kpm)
