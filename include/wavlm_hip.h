@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 1
+#define WAVLM_HIP_ABI_VERSION 2
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -81,11 +81,14 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
                         int32_t act, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, void* stream);
 uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D);
 /* dx: gradient of x (and of the sum s); dr (optional): gradient of r (dx through the input-dropout mask);
- * dgamma/dbeta in param dtype; dy is scaled by grad_scale first (GradMultiply, WavLM/modules.py:60-69). */
+ * dgamma/dbeta in param dtype; dy is scaled by grad_scale first (GradMultiply, WavLM/modules.py:60-69).
+ * dr_colsum (optional, [D], param dtype, same accumulate flag): column sums of the gradient of r, i.e. the bias
+ * gradient of the nn.Linear whose output r is (out_proj / fc2 of a post-LN block, WavLM/WavLM.py:726-740) -- it falls
+ * out of the pass that already reduces dgamma / dbeta over rows. */
 int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd, const void* gamma,
-                        const void* beta, void* dx, void* dr, void* dgamma, void* dbeta, int64_t rows, int32_t D,
-                        int32_t dtype, int32_t param_dtype, int32_t act, float p_in, uint64_t seed_in, float p_out,
-                        uint64_t seed_out, float grad_scale, int32_t accumulate_params, void* workspace,
+                        const void* beta, void* dx, void* dr, void* dgamma, void* dbeta, void* dr_colsum, int64_t rows,
+                        int32_t D, int32_t dtype, int32_t param_dtype, int32_t act, float p_in, uint64_t seed_in,
+                        float p_out, uint64_t seed_out, float grad_scale, int32_t accumulate_params, void* workspace,
                         uint64_t ws_bytes, void* stream);
 
 /* out[c] (+)= sum over rows of x[row, c]; a row counts iff (!include || include[row]) && (!exclude || !exclude[row]).

@@ -260,6 +260,21 @@ def check_layernorm():
         out.append((f"layernorm[{dtype}] in-dropout keep fraction", abs(keep2.float().mean().item() - (1 - p)), 0.02))
         y2.backward(gen(rows, D, seed=9).to(dtype).to(DEV))
         out.append((f"layernorm[{dtype}] in-dropout grad mask", float(((r.grad != 0) != keep2).float().mean().item()), 0.01))
+        # by-product of the backward pass: column sums of dr (the bias gradient of the linear that produced r), fresh
+        # and accumulated into existing tensors, against an explicit column sum of the dr the same call returned
+        dyb = gen(rows, D, seed=19).to(dtype).to(DEV)
+        _y, sv, mean, rstd = ops.layernorm_fwd(x.detach(), r.detach(), g.detach(), b.detach(), 1e-5, act=0, p_in=p, seed_in=999,
+                                               p_out=0.0, seed_out=0, save=True)
+        for p_in in (p, 0.0):
+            dx_, dr_, _, _, cs = ops.layernorm_bwd(dyb, sv, mean, rstd, g.detach(), b.detach(), p_in=p_in, seed_in=999,
+                                                   need_dr=p_in > 0, dr_colsum=True)
+            want = (dr_ if dr_ is not None else dx_).double().sum(0)
+            out.append((f"layernorm[{dtype}] dr colsum by-product (p_in={p_in})", err(cs, want), tol * 4))
+        dg0 = gen(D, seed=21).to(dtype).to(DEV)
+        dg, db_, dc = dg0.clone(), dg0.clone(), dg0.clone()
+        dx_, dr_, _, _, _ = ops.layernorm_bwd(dyb, sv, mean, rstd, g.detach(), b.detach(), p_in=p, seed_in=999, need_dr=True,
+                                              dgamma=dg, dbeta=db_, dr_colsum=dc)
+        out.append((f"layernorm[{dtype}] dr colsum accumulated", err(dc, dg0.double() + dr_.double().sum(0)), tol * 4))
     return out
 
 

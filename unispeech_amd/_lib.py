@@ -44,7 +44,7 @@ SIGNATURES = {
     "wavlm_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_i32,
                                     c_i32, c_f32, c_u64, c_f32, c_u64, c_vp]),
     "wavlm_layernorm_bwd_workspace_bytes": (c_u64, [c_i32]),
-    "wavlm_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
+    "wavlm_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
                                     c_i32, c_i32, c_f32, c_u64, c_f32, c_u64, c_f32, c_i32, c_vp, c_u64, c_vp]),
     "wavlm_colsum_workspace_bytes": (c_u64, [c_i32]),
     "wavlm_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_u64, c_vp]),
@@ -130,7 +130,7 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if h.wavlm_abi_version() != 1:
+        if h.wavlm_abi_version() != 2:
             raise WavlmHipError("libwavlm_hip.so ABI version mismatch")
         _lib = h
     return _lib

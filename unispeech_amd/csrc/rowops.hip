@@ -143,17 +143,24 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // backward of the above.  dx -> gradient of x (and of the un-dropped residual path); dr (optional) ->
-// gradient of r (= dx with the input-dropout mask).  dgamma/dbeta partials: part[block][2][D].
-template <typename T, typename TP, int NC>
+// gradient of r (= dx with the input-dropout mask).  dgamma/dbeta partials: part[block][2 or 3][D]; with CS the third
+// array is the column sum of the gradient of r -- the bias gradient of the nn.Linear that produced r (out_proj / fc2
+// in a post-LN block), which otherwise costs a separate pass over dr.
+template <typename T, typename TP, int NC, bool CS>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
     const float* __restrict__ mean_i, const float* __restrict__ rstd_i, const TP* __restrict__ gamma,
     const TP* __restrict__ beta, T* __restrict__ dx, T* __restrict__ dr, float* __restrict__ part, long rows, int D,
     int act, unsigned th_in, float sc_in, unsigned long long seed_in, unsigned th_out, float sc_out,
     unsigned long long seed_out, float grad_scale) {
-  __shared__ float red[4][2][512];  // cross-wave reduce of one chunk slot (64 lanes x 8 columns) at a time
+  constexpr int NA = CS ? 3 : 2;
+  __shared__ float red[4][NA][512];  // cross-wave reduce of one chunk slot (64 lanes x 8 columns) at a time
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 3;
-  float ag[NC][8], ab[NC][8], gm[NC][8], bt[NC][8];
+  float ag[NC][8], ab[NC][8], gm[NC][8], bt[NC][8], ac[CS ? NC : 1][8];
+#pragma unroll
+  for (int c = 0; c < (CS ? NC : 1); ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ac[c][e] = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int ch = lane + 64 * c;
@@ -201,20 +208,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = grad_scale * rstd * (h[c][e] - s1 - xh[c][e] * s2);  // grad_scale: input gradient only, not dgamma/dbeta
         store8(dx + off, o);
-        if (dr) {
+        if (dr || CS) {
           if (th_in) ln_drop_apply(o, rw_in, cw[c], th_in, sc_in);
-          store8(dr + off, o);
+          if (dr) store8(dr + off, o);
+          if constexpr (CS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ac[c][e] += o[e];
+          }
         }
       }
     }
   }
   // cross-wave reduction of the column accumulators, one chunk-slot at a time
-  float* pg = part + (long)blockIdx.x * 2 * D;
+  float* pg = part + (long)blockIdx.x * NA * D;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { red[wave][0][lane * 8 + e] = ag[c][e]; red[wave][1][lane * 8 + e] = ab[c][e]; }
+    for (int e = 0; e < 8; ++e) {
+      red[wave][0][lane * 8 + e] = ag[c][e]; red[wave][1][lane * 8 + e] = ab[c][e];
+      if constexpr (CS) red[wave][2][lane * 8 + e] = ac[c][e];
+    }
     __syncthreads();
     // 512 columns of this slot, 256 threads -> 2 each, for both arrays
     for (int i = threadIdx.x; i < 512; i += 256) {
@@ -223,6 +237,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         const int col = ch * 8 + (i & 7);
         pg[col] = red[0][0][i] + red[1][0][i] + red[2][0][i] + red[3][0][i];
         pg[D + col] = red[0][1][i] + red[1][1][i] + red[2][1][i] + red[3][1][i];
+        if constexpr (CS) pg[2 * D + col] = red[0][2][i] + red[1][2][i] + red[2][2][i] + red[3][2][i];
       }
     }
   }
@@ -230,13 +245,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 
 // out[c] (+)= sum_b part[b * stride + c].  Block = 64 columns x 16 row slices (coalesced 256-B reads per slice, short
 // dependent-load chains), slices combined through LDS; grid = ceil(n / 64).
-// blockIdx.y selects one of two interleaved partial arrays / outputs (LayerNorm's dgamma, dbeta in one launch)
+// blockIdx.y selects one of up to three interleaved partial arrays / outputs (LayerNorm's dgamma, dbeta and the
+// residual branch's bias gradient in one launch)
 __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int nblk, long stride, int n,
-                                                              void* out, int out_dtype, int accumulate, long part_y, void* out_y) {
+                                                              void* out, int out_dtype, int accumulate, long part_y, void* out_y,
+                                                              void* out_z) {
   __shared__ float red[16][64];
   const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + col;
-  if (blockIdx.y) { part += part_y; out = out_y; }
+  if (blockIdx.y) { part += part_y * blockIdx.y; out = blockIdx.y == 1 ? out_y : out_z; }
   float s = 0.f;
   if (c < n)
     for (int b = slice; b < nblk; b += 16) s += part[(long)b * stride + c];
@@ -429,12 +446,12 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   return wl_check_launch();
 }
 
-uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D) { return (uint64_t)LN_BWD_BLOCKS * 2 * D * sizeof(float); }
+uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D) { return (uint64_t)LN_BWD_BLOCKS * 3 * D * sizeof(float); }
 
 int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd, const void* gamma,
-                        const void* beta, void* dx, void* dr, void* dgamma, void* dbeta, int64_t rows, int32_t D,
-                        int32_t dtype, int32_t param_dtype, int32_t act, float p_in, uint64_t seed_in, float p_out,
-                        uint64_t seed_out, float grad_scale, int32_t accumulate_params, void* workspace,
+                        const void* beta, void* dx, void* dr, void* dgamma, void* dbeta, void* dr_colsum, int64_t rows,
+                        int32_t D, int32_t dtype, int32_t param_dtype, int32_t act, float p_in, uint64_t seed_in,
+                        float p_out, uint64_t seed_out, float grad_scale, int32_t accumulate_params, void* workspace,
                         uint64_t ws_bytes, void* stream) {
   if (!dy || !s || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return WL_EINVAL;
   if (rows <= 0 || D <= 0 || (D & 7) || D > LN_MAXC * 512) return WL_EINVAL;
@@ -445,9 +462,10 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   const float si = drop_scale16(ti), so = drop_scale16(to);
   const unsigned grid = grid_for(rows, 4, LN_BWD_BLOCKS);
   float* part = (float*)workspace;
-#define LN_BWD_N(T, TP, NCS) WL_LAUNCH((layernorm_bwd_kernel<T, TP, NCS>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
+#define LN_BWD_C(T, TP, NCS, CSF) WL_LAUNCH((layernorm_bwd_kernel<T, TP, NCS, CSF>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
     (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, part, (long)rows, (int)D, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale)
+#define LN_BWD_N(T, TP, NCS) do { if (dr_colsum) LN_BWD_C(T, TP, NCS, true); else LN_BWD_C(T, TP, NCS, false); } while (0)
 #define LN_BWD(T, TP) do { if (D <= 512) LN_BWD_N(T, TP, 1); else if (D <= 1024) LN_BWD_N(T, TP, 2); else LN_BWD_N(T, TP, 4); } while (0)
   if (dtype == WL_F32 && param_dtype == WL_F32) LN_BWD(float, float);
   else if (dtype == WL_BF16 && param_dtype == WL_BF16) LN_BWD(bf16_t, bf16_t);
@@ -455,11 +473,13 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   else return WL_EINVAL;
 #undef LN_BWD
 #undef LN_BWD_N
+#undef LN_BWD_C
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   const unsigned g2 = (unsigned)((D + 63) / 64);
-  WL_LAUNCH(colsum_finish_kernel, dim3(g2, 2), dim3(1024), 0, st, part, (int)grid, (long)(2 * D), (int)D, dgamma,
-                     (int)param_dtype, (int)accumulate_params, (long)D, dbeta);
+  const int na = dr_colsum ? 3 : 2;
+  WL_LAUNCH(colsum_finish_kernel, dim3(g2, na), dim3(1024), 0, st, part, (int)grid, (long)(na * D), (int)D, dgamma,
+                     (int)param_dtype, (int)accumulate_params, (long)D, dbeta, dr_colsum);
   return wl_check_launch();
 }
 
@@ -483,7 +503,7 @@ int wavlm_colsum(const void* x, int64_t rows, int32_t N, int64_t ld, int32_t dty
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, part, (int)grid, (long)N,
-                     (int)N, out, (int)out_dtype, (int)accumulate, 0L, (void*)nullptr);
+                     (int)N, out, (int)out_dtype, (int)accumulate, 0L, (void*)nullptr, (void*)nullptr);
   return wl_check_launch();
 }
 

@@ -109,8 +109,22 @@ def _linear_bwd_w(dy2d, x2d, w_dtype, out=None):
     return dW
 
 
-def _param_grads(dy2d, x2d, W, b, has_bias, need_w, need_b, sink_w=None, sink_b=None):
+class BiasGradToken:
+    """Hand-over of a bias gradient from the nn.Linear that owns the bias to the LayerNorm that consumes the linear's
+    output as its residual branch: the LayerNorm backward already reduces dgamma / dbeta over rows, and the column sums
+    of the residual-branch gradient (= that bias gradient) fall out of the same pass.  The linear keeps computing its
+    own bias gradient unless the LayerNorm forward marked the token as taken (it does so only when the bias has a
+    gradient sink), so a code path that never reaches the LayerNorm loses nothing."""
+    __slots__ = ("param", "taken")
+
+    def __init__(self, param):
+        self.param, self.taken = param, False
+
+
+def _param_grads(dy2d, x2d, W, b, has_bias, need_w, need_b, sink_w=None, sink_b=None, bias_tok=None):
     """(dW, db) for a linear layer; a parameter with a gradient sink gets its gradient accumulated in place -> None"""
+    if bias_tok is not None and bias_tok.taken:
+        has_bias = False  # accumulated by the consuming LayerNorm's backward
     dW = db = None
     sw = sink_w if sink_w is not None else _sink(W)
     if sw is not None:
@@ -133,13 +147,14 @@ class LinearFn(torch.autograd.Function):
     sink_w / sink_b: explicit gradient sinks for W / b given as plain views (packed q|k|v projections)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, sink_w=None, sink_b=None):
+    def forward(ctx, x, W, b, sink_w=None, sink_b=None, bias_tok=None):
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
         y = _linear_fwd(x2d, W, b)
         ctx.save_for_backward(x2d, W, b)
         ctx.sinks = (sink_w, sink_b)
+        ctx.bias_tok = bias_tok
         _sink_use(W, sink_w)
         if b is not None:
             _sink_use(b, sink_b)
@@ -156,8 +171,8 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _linear_bwd_x(dy2d, W).view(ctx.xshape)
         dW, db = _param_grads(dy2d, x2d, W, b, b is not None, ctx.needs_input_grad[1], ctx.needs_input_grad[2],
-                              ctx.sinks[0], ctx.sinks[1])
-        return dx, dW, db, None, None
+                              ctx.sinks[0], ctx.sinks[1], ctx.bias_tok)
+        return dx, dW, db, None, None, None
 
 
 class FFNFn(torch.autograd.Function):
@@ -166,7 +181,7 @@ class FFNFn(torch.autograd.Function):
     input-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, p_act, seed):
+    def forward(ctx, x, W1, b1, W2, b2, p_act, seed, b2_tok=None):
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
@@ -183,6 +198,7 @@ class FFNFn(torch.autograd.Function):
             if t is not None:
                 _sink_use(t)
         ctx.p_act, ctx.seed, ctx.xshape = p_act, seed, x.shape
+        ctx.b2_tok = b2_tok
         return y.view(*x.shape[:-1], W2.shape[0])
 
     @staticmethod
@@ -191,7 +207,7 @@ class FFNFn(torch.autograd.Function):
         dy2d = dy.reshape(-1, dy.shape[-1])
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
-        dW2, db2 = _param_grads(dy2d, hd, W2, b2, b2 is not None, True, True)
+        dW2, db2 = _param_grads(dy2d, hd, W2, b2, b2 is not None, True, True, bias_tok=ctx.b2_tok)
         if ctx.p_act > 0:
             dh = _linear_bwd_x(dy2d, W2)
             dh = ops.dropout(dh, ctx.p_act, ctx.seed)
@@ -202,7 +218,7 @@ class FFNFn(torch.autograd.Function):
             du = _linear_bwd_x(dy2d, W2, epi=4, aux=u)
         dW1, db1 = _param_grads(du, x2d, W1, b1, b1 is not None, True, True)
         dx = _linear_bwd_x(du, W1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        return dx, dW1, db1, dW2, db2, None, None
+        return dx, dW1, db1, dW2, db2, None, None, None
 
 
 # --------------------------------------------------------------------------------------------- LayerNorm
@@ -211,13 +227,18 @@ class LayerNormFn(torch.autograd.Function):
     grad_scale multiplies the incoming gradient (GradMultiply at the extractor output)."""
 
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, eps, act, p_in, seed_in, p_out, seed_out, grad_scale):
+    def forward(ctx, x, r, gamma, beta, eps, act, p_in, seed_in, p_out, seed_out, grad_scale, rbias_tok=None):
         xc = x.contiguous()
         rc = r.contiguous() if r is not None else None
         y, s, mean, rstd = ops.layernorm_fwd(xc, rc, gamma, beta, eps, act=act, p_in=p_in, seed_in=seed_in,
                                              p_out=p_out, seed_out=seed_out, save=True)
         ctx.save_for_backward(s, mean, rstd, gamma, beta)
         ctx.cfg = (act, p_in, seed_in, p_out, seed_out, grad_scale, r is not None)
+        ctx.rbias = None
+        if (rbias_tok is not None and r is not None and _sink(rbias_tok.param) is not None
+                and _sink(gamma) is not None and _sink(beta) is not None):
+            rbias_tok.taken = True  # this backward delivers the bias gradient of the linear that produced r
+            ctx.rbias = rbias_tok.param
         _sink_use(gamma)
         _sink_use(beta)
         s_out = s.detach()
@@ -231,24 +252,30 @@ class LayerNormFn(torch.autograd.Function):
         sg, sb = _sink(gamma), _sink(beta)
         if sg is None or sb is None:
             sg = sb = None
-        dx, dr, dgamma, dbeta = ops.layernorm_bwd(dy.contiguous(), s, mean, rstd, gamma, beta, act=act, p_in=p_in,
-                                                  seed_in=seed_in, p_out=p_out, seed_out=seed_out,
-                                                  grad_scale=grad_scale, need_dr=has_r and p_in > 0,
-                                                  dgamma=sg, dbeta=sb)
+        sc = _sink(ctx.rbias) if (ctx.rbias is not None and sg is not None) else None
+        if ctx.rbias is not None and sc is None:
+            raise RuntimeError("gradient sink of a handed-over bias disappeared between forward and backward")
+        dx, dr, dgamma, dbeta, _ = ops.layernorm_bwd(dy.contiguous(), s, mean, rstd, gamma, beta, act=act, p_in=p_in,
+                                                     seed_in=seed_in, p_out=p_out, seed_out=seed_out,
+                                                     grad_scale=grad_scale, need_dr=has_r and p_in > 0,
+                                                     dgamma=sg, dbeta=sb,
+                                                     dr_colsum=sc.view(-1) if sc is not None else None)
         if sg is not None:
             dgamma = dbeta = None  # accumulated in place
             _sink_written(sg); _sink_written(sb)
+        if sc is not None:
+            _sink_written(sc)
         if has_r and dr is None:
             dr = dx
-        return dx, (dr if has_r else None), dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, (dr if has_r else None), dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, *, residual=None, act=0, p_in=0.0, p_out=0.0, training=True,
-               grad_scale=1.0):
+               grad_scale=1.0, residual_bias_tok=None):
     p_in = p_in if training else 0.0
     p_out = p_out if training else 0.0
     return LayerNormFn.apply(x, residual, gamma, beta, eps, act, p_in, next_seed() if p_in > 0 else 0, p_out,
-                             next_seed() if p_out > 0 else 0, grad_scale)
+                             next_seed() if p_out > 0 else 0, grad_scale, residual_bias_tok)
 
 
 # ------------------------------------------------------------------------------------- feature extractor

@@ -132,8 +132,10 @@ def layernorm_fwd(x, r, gamma, beta, eps, *, act=0, p_in=0.0, seed_in=0, p_out=0
 
 
 def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0,
-                  grad_scale=1.0, need_dr=False, dgamma=None, dbeta=None):
-    """returns (dx, dr, dgamma, dbeta); given dgamma / dbeta tensors are accumulated into (+=)"""
+                  grad_scale=1.0, need_dr=False, dgamma=None, dbeta=None, dr_colsum=None):
+    """returns (dx, dr, dgamma, dbeta, dr_colsum); given dgamma / dbeta (/ dr_colsum) tensors are accumulated into (+=).
+    dr_colsum: True -> also return the column sums of dr (fresh tensor); a tensor -> accumulate into it (only together
+    with dgamma / dbeta tensors: the three share the accumulate flag)."""
     dev = _dev(dy)
     _contig(dy); _contig(s)
     D = dy.shape[-1]
@@ -144,14 +146,18 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0,
     if not acc:
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
+    if dr_colsum is True or (dr_colsum is not None and not acc):
+        if torch.is_tensor(dr_colsum):
+            raise ValueError("dr_colsum sink needs dgamma / dbeta sinks")
+        dr_colsum = torch.empty_like(gamma) if not acc else torch.zeros_like(gamma)
     L = _lib.lib()
     need = L.wavlm_layernorm_bwd_workspace_bytes(D)
     ws = workspace(dev, need)
     check(L.wavlm_layernorm_bwd(ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dr),
-                                ptr(dgamma), ptr(dbeta), rows, D, dt(dy), dt(gamma), int(act), float(p_in),
-                                int(seed_in), float(p_out), int(seed_out), float(grad_scale), int(acc), ptr(ws), need,
-                                stream()), "wavlm_layernorm_bwd")
-    return dx, dr, dgamma, dbeta
+                                ptr(dgamma), ptr(dbeta), ptr(dr_colsum), rows, D, dt(dy), dt(gamma), int(act),
+                                float(p_in), int(seed_in), float(p_out), int(seed_out), float(grad_scale), int(acc),
+                                ptr(ws), need, stream()), "wavlm_layernorm_bwd")
+    return dx, dr, dgamma, dbeta, dr_colsum
 
 
 def colsum(x2d, out_dtype, *, include=None, exclude=None, rows=None, N=None, ld=None, out=None, accumulate=False):

@@ -221,7 +221,7 @@ class MultiheadAttention(nn.Module):
             cache[key] = bucket
         return F.RelPosTableFn.apply(self.relative_attention_bias.weight, bucket)
 
-    def forward(self, x, key_padding_u8=None, position_table=None):
+    def forward(self, x, key_padding_u8=None, position_table=None, out_bias_tok=None):
         """x [B, T, D] -> (attn_out [B, T, D], position_table)"""
         B, T, D = x.shape
         if self.has_relative_attention_bias and position_table is None:
@@ -244,7 +244,7 @@ class MultiheadAttention(nn.Module):
         p = self.dropout_module.p if self.training else 0.0
         o = F.AttnCoreFn.apply(qkv, gate, position_table, key_padding_u8, self.num_heads, self.scaling, p,
                                F.next_seed() if p > 0 else 0)
-        out = F.LinearFn.apply(o, self.out_proj.weight, self.out_proj.bias)
+        out = F.LinearFn.apply(o, self.out_proj.weight, self.out_proj.bias, None, None, out_bias_tok)
         return out, position_table
 
 
@@ -291,10 +291,10 @@ class TransformerSentenceEncoderLayer(nn.Module):
         self.fc2 = nn.Linear(ffn_embedding_dim, embedding_dim)
         self.final_layer_norm = nn.LayerNorm(embedding_dim)
 
-    def _ffn(self, x):
+    def _ffn(self, x, b2_tok=None):
         p = self.activation_dropout if self.training else 0.0
         return F.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p,
-                             F.next_seed() if p > 0 else 0)
+                             F.next_seed() if p > 0 else 0, b2_tok)
 
     def forward(self, x, key_padding_u8=None, position_table=None):
         ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
@@ -307,10 +307,16 @@ class TransformerSentenceEncoderLayer(nn.Module):
             f = self._ffn(h)
             x = ResidualAddFn.apply(x, f, p, F.next_seed() if p > 0 else 0)
         else:
-            a, position_table = self.self_attn(x, key_padding_u8, position_table)
-            x, _ = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps, residual=a, p_in=p, training=self.training)
-            f = self._ffn(x)
-            x, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps, residual=f, p_in=p, training=self.training)
+            # post-LN: the LayerNorm that follows a sub-layer also delivers the bias gradient of its last linear
+            grad = torch.is_grad_enabled()
+            ta = F.BiasGradToken(self.self_attn.out_proj.bias) if grad else None
+            a, position_table = self.self_attn(x, key_padding_u8, position_table, out_bias_tok=ta)
+            x, _ = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps, residual=a, p_in=p, training=self.training,
+                                residual_bias_tok=ta)
+            tf = F.BiasGradToken(self.fc2.bias) if grad else None
+            f = self._ffn(x, tf)
+            x, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps, residual=f, p_in=p, training=self.training,
+                                residual_bias_tok=tf)
         return x, None, position_table
 
 
