@@ -12,8 +12,8 @@ from unispeech_amd import ops  # noqa: E402
 dev, bf = "cuda", torch.bfloat16
 ops.gemm_set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2304
-M = 256 * 94
-for K in (64, 256, 768, 1536, 3072, 6144):
+M = int(os.environ.get("KS_M", 256 * 94))
+for K in [int(k) for k in os.environ.get("KS_K", "64,256,768,1536,3072,6144").split(",")]:
     x = torch.randn(M, K, device=dev, dtype=bf)
     W = torch.randn(N, K, device=dev, dtype=bf)
     y = torch.empty(M, N, device=dev, dtype=bf)

@@ -485,28 +485,43 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   float* out = part + (long)blockIdx.x * PW;
   for (int i = threadIdx.x; i < PW; i += 256) out[i] = sm[i] + sm[PW + i] + sm[2 * PW + i] + sm[3 * PW + i];
 }
-// dW[8][hd], dbias[8], dgrep_a[H] from the block partials (256 outputs x 4 slices per pass)
+// dW[8][hd], dbias[8], dgrep_a[H] from the block partials.  Pure load latency: 16 outputs x 64 row slices per block
+// (nblk / 64 loads per thread, four in flight), grid = ceil(PW / 16) -- one block looping over all partials took 33 us.
 __global__ __launch_bounds__(1024) void gate_bwd_finish_kernel(const float* __restrict__ part, int nblk, int H, int hd,
     void* dW, void* dbias, void* da, int pdt) {
-  __shared__ float red[4][256];
+  __shared__ float red[64][17];
   const int PW = 2 * hd + 2 + H;
-  const int col = threadIdx.x & 255, slice = threadIdx.x >> 8;
-  for (int i0 = 0; i0 < PW; i0 += 256) {
-    const int i = i0 + col;
-    float s = 0.f;
-    if (i < PW)
-      for (int b = slice; b < nblk; b += 4) s += part[(long)b * PW + i];
-    red[slice][col] = s;
-    __syncthreads();
-    if (slice == 0 && i < PW) {
-      s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
-      if (i < hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)k * hd + i, pdt, s); }
-      else if (i < 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)(4 + k) * hd + (i - hd), pdt, s); }
-      else if (i == 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dbias, k, pdt, s); }
-      else if (i == 2 * hd + 1) { for (int k = 0; k < 4; ++k) st_elem(dbias, 4 + k, pdt, s); }
-      else st_elem(da, i - (2 * hd + 2), pdt, s);
+  const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + col;
+  float s = 0.f;
+  if (i < PW) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = slice;
+    for (; b + 192 < nblk; b += 256) {
+      s0 += part[(long)b * PW + i];
+      s1 += part[(long)(b + 64) * PW + i];
+      s2 += part[(long)(b + 128) * PW + i];
+      s3 += part[(long)(b + 192) * PW + i];
     }
-    __syncthreads();
+    for (; b < nblk; b += 64) s0 += part[(long)b * PW + i];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[slice][col] = s;
+  __syncthreads();
+  if (slice < 4) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[slice * 16 + k][col];
+    red[slice * 16][col] = t;
+  }
+  __syncthreads();
+  if (slice == 0 && i < PW) {
+    s = (red[0][col] + red[16][col]) + (red[32][col] + red[48][col]);
+    if (i < hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)k * hd + i, pdt, s); }
+    else if (i < 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)(4 + k) * hd + (i - hd), pdt, s); }
+    else if (i == 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dbias, k, pdt, s); }
+    else if (i == 2 * hd + 1) { for (int k = 0; k < 4; ++k) st_elem(dbias, 4 + k, pdt, s); }
+    else st_elem(da, i - (2 * hd + 2), pdt, s);
   }
 }
 
@@ -620,8 +635,8 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
 #undef GB
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  WL_LAUNCH(gate_bwd_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace, (int)grid, (int)H,
-                     (int)hd, dW, dbias, dgrep_a, (int)param_dtype);
+  WL_LAUNCH(gate_bwd_finish_kernel, dim3((unsigned)((2 * hd + 2 + H + 15) / 16)), dim3(1024), 0, st, (const float*)workspace,
+                     (int)grid, (int)H, (int)hd, dW, dbias, dgrep_a, (int)param_dtype);
   return wl_check_launch();
 }
 

@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   float* tabs = reinterpret_cast<float*>(smem + 32768 + 4 * 6144);
   float* kb = tabs + p.Ltab;
   unsigned* colw = reinterpret_cast<unsigned*>(kb + p.Tkb);
+  // d(rel) row of this block: the four waves' diagonal sums are added here (LDS float adds) and leave as ONE row of
+  // 2T - 1 floats -- per-wave rows in HBM cost 4x the partial traffic, a memset, and a 4x longer reduction
+  float* drow = reinterpret_cast<float*>(colw + (p.Tkb >> 1));
   const int T = p.T, H = p.H;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -279,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   unsigned char* skew = smem + 32768 + wave_u * 6144;
   const int ib = blockIdx.x * FA_BQ + 32 * wave_u;
   const int dlo0 = -ib - 31 + T - 1;  // diagonal of skew row 0 at tile 0 (negative for rows past the table)
-  float* wpart = p.tab ? p.dtab_part + (((long)bh * gridDim.x + blockIdx.x) * 4 + wave_u) * (2 * T - 1) : nullptr;
+  if (p.tab)
+    for (int d = threadIdx.x; d < 2 * T - 1; d += 256) drow[d] = 0.f;  // ordered before the first add by the tile loop's barriers
   const long D3 = 3L * H * FA_HD, D = (long)H * FA_HD;
   const bf16_t* base = p.qkv + (long)b * T * D3 + h * FA_HD;
   const int L = 2 * T - 1;
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
       const int gsel = lane >> 4;
       const float v = gsel == 0 ? dacc[0][0] : gsel == 1 ? dacc[1][0] : gsel == 2 ? dacc[2][0] : dacc[3][0];
       const int d = dlo0 + j0 + lane;
-      if (d >= 0 && d < L) wpart[d] = v;
+      if (d >= 0 && d < L) unsafeAtomicAdd(drow + d, v);
     }
     __syncthreads();
     cur ^= 1;
@@ -416,7 +420,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
     // the 31 diagonals past the last tile's first 64 (blocks 4, 5)
     const float v = lane < 16 ? dacc[4][0] : dacc[5][0];
     const int d = dlo0 + 64 * nkv + lane;
-    if (d >= 0 && d < L) wpart[d] = v;
+    if (d >= 0 && d < L) unsafeAtomicAdd(drow + d, v);
+  }
+  if (p.tab) {
+    __syncthreads();
+    float* prow = p.dtab_part + ((long)bh * gridDim.x + blockIdx.x) * L;
+    for (int d = threadIdx.x; d < L; d += 256) prow[d] = drow[d];
   }
   dg += __shfl_xor(dg, 32, 64);
   if (valid_i) {
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   }
 }
 
-// drel[h][d] = sum over (b, q-tile, wave) partial rows: block = 64 d x 16 row slices
+// drel[h][d] = sum over (b, q-tile) partial rows: block = 64 d x 16 row slices
 __global__ __launch_bounds__(1024) void fa_dtab_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               int B, int H, int nchunk, int L) {
   __shared__ float red[16][64];
@@ -657,7 +666,7 @@ int wavlm_attn_fused_fwd(const void* qkv, void* O, float* lse, const float* gate
 
 uint64_t wavlm_attn_fused_bwd_workspace_bytes(int32_t B, int32_t H, int32_t T) {
   const uint64_t nqt = (uint64_t)((T + FA_BQ - 1) / FA_BQ);
-  return ((uint64_t)B * H * nqt * 4 * (2 * (uint64_t)T - 1) + (uint64_t)B * H * T) * sizeof(float);
+  return ((uint64_t)B * H * nqt * (2 * (uint64_t)T - 1) + (uint64_t)B * H * T) * sizeof(float);
 }
 
 // dqkv[B,T,3*H*64], dgate[B,H,T], dtab[H,2T-1] from dO and the forward's (qkv, O, lse)
@@ -677,10 +686,8 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
   const int nqt = (T + FA_BQ - 1) / FA_BQ;
   const int L = 2 * T - 1;
   p.dtab_part = (float*)workspace;
-  p.delta = p.dtab_part + (long)B * H * nqt * 4 * L;
-  // each wave stores every d of its own window range exactly once; everything else must read as zero
-  if (tab && hipMemsetAsync(p.dtab_part, 0, (size_t)B * H * nqt * 4 * L * sizeof(float), st) != hipSuccess) return WL_ELAUNCH;
-  const size_t smem1 = 32768 + 4 * 6144 + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float);
+  p.delta = p.dtab_part + (long)B * H * nqt * L;
+  const size_t smem1 = 32768 + 4 * 6144 + (size_t)(2 * p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float);
   if (p.th) {
     if (fa_set_smem(attn_bwd_dq_kernel<true>, smem1) != WL_OK) return WL_ELAUNCH;
     WL_LAUNCH(attn_bwd_dq_kernel<true>, dim3((unsigned)nqt, (unsigned)(B * H)), dim3(256), smem1, st, p);
@@ -699,7 +706,7 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
   }
   if (tab)
     WL_LAUNCH(fa_dtab_reduce_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)H), dim3(1024), 0, st,
-              (const float*)p.dtab_part, dtab, (int)B, (int)H, nqt * 4, L);
+              (const float*)p.dtab_part, dtab, (int)B, (int)H, nqt, L);
   return wl_check_launch();
 }
 

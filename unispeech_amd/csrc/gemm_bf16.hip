@@ -321,7 +321,7 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   const bool vec = vec_epilogue_ok(d);
   if ((g_gemm_variant == 4 && gemm_pp3_ok(d)) ||
       (g_gemm_variant == 0 && d->N >= 384 && gemm_pp3_ok(d) && gemm_pp_ok(d) &&
-       tile_efficiency(d, nbatch, 192, 384) > 1.25 * tile_efficiency(d, nbatch, 256, 256)))  // six shorter phases per K step cost ~10 %: only where the 256 x 256 tiling quantises badly (N = 768 at 24 k rows)
+       tile_efficiency(d, nbatch, 192, 384) > 1.06 * tile_efficiency(d, nbatch, 256, 256)))  // measured at 24 k rows: N = 768 (+25 %), 2304 (+10 % at K = 768), 3072 (+6 %) go to 192 x 384; N = 2048 and the conv stack (N = 512) stay
     rc = gemm_pp3_launch(p, nbatch, d->transA != 0, d->transB != 0, gemm_epilogue_class(d, vec), st);
   else if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) rc = gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, gemm_epilogue_class(d, vec), st);
   else if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, vec, st);

@@ -243,26 +243,42 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// out[c] (+)= sum_b part[b * stride + c].  Block = 64 columns x 16 row slices (coalesced 256-B reads per slice, short
-// dependent-load chains), slices combined through LDS; grid = ceil(n / 64).
+// out[c] (+)= sum_b part[b * stride + c].  Block = 16 columns x 64 row slices: the kernel is pure load latency (a few MB
+// read through short dependent chains), so the chains are kept short (nblk / 64 loads per thread) and the grid wide
+// (n / 16 blocks); slices are combined through LDS.
 // blockIdx.y selects one of up to three interleaved partial arrays / outputs (LayerNorm's dgamma, dbeta and the
 // residual branch's bias gradient in one launch)
 __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int nblk, long stride, int n,
                                                               void* out, int out_dtype, int accumulate, long part_y, void* out_y,
                                                               void* out_z) {
-  __shared__ float red[16][64];
-  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + col;
+  __shared__ float red[64][17];
+  const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + col;
   if (blockIdx.y) { part += part_y * blockIdx.y; out = blockIdx.y == 1 ? out_y : out_z; }
   float s = 0.f;
-  if (c < n)
-    for (int b = slice; b < nblk; b += 16) s += part[(long)b * stride + c];
+  if (c < n) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = slice;
+    for (; b + 192 < nblk; b += 256) {  // four independent loads in flight per thread
+      s0 += part[(long)b * stride + c];
+      s1 += part[(long)(b + 64) * stride + c];
+      s2 += part[(long)(b + 128) * stride + c];
+      s3 += part[(long)(b + 192) * stride + c];
+    }
+    for (; b < nblk; b += 64) s0 += part[(long)b * stride + c];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[slice][col] = s;
   __syncthreads();
-  if (slice == 0 && c < n) {
-    s = 0.f;
+  if (slice < 4) {  // 64 -> 4 partial sums per column
+    float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += red[k][col];
+    for (int k = 0; k < 16; ++k) t += red[slice * 16 + k][col];
+    red[slice * 16][col] = t;
+  }
+  __syncthreads();
+  if (slice == 0 && c < n) {
+    s = (red[0][col] + red[16][col]) + (red[32][col] + red[48][col]);
     if (accumulate) s += ld_elem(out, c, out_dtype);
     st_elem(out, c, out_dtype, s);
   }
@@ -388,12 +404,24 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
   }
 }
 
-// block partial sums of x^2 (features_pen) -> part[block] (double)
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const void* x, int dt, long n, double* part) {
+// block partial sums of x^2 (features_pen, global gradient norm) -> part[block] (double).  16-byte loads; eight fp32
+// running sums per thread (each over <= n / (8 * threads) terms) folded into a double per thread, doubles from there on.
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const T* __restrict__ x, long n, double* part) {
   __shared__ double red[4];
-  double s = 0.0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float v = ld_elem(x, i, dt);
+  float a[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.f;
+  const long nv = n >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    load8(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = fmaf(v[e], v[e], a[e]);
+  }
+  double s = ((double)a[0] + a[1]) + ((double)a[2] + a[3]) + ((double)a[4] + a[5]) + ((double)a[6] + a[7]);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {  // tail elements
+    const float v = Elem<T>::ld(x + nv * 8 + threadIdx.x);
     s += (double)v * v;
   }
   s = wave_sum_d(s);
@@ -401,12 +429,11 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const void* x, int d
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void sum_finish_d_kernel(const double* part, int n, float* out, float scale) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += part[i];
-    out[0] = (float)(s * scale);
-  }
+__global__ __launch_bounds__(64) void sum_finish_d_kernel(const double* part, int n, float* out, float scale) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[0] = (float)(s * scale);
 }
 
 static inline unsigned grid_for(long work_items, int per_block, unsigned cap) {
@@ -476,7 +503,7 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
 #undef LN_BWD_C
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  const unsigned g2 = (unsigned)((D + 63) / 64);
+  const unsigned g2 = (unsigned)((D + 15) / 16);
   const int na = dr_colsum ? 3 : 2;
   WL_LAUNCH(colsum_finish_kernel, dim3(g2, na), dim3(1024), 0, st, part, (int)grid, (long)(na * D), (int)D, dgamma,
                      (int)param_dtype, (int)accumulate_params, (long)D, dbeta, dr_colsum);
@@ -502,7 +529,7 @@ int wavlm_colsum(const void* x, int64_t rows, int32_t N, int64_t ld, int32_t dty
   else return WL_EINVAL;
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, part, (int)grid, (long)N,
+  WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((N + 15) / 16)), dim3(1024), 0, st, part, (int)grid, (long)N,
                      (int)N, out, (int)out_dtype, (int)accumulate, 0L, (void*)nullptr, (void*)nullptr);
   return wl_check_launch();
 }
@@ -580,7 +607,10 @@ int wavlm_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out
   if (!x || !out || !workspace || n <= 0 || ws_bytes < wavlm_sumsq_workspace_bytes()) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = grid_for(n, 256 * 16, 1024);
-  WL_LAUNCH(sumsq_partial_kernel, dim3(grid), dim3(256), 0, st, x, (int)dtype, (long)n, (double*)workspace);
+  if ((((uintptr_t)x) & 15) != 0) return WL_EINVAL;
+  if (dtype == WL_F32) WL_LAUNCH((sumsq_partial_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (long)n, (double*)workspace);
+  else if (dtype == WL_BF16) WL_LAUNCH((sumsq_partial_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (long)n, (double*)workspace);
+  else return WL_EINVAL;
   WL_LAUNCH(sum_finish_d_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)grid, out, scale);
   return wl_check_launch();
 }
