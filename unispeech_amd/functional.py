@@ -155,9 +155,10 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, W, b)
         ctx.sinks = (sink_w, sink_b)
         ctx.bias_tok = bias_tok
-        _sink_use(W, sink_w)
-        if b is not None:
-            _sink_use(b, sink_b)
+        if ctx.needs_input_grad[1]:  # (all False under no_grad: no backward will match the use)
+            _sink_use(W, sink_w)
+            if b is not None:
+                _sink_use(b, sink_b)
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], W.shape[0])
 
@@ -194,9 +195,10 @@ class FFNFn(torch.autograd.Function):
         hd = ops.dropout(h, p_act, seed) if p_act > 0 else h
         y = _linear_fwd(hd, W2, b2)
         ctx.save_for_backward(x2d, W1, W2, u, hd, b1, b2)
-        for t in (W1, b1, W2, b2):
-            if t is not None:
-                _sink_use(t)
+        if ctx.needs_input_grad[1]:
+            for t in (W1, b1, W2, b2):
+                if t is not None:
+                    _sink_use(t)
         ctx.p_act, ctx.seed, ctx.xshape = p_act, seed, x.shape
         ctx.b2_tok = b2_tok
         return y.view(*x.shape[:-1], W2.shape[0])
@@ -239,8 +241,9 @@ class LayerNormFn(torch.autograd.Function):
                 and _sink(gamma) is not None and _sink(beta) is not None):
             rbias_tok.taken = True  # this backward delivers the bias gradient of the linear that produced r
             ctx.rbias = rbias_tok.param
-        _sink_use(gamma)
-        _sink_use(beta)
+        if ctx.needs_input_grad[2]:
+            _sink_use(gamma)
+            _sink_use(beta)
         s_out = s.detach()
         ctx.mark_non_differentiable(s_out)
         return y, s_out

@@ -265,6 +265,12 @@ class WavLMPretrainModel(WavLM):
             return out
 
         def head_one(x2d, frame_sel_np, need_grad):
+            # a head whose loss carries no weight (pred_nomask_weight == 0) is evaluated for logging only: no graph,
+            # no saved activations, and no pending gradient-sink accumulations for the data-parallel reducer to wait for
+            with torch.set_grad_enabled(bool(need_grad) and torch.is_grad_enabled()):
+                return head_body(x2d, frame_sel_np, need_grad)
+
+        def head_body(x2d, frame_sel_np, need_grad):
             idx_np = np.flatnonzero(frame_sel_np.reshape(-1)).astype(np.int32)
             S = int(idx_np.size)
             inv_np = np.full(n, -1, dtype=np.int32)
