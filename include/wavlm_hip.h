@@ -67,6 +67,11 @@ typedef struct wavlm_gemm_desc {
 
 uint64_t wavlm_gemm_workspace_bytes(const wavlm_gemm_desc* d);
 int wavlm_gemm(const wavlm_gemm_desc* d, void* stream);
+/* n descriptors in one call.  Weight-gradient-shaped problems (transA && transB, same K and split_k >= 2, no epilogue
+ * extras, each with its own workspace) run as ONE grouped split-K launch + one slab reduction each -- the four dW of an
+ * encoder layer (modules.py q/k/v/out_proj, WavLM.py:732-737 fc1/fc2) share the reduction length B*T; anything else is
+ * executed as n wavlm_gemm calls.  Results are identical either way. */
+int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row kernels (one 64-lane wave per row, wave-shuffle reductions).

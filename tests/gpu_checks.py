@@ -212,6 +212,26 @@ def check_gemm_pp3():
     return check_gemm_pp(4, "gemm_pp3")
 
 
+def check_gemm_grouped():
+    """wavlm_gemm_grouped: weight gradients of several linears over the same rows in one grouped split-K launch,
+    accumulated into existing (non-zero) outputs; ragged rows (K tail), ragged M/N tiles, 2-4 members; plus a group the
+    256-wide kernel does not take (sequential fall-back inside the library)."""
+    out = []
+    dtype, tol = torch.bfloat16, TOLBF
+    for n, shapes in [(1000, [(520, 264), (256, 768)]), (2500, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
+                      (777, [(264, 392), (512, 256), (304, 520)]), (300, [(64, 48), (96, 64)])]:
+        items, refs = [], []
+        for k, (N, K) in enumerate(shapes):
+            dy, x = q(gen(n, N, seed=50 + k), dtype), q(gen(n, K, seed=60 + k), dtype)
+            o0 = q(gen(N, K, seed=70 + k), dtype)
+            refs.append(o0.double() + dy.double().t() @ x.double())
+            items.append((dy.to(dtype).to(DEV), x.to(dtype).to(DEV), o0.to(dtype).to(DEV).clone()))
+        ops.gemm_wgrad_grouped(items, dtype)
+        for k, ((N, K), it, ref) in enumerate(zip(shapes, items, refs)):
+            out.append((f"gemm_grouped n={n} member {k} [{N}x{K}]", err(it[2], ref), tol))
+    return out
+
+
 # --------------------------------------------------------------------------------------------------- row ops
 def check_layernorm():
     out = []
@@ -672,7 +692,7 @@ def check_adam():
 
 
 GROUPS = {
-    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
+    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_grouped": check_gemm_grouped, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
     "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv,
     "linear_ffn": check_linear_ffn, "loss": check_loss, "adam": check_adam,
 }

@@ -87,6 +87,14 @@ def _worker(rank, world, port, q):
     Fn._sink_written(span)
     both = red._seen[3] and red._seen[1]
     ok3 = (not first) and second and both
+    # a parameter whose weight gradient is queued for a grouped launch: autograd's hook fires early and must not count
+    hook4 = red._make_hook(4)
+    Fn.WgradGroup.deferred.add(params[4].grad.data_ptr())
+    hook4(params[4])
+    early = red._seen[4]
+    Fn.WgradGroup.deferred.discard(params[4].grad.data_ptr())
+    hook4(params[4])
+    ok3 = ok3 and (not early) and red._seen[4]
     red.finish()
     ok3 = ok3 and not any(red._seen)
     q.put((rank, ok1, ok_avg, local_only, ok2, ok3))

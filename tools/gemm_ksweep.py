@@ -14,10 +14,15 @@ ops.gemm_set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2304
 M = int(os.environ.get("KS_M", 256 * 94))
 for K in [int(k) for k in os.environ.get("KS_K", "64,256,768,1536,3072,6144").split(",")]:
-    x = torch.randn(M, K, device=dev, dtype=bf)
-    W = torch.randn(N, K, device=dev, dtype=bf)
     y = torch.empty(M, N, device=dev, dtype=bf)
-    f = lambda: ops.gemm(x, W, y, M, N, K, lda=K, ldb=K, ldc=N)
+    if os.environ.get("KS_TT"):  # both operands K-strided (the weight-gradient form)
+        x = torch.randn(K, M, device=dev, dtype=bf)
+        W = torch.randn(K, N, device=dev, dtype=bf)
+        f = lambda: ops.gemm(x, W, y, M, N, K, lda=M, ldb=N, ldc=N, transA=True, transB=True)
+    else:
+        x = torch.randn(M, K, device=dev, dtype=bf)
+        W = torch.randn(N, K, device=dev, dtype=bf)
+        f = lambda: ops.gemm(x, W, y, M, N, K, lda=K, ldb=K, ldc=N)
     for _ in range(3):
         f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

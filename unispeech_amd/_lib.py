@@ -41,6 +41,7 @@ SIGNATURES = {
     "wavlm_abi_version": (c_i32, []),
     "wavlm_gemm_workspace_bytes": (c_u64, [C.POINTER(GemmDesc)]),
     "wavlm_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
+    "wavlm_gemm_grouped": (c_i32, [C.POINTER(GemmDesc), c_i32, c_vp]),
     "wavlm_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_i32,
                                     c_i32, c_f32, c_u64, c_f32, c_u64, c_vp]),
     "wavlm_layernorm_bwd_workspace_bytes": (c_u64, [c_i32]),

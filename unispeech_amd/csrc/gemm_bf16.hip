@@ -385,3 +385,53 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   prof_end(pi, st);
   return rc;
 }
+
+int gemm_pp_launch_grouped(GemmP& p, hipStream_t st);  // gemm_pp.hip
+
+// Several weight-gradient-shaped problems (both operands K-strided, same K and split_k >= 2, plain epilogue) as ONE
+// split-K launch of the 256 x 256 kernel plus one slab reduction per problem.  Anything else runs as n wavlm_gemm calls.
+extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* stream) {
+  if (!d || n <= 0) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  bool ok = n >= 2 && n <= 4;
+  for (int i = 0; ok && i < n; ++i) {
+    const wavlm_gemm_desc* e = d + i;
+    ok = e->A && e->B && e->C && e->workspace && e->dtype == WL_BF16 && e->transA && e->transB && e->KB <= 1 &&
+         e->batch_o <= 1 && e->batch_i <= 1 && e->K == d->K && e->split_k == d->split_k && e->split_k >= 2 &&
+         e->epi == 0 && !e->bias && !e->aux && !e->res && e->M > 0 && e->N > 0 && gemm_pp_ok(e) &&
+         aligned16(e->A) && aligned16(e->B) && e->lda % 8 == 0 && e->ldb % 8 == 0 &&
+         vec_epilogue_ok(e) && vec_epilogue_ok(e, true) && e->ws_bytes >= wavlm_gemm_workspace_bytes(e);
+  }
+  if (!ok || g_gemm_variant != 0) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = wavlm_gemm(d + i, stream);
+      if (rc != WL_OK) return rc;
+    }
+    return WL_OK;
+  }
+  GemmP p = make_gemm_params(d);
+  p.ngrp = n;
+  int vb = 0;
+  double flops = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    const wavlm_gemm_desc* e = d + (i < n ? i : n - 1);
+    GemmGrp& g = p.grp[i];
+    g.A = e->A; g.B = e->B; g.ws = (float*)e->workspace; g.lda = e->lda; g.ldb = e->ldb; g.M = e->M; g.N = e->N;
+    g.tiles_m = (e->M + 255) / 256; g.tiles_n = (e->N + 255) / 256;
+    g.vbase = i < n ? vb : 0x7fffffff;
+    if (i < n) { vb += g.tiles_m * g.tiles_n * p.split_k; flops += 2.0 * e->M * e->N * (double)e->K; }
+  }
+  p.vtotal = vb;
+  const int pi = prof_begin(d, st);
+  if (pi >= 0) g_prof.flops[pi] = flops;
+  int rc = gemm_pp_launch_grouped(p, st);
+  for (int i = 0; rc == WL_OK && i < n; ++i) {
+    GemmP pr = make_gemm_params(d + i);
+    const long total = (long)pr.M * pr.N;
+    long blocks = ((total >> 3) + 255) / 256; if (blocks > 2048) blocks = 2048;
+    WL_LAUNCH(gemm_splitk_reduce8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pr, 1);
+    rc = wl_check_launch();
+  }
+  prof_end(pi, st);
+  return rc;
+}

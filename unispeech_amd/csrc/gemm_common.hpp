@@ -3,6 +3,9 @@
 #include "common.hpp"
 #include "../../include/wavlm_hip.h"
 
+// one problem of a grouped split-K launch (gemm_pp.hip): operands, slab base and tile geometry; vbase = first work item
+struct GemmGrp { const void* A; const void* B; float* ws; long lda, ldb; int M, N, tiles_m, tiles_n, vbase; };
+
 struct GemmP {
   const void* A; const void* B; void* C;
   int M, N, K, KB;
@@ -18,6 +21,8 @@ struct GemmP {
   int tiles_m, tiles_n;
   int vtotal, nbatch, skew;  // persistent launch (ping-pong kernels): virtual block count, batch count, start skew
   int patch_m;               // split-K work order: tile-row patch height (0: tiles only, split outermost)
+  int ngrp;                  // > 0: grouped launch, the problems are grp[0 .. ngrp) (A/B/M/N/lda/ldb/ws above are unused)
+  GemmGrp grp[4];
 };
 
 static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
@@ -34,7 +39,7 @@ static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
   p.accumulate = d->accumulate;
   p.split_k = d->split_k < 1 ? 1 : d->split_k;
   p.ws = (float*)d->workspace;
-  p.tiles_m = 0; p.tiles_n = 0; p.vtotal = 0; p.nbatch = 1; p.skew = 0; p.patch_m = 0;
+  p.tiles_m = 0; p.tiles_n = 0; p.vtotal = 0; p.nbatch = 1; p.skew = 0; p.patch_m = 0; p.ngrp = 0;
   return p;
 }
 

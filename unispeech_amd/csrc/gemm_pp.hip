@@ -61,7 +61,7 @@ struct PPCursor {  // position of one half-tile stream in the flattened (K-batch
   int kt;          // K-tile index inside the current K batch
 };
 
-template <bool TA, bool TB, int EP>
+template <bool TA, bool TB, int EP, bool GRP = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 * PP_STAGE
 
@@ -78,6 +78,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 #endif
   for (int vid = blockIdx.x; vid < p.vtotal; vid += gridDim.x) {
   int tm, tn, z, split;
+  GemmP q = p;  // grouped launch: the work item's own problem; otherwise an alias of p
+  if constexpr (GRP) {
+    // Grouped split-K launch (the weight gradients of one encoder layer in ONE launch: 108 tiles x split 2 instead of
+    // four launches with splits of 7-28 -- a quarter of the slab traffic and 3-4x longer K loops per tile).  Work items
+    // are ordered (problem, split, tile); each XCD takes a contiguous run, i.e. tiles of one split of one problem.
+    const int nv = p.vtotal;
+    const int q8 = nv >> 3, rem = nv & 7, xcd = vid & 7, idx = vid >> 3;
+    const int item = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + idx;
+    const int g = (item >= p.grp[1].vbase) + (item >= p.grp[2].vbase) + (item >= p.grp[3].vbase);
+#define PP_SEL(F) (g == 0 ? p.grp[0].F : g == 1 ? p.grp[1].F : g == 2 ? p.grp[2].F : p.grp[3].F)
+    q.A = PP_SEL(A); q.B = PP_SEL(B); q.ws = PP_SEL(ws); q.lda = PP_SEL(lda); q.ldb = PP_SEL(ldb);
+    q.M = PP_SEL(M); q.N = PP_SEL(N); q.tiles_m = PP_SEL(tiles_m); q.tiles_n = PP_SEL(tiles_n);
+    const int local = item - PP_SEL(vbase);
+#undef PP_SEL
+    const int nt_g = q.tiles_m * q.tiles_n;
+    split = local / nt_g;
+    const int tile = local - split * nt_g;
+    tm = tile / q.tiles_n; tn = tile - tm * q.tiles_n;
+    z = 0;
+  } else
   if (p.patch_m == 0) {
     // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (private L2 per XCD); each XCD walks a contiguous
     // run of tiles (neighbours share the A row panel and all of B).  Batch and split are the outer dimensions.
@@ -104,18 +124,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     tm = pi * p.patch_m + qq / p.tiles_n; tn = qq % p.tiles_n;
     z = 0;
   }
-  const int zo = z / p.batch_i, zi = z % p.batch_i;
+  const GemmP& P = q;
+  const int zo = z / P.batch_i, zi = z % P.batch_i;
   const int m0 = tm * 256, n0 = tn * 256;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  const char* Ab = (const char*)((const bf16_t*)p.A + (long)zo * p.sA_o + (long)zi * p.sA_i + (TA ? (long)m0 : (long)m0 * p.lda));
-  const char* Bb = (const char*)((const bf16_t*)p.B + (long)zo * p.sB_o + (long)zi * p.sB_i + (TB ? (long)n0 : (long)n0 * p.ldb));
-  const int kt_per = (p.K + 63) >> 6;
-  const int kv_last = p.K - (kt_per - 1) * 64;
+  const char* Ab = (const char*)((const bf16_t*)P.A + (long)zo * P.sA_o + (long)zi * P.sA_i + (TA ? (long)m0 : (long)m0 * P.lda));
+  const char* Bb = (const char*)((const bf16_t*)P.B + (long)zo * P.sB_o + (long)zi * P.sB_i + (TB ? (long)n0 : (long)n0 * P.ldb));
+  const int kt_per = (P.K + 63) >> 6;
+  const int kv_last = P.K - (kt_per - 1) * 64;
   int t0, t1;
-  gemm_split_range(p.KB * kt_per, p.split_k, split, t0, t1);
+  gemm_split_range(P.KB * kt_per, P.split_k, split, t0, t1);
   const int nt = t1 - t0;
 
   // ---- DMA side: per-lane byte offsets of the two pieces (j) this lane fetches of each half-tile ------------------
@@ -128,8 +149,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 #pragma unroll
     for (int op = 0; op < 2; ++op) {
       const bool TR = op ? TB : TA;
-      const long ld = op ? p.ldb : p.lda;
-      const int rows_valid = op ? p.N - n0 : p.M - m0;
+      const long ld = op ? P.ldb : P.lda;
+      const int rows_valid = op ? P.N - n0 : P.M - m0;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         unsigned v;
@@ -153,13 +174,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
       }
     }
   }
-  const long stepA = TA ? 64 * p.lda : 64, stepB = TB ? 64 * p.ldb : 64;
-  const long jumpA = p.sA_kb - (long)kt_per * stepA, jumpB = p.sB_kb - (long)kt_per * stepB;
+  const long stepA = TA ? 64 * P.lda : 64, stepB = TB ? 64 * P.ldb : 64;
+  const long jumpA = P.sA_kb - (long)kt_per * stepA, jumpB = P.sB_kb - (long)kt_per * stepB;
   PPCursor cur[4];
   {
     const int kb0 = t0 / kt_per, kt0 = t0 - kb0 * kt_per;
-    cur[0].off = cur[1].off = (long)kb0 * p.sA_kb + (long)kt0 * stepA;
-    cur[2].off = cur[3].off = (long)kb0 * p.sB_kb + (long)kt0 * stepB;
+    cur[0].off = cur[1].off = (long)kb0 * P.sA_kb + (long)kt0 * stepA;
+    cur[2].off = cur[3].off = (long)kb0 * P.sB_kb + (long)kt0 * stepB;
     cur[0].kt = cur[1].kt = cur[2].kt = cur[3].kt = kt0;
   }
   // issue half-tile `which` (0 A-top, 1 A-bot, 2 B-left, 3 B-right) of the stream's current K tile into `stage`,
@@ -388,9 +409,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
     // steady steps: everything prefetched (up to tile t+2) is a full tile of the same K batch
-    const int has_tail = (kv_last < 64 && t1 == p.KB * kt_per) ? 1 : 0;
+    const int has_tail = (kv_last < 64 && t1 == P.KB * kt_per) ? 1 : 0;
     // (K batches without a K tail are steady too: the in-section issue carries the cursor wrap)
-    const int n_steady = (kv_last == 64 || p.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
+    const int n_steady = (kv_last == 64 || P.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
     int t = 0;
     for (; t < n_steady; t += 2) {
       k_step(I0{}, std::true_type{}, t);
@@ -421,7 +442,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int mm = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (mm < p.M && nn < p.N) gemm_store(p, z, split, mm, nn, a[j][r]);
+          if (mm < P.M && nn < P.N) gemm_store(P, z, split, mm, nn, a[j][r]);
         }
       }
     };
@@ -452,12 +473,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
         const int rl = id >> 3, ch = id & 7;
         const int mm = mw + i * 32 + rl;
         const int nn = nw + ch * 8;
-        if (mm < p.M && nn < p.N) {
+        if (mm < P.M && nn < P.N) {
           const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
           const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          if constexpr (EP == 1) gemm_store8(p, zo, zi, z, split, mm, nn, v);
-          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(p, zo, zi, mm, nn, v);
+          if constexpr (EP == 1) gemm_store8(P, zo, zi, z, split, mm, nn, v);
+          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(P, zo, zi, mm, nn, v);
         }
       }
     }
@@ -466,7 +487,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 #if PP_PROBE & 64
   if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    unsigned long long* o = (unsigned long long*)p.C + 2048 + (threadIdx.x >> 8) * 16;
+    unsigned long long* o = (unsigned long long*)P.C + 2048 + (threadIdx.x >> 8) * 16;
     for (int i = 0; i < 16; ++i) o[i] = ts[i];
   }
 #endif
@@ -506,6 +527,21 @@ static int pp_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
     WL_LAUNCH((gemm_pp_kernel<TA, TB, E>), grid, dim3(512), smem, st, p); } break;
   switch (ep) { PP_CASE(0) PP_CASE(1) PP_CASE(2) PP_CASE(3) default: PP_CASE(4) }
 #undef PP_CASE
+  return wl_check_launch();
+}
+
+// Grouped split-K launch of K-strided x K-strided problems (p.grp / p.ngrp / p.vtotal / p.split_k filled by the caller):
+// every tile writes its fp32 slab, the caller reduces per problem.
+int gemm_pp_launch_grouped(GemmP& p, hipStream_t st) {
+  constexpr int smem = 2 * PP_STAGE;
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)gemm_pp_kernel<true, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return WL_ELAUNCH;
+    done = true;
+  }
+  p.patch_m = 0; p.skew = 0; p.nbatch = 1;
+  dim3 grid((unsigned)(p.vtotal < 256 ? p.vtotal : 256), 1, 1);
+  WL_LAUNCH((gemm_pp_kernel<true, true, 1, true>), grid, dim3(512), smem, st, p);
   return wl_check_launch();
 }
 

@@ -79,7 +79,11 @@ class GradReducer:
             self._launch(b)
 
     def _make_hook(self, idx):
-        def hook(_p):
+        from . import functional
+
+        def hook(p):
+            if functional.grad_write_deferred(p.grad):
+                return  # its weight gradient is queued for a grouped launch; the sink notification will mark it
             self._mark(idx)
         return hook
 
@@ -125,6 +129,8 @@ class GradReducer:
         ranks afterwards; multiply by `self.scale` (1/world) for the average."""
         if not self.enabled:
             return
+        from . import functional
+        functional.flush_wgrad_groups()
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)

@@ -5,6 +5,8 @@ tensors (cat / permute / contiguous of weights) and scalar bookkeeping.
 
 Layout: activations are channel-last [B, T, C]; the reference's [T, B, C] tensors are transposed views of these.
 """
+import os
+
 import torch
 
 from . import ops
@@ -24,7 +26,12 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
-SINK_LISTENERS = []  # callables(tensor): told which arena slice a backward kernel has just accumulated into (dp.GradReducer)
+SINK_LISTENERS = []
+# Grouped weight-gradient launches (WgradGroup) are OFF by default: measured on one box, same build, 12 grouped launches
+# of 425 us against 48 single ones of ~100 us each (401 us per layer) -- the K loop of the K-strided form runs at
+# ~2.1 us per step either way and 108 tiles x split 2 fill only 216 of 256 CUs; what the grouping saves in slab
+# reduction (0.78 -> 0.41 ms) it loses there.  Kept (and tested) for shapes where the single launches quantise badly.
+WGRAD_GROUPING = os.environ.get("WAVLM_WGRAD_GROUPING", "0") == "1"  # callables(tensor): told which arena slice a backward kernel has just accumulated into (dp.GradReducer)
 
 
 def h2d(a, dev):
@@ -109,6 +116,59 @@ def _linear_bwd_w(dy2d, x2d, w_dtype, out=None):
     return dW
 
 
+class WgradGroup:
+    """Weight gradients of one encoder layer collected during its backward and issued as ONE grouped split-K launch
+    (ops.gemm_wgrad_grouped): the four dW of a layer share the reduction length B*T, and alone each needs a split of
+    7-28 to fill the GPU (fp32 slabs, short K loops).  Members are added by `_param_grads` in backward order; the group
+    fires when `expected` members have arrived, and `flush_wgrad_groups()` (optimizer step / reducer finish) fires
+    whatever is left, so a member that never receives a gradient cannot strand the others."""
+    __slots__ = ("expected", "items", "sinks", "fired")
+    pending = []
+    deferred = set()  # data_ptr of every sink slice whose accumulation is queued but not yet enqueued on the stream
+
+    def __init__(self, expected):
+        self.expected, self.items, self.sinks, self.fired = expected, [], [], False
+
+    def add(self, dy2d, x2d, sink_view, sink):
+        if not self.items:
+            if not WgradGroup.pending:  # first deferred member of this backward pass: make sure the pass ends flushed
+                torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_groups)
+            WgradGroup.pending.append(self)
+        self.items.append((dy2d, x2d, sink_view))
+        self.sinks.append(sink)
+        WgradGroup.deferred.add(sink.data_ptr())
+        if len(self.items) >= self.expected:
+            self.fire()
+
+    def fire(self):
+        if self.fired or not self.items:
+            return
+        self.fired = True
+        if self in WgradGroup.pending:
+            WgradGroup.pending.remove(self)
+        if len(self.items) == 1:
+            dy2d, x2d, out = self.items[0]
+            _linear_bwd_w(dy2d, x2d, out.dtype, out=out)
+        else:
+            ops.gemm_wgrad_grouped(self.items, self.items[0][2].dtype)
+        for sk in self.sinks:
+            WgradGroup.deferred.discard(sk.data_ptr())
+            _sink_written(sk)
+        self.items, self.sinks = [], []
+
+
+def grad_write_deferred(grad_view):
+    """True while the accumulation into this gradient slice is still queued in a WgradGroup: autograd's
+    post-accumulate hook of the parameter fires when the linear's backward returns (with an undefined gradient), which
+    is BEFORE the grouped launch -- the data-parallel reducer must not count the parameter as ready on that hook."""
+    return grad_view is not None and grad_view.data_ptr() in WgradGroup.deferred
+
+
+def flush_wgrad_groups():
+    for g in list(WgradGroup.pending):
+        g.fire()
+
+
 class BiasGradToken:
     """Hand-over of a bias gradient from the nn.Linear that owns the bias to the LayerNorm that consumes the linear's
     output as its residual branch: the LayerNorm backward already reduces dgamma / dbeta over rows, and the column sums
@@ -121,13 +181,15 @@ class BiasGradToken:
         self.param, self.taken = param, False
 
 
-def _param_grads(dy2d, x2d, W, b, has_bias, need_w, need_b, sink_w=None, sink_b=None, bias_tok=None):
+def _param_grads(dy2d, x2d, W, b, has_bias, need_w, need_b, sink_w=None, sink_b=None, bias_tok=None, wgroup=None):
     """(dW, db) for a linear layer; a parameter with a gradient sink gets its gradient accumulated in place -> None"""
     if bias_tok is not None and bias_tok.taken:
         has_bias = False  # accumulated by the consuming LayerNorm's backward
     dW = db = None
     sw = sink_w if sink_w is not None else _sink(W)
-    if sw is not None:
+    if sw is not None and wgroup is not None and WGRAD_GROUPING and dy2d.dtype == torch.bfloat16:
+        wgroup.add(dy2d, x2d, sw.view(W.shape), sw)  # deferred: issued with the layer's other weight gradients
+    elif sw is not None:
         _linear_bwd_w(dy2d, x2d, W.dtype, out=sw.view(W.shape))
         _sink_written(sw)
     elif need_w:
@@ -147,7 +209,7 @@ class LinearFn(torch.autograd.Function):
     sink_w / sink_b: explicit gradient sinks for W / b given as plain views (packed q|k|v projections)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, sink_w=None, sink_b=None, bias_tok=None):
+    def forward(ctx, x, W, b, sink_w=None, sink_b=None, bias_tok=None, wgroup=None):
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
@@ -155,6 +217,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, W, b)
         ctx.sinks = (sink_w, sink_b)
         ctx.bias_tok = bias_tok
+        ctx.wgroup = wgroup
         if ctx.needs_input_grad[1]:  # (all False under no_grad: no backward will match the use)
             _sink_use(W, sink_w)
             if b is not None:
@@ -172,8 +235,8 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _linear_bwd_x(dy2d, W).view(ctx.xshape)
         dW, db = _param_grads(dy2d, x2d, W, b, b is not None, ctx.needs_input_grad[1], ctx.needs_input_grad[2],
-                              ctx.sinks[0], ctx.sinks[1], ctx.bias_tok)
-        return dx, dW, db, None, None, None
+                              ctx.sinks[0], ctx.sinks[1], ctx.bias_tok, ctx.wgroup)
+        return dx, dW, db, None, None, None, None
 
 
 class FFNFn(torch.autograd.Function):
@@ -182,7 +245,7 @@ class FFNFn(torch.autograd.Function):
     input-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, p_act, seed, b2_tok=None):
+    def forward(ctx, x, W1, b1, W2, b2, p_act, seed, b2_tok=None, wgroup=None):
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
@@ -201,6 +264,7 @@ class FFNFn(torch.autograd.Function):
                     _sink_use(t)
         ctx.p_act, ctx.seed, ctx.xshape = p_act, seed, x.shape
         ctx.b2_tok = b2_tok
+        ctx.wgroup = wgroup
         return y.view(*x.shape[:-1], W2.shape[0])
 
     @staticmethod
@@ -209,7 +273,7 @@ class FFNFn(torch.autograd.Function):
         dy2d = dy.reshape(-1, dy.shape[-1])
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
-        dW2, db2 = _param_grads(dy2d, hd, W2, b2, b2 is not None, True, True, bias_tok=ctx.b2_tok)
+        dW2, db2 = _param_grads(dy2d, hd, W2, b2, b2 is not None, True, True, bias_tok=ctx.b2_tok, wgroup=ctx.wgroup)
         if ctx.p_act > 0:
             dh = _linear_bwd_x(dy2d, W2)
             dh = ops.dropout(dh, ctx.p_act, ctx.seed)
@@ -218,9 +282,9 @@ class FFNFn(torch.autograd.Function):
             du = du.view(n, F)
         else:
             du = _linear_bwd_x(dy2d, W2, epi=4, aux=u)
-        dW1, db1 = _param_grads(du, x2d, W1, b1, b1 is not None, True, True)
+        dW1, db1 = _param_grads(du, x2d, W1, b1, b1 is not None, True, True, wgroup=ctx.wgroup)
         dx = _linear_bwd_x(du, W1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        return dx, dW1, db1, dW2, db2, None, None, None
+        return dx, dW1, db1, dW2, db2, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------- LayerNorm

@@ -97,6 +97,39 @@ def gemm(A, B, Cc, M, N, K, *, lda, ldb, ldc, transA=False, transB=False, KB=1, 
     check(L.wavlm_gemm(C.byref(d), stream()), "wavlm_gemm[M=%d N=%d K=%d KB=%d tA=%d tB=%d]" % (M, N, K, KB, transA, transB))
 
 
+def gemm_wgrad_grouped(items, w_dtype):
+    """The weight gradients dW_i[N_i, K_i] (+)= dy_i[n, N_i]^T @ x_i[n, K_i] of several linears that share the row count
+    n, as one grouped split-K launch (wavlm_gemm_grouped).  items: [(dy2d, x2d, out)] with `out` accumulated into."""
+    dev = _dev(items[0][0])
+    n = items[0][0].shape[0]
+    tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in items)
+    split = max(2, min(256 // max(tiles, 1), ((n + 63) // 64) // 8, 64))
+    L = _lib.lib()
+    descs = (GemmDesc * len(items))()
+    need = []
+    for d, (dy, x, out) in zip(descs, items):
+        if dy.shape[0] != n or x.shape[0] != n:
+            raise ValueError("grouped weight gradients need a common row count")
+        _contig(dy); _contig(x); _contig(out)
+        N, K = dy.shape[1], x.shape[1]
+        d.dtype, d.c_dtype = dt(dy), dt(out)
+        d.M, d.N, d.K, d.KB = N, K, n, 1
+        d.transA, d.transB = 1, 1
+        d.lda, d.ldb, d.ldc = N, K, K
+        d.batch_o, d.batch_i = 1, 1
+        d.A, d.B, d.C = ptr(dy), ptr(x), ptr(out)
+        d.alpha, d.epi = 1.0, 0
+        d.accumulate = 1
+        d.split_k = split
+        need.append((int(L.wavlm_gemm_workspace_bytes(C.byref(d))) + 255) // 256 * 256)
+    ws = workspace(dev, sum(need), "gemm")
+    off = 0
+    for d, nb in zip(descs, need):
+        d.workspace, d.ws_bytes = ptr(ws, off), nb
+        off += nb
+    check(L.wavlm_gemm_grouped(descs, len(items), stream()), "wavlm_gemm_grouped[%d]" % len(items))
+
+
 def pick_split(M, N, ktiles, nbatch=1, target_blocks=768):
     """split-K factor so that a small-output / long-reduction GEMM still fills 256 CUs.  Problems the 256 x 256
     ping-pong kernel takes (one block per CU) aim at one full round of 256 blocks; the 128-wide kernel (two to three

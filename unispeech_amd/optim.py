@@ -91,6 +91,8 @@ class FusedAdam:
 
     def step(self, grad_mult=1.0, grad_mult_dev=None):
         """grads are used as grad * grad_mult (* grad_mult_dev[0]); clipping uses the norm of the scaled gradient"""
+        from . import functional
+        functional.flush_wgrad_groups()  # normally empty: groups fire during backward / at its end
         self.step_count += 1
         ops.sumsq(self.flat_grad, 1.0, out=self.gnorm_sq)
         ops.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.flat_grad,

@@ -221,7 +221,7 @@ class MultiheadAttention(nn.Module):
             cache[key] = bucket
         return F.RelPosTableFn.apply(self.relative_attention_bias.weight, bucket)
 
-    def forward(self, x, key_padding_u8=None, position_table=None, out_bias_tok=None):
+    def forward(self, x, key_padding_u8=None, position_table=None, out_bias_tok=None, wgroup=None):
         """x [B, T, D] -> (attn_out [B, T, D], position_table)"""
         B, T, D = x.shape
         if self.has_relative_attention_bias and position_table is None:
@@ -236,7 +236,7 @@ class MultiheadAttention(nn.Module):
         if (pk is not None and torch.is_grad_enabled() and pk[0].data_ptr() == self.q_proj.weight.data_ptr()
                 and pk[2].data_ptr() == self.q_proj.bias.data_ptr() and pk[0].dtype == x.dtype):
             # optimizer-bound packed views of q|k|v (no concatenation; the gradient lands packed in the arena)
-            qkv = F.LinearFn.apply(x, pk[0], pk[2], pk[1], pk[3])
+            qkv = F.LinearFn.apply(x, pk[0], pk[2], pk[1], pk[3], None, wgroup)
         else:
             w = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
             b = torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0)
@@ -244,7 +244,7 @@ class MultiheadAttention(nn.Module):
         p = self.dropout_module.p if self.training else 0.0
         o = F.AttnCoreFn.apply(qkv, gate, position_table, key_padding_u8, self.num_heads, self.scaling, p,
                                F.next_seed() if p > 0 else 0)
-        out = F.LinearFn.apply(o, self.out_proj.weight, self.out_proj.bias, None, None, out_bias_tok)
+        out = F.LinearFn.apply(o, self.out_proj.weight, self.out_proj.bias, None, None, out_bias_tok, wgroup)
         return out, position_table
 
 
@@ -291,30 +291,38 @@ class TransformerSentenceEncoderLayer(nn.Module):
         self.fc2 = nn.Linear(ffn_embedding_dim, embedding_dim)
         self.final_layer_norm = nn.LayerNorm(embedding_dim)
 
-    def _ffn(self, x, b2_tok=None):
+    def _ffn(self, x, b2_tok=None, wgroup=None):
         p = self.activation_dropout if self.training else 0.0
         return F.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p,
-                             F.next_seed() if p > 0 else 0, b2_tok)
+                             F.next_seed() if p > 0 else 0, b2_tok, wgroup)
+
+    def _wgrad_group(self):
+        """the layer's weight gradients (q|k|v packed, out_proj, fc1, fc2) as one grouped launch in backward"""
+        if not torch.is_grad_enabled():
+            return None
+        return F.WgradGroup(4 if self.self_attn._packed is not None else 3)
 
     def forward(self, x, key_padding_u8=None, position_table=None):
         ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
         p = self.dropout if self.training else 0.0
         if self.layer_norm_first:
+            wg = self._wgrad_group()
             h, _ = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps)
-            a, position_table = self.self_attn(h, key_padding_u8, position_table)
+            a, position_table = self.self_attn(h, key_padding_u8, position_table, wgroup=wg)
             x = ResidualAddFn.apply(x, a, p, F.next_seed() if p > 0 else 0)
             h, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps)
-            f = self._ffn(h)
+            f = self._ffn(h, wgroup=wg)
             x = ResidualAddFn.apply(x, f, p, F.next_seed() if p > 0 else 0)
         else:
             # post-LN: the LayerNorm that follows a sub-layer also delivers the bias gradient of its last linear
             grad = torch.is_grad_enabled()
+            wg = self._wgrad_group()
             ta = F.BiasGradToken(self.self_attn.out_proj.bias) if grad else None
-            a, position_table = self.self_attn(x, key_padding_u8, position_table, out_bias_tok=ta)
+            a, position_table = self.self_attn(x, key_padding_u8, position_table, out_bias_tok=ta, wgroup=wg)
             x, _ = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps, residual=a, p_in=p, training=self.training,
                                 residual_bias_tok=ta)
             tf = F.BiasGradToken(self.fc2.bias) if grad else None
-            f = self._ffn(x, tf)
+            f = self._ffn(x, tf, wg)
             x, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps, residual=f, p_in=p, training=self.training,
                                 residual_bias_tok=tf)
         return x, None, position_table
