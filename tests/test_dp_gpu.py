@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, grouped):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,6 +35,7 @@ def _worker(rank, world, port, q):
         torch.cuda.set_device(0)
         import numpy as np
         import unispeech_amd.functional as F
+        F.WGRAD_GROUPING = grouped  # grouped: weight gradients are queued and written later than autograd's hooks fire
         from unispeech_amd.dp import DataParallelWavLM
         from unispeech_amd.optim import FusedAdam
         from unispeech_amd.pretrain import WavLMPretrainConfig, WavLMPretrainModel, WavLMCriterion
@@ -89,11 +90,12 @@ def _worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_dp_world2_sink_gradients_sum_over_ranks():
+@pytest.mark.parametrize("grouped", [False, True])
+def test_dp_world2_sink_gradients_sum_over_ranks(grouped):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, grouped)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

@@ -223,8 +223,10 @@ def test_gradient_sink_matches_autograd_accumulation():
     target = torch.randint(4, 504, (B, 100), generator=g).cuda()
     sample = {"id": torch.arange(B), "net_input": {"source": wav, "padding_mask": torch.zeros(B, T, dtype=torch.bool).cuda()},
               "target_list": [target]}
+    import unispeech_amd.functional as F
     grads = []
-    for use_opt in (False, True):
+    for use_opt, grouped in ((False, False), (True, False), (True, True)):  # grouped: one launch for a layer's weight gradients
+        F.WGRAD_GROUPING = grouped
         model, _sd, _cfg, crit = _base_models(2)
         model = model.cuda().to(torch.bfloat16).train()
         opt = FusedAdam(model.parameters(), model=model) if use_opt else None
@@ -240,11 +242,13 @@ def test_gradient_sink_matches_autograd_accumulation():
             loss, _, _ = crit(model, sample)
             loss.backward()
         grads.append({n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
-    a, b = grads
-    assert a.keys() == b.keys()
-    for n in a:
-        scale = a[n].abs().max().clamp_min(1e-6)
-        assert ((a[n] - b[n]).abs().max() / scale).item() < 2e-2, n
+    F.WGRAD_GROUPING = False
+    a = grads[0]
+    for b in grads[1:]:
+        assert a.keys() == b.keys()
+        for n in a:
+            scale = a[n].abs().max().clamp_min(1e-6)
+            assert ((a[n] - b[n]).abs().max() / scale).item() < 2e-2, n
 
 
 def test_large_structure_vs_reference_golden():
