@@ -73,7 +73,7 @@ SIGNATURES = {
                                c_vp]),
     "wavlm_gate_bwd_workspace_bytes": (c_u64, [c_i32, c_i32]),
     "wavlm_gate_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
-                               c_i32, c_i32, c_vp, c_u64, c_vp]),
+                               c_i32, c_i32, c_i32, c_vp, c_u64, c_vp]),
     "wavlm_attn_softmax_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32,
                                        c_i32, c_f32, c_u64, c_vp]),
     "wavlm_attn_softmax_bwd_workspace_bytes": (c_u64, [c_i32, c_i32, c_i32]),
@@ -131,7 +131,7 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if h.wavlm_abi_version() != 2:
+        if h.wavlm_abi_version() != 3:
             raise WavlmHipError("libwavlm_hip.so ABI version mismatch")
         _lib = h
     return _lib

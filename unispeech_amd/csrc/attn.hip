@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 // dW[8][hd], dbias[8], dgrep_a[H] from the block partials.  Pure load latency: 16 outputs x 64 row slices per block
 // (nblk / 64 loads per thread, four in flight), grid = ceil(PW / 16) -- one block looping over all partials took 33 us.
 __global__ __launch_bounds__(1024) void gate_bwd_finish_kernel(const float* __restrict__ part, int nblk, int H, int hd,
-    void* dW, void* dbias, void* da, int pdt) {
+    void* dW, void* dbias, void* da, int pdt, int accumulate) {
   __shared__ float red[64][17];
   const int PW = 2 * hd + 2 + H;
   const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
@@ -517,11 +517,13 @@ __global__ __launch_bounds__(1024) void gate_bwd_finish_kernel(const float* __re
   __syncthreads();
   if (slice == 0 && i < PW) {
     s = (red[0][col] + red[16][col]) + (red[32][col] + red[48][col]);
-    if (i < hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)k * hd + i, pdt, s); }
-    else if (i < 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dW, (long)(4 + k) * hd + (i - hd), pdt, s); }
-    else if (i == 2 * hd) { for (int k = 0; k < 4; ++k) st_elem(dbias, k, pdt, s); }
-    else if (i == 2 * hd + 1) { for (int k = 0; k < 4; ++k) st_elem(dbias, 4 + k, pdt, s); }
-    else st_elem(da, i - (2 * hd + 2), pdt, s);
+    // accumulate: the outputs are gradient-sink slices (+=)
+    auto put = [&](void* dst, long idx) { st_elem(dst, idx, pdt, accumulate ? s + ld_elem(dst, idx, pdt) : s); };
+    if (i < hd) { for (int k = 0; k < 4; ++k) put(dW, (long)k * hd + i); }
+    else if (i < 2 * hd) { for (int k = 0; k < 4; ++k) put(dW, (long)(4 + k) * hd + (i - hd)); }
+    else if (i == 2 * hd) { for (int k = 0; k < 4; ++k) put(dbias, k); }
+    else if (i == 2 * hd + 1) { for (int k = 0; k < 4; ++k) put(dbias, 4 + k); }
+    else put(da, i - (2 * hd + 2));
   }
 }
 
@@ -617,7 +619,8 @@ uint64_t wavlm_gate_bwd_workspace_bytes(int32_t H, int32_t hd) {
 
 int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void* grep_a, const float* ga,
                    const float* gb, void* dx, void* dW, void* dbias, void* dgrep_a, int32_t B, int32_t T, int32_t H,
-                   int32_t hd, int32_t dtype, int32_t param_dtype, void* workspace, uint64_t ws_bytes, void* stream) {
+                   int32_t hd, int32_t dtype, int32_t param_dtype, int32_t accumulate_params, void* workspace,
+                   uint64_t ws_bytes, void* stream) {
   if (!dgate || !x || !W || !grep_a || !ga || !gb || !dx || !dW || !dbias || !dgrep_a || !workspace) return WL_EINVAL;
   if (B <= 0 || T <= 0 || H <= 0 || H > 64 || hd <= 0 || hd > 64 * GATE_NC || ws_bytes < wavlm_gate_bwd_workspace_bytes(H, hd)) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -636,7 +639,7 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   WL_LAUNCH(gate_bwd_finish_kernel, dim3((unsigned)((2 * hd + 2 + H + 15) / 16)), dim3(1024), 0, st, (const float*)workspace,
-                     (int)grid, (int)H, (int)hd, dW, dbias, dgrep_a, (int)param_dtype);
+                     (int)grid, (int)H, (int)hd, dW, dbias, dgrep_a, (int)param_dtype, (int)accumulate_params);
   return wl_check_launch();
 }
 

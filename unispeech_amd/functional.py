@@ -310,10 +310,13 @@ class LayerNormFn(torch.autograd.Function):
             _sink_use(beta)
         s_out = s.detach()
         ctx.mark_non_differentiable(s_out)
+        ctx.set_materialize_grads(False)  # no zero-filled [rows, D] gradient for the second output
         return y, s_out
 
     @staticmethod
     def backward(ctx, dy, _ds):
+        if dy is None:
+            return (None,) * 12
         s, mean, rstd, gamma, beta = ctx.saved_tensors
         act, p_in, seed_in, p_out, seed_out, grad_scale, has_r = ctx.cfg
         sg, sb = _sink(gamma), _sink(beta)
@@ -563,13 +566,23 @@ class GateFn(torch.autograd.Function):
         gate, ga, gb = ops.gate_fwd(xc, W.contiguous(), bias.contiguous(), a, H)
         ctx.save_for_backward(xc, W, bias, grep_a, ga, gb)
         ctx.H = H
+        if ctx.needs_input_grad[1]:
+            for t in (W, bias, grep_a):
+                _sink_use(t)
         return gate
 
     @staticmethod
     def backward(ctx, dgate):
         xc, W, bias, grep_a, ga, gb = ctx.saved_tensors
+        sinks = (_sink(W), _sink(bias), _sink(grep_a))
+        if any(t is None for t in sinks) or not (W.is_contiguous() and grep_a.is_contiguous()):
+            sinks = None
         dx, dW, dbias, da = ops.gate_bwd(dgate.contiguous(), xc, W.contiguous(), bias, grep_a.contiguous().view(-1),
-                                         ga, gb, ctx.H)
+                                         ga, gb, ctx.H, sinks=None if sinks is None else tuple(t.view(-1) for t in sinks))
+        if sinks is not None:
+            for t in sinks:
+                _sink_written(t)
+            return dx, None, None, None, None
         return dx, dW, dbias, da.view_as(grep_a), None
 
 

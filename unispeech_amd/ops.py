@@ -367,19 +367,26 @@ def gate_fwd(x, W, bias, grep_a, H):
     return gate, ga, gb
 
 
-def gate_bwd(dgate, x, W, bias, grep_a, ga, gb, H):
+def gate_bwd(dgate, x, W, bias, grep_a, ga, gb, H, sinks=None):
+    """returns (dx, dW, dbias, da); sinks = (dW, dbias, da) gradient-sink views -> accumulated in place, returned as None"""
     dev = _dev(x)
     B, T, D = x.shape
     hd = D // H
     dx = torch.empty_like(x)
-    dW = torch.empty_like(W)
-    dbias = torch.empty_like(bias)
-    da = torch.empty_like(grep_a)
+    if sinks is not None:
+        dW, dbias, da = sinks
+    else:
+        dW = torch.empty_like(W)
+        dbias = torch.empty_like(bias)
+        da = torch.empty_like(grep_a)
     L = _lib.lib()
     need = L.wavlm_gate_bwd_workspace_bytes(H, hd)
     ws = workspace(dev, need)
     check(L.wavlm_gate_bwd(ptr(dgate), ptr(x), ptr(W), ptr(grep_a), ptr(ga), ptr(gb), ptr(dx), ptr(dW), ptr(dbias),
-                           ptr(da), B, T, H, hd, dt(x), dt(W), ptr(ws), need, stream()), "wavlm_gate_bwd")
+                           ptr(da), B, T, H, hd, dt(x), dt(W), int(sinks is not None), ptr(ws), need, stream()),
+          "wavlm_gate_bwd")
+    if sinks is not None:
+        return dx, None, None, None
     return dx, dW, dbias, da
 
 
