@@ -184,6 +184,7 @@ def main():
         for _ in range(2):
             step()
         n_l, ms, fl = ops.prof_collect(1)
+        alg_bytes = ops.prof_collect_bytes(1)
         ops.prof_enable(False)
         if ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
@@ -202,7 +203,7 @@ def main():
                     "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (avg over the step's GEMM launches, PMC)",
-                    "algorithmic_bytes_per_launch": None,
+                    "algorithmic_bytes_per_launch": round(alg_bytes / max(n_l, 1)),
                     "launches_per_step": n_l // 2, "gemm_ms_per_step": round(ms / 2, 3),
                     "gemm_algorithmic_tflop_per_step": round(fl / 2 / 1e12, 3),
                     "avg_launch_us": round(ms / max(n_l, 1) * 1e3, 2)}

@@ -248,6 +248,8 @@ void wavlm_prof_enable(int on);
 /* 0: automatic tile choice, 1: force the 128x128 tile (A/B measurements only) */
 void wavlm_gemm_set_variant(int v);
 int wavlm_prof_collect(int dtype, double* total_ms, double* total_flops);
+/* algorithmic HBM bytes of the recorded launches: every operand, output and epilogue tensor counted once */
+double wavlm_prof_collect_bytes(int dtype);
 
 #ifdef __cplusplus
 }

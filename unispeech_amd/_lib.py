@@ -105,6 +105,7 @@ SIGNATURES = {
     "wavlm_prof_enable": (None, [c_i32]),
     "wavlm_gemm_set_variant": (None, [c_i32]),
     "wavlm_prof_collect": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "wavlm_prof_collect_bytes": (C.c_double, [c_i32]),
 }
 
 _ERR = {-1: "invalid argument", -2: "kernel launch failure", -3: "out of memory"}

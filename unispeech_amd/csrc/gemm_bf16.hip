@@ -292,6 +292,7 @@ static struct {
   int enabled, n;
   hipEvent_t ev0[PROF_MAX], ev1[PROF_MAX];
   double flops[PROF_MAX];
+  double bytes[PROF_MAX];  // algorithmic HBM bytes: each operand / output / epilogue tensor touched once
   int dtype[PROF_MAX];
   int created;
 } g_prof;
@@ -305,6 +306,15 @@ static int prof_begin(const wavlm_gemm_desc* d, hipStream_t st) {
   }
   const double nb = (double)(d->batch_o < 1 ? 1 : d->batch_o) * (d->batch_i < 1 ? 1 : d->batch_i);
   g_prof.flops[i] = 2.0 * d->M * d->N * (double)d->K * (d->KB < 1 ? 1 : d->KB) * nb;
+  {
+    const double es = d->dtype == WL_BF16 ? 2.0 : 4.0, cs = d->c_dtype == WL_BF16 ? 2.0 : 4.0;
+    const double kb = d->KB < 1 ? 1 : d->KB, mn = (double)d->M * d->N;
+    // overlapping-row operands (lda < K: strided conv) are counted once per stored element, not once per use
+    const double a_el = (!d->transA && d->lda < d->K) ? (double)d->M * d->lda : (double)d->M * d->K * kb;
+    const double b_el = (double)d->N * d->K * kb;
+    g_prof.bytes[i] = nb * (a_el * es + mn * cs * (d->accumulate ? 2.0 : 1.0) + (d->aux ? mn * 2.0 : 0.0) + (d->res ? mn * 2.0 : 0.0)) +
+                      ((d->sB_o || d->sB_i) ? nb : 1.0) * b_el * es;
+  }
   g_prof.dtype[i] = d->dtype;
   hipEventRecord(g_prof.ev0[i], st);
   return i;
@@ -331,6 +341,13 @@ extern "C" int wavlm_prof_collect(int dtype, double* total_ms, double* total_flo
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   return cnt;
+}
+// algorithmic HBM bytes of the same launches (no synchronisation)
+extern "C" double wavlm_prof_collect_bytes(int dtype) {
+  double by = 0.0;
+  for (int i = 0; i < g_prof.n; ++i)
+    if (dtype < 0 || g_prof.dtype[i] == dtype) by += g_prof.bytes[i];
+  return by;
 }
 
 extern "C" uint64_t wavlm_gemm_workspace_bytes(const wavlm_gemm_desc* d) {
@@ -423,7 +440,12 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
   }
   p.vtotal = vb;
   const int pi = prof_begin(d, st);
-  if (pi >= 0) g_prof.flops[pi] = flops;
+  if (pi >= 0) {
+    g_prof.flops[pi] = flops;
+    double by = 0.0;
+    for (int i = 0; i < n; ++i) by += 2.0 * ((double)d[i].M * d[i].K + (double)d[i].N * d[i].K) + 2.0 * 2.0 * d[i].M * d[i].N;
+    g_prof.bytes[pi] = by;
+  }
   int rc = gemm_pp_launch_grouped(p, st);
   for (int i = 0; rc == WL_OK && i < n; ++i) {
     GemmP pr = make_gemm_params(d + i);

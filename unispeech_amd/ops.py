@@ -535,6 +535,11 @@ def prof_collect(dtype=-1):
     return n, ms.value, fl.value
 
 
+def prof_collect_bytes(dtype=-1):
+    """algorithmic HBM bytes (each operand / output / epilogue tensor once) of the launches prof_collect reports"""
+    return float(_lib.lib().wavlm_prof_collect_bytes(int(dtype)))
+
+
 # ------------------------------------------------------------------------- sampled-instance cosine head
 def gather_dot(X, Y, idx, scale, mask_equal=False):
     """out[s, n] = scale * <X[s], Y[idx[s, n]]>  (rows [., D], idx: int32 [S, N]); mask_equal: columns n >= 1 whose
