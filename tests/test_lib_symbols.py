@@ -28,7 +28,7 @@ def test_header_symbols_exported_and_bound():
         assert n in _lib.SIGNATURES, "no ctypes signature for " + n
     for n in _lib.SIGNATURES:
         assert n in names, "bound but not declared in the header: " + n
-    assert _lib.lib().wavlm_abi_version() == 3
+    assert _lib.lib().wavlm_abi_version() == _lib.ABI_VERSION
 
 
 def test_gemm_desc_layout_matches_header():
