@@ -212,6 +212,27 @@ def check_gemm_pp3():
     return check_gemm_pp(4, "gemm_pp3")
 
 
+def check_gemm_race():
+    """the same ping-pong launch repeated gives bit-identical output (an LDS hazard between the asynchronous operand DMA
+    and the fragment reads would show as run-to-run differences); step-sized shapes, both tile shapes, split-K"""
+    out = []
+    n = 32 * 749
+    for name, M, N, K, tA, tB, split in [("192x384 NN", n, 2304, 768, 0, 0, 1), ("256x256 NN", n, 2048, 768, 0, 0, 1),
+                                          ("256x256 TT split 7", 3072, 768, n, 1, 1, 7), ("192x384 NT", n, 768, 3072, 0, 1, 1)]:
+        A = q(gen(*((K, M) if tA else (M, K)), seed=91), torch.bfloat16).to(torch.bfloat16).to(DEV)
+        B = q(gen(*((K, N) if tB else (N, K)), seed=92), torch.bfloat16).to(torch.bfloat16).to(DEV)
+        C0, diff = None, 0
+        for _ in range(8):
+            C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+            ops.gemm(A, B, C, M, N, K, lda=M if tA else K, ldb=N if tB else K, ldc=N, transA=tA, transB=tB, split_k=split)
+            if C0 is None:
+                C0 = C
+            else:
+                diff += int((C.view(torch.int16) != C0.view(torch.int16)).sum().item())
+        out.append((f"gemm_race {name} {M}x{N}x{K}: differing elements over 8 launches", float(diff), 0.0))
+    return out
+
+
 def check_gemm_grouped():
     """wavlm_gemm_grouped: weight gradients of several linears over the same rows in one grouped split-K launch,
     accumulated into existing (non-zero) outputs; ragged rows (K tail), ragged M/N tiles, 2-4 members; plus a group the
@@ -692,7 +713,7 @@ def check_adam():
 
 
 GROUPS = {
-    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_grouped": check_gemm_grouped, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
+    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
     "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv,
     "linear_ffn": check_linear_ffn, "loss": check_loss, "adam": check_adam,
 }
