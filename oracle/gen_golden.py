@@ -174,10 +174,13 @@ class _Dict:
         return self.n
 
 
-def gen_tiny_pretrain():
+def gen_tiny_pretrain(overrides=None, fname="tiny_pretrain.npz"):
+    """overrides + fname: variants of the same run (gen_tiny_chanmask: channel masking on top of the time mask)"""
     WavLMModel, WavLMConfig, WavLMCriterion, _, _ = ref_shim.fairseq_wavlm()
     cfg = WavLMConfig()
     for k, v in TINY.items():
+        setattr(cfg, k, v)
+    for k, v in (overrides or {}).items():
         setattr(cfg, k, v)
     cfg.label_rate = 50
     cfg.final_dim = 32
@@ -222,9 +225,21 @@ def gen_tiny_pretrain():
     m = compute_mask_indices((2, T), torch.zeros(2, T, dtype=torch.bool), cfg.mask_prob, cfg.mask_length,
                              cfg.mask_selection, cfg.mask_other, min_masks=2, no_overlap=False, min_space=1)
     out["out/mask_seed123"] = m
+    if cfg.mask_channel_prob > 0:
+        # the channel mask is drawn right after the time mask from the same numpy stream (wavlm.py:405-422)
+        C = cfg.encoder_embed_dim
+        out["out/chan_mask_seed123"] = compute_mask_indices((2, C), None, cfg.mask_channel_prob, cfg.mask_channel_length,
+                                                            cfg.mask_channel_selection, cfg.mask_channel_other,
+                                                            no_overlap=cfg.no_mask_channel_overlap,
+                                                            min_space=cfg.mask_channel_min_space)
     for n, p in model.named_parameters():
         out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
-    np.savez_compressed(os.path.join(OUT, "tiny_pretrain.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def gen_tiny_chanmask():
+    """tiny_pretrain with mask_channel_prob 0.25 / mask_channel_length 4 (apply_mask's second half, wavlm.py:405-422)"""
+    gen_tiny_pretrain({"mask_channel_prob": 0.25, "mask_channel_length": 4}, "tiny_chanmask.npz")
 
 
 def gen_tiny_sat():
@@ -365,6 +380,7 @@ if __name__ == "__main__":
     gen_buckets()
     gen_tiny_wavlm()
     gen_tiny_pretrain()
+    gen_tiny_chanmask()
     gen_tiny_large()
     gen_tiny_sat()
     gen_tiny_ils()

@@ -232,8 +232,9 @@ def compute_nce(x, pos, negs, logit_temp):
     return logits.transpose(0, 1)
 
 
-def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, num_classes):
-    """WavLMModel.forward with dropouts 0 (src/fairseq/models/wavlm/wavlm.py:465-576), mask given explicitly."""
+def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, num_classes, chan_mask=None):
+    """WavLMModel.forward with dropouts 0 (src/fairseq/models/wavlm/wavlm.py:465-576), mask given explicitly.
+    chan_mask: bool [B, C] channel mask of apply_mask's second half (wavlm.py:405-422), applied after the time mask."""
     x, feats = project_features(sd, cfg, source)
     T = x.shape[1]
     layers = eval(cfg.conv_feature_layers)
@@ -253,6 +254,8 @@ def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, n
         padding_mask = forward_padding_mask(T, padding_mask)
     if mask_indices is not None:
         x = torch.where(mask_indices.unsqueeze(-1), sd["mask_emb"].view(1, 1, -1), x)
+    if chan_mask is not None:
+        x = torch.where(chan_mask.unsqueeze(1), torch.zeros((), dtype=x.dtype), x)  # x[mask_channel_indices] = 0
     taps = []
     utt = getattr(cfg, "utterance_contrastive_loss", False)
     pl = getattr(cfg, "predict_layers", "")

@@ -62,10 +62,12 @@ def test_extract_features_vs_reference_golden():
         assert rel_err(conv.transpose(1, 2), z["out/conv_features"]) < RTOL
 
 
-def _tiny_pretrain(dtype=torch.float32):
+def _tiny_pretrain(dtype=torch.float32, golden="tiny_pretrain.npz", **overrides):
     from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
-    z = load_golden("tiny_pretrain.npz")
-    cfg = WavLMPretrainConfig(**{k: v for k, v in TINY.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    z = load_golden(golden)
+    d = dict(TINY)
+    d.update(overrides)
+    cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
     m = WavLMPretrainModel(cfg, None, [range(23)])
     m.load_state_dict(golden_state_dict(z))
     m = m.to("cuda").to(dtype).train()
@@ -73,8 +75,11 @@ def _tiny_pretrain(dtype=torch.float32):
     return m, crit, z
 
 
-def test_pretrain_loss_and_grads_vs_reference_golden():
-    model, crit, z = _tiny_pretrain()
+@pytest.mark.parametrize("golden,overrides", [("tiny_pretrain.npz", {}),
+                                              ("tiny_chanmask.npz", {"mask_channel_prob": 0.25, "mask_channel_length": 4})])
+def test_pretrain_loss_and_grads_vs_reference_golden(golden, overrides):
+    """tiny_chanmask: time mask + channel mask drawn from the same numpy stream as the reference's apply_mask"""
+    model, crit, z = _tiny_pretrain(golden=golden, **overrides)
     sample = {"id": torch.arange(2),
               "net_input": {"source": torch.from_numpy(z["in/source"]).cuda(),
                             "padding_mask": torch.from_numpy(z["in/padding_mask"]).cuda()},

@@ -110,14 +110,17 @@ def test_oracle_extract_features(tiny_cfg):
         assert rel_err(rm["x"], z["out/x_masked"]) < RTOL
 
 
-def test_oracle_pretrain_loss_and_grads(tiny_cfg):
-    z = load_golden("tiny_pretrain.npz")
+@pytest.mark.parametrize("golden", ["tiny_pretrain.npz", "tiny_chanmask.npz"])
+def test_oracle_pretrain_loss_and_grads(tiny_cfg, golden):
+    """tiny_chanmask: the same run with mask_channel_prob 0.25 (apply_mask's channel half, wavlm.py:405-422)"""
+    z = load_golden(golden)
     sd = golden_state_dict(z, as_param=True)
     wav = torch.from_numpy(z["in/source"])
     target = torch.from_numpy(z["in/target"])
     pm = torch.from_numpy(z["in/padding_mask"])
     m = torch.from_numpy(z["out/mask_seed123"])
-    net = O.pretrain_forward(sd, tiny_cfg, wav, [target], pm, m, [23])
+    cm = torch.from_numpy(z["out/chan_mask_seed123"]) if "out/chan_mask_seed123" in z.files else None
+    net = O.pretrain_forward(sd, tiny_cfg, wav, [target], pm, m, [23], chan_mask=cm)
     assert rel_err(net["x"].detach(), z["out/x"]) < RTOL
     lm, lu = net["logit_m_list"][0].detach(), net["logit_u_list"][0].detach()
     gm, gu = torch.from_numpy(z["out/logit_m"]), torch.from_numpy(z["out/logit_u"])

@@ -195,8 +195,6 @@ class WavLMPretrainModel(WavLM):
                 padding_mask_cpu: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """output_layer is 1-based.  `padding_mask_cpu` (optional) is a host copy of padding_mask: with it the
         forward needs no device->host transfer at all."""
-        if self.mask_channel_prob > 0 and mask:
-            raise NotImplementedError("channel masking is not supported by the HIP path")
         x, feats = self._features(source)
         B, T, _ = x.shape
         dev = x.device
@@ -225,6 +223,8 @@ class WavLMPretrainModel(WavLM):
         kpm = padding_mask.to(torch.uint8).contiguous().view(-1) if padding_mask is not None else None
         if sel is not None or kpm is not None:
             x = F.SelectRowsFn.apply(x, sel, self.mask_emb if sel is not None else None, kpm)
+        if mask:
+            x = self.apply_channel_mask(x)
         layer = None if output_layer is None else output_layer - 1
         if self.predict_layers is not None and not features_only:
             layer = list(self.predict_layers)

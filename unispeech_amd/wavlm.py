@@ -452,6 +452,11 @@ class WavLM(nn.Module):
         self.no_mask_overlap = cfg.no_mask_overlap
         self.mask_min_space = cfg.mask_min_space
         self.mask_channel_prob = cfg.mask_channel_prob
+        self.mask_channel_selection = getattr(cfg, "mask_channel_selection", "static")
+        self.mask_channel_other = getattr(cfg, "mask_channel_other", 0)
+        self.mask_channel_length = getattr(cfg, "mask_channel_length", 10)
+        self.no_mask_channel_overlap = getattr(cfg, "no_mask_channel_overlap", False)
+        self.mask_channel_min_space = getattr(cfg, "mask_channel_min_space", 1)
         self.dropout_input = nn.Dropout(cfg.dropout_input)
         self.dropout_features = nn.Dropout(cfg.dropout_features)
         self.feature_grad_mult = cfg.feature_grad_mult
@@ -467,6 +472,18 @@ class WavLM(nn.Module):
         return compute_mask_indices((B, T), padding_mask, self.mask_prob, self.mask_length, self.mask_selection,
                                     self.mask_other, min_masks=2, no_overlap=self.no_mask_overlap,
                                     min_space=self.mask_min_space)
+
+    def apply_channel_mask(self, x):
+        """apply_mask's second half (WavLM.py:287-304 / wavlm.py:405-422): a [B, C] span mask drawn from the same numpy
+        stream right after the time mask, expanded over time; masked channels are zeroed (also where mask_emb sits)."""
+        if self.mask_channel_prob <= 0:
+            return x
+        B, _, C = x.shape
+        ch = compute_mask_indices((B, C), None, self.mask_channel_prob, self.mask_channel_length,
+                                  self.mask_channel_selection, self.mask_channel_other,
+                                  no_overlap=self.no_mask_channel_overlap, min_space=self.mask_channel_min_space)
+        keep = F.h2d(np.logical_not(np.asarray(ch)).astype(np.float32), x.device).to(x.dtype)
+        return x * keep.view(B, 1, C)
 
     def forward_padding_mask(self, n_frames: int, padding_mask: torch.Tensor) -> torch.Tensor:
         extra = padding_mask.size(1) % n_frames
@@ -498,8 +515,6 @@ class WavLM(nn.Module):
     def extract_features(self, source: torch.Tensor, padding_mask: Optional[torch.Tensor] = None, mask: bool = False,
                          ret_conv: bool = False, output_layer: Optional[int] = None,
                          ret_layer_results: bool = False):
-        if self.mask_channel_prob > 0 and mask:
-            raise NotImplementedError("channel masking is not supported by the HIP path")
         x, _ = self._features(source)
         B, T, _ = x.shape
         if padding_mask is not None:
@@ -513,6 +528,8 @@ class WavLM(nn.Module):
         kpm = padding_mask.to(torch.uint8).contiguous().view(-1) if padding_mask is not None else None
         if sel is not None or kpm is not None:
             x = F.SelectRowsFn.apply(x, sel, self.mask_emb if sel is not None else None, kpm)
+        if mask:
+            x = self.apply_channel_mask(x)
         x, layer_results, conv_sum = self.encoder(
             x, padding_mask=padding_mask, layer=None if output_layer is None else output_layer - 1, prezeroed=True)
         # the reference returns `features` after three in-place updates (mask, padding zero-fill, += pos_conv)
