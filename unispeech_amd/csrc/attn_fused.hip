@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 // ds_bpermute cost ~22 VALU ops per element.  This form costs 1.5 LDS ops per element and no VALU.)
 // K^T for dQ = dS K is not staged separately: the A operand is read from the K tile itself with the transposing
 // ds_read_b64_tr_b16 (lane i of a 16-lane group addresses key (i >> 2), head-dim columns 4 (i & 3) .. +4).
-template <bool DROP>
+// TAB: relative-position table present (a uniform `if (p.tab)` per element pair inside the score loop cost one basic
+// block, its waits and hazard nops per pair: 34 branches and 92 s_nop per tile iteration)
+template <bool DROP, bool TAB>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per stage: K [kv][hd] 8 KB | V [kv][hd] 8 KB;  then the four waves' skew buffers (96 x 64 B each)
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   unsigned char* skew = smem + 32768 + wave_u * 6144;
   const int ib = blockIdx.x * FA_BQ + 32 * wave_u;
   const int dlo0 = -ib - 31 + T - 1;  // diagonal of skew row 0 at tile 0 (negative for rows past the table)
-  if (p.tab)
+  if constexpr (TAB)
     for (int d = threadIdx.x; d < 2 * T - 1; d += 256) drow[d] = 0.f;  // ordered before the first add by the tile loop's barriers
   const long D3 = 3L * H * FA_HD, D = (long)H * FA_HD;
   const bf16_t* base = p.qkv + (long)b * T * D3 + h * FA_HD;
@@ -348,7 +350,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
     }
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-      // one 32-key block at a time keeps only one (S, dP) accumulator pair live
+      // one 32-key block at a time keeps only one (S, dP) accumulator pair live (computing both pairs up front, so that
+      // block 0's element pass runs under block 1's MFMAs, measured no gain: the pass is VALU-bound either way)
       U4 dsf[2];
       f32x16_t s, dp;
 #pragma unroll
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
             dg = fmaf(ds, tv, dg);
           }
           dsf[r >> 3].u[(r & 7) >> 1] = pack_bf16(dv[0], dv[1]);
-          if (p.tab) {
+          if constexpr (TAB) {
             const unsigned u2 = pack_bf16(g * dv[0], g * dv[1]);
             const int dd = 32 * f + (r & 3) + 8 * (r >> 2);  // + 4 hi is in sk_w
             sk_w[dd * 32] = (unsigned short)u2;
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
           dq[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kbuf(cur), ktr, f2, f, s2), dsf[s2].b, dq[f2], 0, 0, 0);
         }
     }
-    if (p.tab) {
+    if constexpr (TAB) {
       // diagonal sums of this tile; blocks 4, 5 of the previous tile carry into blocks 0, 1
       f32x4_t nacc[6];
 #pragma unroll
@@ -416,13 +419,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
     __syncthreads();
     cur ^= 1;
   }
-  if (p.tab && lane < 32) {
+  if (TAB && lane < 32) {
     // the 31 diagonals past the last tile's first 64 (blocks 4, 5)
     const float v = lane < 16 ? dacc[4][0] : dacc[5][0];
     const int d = dlo0 + 64 * nkv + lane;
     if (d >= 0 && d < L) unsafeAtomicAdd(drow + d, v);
   }
-  if (p.tab) {
+  if constexpr (TAB) {
     __syncthreads();
     float* prow = p.dtab_part + ((long)bh * gridDim.x + blockIdx.x) * L;
     for (int d = threadIdx.x; d < L; d += 256) prow[d] = drow[d];
@@ -689,12 +692,13 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
   p.delta = p.dtab_part + (long)B * H * nqt * L;
   const size_t smem1 = 32768 + 4 * 6144 + (size_t)(2 * p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float);
   if (p.th) {
-    if (fa_set_smem(attn_bwd_dq_kernel<true>, smem1) != WL_OK) return WL_ELAUNCH;
-    WL_LAUNCH(attn_bwd_dq_kernel<true>, dim3((unsigned)nqt, (unsigned)(B * H)), dim3(256), smem1, st, p);
+#define FA_DQ(DR, TB) do { if (fa_set_smem(attn_bwd_dq_kernel<DR, TB>, smem1) != WL_OK) return WL_ELAUNCH; \
+    WL_LAUNCH((attn_bwd_dq_kernel<DR, TB>), dim3((unsigned)nqt, (unsigned)(B * H)), dim3(256), smem1, st, p); } while (0)
+    if (tab) FA_DQ(true, true); else FA_DQ(true, false);
   } else {
-    if (fa_set_smem(attn_bwd_dq_kernel<false>, smem1) != WL_OK) return WL_ELAUNCH;
-    WL_LAUNCH(attn_bwd_dq_kernel<false>, dim3((unsigned)nqt, (unsigned)(B * H)), dim3(256), smem1, st, p);
+    if (tab) FA_DQ(false, true); else FA_DQ(false, false);
   }
+#undef FA_DQ
   const size_t smem2 = 32768 + (size_t)(p.Ltab + 64 + 2 * 256) * sizeof(float);
   const dim3 grid2((unsigned)((T + FA_BK1 - 1) / FA_BK1), (unsigned)(B * H));
   if (p.th) {
