@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 3
+#define WAVLM_HIP_ABI_VERSION 4
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -140,14 +140,15 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
 /* extractor_mode = "layer_norm" (WavLM-Large), block 0: Conv1d(1 -> C, k = 10) -> LayerNorm over the C channels of each
  * frame -> GELU, channel-last (WavLM/WavLM.py:403-418 with mode "layer_norm"; Fp32LayerNorm WavLM/modules.py:31-43).
  * One fused pass forward; backward (dW, dgamma, dbeta; no input gradient) recomputes conv and statistics. */
-int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, const void* gamma, const void* beta,
-                            int32_t param_dtype, void* out, int32_t out_dtype, int32_t B, int64_t T, int32_t C, int32_t kw,
-                            int32_t stride, float eps, void* stream);
+int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, const void* conv_bias, const void* gamma,
+                            const void* beta, int32_t param_dtype, void* out, int32_t out_dtype, int32_t B, int64_t T,
+                            int32_t C, int32_t kw, int32_t stride, float eps, void* stream);
 uint64_t wavlm_conv0_ln_bwd_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride);
-int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, const void* gamma, const void* beta,
-                            int32_t param_dtype, const void* g, int32_t g_dtype, void* dW, void* dgamma, void* dbeta,
-                            int32_t B, int64_t T, int32_t C, int32_t kw, int32_t stride, float eps, float gscale,
-                            void* workspace, uint64_t ws_bytes, void* stream);
+/* conv_bias / dconv_bias: the Conv1d bias of conv_bias=True configurations and its gradient (both optional, [C]) */
+int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, const void* conv_bias, const void* gamma,
+                            const void* beta, int32_t param_dtype, const void* g, int32_t g_dtype, void* dW,
+                            void* dconv_bias, void* dgamma, void* dbeta, int32_t B, int64_t T, int32_t C, int32_t kw,
+                            int32_t stride, float eps, float gscale, void* workspace, uint64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gated relative-position-bias attention (WavLM/modules.py:417-455, 504-563).

@@ -133,14 +133,15 @@ def gen_tiny_wavlm():
     np.savez_compressed(os.path.join(OUT, "tiny_wavlm.npz"), **out)
 
 
-def gen_tiny_large():
+def gen_tiny_large(overrides=None, fname="tiny_large.npz"):
     """WavLM-Large structure at tiny size: extractor_mode 'layer_norm' (LayerNorm + GELU after every conv block) and
     layer_norm_first=True (pre-LN encoder layers + final encoder LayerNorm).  Forward outputs and, through a scalar
     probe loss, every parameter gradient of the standalone reference (WavLM/WavLM.py with the out-of-place x + x_conv
-    patch of ref_shim)."""
+    patch of ref_shim).  overrides + fname: variants (gen_tiny_large_convbias)."""
     ref, _ = ref_shim.standalone(differentiable=True)
     d = dict(TINY)
     d.update(extractor_mode="layer_norm", layer_norm_first=True, normalize=True)
+    d.update(overrides or {})
     cfg = ref.WavLMConfig(d)
     torch.manual_seed(0)
     model = ref.WavLM(cfg)
@@ -163,7 +164,12 @@ def gen_tiny_large():
     (x * probe).sum().backward()
     for n, p in model.named_parameters():
         out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
-    np.savez_compressed(os.path.join(OUT, "tiny_large.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def gen_tiny_large_convbias():
+    """tiny_large with conv_bias=True: Conv1d biases in front of the per-frame LayerNorm of every extractor block"""
+    gen_tiny_large({"conv_bias": True}, "tiny_large_convbias.npz")
 
 
 class _Dict:
@@ -235,6 +241,12 @@ def gen_tiny_pretrain(overrides=None, fname="tiny_pretrain.npz"):
     for n, p in model.named_parameters():
         out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
     np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def gen_tiny_convbias():
+    """tiny_pretrain with conv_bias=True ('default' extractor: block 0's bias cancels in its GroupNorm, blocks 1-6 add it
+    before the GELU)"""
+    gen_tiny_pretrain({"conv_bias": True}, "tiny_convbias.npz")
 
 
 def gen_tiny_chanmask():
@@ -381,7 +393,9 @@ if __name__ == "__main__":
     gen_tiny_wavlm()
     gen_tiny_pretrain()
     gen_tiny_chanmask()
+    gen_tiny_convbias()
     gen_tiny_large()
+    gen_tiny_large_convbias()
     gen_tiny_sat()
     gen_tiny_ils()
     gen_sampled_negatives()

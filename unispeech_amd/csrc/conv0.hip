@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const TW* __restrict__
 // replaced by a 10 x 10 waveform Gram matrix per batch row.
 // part[(b * nchunk + chunk)][12][C]: A, Bq, P[0..9];  partx[(b * nchunk + chunk)][112]: Q[10], XX[10][10]
 #define C0_NQ (2 + C0_KW)
+#define C0_LN_NQ (3 + C0_KW)  // layer_norm mode: dbeta, dgamma, dW[.][0..9], dbias (conv_bias=True; zero work otherwise)
 #define C0_NX 112
 template <typename TW, typename TP, typename TO>
 __global__ __launch_bounds__(256) void conv0_bwd_fused_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
@@ -328,8 +329,8 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_finish_kernel(const float* __
 // reductions per frame, again a single pass over the incoming gradient.
 template <typename TW, typename TP, typename TO>
 __global__ __launch_bounds__(256) void conv0_ln_fwd_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
-    const TP* __restrict__ gamma, const TP* __restrict__ beta, TO* __restrict__ out, long T, int T0, int C, int stride,
-    float eps) {
+    const TP* __restrict__ cbias, const TP* __restrict__ gamma, const TP* __restrict__ beta, TO* __restrict__ out, long T,
+    int T0, int C, int stride, float eps) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* seg = sm;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -338,18 +339,21 @@ __global__ __launch_bounds__(256) void conv0_ln_fwd_kernel(const TW* __restrict_
   stage_wave(wav, T, b, t0, nt, stride, seg);
   float w[8][C0_KW];
   load_w(W, lane, C, w);
-  float gm[8], bt[8];
+  float gm[8], bt[8], cb[8];
   const bool act = lane * 8 < C;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = min(lane * 8 + e, C - 1);
     gm[e] = Elem<TP>::ld(gamma + c); bt[e] = Elem<TP>::ld(beta + c);
+    cb[e] = cbias ? Elem<TP>::ld(cbias + c) : 0.f;  // Conv1d bias (conv_bias=True), added before the LayerNorm
   }
   __syncthreads();
   const float invC = 1.f / (float)C;
   for (int tt = wave; tt < nt; tt += 4) {
     float y[8];
     conv_at(seg, tt, stride, w, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] += cb[e];
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) s += act ? y[e] : 0.f;
@@ -369,8 +373,8 @@ __global__ __launch_bounds__(256) void conv0_ln_fwd_kernel(const TW* __restrict_
 // part[(b * nchunk + chunk)][12][C]: dbeta, dgamma, dW[.][0..9]
 template <typename TW, typename TP, typename TO>
 __global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
-    const TP* __restrict__ gamma, const TP* __restrict__ beta, const TO* __restrict__ g, float* __restrict__ part, long T,
-    int T0, int C, int stride, float eps, float gscale) {
+    const TP* __restrict__ cbias, const TP* __restrict__ gamma, const TP* __restrict__ beta, const TO* __restrict__ g,
+    float* __restrict__ part, long T, int T0, int C, int stride, float eps, float gscale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* seg = sm;
   float* red = sm + ((C0_TCH_BWD - 1) * stride + C0_KW + 3) / 4 * 4;  // [4 waves][512]
@@ -380,18 +384,19 @@ __global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict_
   stage_wave(wav, T, b, t0, nt, stride, seg);
   float w[8][C0_KW];
   load_w(W, lane, C, w);
-  float gm[8], bt[8];
+  float gm[8], bt[8], cb[8];
   const bool act = lane * 8 < C;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = min(lane * 8 + e, C - 1);
     gm[e] = Elem<TP>::ld(gamma + c); bt[e] = Elem<TP>::ld(beta + c);
+    cb[e] = cbias ? Elem<TP>::ld(cbias + c) : 0.f;
   }
   __syncthreads();
-  float a1[8], a2[8], pw[8][C0_KW];
+  float a1[8], a2[8], pw[8][C0_KW], pb[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    a1[e] = 0.f; a2[e] = 0.f;
+    a1[e] = 0.f; a2[e] = 0.f; pb[e] = 0.f;
 #pragma unroll
     for (int k = 0; k < C0_KW; ++k) pw[e][k] = 0.f;
   }
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict_
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float a = 0.f;
+      float a = cb[e];
 #pragma unroll
       for (int k = 0; k < C0_KW; ++k) a = fmaf(xw[k], w[e][k], a);
       y[e] = a; s += act ? a : 0.f;
@@ -429,27 +434,29 @@ __global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float dc = act ? rstd * (h[e] - s1 - xh[e] * s2) : 0.f;
+      pb[e] += dc;  // d(conv bias) = sum over frames of the conv-output gradient
 #pragma unroll
       for (int k = 0; k < C0_KW; ++k) pw[e][k] = fmaf(dc, xw[k], pw[e][k]);
     }
   }
-  float* out = part + ((long)b * gridDim.x + blockIdx.x) * (long)C0_NQ * C;
+  float* out = part + ((long)b * gridDim.x + blockIdx.x) * (long)C0_LN_NQ * C;
 #pragma unroll
-  for (int q = 0; q < C0_NQ; ++q) {
+  for (int q = 0; q < C0_LN_NQ; ++q) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[wave * 512 + lane * 8 + e] = q == 0 ? a1[e] : q == 1 ? a2[e] : pw[e][q >= 2 ? q - 2 : 0];
+    for (int e = 0; e < 8; ++e)
+      red[wave * 512 + lane * 8 + e] = q == 0 ? a1[e] : q == 1 ? a2[e] : q == C0_LN_NQ - 1 ? pb[e] : pw[e][(q >= 2 && q < C0_LN_NQ - 1) ? q - 2 : 0];
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) out[(long)q * C + c] = red[c] + red[512 + c] + red[1024 + c] + red[1536 + c];
   }
 }
 
-// sums the [nblk][12][C] partials: row 0 -> dbeta, row 1 -> dgamma, rows 2.. -> dW[c][k]
+// sums the [nblk][13][C] partials: row 0 -> dbeta, row 1 -> dgamma, rows 2..11 -> dW[c][k], row 12 -> dbias (optional)
 __global__ __launch_bounds__(256) void conv0_ln_bwd_finish_kernel(const float* __restrict__ part, int nblk, int C, void* dW,
-                                                                  void* dgamma, void* dbeta, int pdt) {
+                                                                  void* dgamma, void* dbeta, void* dcbias, int pdt) {
   __shared__ double red[4][64];
   const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + col, n = C0_NQ * C;
+  const int i = blockIdx.x * 64 + col, n = C0_LN_NQ * C;
   double s = 0.0;
   if (i < n)
     for (int b = slice; b < nblk; b += 4) s += part[(long)b * n + i];
@@ -460,6 +467,7 @@ __global__ __launch_bounds__(256) void conv0_ln_bwd_finish_kernel(const float* _
     const int q = i / C, c = i - q * C;
     if (q == 0) st_elem(dbeta, c, pdt, v);
     else if (q == 1) st_elem(dgamma, c, pdt, v);
+    else if (q == C0_LN_NQ - 1) { if (dcbias) st_elem(dcbias, c, pdt, v); }
     else st_elem(dW, (long)c * C0_KW + (q - 2), pdt, v);
   }
 }
@@ -565,13 +573,13 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
 uint64_t wavlm_conv0_ln_bwd_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride) {
   const long T0 = (T - C0_KW) / stride + 1;
   const uint64_t nchunk = (uint64_t)((T0 + C0_TCH_BWD - 1) / C0_TCH_BWD);
-  return (uint64_t)B * nchunk * C0_NQ * C * sizeof(float);
+  return (uint64_t)B * nchunk * C0_LN_NQ * C * sizeof(float);
 }
 
 // extractor_mode "layer_norm", block 0: out[B, T0, C] = gelu(LayerNorm_C(conv0(wav)))  (WavLM/WavLM.py:403-418)
-int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, const void* gamma, const void* beta,
-                            int32_t param_dtype, void* out, int32_t out_dtype, int32_t B, int64_t T, int32_t C, int32_t kw,
-                            int32_t stride, float eps, void* stream) {
+int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, const void* conv_bias, const void* gamma,
+                            const void* beta, int32_t param_dtype, void* out, int32_t out_dtype, int32_t B, int64_t T,
+                            int32_t C, int32_t kw, int32_t stride, float eps, void* stream) {
   if (!wav || !W || !gamma || !beta || !out) return WL_EINVAL;
   if (kw != C0_KW || stride < 1 || stride > 8 || C <= 0 || C > 512 || (C & 7) || B <= 0 || T < kw) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -579,7 +587,7 @@ int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
   const dim3 grid((unsigned)((T0 + C0_TCH - 1) / C0_TCH), (unsigned)B);
   const size_t smem = seg_floats(C0_TCH, stride) * sizeof(float);
 #define FW(TW, TP, TO) WL_LAUNCH((conv0_ln_fwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
-    (const TP*)W, (const TP*)gamma, (const TP*)beta, (TO*)out, (long)T, T0, (int)C, (int)stride, eps)
+    (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (TO*)out, (long)T, T0, (int)C, (int)stride, eps)
   const int key = wav_dtype * 100 + param_dtype * 10 + out_dtype;
   if (key == 0) FW(float, float, float);
   else if (key == 111) FW(bf16_t, bf16_t, bf16_t);
@@ -591,10 +599,10 @@ int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
 }
 
 // backward of the above: dW[C, kw], dgamma[C], dbeta[C] (param dtype) from g = dL/dout; conv0 has no input gradient
-int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, const void* gamma, const void* beta,
-                            int32_t param_dtype, const void* g, int32_t g_dtype, void* dW, void* dgamma, void* dbeta,
-                            int32_t B, int64_t T, int32_t C, int32_t kw, int32_t stride, float eps, float gscale,
-                            void* workspace, uint64_t ws_bytes, void* stream) {
+int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, const void* conv_bias, const void* gamma,
+                            const void* beta, int32_t param_dtype, const void* g, int32_t g_dtype, void* dW,
+                            void* dconv_bias, void* dgamma, void* dbeta, int32_t B, int64_t T, int32_t C, int32_t kw,
+                            int32_t stride, float eps, float gscale, void* workspace, uint64_t ws_bytes, void* stream) {
   if (!wav || !W || !gamma || !beta || !g || !dW || !dgamma || !dbeta || !workspace) return WL_EINVAL;
   if (kw != C0_KW || stride < 1 || stride > 8 || C <= 0 || C > 512 || (C & 7) || B <= 0 || T < kw) return WL_EINVAL;
   if (ws_bytes < wavlm_conv0_ln_bwd_workspace_bytes(B, T, C, stride)) return WL_EINVAL;
@@ -605,7 +613,7 @@ int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   float* part = (float*)workspace;
   const size_t smem = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float);
 #define BW(TW, TP, TO) WL_LAUNCH((conv0_ln_bwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
-    (const TP*)W, (const TP*)gamma, (const TP*)beta, (const TO*)g, part, (long)T, T0, (int)C, (int)stride, eps, gscale)
+    (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (const TO*)g, part, (long)T, T0, (int)C, (int)stride, eps, gscale)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
   if (key == 0) BW(float, float, float);
   else if (key == 111) BW(bf16_t, bf16_t, bf16_t);
@@ -615,9 +623,9 @@ int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
 #undef BW
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
-  const int n = C0_NQ * C;
+  const int n = C0_LN_NQ * C;
   WL_LAUNCH(conv0_ln_bwd_finish_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, (int)(B * nchunk), (int)C, dW,
-            dgamma, dbeta, (int)param_dtype);
+            dgamma, dbeta, dconv_bias, (int)param_dtype);
   return wl_check_launch();
 }
 

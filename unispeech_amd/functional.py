@@ -372,18 +372,19 @@ class Conv0LNFn(torch.autograd.Function):
     (WavLM-Large; WavLM/WavLM.py:403-418)"""
 
     @staticmethod
-    def forward(ctx, wav, W, gamma, beta, stride, eps, out_dtype):
+    def forward(ctx, wav, W, gamma, beta, stride, eps, out_dtype, bias=None):
         wav = wav.contiguous()
-        y = ops.conv0_ln_gelu_fwd(wav, W.contiguous(), gamma, beta, stride, eps, out_dtype)
-        ctx.save_for_backward(wav, W, gamma, beta)
+        y = ops.conv0_ln_gelu_fwd(wav, W.contiguous(), gamma, beta, stride, eps, out_dtype, bias=bias)
+        ctx.save_for_backward(wav, W, gamma, beta, bias)
         ctx.stride, ctx.eps = stride, eps
         return y
 
     @staticmethod
     def backward(ctx, g):
-        wav, W, gamma, beta = ctx.saved_tensors
-        dW, dgamma, dbeta = ops.conv0_ln_gelu_bwd(wav, W.contiguous(), gamma, beta, g.contiguous(), ctx.stride, ctx.eps)
-        return None, dW, dgamma, dbeta, None, None, None
+        wav, W, gamma, beta, bias = ctx.saved_tensors
+        dW, dgamma, dbeta, dbias = ops.conv0_ln_gelu_bwd(wav, W.contiguous(), gamma, beta, g.contiguous(), ctx.stride,
+                                                         ctx.eps, bias=bias)
+        return None, dW, dgamma, dbeta, None, None, None, dbias
 
 
 def _conv_geometry(T_in, k, s):
@@ -402,13 +403,17 @@ class ConvStackFn(torch.autograd.Function):
     du_{i-1} = dx * gelu'(u_{i-1}) straight into the zero-padded buffer the next (earlier) layer consumes."""
 
     @staticmethod
-    def forward(ctx, x, specs, act, *weights):
+    def forward(ctx, x, specs, act, *params):
         """act=True: GELU fused (default mode); act=False: plain convolution (layer_norm mode: the LayerNorm + GELU
-        that follows is a LayerNormFn)"""
+        that follows is a LayerNormFn).  params: one weight per layer, then (conv_bias=True) one bias per layer."""
         B = x.shape[0]
+        nl = len(specs)
+        weights = params[:nl]
+        biases = params[nl:] if len(params) > nl else (None,) * nl
+        ctx.has_bias = len(params) > nl
         xs, us, wfs = [], [], []
         cur = x.contiguous()
-        for (k, s), W in zip(specs, weights):
+        for (k, s), W, bias in zip(specs, weights, biases):
             Cout, Cin, _ = W.shape
             T_in = cur.shape[1]
             T_out = (T_in - k) // s + 1
@@ -417,7 +422,7 @@ class ConvStackFn(torch.autograd.Function):
             u = torch.empty_like(y) if act else y.new_empty(0)
             ops.gemm(cur, Wf, y, T_out, Cout, k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout, batch=(B, 1),
                      sA=(T_in * Cin, 0), sC=(T_out * Cout, 0), epi=3 if act else 0, aux=u if act else None, ld_aux=Cout,
-                     sAux=(T_out * Cout, 0))
+                     sAux=(T_out * Cout, 0), bias=bias)
             xs.append(cur); us.append(u); wfs.append(Wf)
             cur = y
         ctx.specs = specs
@@ -434,6 +439,7 @@ class ConvStackFn(torch.autograd.Function):
         B = dy.shape[0]
         dev = dy.device
         grads = [None] * nl
+        bgrads = [None] * nl
         # du_L = dy * gelu'(u_L), laid out with the zero rows layer L's data-gradient GEMMs read
         k, s = specs[-1]
         T_out, J, fp, bp = _conv_geometry(xs[-1].shape[1], k, s)
@@ -455,6 +461,9 @@ class ConvStackFn(torch.autograd.Function):
                 ops.gemm(P, x, dWf, Cout, k * Cin, T_out, lda=Cout, ldb=s * Cin, ldc=k * Cin, transA=True, transB=True,
                          a_off=fp * Cout, KB=B, sA_kb=Tp * Cout, sB_kb=T_in * Cin, split_k=split)
                 grads[i] = dWf.view(Cout, k, Cin).permute(0, 2, 1)
+            if ctx.has_bias and ctx.needs_input_grad[3 + nl + i]:
+                # bias gradient = column sums of du_i; the zero pad rows of the staged buffer add nothing
+                bgrads[i] = ops.colsum(P.reshape(-1, Cout), W.dtype)
             # ---- data gradient
             need_dx = i > 0 or ctx.needs_input_grad[0]
             if not need_dx:
@@ -486,7 +495,7 @@ class ConvStackFn(torch.autograd.Function):
                          sAux=(T_in * Cin, 0))
             P = nxt
         dx = P if ctx.needs_input_grad[0] else None
-        return (dx, None, None) + tuple(grads)
+        return (dx, None, None) + tuple(grads) + (tuple(bgrads) if ctx.has_bias else ())
 
 
 # ---------------------------------------------------------------------------------------------- pos_conv

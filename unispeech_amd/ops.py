@@ -310,32 +310,34 @@ def conv0_gn_gelu_bwd(wav, W, gamma, beta, g, stats, stride, gscale=1.0):
     return dW, dgamma, dbeta
 
 
-def conv0_ln_gelu_fwd(wav, W, gamma, beta, stride, eps, out_dtype):
-    """extractor_mode 'layer_norm', block 0: gelu(LayerNorm_C(conv0(wav))) -> [B, T0, C]"""
+def conv0_ln_gelu_fwd(wav, W, gamma, beta, stride, eps, out_dtype, bias=None):
+    """extractor_mode 'layer_norm', block 0: gelu(LayerNorm_C(conv0(wav) + bias)) -> [B, T0, C]"""
     dev = _dev(wav); _contig(wav); _contig(W)
     B, T = wav.shape
     Cc, _, kw = W.shape
     T0 = (T - kw) // stride + 1
     out = torch.empty((B, T0, Cc), dtype=out_dtype, device=dev)
-    check(_lib.lib().wavlm_conv0_ln_gelu_fwd(ptr(wav), dt(wav), ptr(W), ptr(gamma), ptr(beta), dt(W), ptr(out), dt(out),
-                                             B, T, Cc, kw, stride, float(eps), stream()), "wavlm_conv0_ln_gelu_fwd")
+    check(_lib.lib().wavlm_conv0_ln_gelu_fwd(ptr(wav), dt(wav), ptr(W), ptr(bias), ptr(gamma), ptr(beta), dt(W), ptr(out),
+                                             dt(out), B, T, Cc, kw, stride, float(eps), stream()), "wavlm_conv0_ln_gelu_fwd")
     return out
 
 
-def conv0_ln_gelu_bwd(wav, W, gamma, beta, g, stride, eps, gscale=1.0):
+def conv0_ln_gelu_bwd(wav, W, gamma, beta, g, stride, eps, gscale=1.0, bias=None):
+    """returns (dW, dgamma, dbeta, dbias); dbias is None without a conv bias"""
     dev = _dev(wav); _contig(g)
     B, T = wav.shape
     Cc, _, kw = W.shape
     dW = torch.empty_like(W)
     dgamma = torch.empty_like(gamma)
     dbeta = torch.empty_like(beta)
+    dbias = torch.empty_like(bias) if bias is not None else None
     L = _lib.lib()
     need = L.wavlm_conv0_ln_bwd_workspace_bytes(B, T, Cc, stride)
     ws = workspace(dev, need)
-    check(L.wavlm_conv0_ln_gelu_bwd(ptr(wav), dt(wav), ptr(W), ptr(gamma), ptr(beta), dt(W), ptr(g), dt(g), ptr(dW),
-                                    ptr(dgamma), ptr(dbeta), B, T, Cc, kw, stride, float(eps), float(gscale), ptr(ws),
-                                    need, stream()), "wavlm_conv0_ln_gelu_bwd")
-    return dW, dgamma, dbeta
+    check(L.wavlm_conv0_ln_gelu_bwd(ptr(wav), dt(wav), ptr(W), ptr(bias), ptr(gamma), ptr(beta), dt(W), ptr(g), dt(g),
+                                    ptr(dW), ptr(dbias), ptr(dgamma), ptr(dbeta), B, T, Cc, kw, stride, float(eps),
+                                    float(gscale), ptr(ws), need, stream()), "wavlm_conv0_ln_gelu_bwd")
+    return dW, dgamma, dbeta, dbias
 
 
 # ---------------------------------------------------------------------------------------- attention

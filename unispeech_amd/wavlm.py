@@ -123,26 +123,30 @@ class ConvFeatureExtractionModel(nn.Module):
         """x: waveform [B, T] -> features [B, T', C] (channel-last; the reference returns [B, C, T'])"""
         blk0 = self.conv_layers[0]
         conv0 = blk0[0]
-        if conv0.bias is not None:
-            raise NotImplementedError("conv_bias=True is not supported by the HIP path")
+        has_bias = conv0.bias is not None  # conv_bias=True: Conv1d biases on every block
         wdt = conv0.weight.dtype
         if x.dtype != wdt:
             x = x.to(wdt)
+        rest = list(self.conv_layers)[1:]
         if self.mode == "layer_norm":
             # every block: conv -> LayerNorm over channels -> GELU (WavLM/WavLM.py:403-418).  Block 0 is one fused
-            # kernel; blocks 1.. are an overlapping-row GEMM followed by the fused LayerNorm + GELU row kernel.
+            # kernel; blocks 1.. are an overlapping-row GEMM (bias in its epilogue) followed by the fused LayerNorm +
+            # GELU row kernel.
             ln0 = blk0[2][1]
-            y = F.Conv0LNFn.apply(x, conv0.weight, ln0.weight, ln0.bias, self.specs[0][1], ln0.eps, wdt)
-            for blk, spec in zip(list(self.conv_layers)[1:], self.specs[1:]):
+            y = F.Conv0LNFn.apply(x, conv0.weight, ln0.weight, ln0.bias, self.specs[0][1], ln0.eps, wdt, conv0.bias)
+            for blk, spec in zip(rest, self.specs[1:]):
                 ln = blk[2][1]
-                v = F.ConvStackFn.apply(y, (spec,), False, blk[0].weight)
+                params = (blk[0].weight,) + ((blk[0].bias,) if has_bias else ())
+                v = F.ConvStackFn.apply(y, (spec,), False, *params)
                 y, _ = F.layer_norm(v, ln.weight, ln.bias, ln.eps, act=1)
             return y
+        # default mode: GroupNorm(C, C) normalises every channel over time, so block 0's Conv1d bias cancels exactly in
+        # the forward and has a zero gradient; it is accepted (checkpoint compatibility) and left without a gradient
         gn = blk0[2]
         y = F.Conv0Fn.apply(x, conv0.weight, gn.weight, gn.bias, self.specs[0][1], gn.eps, wdt)
-        weights = [blk[0].weight for blk in list(self.conv_layers)[1:]]
-        if weights:
-            y = F.ConvStackFn.apply(y, tuple(self.specs[1:]), True, *weights)
+        params = [blk[0].weight for blk in rest] + ([blk[0].bias for blk in rest] if has_bias else [])
+        if rest:
+            y = F.ConvStackFn.apply(y, tuple(self.specs[1:]), True, *params)
         return y
 
 
