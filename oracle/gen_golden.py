@@ -311,9 +311,10 @@ def gen_tiny_sat():
     np.savez_compressed(os.path.join(OUT, "tiny_sat.npz"), **out)
 
 
-def gen_tiny_ils():
+def gen_tiny_ils(overrides=None, fname="tiny_ils.npz", vocabs=(23,)):
     """ILS-HuBERT at tiny size (fairseq ILSHubertModel, predict_layers [1, 2], shared final_proj / label embeddings) +
-    HubertCriterion: loss, logits of both layers and every parameter gradient."""
+    HubertCriterion: loss, logits of both layers and every parameter gradient.  overrides / vocabs: the per-layer
+    variants (gen_tiny_ils_variants)."""
     ref_shim.fairseq_wavlm()
     from fairseq.criterions.hubert_criterion import HubertCriterion
     from fairseq.models.hubert import ils_hubert as ih
@@ -324,24 +325,27 @@ def gen_tiny_ils():
     cfg.label_rate = 50
     cfg.final_dim = 32
     cfg.predict_layers = "[1,2]"
-    V = 23
+    for k, v in (overrides or {}).items():
+        setattr(cfg, k, v)
     torch.manual_seed(0)
-    model = ih.ILSHubertModel(cfg, SimpleNamespace(sample_rate=16000), [_Dict(V)])
+    model = ih.ILSHubertModel(cfg, SimpleNamespace(sample_rate=16000), [_Dict(V) for V in vocabs])
     model.train()
     crit = HubertCriterion(SimpleNamespace(), 1.0, 0.0, loss_weights=[10.0])
     out = sd_to_np(model.state_dict())
     g = torch.Generator().manual_seed(555)
     wav = torch.randn(2, 16000, generator=g)
-    target = torch.randint(4, V, (2, 50), generator=g)
+    targets = [torch.randint(4, V, (2, 50), generator=g) for V in vocabs]
     pm = torch.zeros(2, 16000, dtype=torch.bool)
-    sample = {"id": torch.arange(2), "net_input": {"source": wav, "padding_mask": pm}, "target_list": [target]}
+    sample = {"id": torch.arange(2), "net_input": {"source": wav, "padding_mask": pm}, "target_list": targets}
     np.random.seed(222)
     loss, sample_size, log = crit(model, sample)
     loss.backward()
     np.random.seed(222)
-    net = model(target_list=[target], source=wav, padding_mask=pm)
+    net = model(target_list=targets, source=wav, padding_mask=pm)
     out["in/source"] = wav.numpy()
-    out["in/target"] = target.numpy()
+    out["in/target"] = targets[0].numpy()
+    for i, t in enumerate(targets):
+        out["in/target%d" % i] = t.numpy()
     out["out/loss"] = np.float64(loss.item())
     out["out/sample_size"] = np.int64(sample_size)
     out["out/n_logit_m"] = np.int64(len(net["logit_m_list"]))
@@ -356,7 +360,17 @@ def gen_tiny_ils():
     out["out/mask_seed222"] = m
     for n, p in model.named_parameters():
         out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
-    np.savez_compressed(os.path.join(OUT, "tiny_ils.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def gen_tiny_ils_variants():
+    """ils_hubert.py:78-107, 207-273: per-layer final_proj + label embeddings (separate_label_embeds, two label sets, with
+    two label sets), and one label set per predicted layer (separate_layer_targets + weighted_sum, vocabularies of
+    different size so that label_embs_concat is padded to the larger one)"""
+    gen_tiny_ils({"separate_label_embeds": True}, "tiny_ils_sep_embeds.npz", vocabs=(23, 17))
+    # weighted_sum (hubert_criterion.py:73-76: per-layer losses weighted by softmax(model.weights)) needs one loss per layer
+    gen_tiny_ils({"separate_layer_targets": True, "separate_label_embeds": True, "weighted_sum": True},
+                 "tiny_ils_sep_targets.npz", vocabs=(23, 17))
 
 
 def gen_sampled_negatives():
@@ -398,6 +412,7 @@ if __name__ == "__main__":
     gen_tiny_large_convbias()
     gen_tiny_sat()
     gen_tiny_ils()
+    gen_tiny_ils_variants()
     gen_sampled_negatives()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -266,15 +266,22 @@ def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, n
                                          collect=pl, collected=collected)
     pad = padding_mask if padding_mask is not None else torch.zeros(y.shape[:2], dtype=torch.bool)
     lec = sd["label_embs_concat"]
-    label_embs_list = (lec[0] if lec.dim() == 3 else lec).split(num_classes, 0)
     sources = collected if pl is not None else [y]  # ILS-SSL (ils_hubert.py:180-250): same head on every collected layer
+    sep_emb = getattr(cfg, "separate_label_embeds", False)    # per-layer final_proj + label embeddings (ils_hubert.py:78-86)
+    sep_tgt = getattr(cfg, "separate_layer_targets", False)   # label set i belongs to predicted layer i (207-236)
 
     def pred(sel):
         out = []
-        for src in sources:
-            proj = F.linear(src[sel], sd["final_proj.weight"], sd["final_proj.bias"])
-            for i, t in enumerate(target_list):
-                emb = label_embs_list[i]
+        for li, src in enumerate(sources):
+            fw = sd["final_proj.%d.weight" % li] if sep_emb else sd["final_proj.weight"]
+            fb = sd["final_proj.%d.bias" % li] if sep_emb else sd["final_proj.bias"]
+            proj = F.linear(src[sel], fw, fb)
+            embs = lec[li] if (sep_emb or sep_tgt) else (lec[0] if lec.dim() == 3 else lec)
+            if sep_tgt:
+                pairs = [(embs[:num_classes[li]], target_list[li])]
+            else:
+                pairs = list(zip(embs.split(num_classes, 0), target_list))
+            for emb, t in pairs:
                 pos = torch.index_select(emb, 0, t[sel].long())
                 negs = emb.unsqueeze(1).expand(-1, proj.size(0), -1)
                 out.append(compute_nce(proj, pos, negs, cfg.logit_temp))
@@ -285,6 +292,8 @@ def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, n
            "logit_m_list": pred(torch.logical_and(~pad, m)), "logit_u_list": pred(torch.logical_and(~pad, ~m))}
     if utt:
         out.update(utterance_contrastive(sd, cfg, taps[0], torch.logical_and(~pad, m)))
+    if getattr(cfg, "weighted_sum", False):
+        out["layer_weights"] = sd["weights"]  # hubert_criterion.py:73-76: per-layer losses x softmax(model.weights)
     return out
 
 
@@ -361,18 +370,20 @@ def criterion(net_output, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_w
     log = {}
     lm = [l.float() for l in net_output["logit_m_list"]]
     lu = [l.float() for l in net_output["logit_u_list"]]
+    lw = net_output.get("layer_weights")
+    nw = F.softmax(lw.float(), dim=-1) if lw is not None else None
     for i, l in enumerate(lm):
         li = F.cross_entropy(l, l.new_zeros(l.size(0), dtype=torch.long), reduction="sum")
         log[f"loss_m_{i}"] = li
         if pred_masked_weight > 0:
-            loss = loss + pred_masked_weight * li
+            loss = loss + pred_masked_weight * (li if nw is None else nw[i] * li)
     if pred_masked_weight > 0:
         sample_size += lm[0].size(0)
     for i, l in enumerate(lu):
         li = F.cross_entropy(l, l.new_zeros(l.size(0), dtype=torch.long), reduction="sum")
         log[f"loss_u_{i}"] = li
         if pred_nomask_weight > 0:
-            loss = loss + pred_nomask_weight * li
+            loss = loss + pred_nomask_weight * (li if nw is None else nw[i] * li)
     if pred_nomask_weight > 0:
         sample_size += lu[0].size(0)
     if loss_weights is not None:

@@ -329,22 +329,30 @@ def test_unispeech_sat_head_vs_reference_golden():
         assert (g - ref).abs().max().item() <= tol, (n, (g - ref).abs().max().item(), tol)
 
 
-def test_ils_hubert_vs_reference_golden():
+ILS_CASES = [("tiny_ils.npz", {}, (23,)),
+             ("tiny_ils_sep_embeds.npz", {"separate_label_embeds": True}, (23, 17)),
+             ("tiny_ils_sep_targets.npz", {"separate_layer_targets": True, "separate_label_embeds": True, "weighted_sum": True}, (23, 17))]
+
+@pytest.mark.parametrize("golden,overrides,vocabs", ILS_CASES)
+def test_ils_hubert_vs_reference_golden(golden, overrides, vocabs):
     """ILS-SSL on the HIP path against the golden generated from the reference's ILSHubertModel:
-    criterion loss and every parameter gradient with the head on layers [1, 2]."""
+    criterion loss and every parameter gradient with the head on layers [1, 2]; also per-layer heads / label sets and
+    softmax-weighted layer losses."""
     from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
-    z = load_golden("tiny_ils.npz")
+    z = load_golden(golden)
     d = dict(TINY)
     d.update(predict_layers="[1,2]", gru_rel_pos=False)  # HuBERT config: relative position bias without the gate
+    d.update(overrides)
     cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
-    m = WavLMPretrainModel(cfg, None, [range(23)])
+    m = WavLMPretrainModel(cfg, None, [range(V) for V in vocabs])
     m.load_state_dict(golden_state_dict(z), strict=True)
     m = m.to("cuda").train()
     crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0])
     pm = torch.zeros(2, 16000, dtype=torch.bool)
     sample = {"id": torch.arange(2),
               "net_input": {"source": torch.from_numpy(z["in/source"]).cuda(), "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
-              "target_list": [torch.from_numpy(z["in/target"]).cuda()]}
+              "target_list": ([torch.from_numpy(z["in/target%d" % i]).cuda() for i in range(len(vocabs))]
+                              if "in/target0" in z.files else [torch.from_numpy(z["in/target"]).cuda()])}
     np.random.seed(222)
     loss, sample_size, _ = crit(m, sample)
     assert sample_size == int(z["out/sample_size"])

@@ -222,20 +222,45 @@ def test_oracle_unispeech_sat_head():
         assert (g - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8, k
 
 
-def test_oracle_ils_hubert():
+ILS_CASES = [("tiny_ils.npz", {}, (23,)),
+             ("tiny_ils_sep_embeds.npz", {"separate_label_embeds": True}, (23, 17)),
+             ("tiny_ils_sep_targets.npz", {"separate_layer_targets": True, "separate_label_embeds": True, "weighted_sum": True}, (23, 17))]
+
+@pytest.mark.parametrize("golden,overrides,vocabs", ILS_CASES)
+def test_seeded_init_ils_variants(golden, overrides, vocabs):
+    """parameter creation order of the ILS heads (ils_hubert.py:70-107): same seed -> bit-identical initial weights"""
+    z = load_golden(golden)
+    ref_sd = golden_state_dict(z)
+    d = dict(TINY)
+    d.update(predict_layers="[1,2]", gru_rel_pos=False)
+    d.update(overrides)
+    cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    torch.manual_seed(0)
+    model = WavLMPretrainModel(cfg, None, [range(V) for V in vocabs])
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(ref_sd.keys())
+    for k in ref_sd:
+        assert torch.equal(sd[k], ref_sd[k]), k
+
+
+@pytest.mark.parametrize("golden,overrides,vocabs", ILS_CASES)
+def test_oracle_ils_hubert(golden, overrides, vocabs):
     """ILS-SSL: the masked-prediction head on the outputs of layers [1, 2] against the golden
-    generated from the reference's ILSHubertModel + HubertCriterion: logits of both layers, loss, gradients."""
+    generated from the reference's ILSHubertModel + HubertCriterion: logits of both layers, loss, gradients.  Variants:
+    per-layer final_proj / label embeddings, one label set per layer with softmax-weighted layer losses."""
     from conftest import Cfg, TINY
-    z = load_golden("tiny_ils.npz")
+    z = load_golden(golden)
     d = dict(TINY)
     d.update(predict_layers="[1,2]", gru_rel_pos=False)  # HuBERT config: relative position bias without the gate
+    d.update(overrides)
     cfg = Cfg(**d)
     sd = golden_state_dict(z, as_param=True)
     wav = torch.from_numpy(z["in/source"])
-    target = torch.from_numpy(z["in/target"])
+    targets = [torch.from_numpy(z["in/target%d" % i]) for i in range(len(vocabs))] if "in/target0" in z.files \
+        else [torch.from_numpy(z["in/target"])]
     m = torch.from_numpy(z["out/mask_seed222"])
-    net = O.pretrain_forward(sd, cfg, wav, [target], torch.zeros(2, 16000, dtype=torch.bool), m, [23])
-    assert len(net["logit_m_list"]) == int(z["out/n_logit_m"]) == 2
+    net = O.pretrain_forward(sd, cfg, wav, targets, torch.zeros(2, 16000, dtype=torch.bool), m, list(vocabs))
+    assert len(net["logit_m_list"]) == int(z["out/n_logit_m"])
     for i, l in enumerate(net["logit_m_list"]):
         ref = torch.from_numpy(z["out/logit_m%d" % i])
         fin = torch.isfinite(ref)

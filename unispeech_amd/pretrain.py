@@ -124,15 +124,26 @@ class WavLMPretrainModel(WavLM):
         # re-creates final_proj and a 3-D label_embs_concat [1, V, F] after the base constructor
         pl = getattr(cfg, "predict_layers", "")
         self.predict_layers = eval(pl) if pl else None
+        self.separate_label_embeds = self.separate_layer_targets = self.weighted_sum = False
         if self.predict_layers is not None:
-            if getattr(cfg, "separate_label_embeds", False) or getattr(cfg, "separate_layer_targets", False) \
-                    or getattr(cfg, "weighted_sum", False) or cfg.layer_norm_first:
-                raise NotImplementedError("ILS options separate_label_embeds / separate_layer_targets / weighted_sum / "
-                                          "pre-LN are not supported by the HIP path")
-            self.final_proj = nn.Linear(cfg.encoder_embed_dim,
-                                        final_dim * (len(dictionaries) if self.untie_final_proj else 1))
+            if cfg.layer_norm_first:
+                raise NotImplementedError("pre-LN ILS (post_layer_norm on the tapped layers) is not supported by the HIP path")
+            # ils_hubert.py:70-107, same creation order (seeded-init parity): final_proj module(s), `weights`, label embeddings
+            self.separate_label_embeds = bool(getattr(cfg, "separate_label_embeds", False))
+            self.separate_layer_targets = bool(getattr(cfg, "separate_layer_targets", False))
+            self.weighted_sum = bool(getattr(cfg, "weighted_sum", False))
+            L = len(self.predict_layers)
+            out_dim = final_dim * (1 if (self.separate_layer_targets or not self.untie_final_proj) else len(dictionaries))
+            if self.separate_label_embeds:
+                self.final_proj = nn.Sequential(*[nn.Linear(cfg.encoder_embed_dim, out_dim) for _ in range(L)])
+            else:
+                self.final_proj = nn.Linear(cfg.encoder_embed_dim, out_dim)
+            if self.weighted_sum:
+                self.weights = nn.Parameter(torch.zeros(L))  # per-layer loss weights (softmax), used by the criterion
             if self.num_classes is not None:
-                self.label_embs_concat = nn.Parameter(torch.FloatTensor(1, sum(self.num_classes), final_dim))
+                layer_dim = L if (self.separate_layer_targets or self.separate_label_embeds) else 1
+                embed_dim = sum(self.num_classes) if not self.separate_layer_targets else max(self.num_classes)
+                self.label_embs_concat = nn.Parameter(torch.FloatTensor(layer_dim, embed_dim, final_dim))
                 nn.init.uniform_(self.label_embs_concat)
         # speaker-aware head of UniSpeech-SAT (unispeech_sat.py:382-406): parameters in the reference's creation order
         self.utterance_contrastive_loss = getattr(cfg, "utterance_contrastive_loss", False)
@@ -242,8 +253,16 @@ class WavLMPretrainModel(WavLM):
 
         pad_np = pad_cpu.numpy() if pad_cpu is not None else np.zeros((B, T), dtype=bool)
         m_np = mask_np if mask_np is not None else np.zeros((B, T), dtype=bool)
-        lec = self.label_embs_concat[0] if self.label_embs_concat.dim() == 3 else self.label_embs_concat
-        label_embs_list = lec.split(self.num_classes, 0)
+        def layer_head(li):
+            """(final_proj module, [(label embeddings, target)]) of predicted layer li (ils_hubert.py:207-236)"""
+            fp = self.final_proj[li] if self.separate_label_embeds else self.final_proj
+            lec = self.label_embs_concat
+            if lec.dim() == 3:
+                lec = lec[li] if (self.separate_label_embeds or self.separate_layer_targets) else lec[0]
+            if self.separate_layer_targets:
+                return fp, [(lec[:self.num_classes[li]], target_list[li])], False
+            return fp, list(zip(lec.split(self.num_classes, 0), target_list)), self.untie_final_proj
+
         n = B * T
         if self.predict_layers is not None:
             # ILS: the head runs on every collected layer output ([T, B, C] views -> [B, T, C])
@@ -260,17 +279,17 @@ class WavLMPretrainModel(WavLM):
 
         def head(frame_sel_np, need_grad):
             out = []
-            for x2d in sources:
-                out.extend(head_one(x2d, frame_sel_np, need_grad))
+            for li, x2d in enumerate(sources):
+                out.extend(head_one(x2d, frame_sel_np, need_grad, li))
             return out
 
-        def head_one(x2d, frame_sel_np, need_grad):
+        def head_one(x2d, frame_sel_np, need_grad, li=0):
             # a head whose loss carries no weight (pred_nomask_weight == 0) is evaluated for logging only: no graph,
             # no saved activations, and no pending gradient-sink accumulations for the data-parallel reducer to wait for
             with torch.set_grad_enabled(bool(need_grad) and torch.is_grad_enabled()):
-                return head_body(x2d, frame_sel_np, need_grad)
+                return head_body(x2d, frame_sel_np, need_grad, li)
 
-        def head_body(x2d, frame_sel_np, need_grad):
+        def head_body(x2d, frame_sel_np, need_grad, li):
             idx_np = np.flatnonzero(frame_sel_np.reshape(-1)).astype(np.int32)
             S = int(idx_np.size)
             inv_np = np.full(n, -1, dtype=np.int32)
@@ -278,16 +297,15 @@ class WavLMPretrainModel(WavLM):
             idx = F.h2d(idx_np, dev)
             inv = F.h2d(inv_np, dev)
             rows = F.GatherRowsFn.apply(x2d, idx, inv)
-            proj = F.LinearFn.apply(rows, self.final_proj.weight, self.final_proj.bias)
-            projs = proj.chunk(len(target_list), dim=-1) if self.untie_final_proj else [proj] * len(target_list)
+            fp, pairs, untied = layer_head(li)
+            proj = F.LinearFn.apply(rows, fp.weight, fp.bias)
+            projs = proj.chunk(len(pairs), dim=-1) if untied else [proj] * len(pairs)
             out = []
             idx64 = idx.long()
-            for i, (pj, t) in enumerate(zip(projs, target_list)):
+            for pj, (emb, t) in zip(projs, pairs):
                 tt = t[:, tinds_dev(t.device)].reshape(-1).index_select(0, idx64).to(torch.int32)
-                loss, ncorrect = F.MaskedPredLossFn.apply(pj.contiguous(), label_embs_list[i], tt, self.logit_temp,
-                                                          need_grad)
-                out.append({"loss": loss, "correct": ncorrect, "count": S, "proj": pj, "target": tt,
-                            "label_embs": label_embs_list[i]})
+                loss, ncorrect = F.MaskedPredLossFn.apply(pj.contiguous(), emb, tt, self.logit_temp, need_grad)
+                out.append({"loss": loss, "correct": ncorrect, "count": S, "proj": pj, "target": tt, "label_embs": emb})
             return out
 
         result["masked"] = head(np.logical_and(~pad_np, m_np), True) if not self.skip_masked else None
@@ -447,14 +465,24 @@ class WavLMCriterion(nn.Module):
         assert self.pred_masked_weight == 0 or len(heads_m) > 0
         for i, h in enumerate(heads_m):
             logging_output[f"loss_m_{i}"] = num(h["loss"].detach()[0])
+        # ILS weighted_sum (hubert_criterion.py:73-76, 88-91): per-layer losses weighted by softmax(model.weights)
+        lw = getattr(model, "weights", None) if getattr(model, "weighted_sum", False) else None
+        nw = torch.softmax(lw.float(), dim=-1) if lw is not None else None
+
+        def total(heads):
+            if nw is None:
+                return sum(h["loss"][0] for h in heads)
+            assert len(heads) == nw.numel(), "weighted_sum needs one loss per predicted layer"
+            return sum(nw[i] * h["loss"][0] for i, h in enumerate(heads))
+
         if self.pred_masked_weight > 0:
-            loss = loss + self.pred_masked_weight * sum(h["loss"][0] for h in heads_m)
+            loss = loss + self.pred_masked_weight * total(heads_m)
             sample_size += heads_m[0]["count"]
         assert self.pred_nomask_weight == 0 or len(heads_u) > 0
         for i, h in enumerate(heads_u):
             logging_output[f"loss_u_{i}"] = num(h["loss"].detach()[0])
         if self.pred_nomask_weight > 0:
-            loss = loss + self.pred_nomask_weight * sum(h["loss"][0] for h in heads_u)
+            loss = loss + self.pred_nomask_weight * total(heads_u)
             sample_size += heads_u[0]["count"]
 
         if self.loss_weights is not None:
