@@ -166,6 +166,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # the model, optimizer arenas and cached workspaces are long-lived: move them out of the cyclic collector's young
+    # generations so that a full collection cannot stall the launch thread for milliseconds mid-step (a training loop
+    # would do the same once after its first step)
+    import gc
+    gc.collect()
+    gc.freeze()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
