@@ -28,7 +28,14 @@ def _dev(t):
     return t.device
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """torch's current HIP stream of the current device as a raw handle (one per launch: the Stream-object route costs
+    ~1.5 us of the launch thread per call)"""
+    if _RAW_STREAM is not None:
+        return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
