@@ -1,5 +1,5 @@
 """How far ahead of the GPU is the launch thread?  Per step: host time to ENQUEUE the step (step() called on an idle GPU,
-no synchronisation inside) against the time until the GPU has finished it.  usage: python tools/host_time.py [steps]"""
+no synchronisation inside) against the time until the GPU has finished it.  usage: python tools/host_time.py [steps] [batch]"""
 import gc
 import os
 import sys
@@ -21,7 +21,8 @@ torch.manual_seed(0)
 model = WavLMPretrainModel(cfg, None, [range(bench.V)]).to(dev).to(torch.bfloat16).train()
 opt = FusedAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=10.0, model=model)
 crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0], defer_logging=True)
-B, T = bench.BATCH_PER_GPU, int(bench.SECONDS * bench.SR)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else bench.BATCH_PER_GPU  # batch 1: the same launches with ~no GPU work
+T = int(bench.SECONDS * bench.SR)
 g = torch.Generator().manual_seed(1234)
 wav = torch.randn(B, T, generator=g).to(dev).to(torch.bfloat16)
 pm_cpu = torch.zeros(B, T, dtype=torch.bool)

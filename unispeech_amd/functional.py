@@ -486,8 +486,11 @@ class ConvStackFn(torch.autograd.Function):
                 Jr = J[r]
                 if Jr == 0:
                     raise NotImplementedError("conv kernel narrower than its stride")
-                taps = [r + s * (Jr - 1 - jj) for jj in range(Jr)]
-                Wb = W[:, :, taps].permute(1, 2, 0).reshape(Cin, Jr * Cout).contiguous()
+                # taps r + s*(Jr-1), ..., r + s, r of this stride phase, newest first.  As a strided slice + flip: indexing
+                # with a Python list builds the index tensor on the host and copies it with a blocking H2D transfer, i.e.
+                # a stream synchronisation in the middle of backward (measured: the launch thread stalled 23 ms here
+                # every step and lost all its run-ahead for the rest of the step)
+                Wb = W[:, :, r::s].flip(2).permute(1, 2, 0).reshape(Cin, Jr * Cout).contiguous()
                 Mr = (T_in - r + s - 1) // s
                 ops.gemm(P, Wb, nxt, Mr, Cin, Jr * Cout, lda=Cout, ldb=Jr * Cout, ldc=s * Cin, batch=(B, 1),
                          a_off=(fp - Jr + 1) * Cout, sA=(Tp * Cout, 0), c_off=(fpp + r) * Cin, sC=(Tpp * Cin, 0),
