@@ -123,6 +123,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from unispeech_amd import functional as WF
     from unispeech_amd import ops
     from unispeech_amd.dp import DataParallelWavLM
     from unispeech_amd.optim import FusedAdam
@@ -151,7 +152,9 @@ def main():
         loss.backward()
         if world > 1:
             net.all_reduce_grads()
-            sst = torch.tensor([float(ss)], dtype=torch.float32, device=dev)
+            # pinned + asynchronous: torch.tensor(..., device=dev) is a blocking H2D copy, i.e. a stream synchronisation
+            # that would cost the launch thread its run-ahead in every data-parallel step
+            sst = WF.h2d(torch.tensor([float(ss)], dtype=torch.float32), dev)
             dist.all_reduce(sst)
             opt.step(grad_mult=1.0, grad_mult_dev=sst.reciprocal())
         else:
