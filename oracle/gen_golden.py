@@ -254,7 +254,7 @@ def gen_tiny_chanmask():
     gen_tiny_pretrain({"mask_channel_prob": 0.25, "mask_channel_length": 4}, "tiny_chanmask.npz")
 
 
-def gen_tiny_sat():
+def gen_tiny_sat(overrides=None, fname="tiny_sat.npz"):
     """UniSpeech-SAT at tiny size (fairseq UniSpeechSATModel, utterance_contrastive_loss with 2 in-utterance and 5
     cross-utterance instances tapped after layer 1 of 2) + HubertCriterion with loss_weights [10, 5, 0]: loss, the
     speaker logits statistics and every parameter gradient."""
@@ -268,6 +268,8 @@ def gen_tiny_sat():
             setattr(cfg, k, v)
     cfg.relative_position_embedding = False
     cfg.gru_rel_pos = False
+    for k, v in (overrides or {}).items():
+        setattr(cfg, k, v)
     cfg.label_rate = 50
     cfg.final_dim = 32
     cfg.utterance_contrastive_loss = True
@@ -308,7 +310,107 @@ def gen_tiny_sat():
     out["out/mask_seed321"] = m
     for n, p in model.named_parameters():
         out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
-    np.savez_compressed(os.path.join(OUT, "tiny_sat.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def gen_tiny_boundary():
+    """tiny_pretrain with boundary_mask=True and a label sequence SHORTER than the frame sequence: exercises the two
+    branches of the fairseq model no other fixture reaches -- apply_mask's boundary branch (wavlm.py:363-387: row 0 carries
+    segment boundaries -> one np.random.binomial coin per segment; row 1 has none -> per-row compute_mask_indices((1, T)))
+    and forward_targets' trim (wavlm.py:440-451: 49 frames vs 45 labels -> 45 frames kept)."""
+    WavLMModel, WavLMConfig, WavLMCriterion, _, _ = ref_shim.fairseq_wavlm()
+    cfg = WavLMConfig()
+    for k, v in TINY.items():
+        setattr(cfg, k, v)
+    cfg.label_rate = 50
+    cfg.final_dim = 32
+    cfg.logit_temp = 0.1
+    cfg.skip_masked = cfg.skip_nomask = cfg.untie_final_proj = cfg.target_glu = False
+    cfg.boundary_mask = True
+    cfg.expand_attention_head_size = -1
+    V = 23
+    torch.manual_seed(0)
+    model = WavLMModel(cfg, SimpleNamespace(sample_rate=16000), [_Dict(V)])
+    model.train()
+    crit = WavLMCriterion(SimpleNamespace(), 1.0, 0.0, loss_weights=[10.0])
+    out = sd_to_np(model.state_dict())
+    g = torch.Generator().manual_seed(4242)
+    wav = torch.randn(2, 16000, generator=g)
+    target = torch.randint(4, V, (2, 45), generator=g)
+    pm = torch.zeros(2, 16000, dtype=torch.bool)
+    boundary = [[0, 4, 9, 13, 20, 22, 30, 37, 41, 45], []]
+    sample = {"id": torch.arange(2), "net_input": {"source": wav, "padding_mask": pm, "boundary": boundary},
+              "target_list": [target]}
+    np.random.seed(909)
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    np.random.seed(909)
+    net = model(target_list=[target], source=wav, padding_mask=pm, boundary=boundary)
+    out["in/source"] = wav.numpy()
+    out["in/target"] = target.numpy()
+    out["in/boundary0"] = np.array(boundary[0], dtype=np.int64)
+    out["out/loss"] = np.float64(loss.item())
+    out["out/sample_size"] = np.int64(sample_size)
+    for k, v in log.items():
+        out["log/" + k] = np.float64(v)
+    out["out/logit_m"] = net["logit_m_list"][0].detach().float().numpy()
+    out["out/x"] = net["x"].detach().numpy()
+    assert net["x"].shape[1] == 45
+    # the mask the forward consumed: recovered from the reference's own output (`features` holds mask_emb on masked frames
+    # before pos_conv is added -> not recoverable there); re-draw it with the reference's functions instead
+    np.random.seed(909)
+    from fairseq.data.data_utils import compute_mask_indices
+    m = np.full((2, 45), False)
+    coin = np.random.binomial(1, 0.5, size=len(boundary[0]) - 1)
+    for j in np.argwhere(coin == 1)[:, 0]:
+        m[0][boundary[0][j]:boundary[0][j + 1]] = True
+    m[1] = compute_mask_indices((1, 45), None, cfg.mask_prob, cfg.mask_length, cfg.mask_selection, cfg.mask_other,
+                                min_masks=2, no_overlap=False, min_space=1)
+    assert int(m.sum()) == int(sample_size), (int(m.sum()), int(sample_size))
+    out["out/mask_seed909"] = m
+    for n, p in model.named_parameters():
+        out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_boundary.npz"), **out)
+
+
+def gen_tiny_sat_variants():
+    """tiny_sat with the gated relative position bias ON (post-LN), and UniSpeech-SAT *Large* structure (BASELINE.json
+    configs[4]): extractor_mode 'layer_norm' + pre-LN encoder, whose speaker tap goes through `layer_norm_for_extract`
+    (unispeech_sat.py:1197,1208)."""
+    gen_tiny_sat({"relative_position_embedding": True, "gru_rel_pos": True}, "tiny_sat_relpos.npz")
+    gen_tiny_sat({"relative_position_embedding": True, "gru_rel_pos": True, "extractor_mode": "layer_norm",
+                  "layer_norm_first": True}, "tiny_sat_large.npz")
+
+
+def gen_adam_clip():
+    """The reference optimizer stack on fixed gradients for 4 updates: fairseq Adam (optim/adam.py:148-228) after
+    multiply_grads(c) and utils.clip_grad_norm_ (utils.py:338-388) -- the sequence trainer.py:796-812 runs; in bf16 mode
+    _FP16OptimizerMixin folds both factors into _multiply_factor (optim/fp16_optimizer.py:182-218), same arithmetic.
+    Update 2 has a large gradient (clipped), the others are not clipped."""
+    ref_shim.install()
+    import fairseq  # noqa: F401
+    from fairseq import utils as futils
+    from fairseq.optim.adam import Adam
+    g = torch.Generator().manual_seed(77)
+    n = 10007
+    p = torch.nn.Parameter(torch.randn(n, generator=g))
+    lr, betas, eps, wd, max_norm = 5e-4, (0.9, 0.98), 1e-6, 0.01, 1.0
+    opt = Adam([p], lr=lr, betas=betas, eps=eps, weight_decay=wd)
+    out = {"in/p0": p.detach().numpy().copy(), "in/hyper": np.array([lr, betas[0], betas[1], eps, wd, max_norm])}
+    for step in range(1, 5):
+        gr = torch.randn(n, generator=g) * (2.0 if step == 2 else 0.01)
+        mult = 1.0 / (3.0 + step)
+        p.grad = gr.clone() * mult
+        gn = futils.clip_grad_norm_([p], max_norm)
+        opt.step()
+        st = opt.state[p]
+        out["in/grad%d" % step] = gr.numpy()
+        out["in/mult%d" % step] = np.float64(mult)
+        out["out/gnorm%d" % step] = np.float64(float(gn))
+        out["out/p%d" % step] = p.detach().numpy().copy()
+        out["out/m%d" % step] = st["exp_avg"].numpy().copy()
+        out["out/v%d" % step] = st["exp_avg_sq"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "adam_clip.npz"), **out)
 
 
 def gen_tiny_ils(overrides=None, fname="tiny_ils.npz", vocabs=(23,)):
@@ -402,6 +504,10 @@ if __name__ == "__main__":
     if not ref_shim.available():
         raise SystemExit("reference tree not found at %s" % ref_shim.REF_ROOT)
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1:  # python oracle/gen_golden.py gen_tiny_boundary gen_adam_clip ...: only those
+        for name in sys.argv[1:]:
+            globals()[name]()
+        raise SystemExit(0)
     gen_masks()
     gen_buckets()
     gen_tiny_wavlm()
@@ -411,6 +517,9 @@ if __name__ == "__main__":
     gen_tiny_large()
     gen_tiny_large_convbias()
     gen_tiny_sat()
+    gen_tiny_sat_variants()
+    gen_tiny_boundary()
+    gen_adam_clip()
     gen_tiny_ils()
     gen_tiny_ils_variants()
     gen_sampled_negatives()

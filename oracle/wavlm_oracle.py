@@ -8,7 +8,7 @@ Why a restatement and not the reference itself: /root/reference does not exist o
 there need a self-contained checker.  Pinning: tests/test_oracle_vs_golden.py checks every function here against
 fixtures in tests/golden/ that oracle/gen_golden.py produced by running the *reference's own Python*
 (WavLM/WavLM.py and src/fairseq WavLMModel + WavLMCriterion) in the build container, and -- when /root/reference is
-present -- tests/test_oracle_vs_reference.py re-runs the reference live at larger sizes.  The reference ships no
+present -- tests/test_oracle_vs_reference.py re-runs the reference live at WavLM-Base width (12 layers, d=768, padded row).  The reference ships no
 golden vectors or tests of its own, so those reference-generated fixtures are the pin.
 
 All functions take a parameter dict `sd` keyed exactly like the reference state_dict and a config object with the
@@ -191,6 +191,9 @@ def transformer_encoder(sd, cfg, x, padding_mask=None, tgt_layer=None, prefix="e
     x = x.transpose(0, 1)
     if cfg.layer_norm_first and tgt_layer is None:
         x = F.layer_norm(x, (D,), sd[prefix + "layer_norm.weight"], sd[prefix + "layer_norm.bias"], 1e-5)
+        if taps:  # pre-LN UniSpeech-SAT: the speaker tap gets its own final LayerNorm (unispeech_sat.py:1197, 1205-1208)
+            taps[0] = F.layer_norm(taps[0], (D,), sd[prefix + "layer_norm_for_extract.weight"],
+                                   sd[prefix + "layer_norm_for_extract.bias"], 1e-5)
     return x, layer_results, conv_sum
 
 
@@ -418,3 +421,53 @@ def adam_reference_step(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
         p = p + p * (-weight_decay * lr)
     p = p - step_size * (m / denom)
     return p, m, v
+
+
+def grad_norm(grads):
+    """utils.clip_grad_norm_'s total norm (src/fairseq/utils.py:358-375): L2 norm of the per-tensor fp32 L2 norms"""
+    grads = list(grads)
+    if len(grads) == 1:
+        return float(torch.norm(grads[0], p=2, dtype=torch.float32))
+    return float(torch.norm(torch.stack([torch.norm(g, p=2, dtype=torch.float32) for g in grads])))
+
+
+def clip_coef(total_norm, max_norm):
+    """clip coefficient of utils.clip_grad_norm_ (utils.py:380-384) == the factor _FP16OptimizerMixin.clip_grad_norm
+    folds into _multiply_factor when there is no loss scaler, i.e. in bf16 mode (optim/fp16_optimizer.py:186-203)"""
+    if max_norm <= 0:
+        return 1.0
+    return min(1.0, float(max_norm) / (float(total_norm) + 1e-6))
+
+
+def train_steps(sd, cfg, batches, num_classes, lr, betas, eps, weight_decay, max_norm, loss_weights=(10.0,)):
+    """`len(batches)` optimizer updates of the reference training loop in fp32 on the CPU, restated:
+    forward + criterion + backward (models/wavlm/wavlm.py:465-576, criterions/wavlm_criterion.py:52-138), GradMultiply on
+    the extractor (modules/grad_multiply.py), multiply_grads(1 / sample_size) (trainer.py:796-801, one worker),
+    clip_grad_norm (utils.py:338-388), Adam (optim/adam.py:203-224).  batches: [(wav, target, padding_mask, mask)].
+    `sd` holds the initial parameters (plain tensors); returns (losses, sample_sizes, grad_norms, final sd)."""
+    names = [k for k, v in sd.items() if v.is_floating_point()]
+    p = {k: sd[k].detach().clone() for k in sd}
+    m = {k: torch.zeros_like(p[k]) for k in names}
+    v = {k: torch.zeros_like(p[k]) for k in names}
+    losses, sizes, norms = [], [], []
+    fgm = cfg.feature_grad_mult
+    for step, (wav, target, pm, mask) in enumerate(batches, 1):
+        leaf = {k: (t.detach().clone().requires_grad_(True) if k in m else t) for k, t in p.items()}
+        net = pretrain_forward(leaf, cfg, wav, [target], pm, mask, num_classes)
+        loss, ss, _ = criterion(net, 1.0, 0.0, list(loss_weights))
+        loss.backward()
+        grads = {}
+        for k in names:
+            g = leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(leaf[k])
+            if k.startswith("feature_extractor.") and fgm > 0 and fgm != 1.0:
+                g = g * fgm
+            grads[k] = g / float(ss)
+        gn = grad_norm(grads.values())
+        c = clip_coef(gn, max_norm)
+        for k in names:
+            p[k], m[k], v[k] = adam_reference_step(p[k], grads[k] * c, m[k], v[k], step, lr, betas[0], betas[1], eps,
+                                                   weight_decay)
+        losses.append(float(loss))
+        sizes.append(int(ss))
+        norms.append(gn)
+    return losses, sizes, norms, p

@@ -289,15 +289,24 @@ def test_large_structure_vs_reference_golden(golden, conv_bias):
         assert (g - ref).abs().max().item() <= tol, (n, (g - ref).abs().max().item(), tol)
 
 
-def test_unispeech_sat_head_vs_reference_golden():
+SAT_CASES = [("tiny_sat.npz", {}),
+             ("tiny_sat_relpos.npz", {"relative_position_embedding": True, "gru_rel_pos": True}),
+             ("tiny_sat_large.npz", {"relative_position_embedding": True, "gru_rel_pos": True,
+                                     "extractor_mode": "layer_norm", "layer_norm_first": True})]
+
+
+@pytest.mark.parametrize("golden,overrides", SAT_CASES)
+def test_unispeech_sat_head_vs_reference_golden(golden, overrides):
     """UniSpeech-SAT utterance-contrastive head (speaker tap after layer 1, spk_proj, sampled
     in-/cross-utterance instances, gathered cosine logits, BCE) on the HIP path against the reference-generated golden:
-    total criterion loss, speaker loss + statistics, and every parameter gradient."""
+    total criterion loss, speaker loss + statistics, and every parameter gradient.  Variants: gated relative position
+    bias on; UniSpeech-SAT Large structure (layer_norm extractor, pre-LN encoder, tap through layer_norm_for_extract)."""
     from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
-    z = load_golden("tiny_sat.npz")
+    z = load_golden(golden)
     d = dict(TINY)
     d.update(relative_position_embedding=False, gru_rel_pos=False, utterance_contrastive_loss=True,
              utterance_contrastive_layer=1, num_instances=2, cross_sample_instances=5)
+    d.update(overrides)
     cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
     m = WavLMPretrainModel(cfg, None, [range(23)])
     missing = m.load_state_dict(golden_state_dict(z), strict=True)
@@ -389,3 +398,58 @@ def test_sampled_negatives_loss_vs_reference_golden():
     loss.sum().backward()
     assert rel_err(x.grad.reshape(B, T, C), z["grad/x"]) < GTOL
     assert rel_err(y.grad.reshape(B, T, C), z["grad/y"]) < GTOL
+
+
+def test_boundary_mask_and_target_trim_vs_reference_golden():
+    """boundary_mask=True (segment boundaries on row 0, none on row 1) with labels shorter than the frame sequence
+    (49 frames -> 45): the two branches of the fairseq forward no other fixture reaches (wavlm.py:363-387, 440-451), HIP
+    path against the golden generated from the reference's WavLMModel + WavLMCriterion."""
+    model, crit, z = _tiny_pretrain(golden="tiny_boundary.npz", boundary_mask=True)
+    pm = torch.zeros(2, 16000, dtype=torch.bool)
+    sample = {"id": torch.arange(2),
+              "net_input": {"source": torch.from_numpy(z["in/source"]).cuda(), "padding_mask": pm.cuda(),
+                            "boundary": [list(z["in/boundary0"]), []]},
+              "target_list": [torch.from_numpy(z["in/target"]).cuda()]}
+    np.random.seed(909)
+    loss, sample_size, log = crit(model, sample)
+    assert sample_size == int(z["out/sample_size"])
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
+    loss.backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+    for n, p in model.named_parameters():
+        ref = torch.from_numpy(z["grad/" + n])
+        g = p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(ref)
+        tol = GTOL * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8
+        assert (g - ref).abs().max().item() <= tol, (n, (g - ref).abs().max().item(), tol)
+    np.random.seed(909)
+    with torch.no_grad():
+        net = model(target_list=sample["target_list"], **sample["net_input"])
+    assert net["x"].shape[1] == 45 and rel_err(net["x"], z["out/x"]) < RTOL
+    ref = torch.from_numpy(z["out/logit_m"])
+    lm = model.get_logits(net, True)[0].cpu()
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(lm), fin) and rel_err(lm[fin], ref[fin]) < RTOL
+
+
+def test_fused_adam_vs_reference_optimizer_golden():
+    """FusedAdam (one sum-of-squares launch + one update kernel, clip coefficient derived on the device) against
+    tests/golden/adam_clip.npz: 4 updates of the reference's Adam after multiply_grads + clip_grad_norm_ (update 2 clips).
+    fp32 arena: 1e-6 on the parameters; bf16 arena: the fp32 master copy tracks the golden as far as bf16 gradients allow."""
+    from unispeech_amd.optim import FusedAdam
+    z = load_golden("adam_clip.npz")
+    lr, b1, b2, eps, wd, max_norm = [float(v) for v in z["in/hyper"]]
+    for dtype, tol in ((torch.float32, 2e-6), (torch.bfloat16, 2e-3)):
+        p = torch.nn.Parameter(torch.from_numpy(z["in/p0"]).clone().cuda().to(dtype))
+        opt = FusedAdam([p], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, clip_norm=max_norm)
+        if dtype == torch.bfloat16:
+            opt.master.copy_(torch.from_numpy(z["in/p0"]).cuda())  # the golden starts from the fp32 values
+        for step in range(1, 5):
+            opt.zero_grad()
+            p.grad.copy_(torch.from_numpy(z["in/grad%d" % step]).cuda().to(dtype))
+            mult = float(z["in/mult%d" % step])
+            opt.step(grad_mult=mult)
+            gn = opt.grad_norm(mult)
+            assert abs(gn - float(z["out/gnorm%d" % step])) <= (1e-5 if dtype == torch.float32 else 5e-3) * gn
+            assert rel_err(opt.master, z["out/p%d" % step]) < tol, (dtype, step)
+            if dtype == torch.float32:
+                assert rel_err(opt.exp_avg, z["out/m%d" % step]) < 1e-5 and rel_err(opt.exp_avg_sq, z["out/v%d" % step]) < 1e-5

@@ -184,19 +184,45 @@ def test_oracle_large_structure(golden):
         assert (g - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8, k
 
 
-def _sat_cfg():
+def _sat_cfg(**overrides):
     from conftest import Cfg, TINY
     d = dict(TINY)
     d.update(relative_position_embedding=False, gru_rel_pos=False, utterance_contrastive_loss=True,
              utterance_contrastive_layer=1, num_instances=2, cross_sample_instances=5)
+    d.update(overrides)
     return Cfg(**d)
 
 
-def test_oracle_unispeech_sat_head():
+SAT_CASES = [("tiny_sat.npz", {}),
+             ("tiny_sat_relpos.npz", {"relative_position_embedding": True, "gru_rel_pos": True}),
+             ("tiny_sat_large.npz", {"relative_position_embedding": True, "gru_rel_pos": True,
+                                     "extractor_mode": "layer_norm", "layer_norm_first": True})]
+
+
+@pytest.mark.parametrize("golden,overrides", SAT_CASES)
+def test_seeded_init_sat_variants(golden, overrides):
+    """parameter set / creation order of the UniSpeech-SAT model incl. encoder.layer_norm_for_extract of the pre-LN
+    (Large) structure (unispeech_sat.py:1195-1200): same seed -> bit-identical initial weights, strict state-dict load"""
+    z = load_golden(golden)
+    ref_sd = golden_state_dict(z)
+    d = dict(vars(_sat_cfg(**overrides)))
+    cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    torch.manual_seed(0)
+    model = WavLMPretrainModel(cfg, None, [range(23)])
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(ref_sd.keys()), set(sd.keys()) ^ set(ref_sd.keys())
+    for k in ref_sd:
+        assert torch.equal(sd[k], ref_sd[k]), k
+
+
+@pytest.mark.parametrize("golden,overrides", SAT_CASES)
+def test_oracle_unispeech_sat_head(golden, overrides):
     """UniSpeech-SAT utterance-contrastive head against the reference-generated golden: total loss,
-    speaker loss / statistics and every parameter gradient; instance indices come from the same torch.randint stream."""
-    z = load_golden("tiny_sat.npz")
-    cfg = _sat_cfg()
+    speaker loss / statistics and every parameter gradient; instance indices come from the same torch.randint stream.
+    Variants: gated relative position bias on; the Large structure (layer_norm extractor, pre-LN encoder, speaker tap
+    through layer_norm_for_extract; BASELINE.json configs[4])."""
+    z = load_golden(golden)
+    cfg = _sat_cfg(**overrides)
     sd = golden_state_dict(z, as_param=True)
     wav = torch.from_numpy(z["in/source"])
     target = torch.from_numpy(z["in/target"])
@@ -303,3 +329,59 @@ def test_sampled_negatives_oracle_and_index_stream():
     assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
     loss.backward()
     assert rel_err(x.grad, z["grad/x"]) < 5e-4 and rel_err(y.grad, z["grad/y"]) < 5e-4
+
+
+def test_boundary_mask_and_target_trim_host_logic_and_oracle(tiny_cfg):
+    """boundary_mask=True with segment boundaries on row 0 only, labels shorter than the frame sequence
+    (tests/golden/tiny_boundary.npz, generated from the reference's WavLMModel): the host mask logic of the product
+    (pretrain._mask_numpy: binomial coin per segment / per-row compute_mask_indices; forward_targets trim 49 -> 45) is
+    bit-exact with the reference, and the oracle reproduces loss, logits and every gradient with that mask."""
+    z = load_golden("tiny_boundary.npz")
+    d = dict(TINY)
+    d.update(boundary_mask=True)
+    cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    model = WavLMPretrainModel(cfg, None, [range(23)])
+    target = torch.from_numpy(z["in/target"])
+    T, tinds = model.forward_targets(49, [target])
+    assert T == 45 and torch.equal(tinds, torch.arange(45))
+    boundary = [list(z["in/boundary0"]), []]
+    np.random.seed(909)
+    m = model._mask_numpy(2, T, torch.zeros(2, T, dtype=torch.bool), boundary)
+    assert np.array_equal(m, z["out/mask_seed909"])
+    sd = golden_state_dict(z, as_param=True)
+    net = O.pretrain_forward(sd, tiny_cfg, torch.from_numpy(z["in/source"]), [target],
+                             torch.zeros(2, 16000, dtype=torch.bool), torch.from_numpy(m), [23])
+    assert net["x"].shape[1] == 45
+    assert rel_err(net["x"].detach(), z["out/x"]) < RTOL
+    ref = torch.from_numpy(z["out/logit_m"])
+    fin = torch.isfinite(ref)
+    assert rel_err(net["logit_m_list"][0].detach()[fin], ref[fin]) < RTOL
+    loss, ss, _ = O.criterion(net, 1.0, 0.0, [10.0])
+    assert ss == int(z["out/sample_size"])
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
+    loss.backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+    for k, p in sd.items():
+        if not p.is_floating_point():
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        if k.startswith("feature_extractor."):
+            g = g * tiny_cfg.feature_grad_mult
+        ref = torch.from_numpy(z["grad/" + k])
+        assert (g - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8, k
+
+
+def test_oracle_adam_clip_vs_reference_golden():
+    """oracle.adam_reference_step + grad_norm + clip_coef against tests/golden/adam_clip.npz: 4 updates of the
+    reference's Adam after multiply_grads + clip_grad_norm_ (update 2 is clipped)."""
+    z = load_golden("adam_clip.npz")
+    lr, b1, b2, eps, wd, max_norm = [float(v) for v in z["in/hyper"]]
+    p = torch.from_numpy(z["in/p0"]).clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 5):
+        g = torch.from_numpy(z["in/grad%d" % step]) * float(z["in/mult%d" % step])
+        gn = O.grad_norm([g])
+        assert abs(gn - float(z["out/gnorm%d" % step])) <= 1e-6 * gn
+        p, m, v = O.adam_reference_step(p, g * O.clip_coef(gn, max_norm), m, v, step, lr, b1, b2, eps, wd)
+        assert rel_err(p, z["out/p%d" % step]) < 1e-6
+        assert rel_err(m, z["out/m%d" % step]) < 1e-5 and rel_err(v, z["out/v%d" % step]) < 1e-5

@@ -429,6 +429,8 @@ class WavLMPretrainModel(WavLM):
         if self.utterance_contrastive_loss:
             self.project_q = None
             self.spk_proj = None
+        if hasattr(self.encoder, "layer_norm_for_extract"):  # unispeech_sat.py:833-834
+            self.encoder.layer_norm_for_extract = None
 
 
 class WavLMCriterion(nn.Module):

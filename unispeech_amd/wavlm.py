@@ -365,6 +365,10 @@ class TransformerEncoder(nn.Module):
         ])
         self.layer_norm_first = args.layer_norm_first
         self.layer_norm = nn.LayerNorm(self.embedding_dim)
+        if self.layer_norm_first and getattr(args, "utterance_contrastive_loss", False):
+            # UniSpeech-SAT's encoder (unispeech_sat.py:1195-1197): the speaker tap of a pre-LN stack gets its own final
+            # LayerNorm.  Created only for SAT configs so that WavLM-Large state dicts still load strictly.
+            self.layer_norm_for_extract = nn.LayerNorm(self.embedding_dim)
         self.layerdrop = args.encoder_layerdrop
         self.apply(init_bert_params)
 
