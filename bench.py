@@ -3,6 +3,8 @@
 bf16, 32 x 15 s utterances per GPU, masked-prediction loss, forward + backward + gradient reduction + fused Adam.
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N ...                        # no launcher: re-executes itself under torch.distributed.run
+    python bench.py --config large ...                  # WavLM-Large, 20 s utterances (configs[3] per-GPU slice)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W          # one rank per GPU over RCCL, weak scaling
 
@@ -10,7 +12,7 @@ Synthetic data of the real shape (randn waveform, random k-means labels), random
 architecture; recipe dropouts on (dropout 0.1, attention_dropout 0.1, dropout_input 0.1), layerdrop 0 (no layer is
 ever skipped inside the timed region).  Rank 0 prints ONE JSON line.  Extra legs outside the timed region:
 `roofline` (HIP-event timing of every bf16 MFMA GEMM launch during two extra steps) and `cpu_baseline` (the CPU
-oracle timed on the host cores on a bounded 2 x 15 s sample; rank 0, N=1 only).
+oracle timed on the host cores on a bounded 1 x 15 s sample, thread count chosen by a sweep; rank 0, N=1 only).
 """
 import argparse
 import json
@@ -33,35 +35,51 @@ V = 504
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md line 42
 
 
-def base_cfg(training_dropouts=True):
+# name -> (layers, d, ffn, heads, extractor_mode, layer_norm_first, seconds, label); "base" is BASELINE.json configs[1]
+# (the headline), "large" the per-GPU slice of configs[3] (WavLM-Large, 20 s utterances)
+CONFIGS = {
+    "base": dict(L=12, D=768, F=3072, H=12, mode="default", pre_ln=False, seconds=15.0,
+                 name="WavLM-Base (12L, d=768)", baseline="BASELINE.json configs[1]", fgm=0.1),
+    "large": dict(L=24, D=1024, F=4096, H=16, mode="layer_norm", pre_ln=True, seconds=20.0,
+                  name="WavLM-Large (24L, d=1024)", baseline="per-GPU slice of BASELINE.json configs[3]", fgm=1.0),
+}
+
+
+def base_cfg(training_dropouts=True, config="base"):
     from unispeech_amd.pretrain import WavLMPretrainConfig
+    c = CONFIGS[config]
     d = 0.1 if training_dropouts else 0.0
     return WavLMPretrainConfig(
-        encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, encoder_attention_heads=12,
+        encoder_layers=c["L"], encoder_embed_dim=c["D"], encoder_ffn_embed_dim=c["F"], encoder_attention_heads=c["H"],
         dropout=d, attention_dropout=d, activation_dropout=0.0, encoder_layerdrop=0.0, dropout_input=d,
-        dropout_features=d, feature_grad_mult=0.1, mask_prob=0.80, mask_length=10, final_dim=256, logit_temp=0.1,
-        relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True, label_rate=50,
-        extractor_mode="default", conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2")
+        dropout_features=d, feature_grad_mult=c["fgm"], mask_prob=0.80, mask_length=10, final_dim=256 if config == "base" else 768,
+        logit_temp=0.1, relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True,
+        label_rate=50, extractor_mode=c["mode"], layer_norm_first=c["pre_ln"],
+        conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2")
 
 
-def algorithmic_flops_per_step(B, T):
-    """forward FLOPs of WavLM-Base for B utterances of T samples, x3 for forward+backward"""
+def algorithmic_flops_per_step(B, T, config="base"):
+    """forward FLOPs of the model for B utterances of T samples, x3 for forward+backward"""
+    c = CONFIGS[config]
     fl = 0.0
     t, cin = T, 1
-    for (c, k, s) in [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2:
+    for (co, k, s) in [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2:
         t = (t - k) // s + 1
-        fl += 2.0 * B * t * c * cin * k
-        cin = c
-    n, D, Fd, H = B * t, 768, 3072, 12
+        fl += 2.0 * B * t * co * cin * k
+        cin = co
+    n, D, Fd, H = B * t, c["D"], c["F"], c["H"]
     fl += 2.0 * n * 512 * D                      # post_extract_proj
     fl += 2.0 * n * D * (D // 16) * 128          # pos_conv
     per_layer = 2.0 * n * D * D * 4 + 2.0 * n * D * Fd * 2 + 2.0 * B * H * t * t * (D // H) * 2
-    fl += 12 * per_layer
+    fl += c["L"] * per_layer
     return 3.0 * fl
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """reference algorithm (CPU oracle, fp32, all host cores) on a 2 x 15 s sample: forward + loss + backward"""
+def cpu_baseline():
+    """reference algorithm (CPU oracle = PyTorch fp32 on the host cores) on a bounded sample of the same workload:
+    forward + loss + backward of ONE 15 s utterance through the 12-layer model, 1 warm-up + 3 timed iterations, median.
+    The thread count is chosen by a quick sweep on a 3 s utterance (all cores is NOT the fastest: oversubscribed OpenMP
+    regions on many small ops), and stated in `cores`."""
     from oracle import wavlm_oracle as O
     from unispeech_amd.masking import compute_mask_indices
     from unispeech_amd.pretrain import WavLMPretrainModel
@@ -69,31 +87,53 @@ def cpu_baseline(seconds_budget=30.0):
     torch.manual_seed(0)
     sd = {k: v.detach().clone().requires_grad_(v.is_floating_point())
           for k, v in WavLMPretrainModel(cfg, None, [range(V)]).state_dict().items()}
-    B, T = 2, int(SECONDS * SR)
-    g = torch.Generator().manual_seed(1234)
-    wav = torch.randn(B, T, generator=g)
-    target = torch.randint(4, V, (B, int(50 * SECONDS)), generator=g)
-    pm = torch.zeros(B, T, dtype=torch.bool)
-    np.random.seed(123)
-    mask = torch.from_numpy(compute_mask_indices((B, 749), torch.zeros(B, 749, dtype=torch.bool), cfg.mask_prob,
-                                                 cfg.mask_length, "static", 0, min_masks=2))
-    times = []
-    t_start = time.time()
-    for it in range(4):
+
+    def run(seconds, seed):
+        B, T = 1, int(seconds * SR)
+        g = torch.Generator().manual_seed(seed)
+        wav = torch.randn(B, T, generator=g)
+        Tp = T
+        for k, s_ in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
+            Tp = (Tp - k) // s_ + 1
+        target = torch.randint(4, V, (B, max(int(50 * seconds), Tp)), generator=g)
+        pm = torch.zeros(B, T, dtype=torch.bool)
+        np.random.seed(123)
+        mask = torch.from_numpy(compute_mask_indices((B, Tp), torch.zeros(B, Tp, dtype=torch.bool), cfg.mask_prob,
+                                                     cfg.mask_length, "static", 0, min_masks=2))
         for p in sd.values():
             p.grad = None
         t0 = time.time()
         net = O.pretrain_forward(sd, cfg, wav, [target], pm, mask, [V])
         loss, _, _ = O.criterion(net, 1.0, 0.0, [10.0])
         loss.backward()
-        dt = time.time() - t0
-        if it > 0:
-            times.append(dt)
-        if time.time() - t_start > seconds_budget and times:
-            break
-    med = sorted(times)[len(times) // 2]
-    return {"value": round(B * SECONDS / med, 2), "unit": "audio-s/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": "oracle fwd+loss+bwd fp32, B=2 x 15 s, median of %d after 1 warm-up" % len(times)}
+        return time.time() - t0
+
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu})
+    old = torch.get_num_threads()
+    sweep = {}
+    torch.set_num_threads(cands[0])
+    run(3.0, 1)  # warm-up (allocator, oneDNN primitive caches)
+    for c in cands:
+        torch.set_num_threads(c)
+        sweep[c] = run(3.0, 1)
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    run(SECONDS, 2)
+    times = sorted(run(SECONDS, 2) for _ in range(3))
+    torch.set_num_threads(old)
+    return {"value": round(SECONDS / times[1], 2), "unit": "audio-s/s", "cores": best, "kind": "port",
+            "sample": "oracle fwd+loss+bwd fp32, 12 layers, B=1 x 15 s, median of 3 after 1 warm-up; threads chosen by a "
+                      "sweep on a 3 s utterance: %s (host has %d)" % ({c: round(t, 2) for c, t in sweep.items()}, ncpu)}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -102,13 +142,28 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="base",
+                    help="base = BASELINE.json configs[1] (the headline); large = WavLM-Large, 20 s utterances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1),
+        # the counterpart of distributed_utils.call_main spawning the ranks (src/fairseq/distributed/utils.py:332-367)
+        if os.environ.get("WAVLM_SHARED_GPU") != "1" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    SECONDS = CONFIGS[args.config]["seconds"]
     # WAVLM_SHARED_GPU=1 + WAVLM_DIST_BACKEND=gloo: functional test of the N > 1 path on a single-GPU box (all ranks on
     # cuda:0, gradients reduced through gloo); the real thing is one rank per GPU over RCCL ("nccl")
     if os.environ.get("WAVLM_SHARED_GPU") == "1":
@@ -129,7 +184,7 @@ def main():
     from unispeech_amd.optim import FusedAdam
     from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainModel
 
-    cfg = base_cfg(True)
+    cfg = base_cfg(True, args.config)
     torch.manual_seed(0)
     model = WavLMPretrainModel(cfg, None, [range(V)]).to(dev).to(torch.bfloat16).train()
     opt = FusedAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=10.0, model=model)
@@ -199,19 +254,25 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x 2 on
             # gfx950 + WRITE_SIZE, tools/pmc_traffic.py); counters cannot be read from inside the run
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "r01", "gemm_hbm_traffic.json")
-            if os.path.exists(tj):
-                try:
-                    traffic = round(json.load(open(tj))["gemm_hbm_bytes_per_launch"])
-                except Exception:
-                    traffic = None
+            traffic, traffic_src = None, None
+            if args.config == "base":
+                for rnd in ("r02", "r01"):
+                    tj = os.path.join(ROOT, "profiles", rnd, "gemm_hbm_traffic.json")
+                    if os.path.exists(tj):
+                        try:
+                            traffic = round(json.load(open(tj))["gemm_hbm_bytes_per_launch"])
+                            traffic_src = "profiles/%s/gemm_hbm_traffic.json (committed rocprofv3 PMC passes of this " \
+                                          "command, not this run)" % rnd
+                            break
+                        except Exception:
+                            traffic = None
             roof = {"bound": "mfma",
                     "kernel": "bf16 MFMA GEMM family (gemm_pp_kernel 256x256, gemm_pp3_kernel 192x384, gemm_bf16_kernel "
                               "128-wide): every dense contraction of the step",
                     "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (avg over the step's GEMM launches, PMC)",
+                    "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(alg_bytes / max(n_l, 1)),
                     "launches_per_step": n_l // 2, "gemm_ms_per_step": round(ms / 2, 3),
                     "gemm_algorithmic_tflop_per_step": round(fl / 2 / 1e12, 3),
@@ -221,23 +282,28 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * SECONDS * args.steps / dt
+        c = CONFIGS[args.config]
+        Tp = T
+        for k_, s_ in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
+            Tp = (Tp - k_) // s_ + 1
         out = {
-            "metric": "audio-seconds/sec pretraining, WavLM-Base 15s@16kHz", "value": round(value, 1),
+            "metric": "audio-seconds/sec pretraining, %s %ds@16kHz" % (c["name"].split(" (")[0], int(SECONDS)),
+            "value": round(value, 1),
             "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "WavLM-Base (12L, d=768) pretrain fwd+bwd+grad-reduce+fused-Adam, bf16, "
-                                   "batch=%dx15s per GPU, masked-pred loss (BASELINE.json configs[1]%s)"
-                                   % (B, "" if world == 1 else ", dp%d" % world),
-                       "global_batch": world * B, "seconds_per_utt": SECONDS, "frames_per_utt": 749,
+            "config": {"workload": "%s pretrain fwd+bwd+grad-reduce+fused-Adam, bf16, "
+                                   "batch=%dx%ds per GPU, masked-pred loss (%s%s)"
+                                   % (c["name"], B, int(SECONDS), c["baseline"], "" if world == 1 else ", dp%d" % world),
+                       "global_batch": world * B, "seconds_per_utt": SECONDS, "frames_per_utt": Tp,
                        "parallelism": "dp%d" % world, "dropout": 0.1, "attention_dropout": 0.1, "layerdrop": 0.0,
                        "mask_prob": 0.8, "optimizer": "fused Adam, fp32 master, clip 10"},
             "final_loss": final_loss,
-            "model_tflops": round(algorithmic_flops_per_step(B, T) / (ms_per_step * 1e-3) / 1e12, 1),
+            "model_tflops": round(algorithmic_flops_per_step(B, T, args.config) / (ms_per_step * 1e-3) / 1e12, 1),
         }
         if roof is not None:
             out["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "base":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

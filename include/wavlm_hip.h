@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 4
+#define WAVLM_HIP_ABI_VERSION 5
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -248,6 +248,11 @@ int wavlm_adam_step(float* p, float* m, float* v, const void* grad, int32_t grad
 void wavlm_prof_enable(int on);
 /* 0: automatic tile choice, 1: force the 128x128 tile (A/B measurements only) */
 void wavlm_gemm_set_variant(int v);
+/* Data-parallel runs: leave `n` of the 256 CUs out of every PERSISTENT GEMM launch (grid 256 - n), so that the RCCL
+ * kernels of the gradient all-reduce (side stream; replaces the blocking all-reduce after backward of
+ * src/fairseq/distributed/legacy_distributed_data_parallel.py:132-165) find free CUs while backward is still running.
+ * 0 (default) = use the whole chip.  Values are clamped to [0, 64]. */
+void wavlm_set_reserved_cus(int n);
 int wavlm_prof_collect(int dtype, double* total_ms, double* total_flops);
 /* algorithmic HBM bytes of the recorded launches: every operand, output and epilogue tensor counted once */
 double wavlm_prof_collect_bytes(int dtype);

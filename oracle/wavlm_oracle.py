@@ -439,12 +439,16 @@ def clip_coef(total_norm, max_norm):
     return min(1.0, float(max_norm) / (float(total_norm) + 1e-6))
 
 
-def train_steps(sd, cfg, batches, num_classes, lr, betas, eps, weight_decay, max_norm, loss_weights=(10.0,)):
+def train_steps(sd, cfg, batches, num_classes, lr, betas, eps, weight_decay, max_norm, loss_weights=(10.0,),
+                model_dtype=None, return_grads=False):
     """`len(batches)` optimizer updates of the reference training loop in fp32 on the CPU, restated:
     forward + criterion + backward (models/wavlm/wavlm.py:465-576, criterions/wavlm_criterion.py:52-138), GradMultiply on
     the extractor (modules/grad_multiply.py), multiply_grads(1 / sample_size) (trainer.py:796-801, one worker),
     clip_grad_norm (utils.py:338-388), Adam (optim/adam.py:203-224).  batches: [(wav, target, padding_mask, mask)].
-    `sd` holds the initial parameters (plain tensors); returns (losses, sample_sizes, grad_norms, final sd)."""
+    `sd` holds the initial parameters (plain tensors); returns (losses, sample_sizes, grad_norms, final sd).
+    model_dtype=torch.bfloat16 restates the reference's --bf16 parameter handling (optim/fp16_optimizer.py:269-289,
+    106-133): fp32 master parameters are updated, the model computes with their bf16 rounding (here: rounded values in
+    fp32 arithmetic, i.e. only the parameter rounding of that mode, not its activation rounding)."""
     names = [k for k, v in sd.items() if v.is_floating_point()]
     p = {k: sd[k].detach().clone() for k in sd}
     m = {k: torch.zeros_like(p[k]) for k in names}
@@ -452,7 +456,9 @@ def train_steps(sd, cfg, batches, num_classes, lr, betas, eps, weight_decay, max
     losses, sizes, norms = [], [], []
     fgm = cfg.feature_grad_mult
     for step, (wav, target, pm, mask) in enumerate(batches, 1):
-        leaf = {k: (t.detach().clone().requires_grad_(True) if k in m else t) for k, t in p.items()}
+        def model_copy(t):
+            return t.detach().to(model_dtype).float() if model_dtype is not None else t.detach().clone()
+        leaf = {k: (model_copy(t).requires_grad_(True) if k in m else t) for k, t in p.items()}
         net = pretrain_forward(leaf, cfg, wav, [target], pm, mask, num_classes)
         loss, ss, _ = criterion(net, 1.0, 0.0, list(loss_weights))
         loss.backward()
@@ -467,7 +473,9 @@ def train_steps(sd, cfg, batches, num_classes, lr, betas, eps, weight_decay, max
         for k in names:
             p[k], m[k], v[k] = adam_reference_step(p[k], grads[k] * c, m[k], v[k], step, lr, betas[0], betas[1], eps,
                                                    weight_decay)
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         sizes.append(int(ss))
         norms.append(gn)
+        if return_grads:
+            return losses, sizes, norms, p, {k: grads[k] * float(ss) for k in names}  # first update only, unnormalised
     return losses, sizes, norms, p

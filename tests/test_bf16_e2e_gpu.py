@@ -1,0 +1,202 @@
+"""End-to-end parity of the BENCHMARKED configuration: the bf16 HIP path (gemm_pp / gemm_pp3 with fused epilogues,
+fused attention, bf16 LayerNorm / colsum / gradient-sink path, packed q|k|v, FusedAdam) against the fp32 CPU oracle.
+
+Every other model-level parity test runs the fp32 mode of the kernels (exact-FMA GEMM, unfused attention).  Here
+the 12-layer WavLM-Base model is `.bfloat16()` with FusedAdam bound -- exactly what bench.py times, dropouts 0 -- and
+  (a) loss and EVERY parameter gradient of one step at 2 x 15 s are compared with the oracle,
+  (b) a 10-update loss / gradient-norm trajectory (fwd + bwd + clip + Adam) is compared with oracle.train_steps,
+  (c) at the bench batch (32 x 15 s) the bf16 loss is compared with the fp32 mode of the HIP path (whose parity with the
+      oracle the other tests establish), because the CPU oracle cannot afford B = 32.
+
+Tolerances (bf16 has 8 significand bits, unit round-off u = 2^-9 = 1.95e-3; activations are rounded to bf16 between
+kernels, accumulation is fp32): the oracle receives the SAME bf16-rounded weights and waveform, so the differences
+below are arithmetic only.
+  loss: 2e-3 relative (a sum over ~1e3 frames of log-softmax terms whose logits carry ~u relative error each;
+        independent errors average out);
+  gradients: per tensor, relative L2 error <= 4e-2 and cosine >= 0.999, max-abs error <= 6e-2 of the tensor's max-abs
+        (~30 u: every gradient passes through <= 12 layers x ~6 bf16 roundings, errors add in quadrature -> sqrt(72) u
+        = 1.7e-2 expected, x2.4 margin; measured worst case 3.1e-2 on the 8 x 64 grep_linear.weight of the gate, whose
+        gradient is a sum over all (batch, head, frame) of bf16 attention-backward terms; every other tensor is below 3e-2;
+        analytically-zero gradients are compared on an absolute floor);
+  trajectory: loss within 1e-2 relative and gradient norm within 3e-2 at each of the 10 updates.
+The measured errors are printed and carried in the assertion messages.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Cfg, TINY
+
+pytestmark = pytest.mark.gpu
+
+U = 2.0 ** -9
+BASE = dict(TINY)
+BASE.update(encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, encoder_attention_heads=12,
+            conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2", conv_pos=128, conv_pos_groups=16,
+            num_buckets=320, max_distance=800, mask_length=10, mask_prob=0.8, final_dim=256)
+V = 504
+ADAM = dict(lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
+CLIP = 10.0
+
+
+def _build(dtype, with_opt=True):
+    from unispeech_amd.optim import FusedAdam
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
+    cfg = WavLMPretrainConfig(**{k: v for k, v in BASE.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    torch.manual_seed(0)
+    model = WavLMPretrainModel(cfg, None, [range(V)])
+    # the reference's --bf16 mode rounds the freshly initialised parameters to bf16 (trainer.py:90-92); the oracle starts
+    # from those rounded values, so both sides hold identical parameters
+    sd = {k: (v.detach().to(torch.bfloat16).float() if v.is_floating_point() else v.detach().clone())
+          for k, v in model.state_dict().items()}
+    model = model.cuda().to(dtype).train()
+    opt = FusedAdam(model.parameters(), clip_norm=CLIP, model=model, **ADAM) if with_opt else None
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0])
+    return model, opt, crit, sd, Cfg(**BASE)
+
+
+def _batch(B, seconds, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    T = int(16000 * seconds)
+    wav = torch.randn(B, T, generator=g).to(torch.bfloat16)       # trainer.py:1141-1152: the waveform is cast too
+    target = torch.randint(4, V, (B, int(50 * seconds)), generator=g)
+    pm = torch.zeros(B, T, dtype=torch.bool)
+    return wav, target, pm
+
+
+def _frames(T, cfg):
+    for _, k, s in eval(cfg.conv_feature_layers):
+        T = (T - k) // s + 1
+    return T
+
+
+def _oracle_threads():
+    # 128 host threads are slower than 16-32 for these sizes (bench.py's cpu_baseline sweep)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+
+
+def test_bf16_step_loss_and_all_gradients_vs_fp32_oracle():
+    from oracle import wavlm_oracle as O
+    from unispeech_amd.masking import compute_mask_indices
+    _oracle_threads()
+    model, opt, crit, sd, cfg = _build(torch.bfloat16)
+    B, seconds = 2, 15.0
+    wav, target, pm = _batch(B, seconds)
+    sample = {"id": torch.arange(B), "net_input": {"source": wav.cuda(), "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+              "target_list": [target.cuda()]}
+    opt.zero_grad()
+    np.random.seed(123)
+    loss, ss, _ = crit(model, sample)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
+
+    Tp = min(_frames(wav.shape[1], cfg), target.shape[1])
+    np.random.seed(123)
+    m = compute_mask_indices((B, Tp), torch.zeros(B, Tp, dtype=torch.bool), cfg.mask_prob, cfg.mask_length, "static", 0,
+                             min_masks=2, no_overlap=False, min_space=1)
+    losses, sizes, _, _, og = O.train_steps(sd, cfg, [(wav.float(), target, pm, torch.from_numpy(m))], [V], max_norm=CLIP,
+                                            return_grads=True, **ADAM)
+    assert ss == sizes[0]
+    rel_loss = abs(loss.item() - losses[0]) / abs(losses[0])
+    gmax = max(g.abs().max().item() for g in og.values())
+    worst_l2, worst_max, worst_cos, bad, rows = ("", 0.0), ("", 0.0), ("", 1.0), [], []
+    for n, g in grads.items():
+        ref = og[n]
+        scale = ref.abs().max().item()
+        if scale < 1e-5 * gmax:   # analytically zero (k_proj.bias): absolute floor
+            if g.abs().max().item() > 1e-3 * gmax:
+                bad.append((n, "zero-gradient", g.abs().max().item(), gmax))
+            continue
+        d = (g.double() - ref.double())
+        l2 = (d.norm() / ref.double().norm()).item()
+        mx = d.abs().max().item() / scale
+        cos = torch.nn.functional.cosine_similarity(g.double().flatten(), ref.double().flatten(), dim=0).item()
+        if l2 > worst_l2[1]:
+            worst_l2 = (n, l2)
+        if mx > worst_max[1]:
+            worst_max = (n, mx)
+        if cos < worst_cos[1]:
+            worst_cos = (n, cos)
+        rows.append((l2, mx, cos, n))
+        if l2 > 4e-2 or mx > 6e-2 or cos < 0.999:
+            bad.append((n, l2, mx, cos))
+    msg = ("bf16 vs fp32 oracle, 12L 2x15s: loss %.4f vs %.4f (rel %.2e); worst grad rel-L2 %s %.2e, max-abs %s %.2e, "
+           "cos %s %.6f" % (loss.item(), losses[0], rel_loss, *worst_l2, *worst_max, *worst_cos))
+    rows.sort(reverse=True)
+    msg += "\n  five worst tensors (rel-L2, max-abs, cos): " + "; ".join("%s %.2e %.2e %.5f" % (r[3], r[0], r[1], r[2]) for r in rows[:5])
+    msg += "\n  median rel-L2 over %d tensors: %.2e" % (len(rows), rows[len(rows) // 2][0])
+    print(msg)
+    assert rel_loss < 2e-3, msg
+    assert not bad, msg + "\n" + "\n".join(map(str, bad[:20]))
+
+
+def test_bf16_ten_update_trajectory_vs_fp32_oracle():
+    """10 optimizer updates (fresh masks every update, same utterances) at 12 layers, 2 x 5 s: bf16 HIP path + FusedAdam
+    against oracle.train_steps (fp32 arithmetic, the reference's bf16-mode parameter rounding, clip 10, Adam)."""
+    from oracle import wavlm_oracle as O
+    from unispeech_amd.masking import compute_mask_indices
+    _oracle_threads()
+    model, opt, crit, sd, cfg = _build(torch.bfloat16)
+    B, seconds, n_upd = 2, 5.0, 10
+    wav, target, pm = _batch(B, seconds, seed=99)
+    sample = {"id": torch.arange(B), "net_input": {"source": wav.cuda(), "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+              "target_list": [target.cuda()]}
+    np.random.seed(555)
+    hip_loss, hip_gn, hip_ss = [], [], []
+    for _ in range(n_upd):
+        opt.zero_grad()
+        loss, ss, _ = crit(model, sample)
+        loss.backward()
+        opt.step(grad_mult=1.0 / ss)
+        hip_loss.append(loss.item()); hip_ss.append(ss); hip_gn.append(opt.grad_norm(1.0 / ss))
+    Tp = min(_frames(wav.shape[1], cfg), target.shape[1])
+    np.random.seed(555)
+    batches = []
+    for _ in range(n_upd):
+        m = compute_mask_indices((B, Tp), torch.zeros(B, Tp, dtype=torch.bool), cfg.mask_prob, cfg.mask_length, "static",
+                                 0, min_masks=2, no_overlap=False, min_space=1)
+        for _l in range(cfg.encoder_layers):
+            np.random.random()  # the encoder's per-layer layerdrop draw (wavlm.py:728) keeps the numpy stream aligned
+        batches.append((wav.float(), target, pm, torch.from_numpy(m)))
+    o_loss, o_ss, o_gn, _ = O.train_steps(sd, cfg, batches, [V], max_norm=CLIP, model_dtype=torch.bfloat16, **ADAM)
+    assert hip_ss == o_ss
+    rl = [abs(a - b) / abs(b) for a, b in zip(hip_loss, o_loss)]
+    rg = [abs(a - b) / abs(b) for a, b in zip(hip_gn, o_gn)]
+    msg = ("10-update trajectory bf16 HIP vs fp32 oracle\n  hip loss %s\n  ora loss %s\n  rel %s\n  hip gnorm %s\n  ora gnorm %s\n  rel %s"
+           % (["%.3f" % v for v in hip_loss], ["%.3f" % v for v in o_loss], ["%.1e" % v for v in rl],
+              ["%.4f" % v for v in hip_gn], ["%.4f" % v for v in o_gn], ["%.1e" % v for v in rg]))
+    print(msg)
+    assert o_loss[-1] < o_loss[0], "the trajectory must actually move: " + msg
+    assert max(rl) < 1e-2 and max(rg) < 3e-2, msg
+
+
+def test_bf16_loss_at_bench_batch_vs_fp32_hip_mode():
+    """configs[1] batch (32 x 15 s), dropouts 0: the loss of the bf16 path against the fp32 mode of the same HIP path
+    (exact-FMA GEMMs, unfused attention) with identical masks and bf16-rounded parameters; 2e-3 relative as above."""
+    B, seconds = 32, 15.0
+    wav, target, pm = _batch(B, seconds, seed=7)
+    out = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        model, _, crit, _, _ = _build(dtype, with_opt=False)
+        if dtype == torch.float32:
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.copy_(p.to(torch.bfloat16).float())
+        sample = {"id": torch.arange(B),
+                  "net_input": {"source": wav.cuda().to(dtype), "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+                  "target_list": [target.cuda()]}
+        np.random.seed(4321)
+        with torch.no_grad():
+            loss, ss, log = crit(model, sample)
+        out[dtype] = (loss.item(), ss, log["correct_m_0"])
+        del model
+        torch.cuda.empty_cache()
+    (l32, s32, c32), (l16, s16, c16) = out[torch.float32], out[torch.bfloat16]
+    rel = abs(l16 - l32) / abs(l32)
+    msg = "B=32x15s loss bf16 %.3f vs fp32-HIP %.3f (rel %.2e), sample_size %d, correct %d vs %d" % (l16, l32, rel, s16, c16, c32)
+    print(msg)
+    assert s16 == s32
+    assert rel < 2e-3, msg

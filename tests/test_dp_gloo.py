@@ -97,7 +97,30 @@ def _worker(rank, world, port, q):
     ok3 = ok3 and (not early) and red._seen[4]
     red.finish()
     ok3 = ok3 and not any(red._seen)
-    q.put((rank, ok1, ok_avg, local_only, ok2, ok3))
+    # 4) rank-dependent readiness (encoder_layerdrop: each rank skips different layers, so different buckets stay
+    #    un-ready during backward): the order in which all-reduces are ISSUED must still be identical on all ranks
+    flat.zero_()
+    issued = []
+    orig_launch = red._launch
+    red._launch = lambda b: (issued.append(b), orig_launch(b))[1]
+    order = sorted(range(len(params)), key=lambda i: -offsets[i])      # the order backward produces gradients in
+    skip = order[1] if rank == 0 else order[-2]                          # each rank "drops" a different parameter
+    for i in order:
+        if i != skip:
+            params[i].grad.add_(float(rank + 1))
+            red._mark(i)
+    mid = list(issued)
+    red.finish()
+    ok4 = issued == list(range(len(red.buckets))) and mid == list(range(len(mid)))
+    want = torch.full_like(flat, 3.0)
+    for r_, sk in ((0, order[1]), (1, order[-2])):
+        want[offsets[sk]:offsets[sk] + params[sk].numel()] -= float(r_ + 1)
+    pad = torch.ones_like(flat, dtype=torch.bool)
+    for p_, o_ in zip(params, offsets):
+        pad[o_:o_ + p_.numel()] = False
+    ok4 = ok4 and torch.allclose(flat[~pad], want[~pad])
+    red._launch = orig_launch
+    q.put((rank, ok1, ok_avg, local_only, ok2, ok3, ok4))
     dist.destroy_process_group()
 
 

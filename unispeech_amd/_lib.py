@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVLM_HIP_LIB") or os.path.join(_HERE, "lib", "libwavlm_hip.so")
 
 _lib = None
-ABI_VERSION = 4  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 5  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
 
 F32, BF16 = 0, 1
 
@@ -105,6 +105,7 @@ SIGNATURES = {
                                 c_i64, c_f32, c_vp, c_vp, c_f32, c_vp]),
     "wavlm_prof_enable": (None, [c_i32]),
     "wavlm_gemm_set_variant": (None, [c_i32]),
+    "wavlm_set_reserved_cus": (None, [c_i32]),
     "wavlm_prof_collect": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wavlm_prof_collect_bytes": (C.c_double, [c_i32]),
 }

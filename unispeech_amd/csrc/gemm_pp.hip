@@ -501,6 +501,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 }
 
 int g_pp_mode = 1;  // 0: one block per tile, 1: persistent (256 blocks), 2: persistent with start skew
+int g_pp_reserved_cus = 0;  // data-parallel runs: persistent grids leave this many CUs to the RCCL kernels
+extern "C" void wavlm_set_reserved_cus(int n) { g_pp_reserved_cus = n < 0 ? 0 : (n > 64 ? 64 : n); }
 
 template <bool TA, bool TB>
 static int pp_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
@@ -516,7 +518,8 @@ static int pp_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
   p.skew = (g_pp_mode == 2 && p.vtotal >= 768) ? (kt * 11 / 100 > 0 ? kt * 11 / 100 : 1) : 0;  // s_sleep(127) ~ 3.9 us; one step ~ a quarter of a tile's main loop (1.72 us per K step)
   // persistent launch pays on the transformer GEMMs (4-5 rounds: +5-10 %); the long conv GEMMs (24 rounds) measured
   // 1 % better with one block per tile
-  dim3 grid((unsigned)(g_pp_mode == 0 || p.vtotal < 256 || p.vtotal > 2048 ? p.vtotal : 256), 1, 1);
+  const int pgrid = 256 - g_pp_reserved_cus;
+  dim3 grid((unsigned)(g_pp_mode == 0 || p.vtotal < pgrid || p.vtotal > 2048 ? p.vtotal : pgrid), 1, 1);
   constexpr int smem = 2 * PP_STAGE;
   static bool done[5] = {false, false, false, false, false};
 #define PP_CASE(E) case E: { \
@@ -540,7 +543,8 @@ int gemm_pp_launch_grouped(GemmP& p, hipStream_t st) {
     done = true;
   }
   p.patch_m = 0; p.skew = 0; p.nbatch = 1;
-  dim3 grid((unsigned)(p.vtotal < 256 ? p.vtotal : 256), 1, 1);
+  const int pgrid = 256 - g_pp_reserved_cus;
+  dim3 grid((unsigned)(p.vtotal < pgrid ? p.vtotal : pgrid), 1, 1);
   WL_LAUNCH((gemm_pp_kernel<true, true, 1, true>), grid, dim3(512), smem, st, p);
   return wl_check_launch();
 }

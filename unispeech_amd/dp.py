@@ -29,6 +29,13 @@ class GradReducer:
         self.sync = True
         self.is_cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.is_cuda and self.enabled) else None
+        if self.is_cuda and self.enabled:
+            # a persistent 256-block GEMM owns every CU (128 KiB of LDS + all VGPRs per block), so an all-reduce launched
+            # on the side stream would only start at the next kernel boundary: persistent grids shrink to 256 - n and
+            # leave n CUs (default 8 = one per XCD) to the RCCL kernels while backward is still running
+            import os
+            from . import ops
+            ops.set_reserved_cus(int(os.environ.get("WAVLM_DP_RESERVED_CUS", "8")))
         # buckets = disjoint contiguous arena ranges, cut walking the arena from its END (gradients of the last layers
         # are produced first).  The walk is in arena-offset order, not parameter order: the optimizer lays packed
         # groups (q|k|v) out of registration order, and ranges cut by parameter index could overlap there.
@@ -56,6 +63,7 @@ class GradReducer:
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._seen = [False] * len(self.params)
+        self._next = 0  # buckets are launched strictly in index order on every rank (see _mark)
         self._works = []
         # arena element offsets (sorted) for sink notifications: backward kernels that accumulate straight into the
         # arena (functional._sink) report the slice they wrote; a packed q|k|v slice covers three parameters
@@ -73,10 +81,17 @@ class GradReducer:
         if not (self.enabled and self.sync) or self._seen[idx]:
             return
         self._seen[idx] = True
-        b = self.bucket_of[idx]
-        self._ready[b] += 1
-        if self._ready[b] == self.buckets[b]["n"] and not self._launched[b]:
-            self._launch(b)
+        self._ready[self.bucket_of[idx]] += 1
+        # Collectives must be issued in the SAME order on every rank, but readiness is data dependent: with
+        # encoder_layerdrop > 0 each rank drops different layers (the numpy streams diverge with the batch-dependent mask
+        # draws), a dropped layer's bucket never becomes ready during backward, and a rank that skipped it would pair its
+        # next all-reduce with a different bucket on its peers (hang, or silently mixed gradients).  Hence strict index
+        # order, as torch DDP does: bucket b starts only when it is complete AND all buckets before it have started;
+        # whatever is held back goes out in finish(), still in index order.  Bucket 0 is the END of the arena (the last
+        # layers), i.e. the order backward produces gradients in, so nothing is delayed when no layer is dropped.
+        while self._next < len(self.buckets) and self._ready[self._next] == self.buckets[self._next]["n"]:
+            self._launch(self._next)
+            self._next += 1
 
     def _make_hook(self, idx):
         from . import functional
@@ -131,9 +146,9 @@ class GradReducer:
             return
         from . import functional
         functional.flush_wgrad_groups()
-        for b in range(len(self.buckets)):
-            if not self._launched[b]:
-                self._launch(b)
+        for b in range(self._next, len(self.buckets)):  # index order; everything before _next is already in flight
+            assert not self._launched[b]
+            self._launch(b)
         for w in self._works:
             w.wait()
         if self.comm_stream is not None:
@@ -142,6 +157,7 @@ class GradReducer:
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._seen = [False] * len(self.params)
+        self._next = 0
 
     @property
     def scale(self):

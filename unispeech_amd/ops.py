@@ -533,6 +533,11 @@ def gemm_set_variant(v):
     _lib.lib().wavlm_gemm_set_variant(int(v))
 
 
+def set_reserved_cus(n):
+    """leave n CUs out of every persistent GEMM grid (data-parallel runs: room for the RCCL kernels)"""
+    _lib.lib().wavlm_set_reserved_cus(int(n))
+
+
 def prof_enable(on):
     _lib.lib().wavlm_prof_enable(1 if on else 0)
 
