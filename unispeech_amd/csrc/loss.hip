@@ -52,8 +52,12 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
     float sum = 0.f;
     for (int c = lane; c < V; c += 64) sum += expf(lr[c] - mx);
     sum = wave_sum(sum);
+    // a label outside [0, V) (pad / special id leaking through, dictionary that does not match the label set) must not
+    // become an out-of-bounds read: the row's loss is NaN -- loud (fairseq's NaN detector, trainer.py:840-855) where the
+    // reference's index_select raises -- and its gradient row is zero
     const int t = target[row];
-    const float lt = lr[t];
+    const bool valid = (unsigned)t < (unsigned)V;
+    const float lt = valid ? lr[t] : __builtin_nanf("");
     if (lane == 0) {
       loss_rows[row] = (mx + logf(sum)) - lt;
       correct_rows[row] = (lt >= mx) ? 1.f : 0.f;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
       const float inv = 1.f / sum;
       for (int c = lane; c < ldd; c += 64) {
         float g = 0.f;
-        if (c < V) g = weight * (expf(lr[c] - mx) * inv - (c == t ? 1.f : 0.f));
+        if (c < V && valid) g = weight * (expf(lr[c] - mx) * inv - (c == t ? 1.f : 0.f));
         Elem<TO>::st(dlogits + row * ldd + c, g);
       }
     }

@@ -92,6 +92,8 @@ def _linear_fwd(x2d, W, b, *, epi=0, aux=None, res=None, out_dtype=None):
     n, K = x2d.shape
     N = W.shape[0]
     y = torch.empty((n, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
+    if n == 0:  # empty frame selection (e.g. a batch with nothing masked): the reference yields empty logits / zero loss
+        return y
     ops.gemm(x2d, W, y, n, N, K, lda=K, ldb=K, ldc=N, bias=b, epi=epi, aux=aux, ld_aux=N, res=res, ld_res=N)
     return y
 
@@ -101,6 +103,8 @@ def _linear_bwd_x(dy2d, W, *, epi=0, aux=None, res=None):
     n, N = dy2d.shape
     K = W.shape[1]
     dx = torch.empty((n, K), dtype=dy2d.dtype, device=dy2d.device)
+    if n == 0:
+        return dx
     ops.gemm(dy2d, W, dx, n, K, N, lda=N, ldb=K, ldc=K, transB=True, epi=epi, aux=aux, ld_aux=K, res=res, ld_res=K)
     return dx
 
@@ -110,6 +114,8 @@ def _linear_bwd_w(dy2d, x2d, w_dtype, out=None):
     n, N = dy2d.shape
     K = x2d.shape[1]
     dW = out if out is not None else torch.empty((N, K), dtype=w_dtype, device=dy2d.device)
+    if n == 0:  # no rows: the gradient contribution is zero
+        return dW if out is not None else dW.zero_()
     split = ops.pick_split(N, K, (n + 63) // 64)
     ops.gemm(dy2d, x2d, dW, N, K, n, lda=N, ldb=K, ldc=K, transA=True, transB=True, split_k=split,
              accumulate=out is not None)
@@ -197,10 +203,11 @@ def _param_grads(dy2d, x2d, W, b, has_bias, need_w, need_b, sink_w=None, sink_b=
     if has_bias:
         sb = sink_b if sink_b is not None else _sink(b)
         if sb is not None:
-            ops.colsum(dy2d, W.dtype, out=sb.view(-1), accumulate=True)
+            if dy2d.shape[0] > 0:
+                ops.colsum(dy2d, W.dtype, out=sb.view(-1), accumulate=True)
             _sink_written(sb)
         elif need_b:
-            db = ops.colsum(dy2d, W.dtype)
+            db = ops.colsum(dy2d, W.dtype) if dy2d.shape[0] > 0 else torch.zeros(W.shape[0], dtype=W.dtype, device=W.device)
     return dW, db
 
 
@@ -691,11 +698,15 @@ class GatherRowsFn(torch.autograd.Function):
     def forward(ctx, x2d, idx, inv_idx):
         ctx.save_for_backward(inv_idx)
         ctx.n = x2d.shape[0]
+        if idx.numel() == 0:
+            return x2d.new_empty((0, x2d.shape[1]))
         return ops.gather_rows(x2d.contiguous(), idx, idx.numel())
 
     @staticmethod
     def backward(ctx, dy):
         (inv_idx,) = ctx.saved_tensors
+        if dy.shape[0] == 0:
+            return dy.new_zeros((ctx.n, dy.shape[1])), None, None
         return ops.gather_rows(dy.contiguous(), inv_idx, ctx.n), None, None
 
 
@@ -729,6 +740,13 @@ class MaskedPredLossFn(torch.autograd.Function):
         V = label_embs.shape[0]
         dev = proj.device
         act_dtype = proj.dtype
+        if S == 0:
+            ctx.save_for_backward(proj, label_embs)
+            ctx.dims = (0, V, F, 0, temp)
+            z = torch.zeros(1, dtype=torch.float32, device=dev)
+            nc = torch.zeros(1, dtype=torch.float32, device=dev)
+            ctx.mark_non_differentiable(nc)
+            return z, nc
         pn, inv_p = ops.l2norm_fwd(proj.contiguous(), act_dtype)
         en, inv_e = ops.l2norm_fwd(label_embs.contiguous(), act_dtype)
         logits = torch.empty((max(S, 1), V), dtype=torch.float32, device=dev)
@@ -746,11 +764,12 @@ class MaskedPredLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _dc):
-        pn, en, inv_p, inv_e, dlog, proj, label_embs = ctx.saved_tensors
         S, V, F, ldd, temp = ctx.dims
-        dev = pn.device
         if S == 0:
+            proj, label_embs = ctx.saved_tensors
             return torch.zeros_like(proj), torch.zeros_like(label_embs), None, None, None
+        pn, en, inv_p, inv_e, dlog, proj, label_embs = ctx.saved_tensors
+        dev = pn.device
         g = dloss.reshape(1).to(torch.float32)
         # d pn = dlogits @ en / temp ; d en = dlogits^T @ pn / temp
         dpn = torch.empty((S, F), dtype=pn.dtype, device=dev)

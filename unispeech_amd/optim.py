@@ -104,14 +104,74 @@ class FusedAdam:
         """host value of the (scaled) global gradient norm -- synchronises; logging only"""
         return float(self.gnorm_sq.sqrt().item()) * abs(grad_mult)
 
-    def state_dict(self):
-        return {"step": self.step_count, "master": self.master, "exp_avg": self.exp_avg,
-                "exp_avg_sq": self.exp_avg_sq, "lr": self.lr}
+    def _layout(self):
+        """(offset, numel, shape) of every parameter in arena order of registration: what a checkpoint must agree on"""
+        return [(int(o), int(p.numel()), tuple(p.shape)) for p, o in zip(self.params, self.offsets)]
 
-    def load_state_dict(self, sd):
+    def state_dict(self, names=None):
+        """Flat arenas + the layout they were written with.  `names` (optional, one per parameter, e.g. from
+        model.named_parameters()) are stored too, so that a checkpoint can be re-homed into an arena laid out differently
+        (another packing rule, a head added or removed) parameter by parameter."""
+        sd = {"step": self.step_count, "master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+              "lr": self.lr, "numel": self.numel, "layout": self._layout()}
+        if names is not None:
+            names = list(names)
+            if len(names) != len(self.params):
+                raise ValueError("names must have one entry per optimized parameter")
+            sd["names"] = names
+        return sd
+
+    def load_state_dict(self, sd, names=None):
+        """Same layout: three arena copies.  Different layout: matched by parameter name (both sides must carry names) and
+        copied slice by slice; a parameter whose shape changed, or a layout mismatch without names, raises instead of
+        silently misaligning the moments."""
         self.step_count = sd["step"]
-        self.master.copy_(sd["master"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        saved = sd.get("layout")
+        same = saved is None or [tuple(x[:2]) + (tuple(x[2]),) for x in saved] == self._layout()
+        if same and sd["master"].numel() == self.numel:
+            self.master.copy_(sd["master"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        else:
+            src_names = sd.get("names")
+            if src_names is None or names is None:
+                raise ValueError("optimizer state was saved with a different arena layout; pass parameter names on both "
+                                 "sides (state_dict(names=...), load_state_dict(sd, names=...)) to re-home it")
+            where = {n: (o, k, shp) for n, (o, k, shp) in zip(src_names, sd["layout"])}
+            for n, p, o in zip(names, self.params, self.offsets):
+                if n not in where:
+                    continue  # new parameter: keeps its fresh state
+                so, sk, sshape = where[n]
+                if tuple(sshape) != tuple(p.shape):
+                    raise ValueError("optimizer state of %s has shape %s, the parameter has %s" % (n, sshape, tuple(p.shape)))
+                for dst, key in ((self.master, "master"), (self.exp_avg, "exp_avg"), (self.exp_avg_sq, "exp_avg_sq")):
+                    dst[o:o + sk].copy_(sd[key][so:so + sk])
         if self.lowp:
             self.flat_param.copy_(self.master)
+
+    def fairseq_state_dict(self):
+        """Per-parameter state in the shape torch.optim / fairseq's Adam checkpoint it (optim/adam.py:176-195:
+        state[i] = {step, exp_avg, exp_avg_sq}, param_groups with lr / betas / eps / weight_decay), fp32 views of the
+        arenas -- what `optimizer_history` / `last_optimizer_state` of a reference checkpoint hold (trainer.py:373-411)."""
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            n = p.numel()
+            state[i] = {"step": self.step_count, "exp_avg": self.exp_avg[o:o + n].view(p.shape),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape)}
+        return {"state": state, "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps,
+                                                  "weight_decay": self.weight_decay, "amsgrad": False,
+                                                  "params": list(range(len(self.params)))}]}
+
+    def load_fairseq_state_dict(self, fsd):
+        """inverse of fairseq_state_dict(): Adam moments of a reference checkpoint into the arenas (master weights come
+        from the model's own state dict)"""
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            st = fsd["state"].get(i)
+            if st is None:
+                continue
+            n = p.numel()
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step_count = int(st["step"])
+        g = fsd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]

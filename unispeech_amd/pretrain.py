@@ -180,6 +180,23 @@ class WavLMPretrainModel(WavLM):
         target_inds = (torch.arange(feat_tsz).float() * self.feat2tar_ratio).long()
         return feat_tsz, target_inds
 
+    def _check_targets(self, target_list):
+        """Label ids outside [0, V) -- a pad / special symbol leaking through, or a dictionary that does not match the label
+        set -- raise in the reference (index_select, wavlm.py:531).  Here: labels still on the host (or WAVLM_VALIDATE_TARGETS=1)
+        are range-checked and raise IndexError; labels already on the device are NOT read back (that would be a host
+        synchronisation per step) -- the loss kernel guards the index and turns such a row's loss into NaN instead."""
+        if self.num_classes is None:
+            return
+        import os
+        force = os.environ.get("WAVLM_VALIDATE_TARGETS") == "1"
+        for i, t in enumerate(target_list):
+            if t.numel() == 0 or not (force or t.device.type == "cpu"):
+                continue
+            V = self.num_classes[min(i, len(self.num_classes) - 1)]
+            lo, hi = (int(v) for v in torch.aminmax(t))
+            if lo < 0 or hi >= V:
+                raise IndexError("label set %d holds ids in [%d, %d] but its dictionary has %d entries" % (i, lo, hi, V))
+
     def _mask_numpy(self, B, T, padding_cpu, boundary):
         if self.mask_prob <= 0:
             return None
@@ -250,6 +267,7 @@ class WavLMPretrainModel(WavLM):
         result = {"x": x, "padding_mask": padding_mask, "features": conv_sum, "layer_results": layer_results}
         if features_only:
             return result
+        self._check_targets(target_list)
 
         pad_np = pad_cpu.numpy() if pad_cpu is not None else np.zeros((B, T), dtype=bool)
         m_np = mask_np if mask_np is not None else np.zeros((B, T), dtype=bool)
@@ -389,6 +407,8 @@ class WavLMPretrainModel(WavLM):
         codebook row v, with the positive's own row set to -inf (wavlm.py:426-438)"""
         pj, emb, tt = h["proj"], h["label_embs"], h["target"]
         S, V = pj.shape[0], emb.shape[0]
+        if S == 0:
+            return torch.empty((0, V + 1), dtype=torch.float32, device=pj.device)
         pn, _ = F.ops.l2norm_fwd(pj.detach().contiguous(), torch.float32 if pj.dtype == torch.float32 else pj.dtype)
         en, _ = F.ops.l2norm_fwd(emb.detach().contiguous(), pn.dtype)
         logits = torch.empty((max(S, 1), V), dtype=torch.float32, device=pj.device)
@@ -442,7 +462,10 @@ class WavLMCriterion(nn.Module):
 
     def __init__(self, task=None, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_weights=None, log_keys=None,
                  defer_logging=False):
-        super().__init__()
+        # nn.Module.__init__ directly (not super()): in the fairseq plugin this class is mixed in front of FairseqCriterion,
+        # whose __init__ takes `task` and is called by the plugin subclass itself
+        if not hasattr(self, "_modules"):
+            nn.Module.__init__(self)
         self.task = task
         self.pred_masked_weight = pred_masked_weight
         self.pred_nomask_weight = pred_nomask_weight
@@ -503,8 +526,10 @@ class WavLMCriterion(nn.Module):
         logging_output = {"loss": num(loss.detach()), "ntokens": sample_size, "nsentences": nsent,
                           "sample_size": sample_size, **logging_output}
         for lk in self.log_keys:
-            if lk in net_output:
-                logging_output[lk] = float(net_output[lk])
+            if lk in net_output and net_output[lk] is not None:
+                v = net_output[lk]
+                logging_output[lk] = (v.detach().float().reshape(()) if (self.defer_logging and torch.is_tensor(v))
+                                      else float(v))
         for i, h in enumerate(heads_m):
             logging_output[f"correct_m_{i}"] = num(h["correct"][0]) if self.defer_logging else int(h["correct"].item())
             logging_output[f"count_m_{i}"] = h["count"]
@@ -545,4 +570,9 @@ class WavLMCriterion(nn.Module):
 
     @staticmethod
     def logging_outputs_can_be_summed() -> bool:
-        return False
+        """True: every logging value is a scalar (number or 0-dim / 1-element tensor) and reduce_metrics only ever sums
+        them across workers, so the Trainer may all-reduce them (trainer.py:1265-1303 _fast_stat_sync_sum ->
+        distributed/utils.py:605-651 all_reduce_dict: device scalars in ONE device all-reduce) instead of pickling every
+        worker's dict through all_gather_list (distributed/utils.py:532-602: D2H + pickle + all-gather of 16 KiB buffers).
+        The reference's criterion returns False (wavlm_criterion.py:200-207)."""
+        return True

@@ -472,6 +472,13 @@ class WavLM(nn.Module):
         self.encoder = TransformerEncoder(cfg)
         self.layer_norm = nn.LayerNorm(self.embed)
 
+    def half(self):
+        """the reference recipes pass --fp16 (trainer.py:86-89 then calls model.half()); the gfx950 kernels compute in
+        bf16 (MFMA, fp32 accumulate, no loss scaling needed) or fp32 -- fail here, not at the first kernel launch"""
+        raise NotImplementedError(
+            "unispeech_amd: fp16 is not supported on the MI355X path; run bf16 instead (cfg.common.bf16=True with "
+            "cfg.common.tpu=False -- see INTEGRATION.md section 1, 'Precision') or fp32")
+
     # -- host-side pieces -------------------------------------------------------------------------------------
     def compute_mask(self, B, T, padding_mask):
         """bool numpy [B, T]; consumes the global numpy RNG exactly like apply_mask (WavLM.py:271-285)"""
