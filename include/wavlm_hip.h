@@ -243,6 +243,25 @@ int wavlm_adam_step(float* p, float* m, float* v, const void* grad, int32_t grad
                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Gumbel-softmax vector quantiser on projected logits [n, G*V] (replaces the per-row part of
+ * src/fairseq/modules/gumbel_vector_quantizer.py:157-213; the weight projection is a wavlm_gemm, the codebook product a
+ * wavlm_gather_rows with the returned indices).
+ *   fwd: idx[n*G] = g*V + argmax (training: of (logits + gumbel)/tau, else of the raw logits); ysoft[n*G, V] =
+ *        softmax((logits + gumbel)/tau) (training only); noise = the Gumbel draws [n*G, V] (fp32) or NULL for a device
+ *        counter hash of `seed`; part[wavlm_gumbel_vq_partial_rows(n)][2*G*V] = per-wave column sums of softmax(raw
+ *        logits) and of the hard one-hot (sum the rows with wavlm_colsum).
+ *   perplexity: sums[2][G*V] -> out[0] = prob_perplexity, out[1] = code_perplexity, dA[G*V] = d prob_ppl / d avg_probs.
+ *   bwd: dlogits = ysoft*(dret - <ysoft,dret>)/tau (if ysoft/dret given) + dppl[0] * softmax(raw)*(dA - <softmax,dA>)/n
+ *        (if dppl given).  G <= 4, V <= 320.
+ * ------------------------------------------------------------------------------------------ */
+uint64_t wavlm_gumbel_vq_partial_rows(int64_t n);
+int wavlm_gumbel_vq_fwd(const void* logits, int32_t dtype, const float* noise, uint64_t seed, float tau, int32_t training,
+                        int64_t n, int32_t G, int32_t V, float* ysoft, int32_t* idx, float* part, void* stream);
+int wavlm_vq_perplexity(const float* sums, int64_t n, int32_t G, int32_t V, float* out, float* dA, void* stream);
+int wavlm_gumbel_vq_bwd(const void* logits, int32_t dtype, const float* ysoft, const float* dret, const float* dA,
+                        const float* dppl, float tau, int64_t n, int32_t G, int32_t V, void* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): HIP events around every wavlm_gemm launch while enabled.
  * ------------------------------------------------------------------------------------------ */
 void wavlm_prof_enable(int on);

@@ -470,9 +470,66 @@ def gen_tiny_ils_variants():
     two label sets), and one label set per predicted layer (separate_layer_targets + weighted_sum, vocabularies of
     different size so that label_embs_concat is padded to the larger one)"""
     gen_tiny_ils({"separate_label_embeds": True}, "tiny_ils_sep_embeds.npz", vocabs=(23, 17))
+    # pre-LN ILS: post_layer_norm on every tapped layer (ils_hubert.py:73-76, 186-187), LayerNorm extractor
+    gen_tiny_ils({"layer_norm_first": True, "extractor_mode": "layer_norm"}, "tiny_ils_preln.npz")
     # weighted_sum (hubert_criterion.py:73-76: per-layer losses weighted by softmax(model.weights)) needs one loss per layer
     gen_tiny_ils({"separate_layer_targets": True, "separate_label_embeds": True, "weighted_sum": True},
                  "tiny_ils_sep_targets.npz", vocabs=(23, 17))
+
+
+def gen_tiny_w2v2():
+    """wav2vec 2.0 at tiny size: the reference's Wav2Vec2Model (quantize_targets with a 2 x 20 Gumbel codebook, 7 in-utterance +
+    3 cross-utterance negatives) + Wav2vecCriterion(infonce, loss_weights [0.1, 10]) in train mode: loss, logits, perplexities
+    and every parameter gradient.  The Gumbel noise (F.gumbel_softmax) and the negative indices (torch.randint) come from the
+    torch CPU generator seeded with 31 right before the forward; the time mask from numpy seed 77."""
+    ref_shim.fairseq_wavlm()
+    from fairseq.criterions.wav2vec_criterion import Wav2vecCriterion
+    from fairseq.models.wav2vec import wav2vec2 as w2
+    cfg = w2.Wav2Vec2Config()
+    for k, v in TINY.items():
+        if hasattr(cfg, k):
+            setattr(cfg, k, v)
+    cfg.final_dim = 32
+    cfg.quantize_targets = True
+    cfg.latent_vars, cfg.latent_groups, cfg.latent_dim = 20, 2, 0
+    cfg.latent_temp = (2.0, 0.5, 0.999995)
+    cfg.num_negatives, cfg.cross_sample_negatives = 7, 3
+    cfg.logit_temp = 0.1
+    cfg.pretrained_path = None
+    torch.manual_seed(0)
+    model = w2.Wav2Vec2Model(cfg)
+    model.train()
+    crit = Wav2vecCriterion(SimpleNamespace(), infonce=True, loss_weights=[0.1, 10.0])
+    out = sd_to_np(model.state_dict())
+    g = torch.Generator().manual_seed(808)
+    wav = torch.randn(3, 16000, generator=g)
+    pm = torch.zeros(3, 16000, dtype=torch.bool)
+    sample = {"id": torch.arange(3), "net_input": {"source": wav, "padding_mask": pm}}
+    np.random.seed(77)
+    torch.manual_seed(31)
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    np.random.seed(77)
+    torch.manual_seed(31)
+    with torch.no_grad():
+        net = model(source=wav, padding_mask=pm)
+    out["in/source"] = wav.numpy()
+    out["out/loss"] = np.float64(loss.item())
+    out["out/sample_size"] = np.int64(sample_size)
+    for k, v in log.items():
+        out["log/" + k] = np.float64(v)
+    out["out/logits"] = model.get_logits(net).float().numpy()
+    out["out/prob_perplexity"] = np.float64(net["prob_perplexity"].item())
+    out["out/code_perplexity"] = np.float64(net["code_perplexity"].item())
+    out["out/features_pen"] = np.float64(net["features_pen"].item())
+    np.random.seed(77)
+    from fairseq.data.data_utils import compute_mask_indices
+    T = net["features"].shape[1]
+    out["out/mask_seed77"] = compute_mask_indices((3, T), torch.zeros(3, T, dtype=torch.bool), cfg.mask_prob, cfg.mask_length,
+                                                  cfg.mask_selection, cfg.mask_other, min_masks=2, no_overlap=False, min_space=1)
+    for n, p in model.named_parameters():
+        out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_w2v2.npz"), **out)
 
 
 def gen_sampled_negatives():
@@ -523,5 +580,6 @@ if __name__ == "__main__":
     gen_tiny_ils()
     gen_tiny_ils_variants()
     gen_sampled_negatives()
+    gen_tiny_w2v2()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

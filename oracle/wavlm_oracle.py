@@ -189,8 +189,8 @@ def transformer_encoder(sd, cfg, x, padding_mask=None, tgt_layer=None, prefix="e
     if r is not None:
         x = r
     x = x.transpose(0, 1)
-    if cfg.layer_norm_first and tgt_layer is None:
-        x = F.layer_norm(x, (D,), sd[prefix + "layer_norm.weight"], sd[prefix + "layer_norm.bias"], 1e-5)
+    if cfg.layer_norm_first and tgt_layer is None and collect is None:  # `layer is None` (wavlm.py:699-701): a tapped-layer
+        x = F.layer_norm(x, (D,), sd[prefix + "layer_norm.weight"], sd[prefix + "layer_norm.bias"], 1e-5)  # list skips it
         if taps:  # pre-LN UniSpeech-SAT: the speaker tap gets its own final LayerNorm (unispeech_sat.py:1197, 1205-1208)
             taps[0] = F.layer_norm(taps[0], (D,), sd[prefix + "layer_norm_for_extract.weight"],
                                    sd[prefix + "layer_norm_for_extract.bias"], 1e-5)
@@ -270,6 +270,10 @@ def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, n
     pad = padding_mask if padding_mask is not None else torch.zeros(y.shape[:2], dtype=torch.bool)
     lec = sd["label_embs_concat"]
     sources = collected if pl is not None else [y]  # ILS-SSL (ils_hubert.py:180-250): same head on every collected layer
+    if pl is not None and cfg.layer_norm_first:  # pre-LN ILS: one LayerNorm per tapped layer (ils_hubert.py:73-76, 186-187)
+        D = sources[0].shape[-1]
+        sources = [F.layer_norm(t, (D,), sd["post_layer_norm.%d.weight" % i], sd["post_layer_norm.%d.bias" % i], 1e-5)
+                   for i, t in enumerate(sources)]
     sep_emb = getattr(cfg, "separate_label_embeds", False)    # per-layer final_proj + label embeddings (ils_hubert.py:78-86)
     sep_tgt = getattr(cfg, "separate_layer_targets", False)   # label set i belongs to predicted layer i (207-236)
 
@@ -479,3 +483,85 @@ def train_steps(sd, cfg, batches, num_classes, lr, betas, eps, weight_decay, max
         if return_grads:
             return losses, sizes, norms, p, {k: grads[k] * float(ss) for k in names}  # first update only, unnormalised
     return losses, sizes, norms, p
+
+
+# ------------------------------------------------------------------------------ wav2vec 2.0
+def gumbel_vq(sd, prefix, x, groups, num_vars, tau, training):
+    """GumbelVectorQuantizer.forward (src/fairseq/modules/gumbel_vector_quantizer.py:157-213), combine_groups=False,
+    time_first=True.  x [B, T, C].  Training draws the Gumbel noise with F.gumbel_softmax from the global torch generator,
+    exactly as the reference does."""
+    bsz, tsz, fsz = x.shape
+    lg = F.linear(x.reshape(-1, fsz), sd[prefix + "weight_proj.weight"], sd[prefix + "weight_proj.bias"])
+    lg = lg.view(bsz * tsz * groups, -1)
+    _, k = lg.max(-1)
+    hard_x = lg.new_zeros(*lg.shape).scatter_(-1, k.view(-1, 1), 1.0).view(bsz * tsz, groups, -1)
+    hard_probs = torch.mean(hard_x.float(), dim=0)
+    code_ppl = torch.exp(-torch.sum(hard_probs * torch.log(hard_probs + 1e-7), dim=-1)).sum()
+    avg_probs = torch.softmax(lg.view(bsz * tsz, groups, -1).float(), dim=-1).mean(dim=0)
+    prob_ppl = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-7), dim=-1)).sum()
+    if training:
+        y = F.gumbel_softmax(lg.float(), tau=tau, hard=True).type_as(lg)
+    else:
+        y = hard_x
+    y = y.view(bsz * tsz, -1)
+    out = (y.unsqueeze(-1) * sd[prefix + "vars"]).view(bsz * tsz, groups, num_vars, -1).sum(-2).view(bsz, tsz, -1)
+    return {"x": out, "prob_perplexity": prob_ppl, "code_perplexity": code_ppl, "num_vars": num_vars * groups}
+
+
+def wav2vec2_forward(sd, cfg, source, padding_mask, mask_indices, training=True):
+    """Wav2Vec2Model.forward (src/fairseq/models/wav2vec/wav2vec2.py:556-718) with dropouts 0, the time mask given
+    explicitly, default options (quantize_input / negatives_from_everywhere / codebook_negatives / target_glu / transpose
+    off).  Returns the reference's result dict with `x` = logits [N+1, B, T_m]."""
+    feats = conv_feature_extractor(sd, cfg, source)
+    features_pen = feats.float().pow(2).mean()
+    features = feats.transpose(1, 2)
+    C = features.shape[-1]
+    features = F.layer_norm(features, (C,), sd["layer_norm.weight"], sd["layer_norm.bias"], 1e-5)
+    unmasked = features
+    T = features.shape[1]
+    if padding_mask is not None:
+        padding_mask = forward_padding_mask(T, padding_mask)
+    if "post_extract_proj.weight" in sd:
+        features = F.linear(features, sd["post_extract_proj.weight"], sd["post_extract_proj.bias"])
+    x = torch.where(mask_indices.unsqueeze(-1), sd["mask_emb"].view(1, 1, -1), features)
+    B = x.shape[0]
+    y = unmasked[mask_indices].view(B, -1, C)
+    x, _, _ = transformer_encoder(sd, cfg, x, padding_mask, None)
+    res = {"features_pen": features_pen, "padding_mask": padding_mask}
+    if cfg.quantize_targets:
+        q = gumbel_vq(sd, "quantizer.", y, cfg.latent_groups, cfg.latent_vars, cfg.latent_temp[0], training)
+        y = F.linear(q["x"], sd["project_q.weight"], sd["project_q.bias"])
+        gumbel_vq(sd, "quantizer.", unmasked, cfg.latent_groups, cfg.latent_vars, cfg.latent_temp[0], training)  # results['q'] (wav2vec2.py:655)
+        res.update(prob_perplexity=q["prob_perplexity"], code_perplexity=q["code_perplexity"], num_vars=q["num_vars"])
+    else:
+        y = F.linear(y, sd["project_q.weight"], sd["project_q.bias"])
+    Tm = y.shape[1]
+    from unispeech_amd.functional import sample_negatives_indices  # host index draws: pinned bit-exact by sampled_negatives.npz
+    neg = sample_negatives_indices(B, Tm, Tm, cfg.num_negatives, cfg.cross_sample_negatives)
+    xm = F.linear(x[mask_indices].view(B, -1, x.size(-1)), sd["final_proj.weight"], sd["final_proj.bias"])
+    res["x"] = sampled_negatives_logits(xm, y, neg, cfg.num_negatives + cfg.cross_sample_negatives, cfg.logit_temp)
+    return res
+
+
+def wav2vec_criterion(res, loss_weights=None):
+    """Wav2vecCriterion.get_loss with infonce (criterions/wav2vec_criterion.py:44-123)"""
+    loss, l2 = infonce_loss(res["x"])
+    sample_size = l2.size(0)
+    log = {"loss_0": loss.detach().clone()}
+    if loss_weights is not None:
+        extra = []
+        if "prob_perplexity" in res:
+            extra.append((res["num_vars"] - res["prob_perplexity"]) / res["num_vars"])
+        extra.append(res["features_pen"])
+        w = list(loss_weights)
+        if len(w) == 1 and len(extra) != 1:
+            w = [w[0]] * len(extra)
+        for i, (p, c) in enumerate(zip(extra, w)):
+            if c != 0:
+                p = c * p.float() * sample_size
+                loss = loss + p
+                log["loss_%d" % (i + 1)] = p.detach()
+    mx, mn = l2.argmax(-1) == 0, l2.argmin(-1) == 0
+    log["correct"] = int(mx.long().sum().item() - (mx & mn).long().sum().item())
+    log["count"] = int(mx.numel())
+    return loss, sample_size, log

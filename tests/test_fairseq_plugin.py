@@ -37,6 +37,10 @@ def test_register_through_reference_registries():
     assert m.label_embs_concat.shape == (23, 32)
     assert Criterion.logging_outputs_can_be_summed() is True
     assert "hubert_mi355x" in MODEL_REGISTRY and "ils_hubert_mi355x" in MODEL_REGISTRY
+    assert "wav2vec2_mi355x" in MODEL_REGISTRY and "wav2vec_mi355x" in CRITERION_REGISTRY
+    w = CRITERION_REGISTRY["wav2vec_mi355x"].build_criterion(SimpleNamespace(infonce=True, loss_weights=[0.1, 10.0], log_keys=[]),
+                                                            SimpleNamespace())
+    assert w.infonce and w.loss_weights == [0.1, 10.0]
 
 
 def test_register_override_replaces_builtins_and_model_half_raises():

@@ -339,6 +339,7 @@ def test_unispeech_sat_head_vs_reference_golden(golden, overrides):
 
 
 ILS_CASES = [("tiny_ils.npz", {}, (23,)),
+             ("tiny_ils_preln.npz", {"layer_norm_first": True, "extractor_mode": "layer_norm"}, (23,)),
              ("tiny_ils_sep_embeds.npz", {"separate_label_embeds": True}, (23, 17)),
              ("tiny_ils_sep_targets.npz", {"separate_layer_targets": True, "separate_label_embeds": True, "weighted_sum": True}, (23, 17))]
 
@@ -455,3 +456,53 @@ def test_fused_adam_vs_reference_optimizer_golden():
             if dtype == torch.float32:
                 assert rel_err(opt.exp_avg[:n], z["out/m%d" % step]) < 1e-5
                 assert rel_err(opt.exp_avg_sq[:n], z["out/v%d" % step]) < 1e-5
+
+
+def test_wav2vec2_model_vs_reference_golden():
+    """wav2vec 2.0 (north_star's `src/fairseq/models/wav2vec` encoder) on the HIP path against the golden
+    generated from the reference's Wav2Vec2Model + Wav2vecCriterion(infonce): Gumbel quantiser in train mode (noise drawn on
+    the host from the torch CPU generator, the reference's own draws), sampled negatives, fused InfoNCE, diversity and
+    features penalties: loss, reference-shaped logits, perplexities and every parameter gradient."""
+    from test_oracle_vs_golden import W2V2
+    from unispeech_amd.wav2vec2 import Wav2Vec2Config, Wav2Vec2Model, Wav2vecCriterion
+    z = load_golden("tiny_w2v2.npz")
+    cfg = Wav2Vec2Config(**{k: v for k, v in W2V2.items() if k in Wav2Vec2Config.__dataclass_fields__})
+    m = Wav2Vec2Model(cfg)
+    m.load_state_dict(golden_state_dict(z), strict=True)
+    m = m.cuda().train()
+    m.quantizer.gumbel_noise = "host"
+    crit = Wav2vecCriterion(None, infonce=True, loss_weights=[0.1, 10.0])
+    pm = torch.zeros(3, 16000, dtype=torch.bool)
+    sample = {"id": torch.arange(3), "net_input": {"source": torch.from_numpy(z["in/source"]).cuda(), "padding_mask": pm.cuda(),
+                                                   "padding_mask_cpu": pm}}
+    np.random.seed(77)
+    torch.manual_seed(31)
+    loss, ss, log = crit(m, sample)
+    assert ss == int(z["out/sample_size"])
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"])), (loss.item(), float(z["out/loss"]))
+    assert int(log["correct"]) == int(z["log/correct"])
+    for k in ("loss_0", "loss_1", "loss_2"):
+        assert abs(log[k] - float(z["log/" + k])) < RTOL * abs(float(z["log/" + k])) + 1e-6, k
+    loss.backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+    for n, p in m.named_parameters():
+        ref = torch.from_numpy(z["grad/" + n])
+        g = p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(ref)
+        tol = GTOL * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8
+        assert (g - ref).abs().max().item() <= tol, (n, (g - ref).abs().max().item(), tol)
+    np.random.seed(77)
+    torch.manual_seed(31)
+    with torch.no_grad():
+        net = m(**sample["net_input"])
+        lg = m.get_logits(net).cpu()
+    ref = torch.from_numpy(z["out/logits"])
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(lg), fin) and rel_err(lg[fin], ref[fin]) < RTOL
+    assert abs(float(net["prob_perplexity"]) - float(z["out/prob_perplexity"])) < RTOL * float(z["out/prob_perplexity"])
+    assert abs(float(net["code_perplexity"]) - float(z["out/code_perplexity"])) < RTOL * float(z["out/code_perplexity"])
+    # device-drawn Gumbel noise (the production mode): same law, different stream -> finite, plausible perplexities
+    m.quantizer.gumbel_noise = "device"
+    np.random.seed(77)
+    torch.manual_seed(31)
+    loss2, _, _ = crit(m, sample)
+    assert torch.isfinite(loss2) and abs(loss2.item() - loss.item()) < 0.2 * abs(loss.item())

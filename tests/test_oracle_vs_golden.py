@@ -249,6 +249,7 @@ def test_oracle_unispeech_sat_head(golden, overrides):
 
 
 ILS_CASES = [("tiny_ils.npz", {}, (23,)),
+             ("tiny_ils_preln.npz", {"layer_norm_first": True, "extractor_mode": "layer_norm"}, (23,)),
              ("tiny_ils_sep_embeds.npz", {"separate_label_embeds": True}, (23, 17)),
              ("tiny_ils_sep_targets.npz", {"separate_layer_targets": True, "separate_label_embeds": True, "weighted_sum": True}, (23, 17))]
 
@@ -385,3 +386,62 @@ def test_oracle_adam_clip_vs_reference_golden():
         p, m, v = O.adam_reference_step(p, g * O.clip_coef(gn, max_norm), m, v, step, lr, b1, b2, eps, wd)
         assert rel_err(p, z["out/p%d" % step]) < 1e-6
         assert rel_err(m, z["out/m%d" % step]) < 1e-5 and rel_err(v, z["out/v%d" % step]) < 1e-5
+
+
+W2V2 = dict(TINY)
+W2V2.update(final_dim=32, quantize_targets=True, latent_vars=20, latent_groups=2, latent_dim=0,
+            latent_temp=(2.0, 0.5, 0.999995), num_negatives=7, cross_sample_negatives=3, logit_temp=0.1,
+            relative_position_embedding=False, gru_rel_pos=False)
+
+
+def _w2v2_cfg():
+    from unispeech_amd.wav2vec2 import Wav2Vec2Config
+    return Wav2Vec2Config(**{k: v for k, v in W2V2.items() if k in Wav2Vec2Config.__dataclass_fields__})
+
+
+def test_seeded_init_wav2vec2_model():
+    """parameter set and creation order of Wav2Vec2Model incl. the Gumbel quantiser (wav2vec2.py:276-395,
+    gumbel_vector_quantizer.py:41-74): same seed -> bit-identical initial weights, strict state-dict load"""
+    from unispeech_amd.wav2vec2 import Wav2Vec2Model
+    z = load_golden("tiny_w2v2.npz")
+    ref_sd = golden_state_dict(z)
+    torch.manual_seed(0)
+    model = Wav2Vec2Model(_w2v2_cfg())
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(ref_sd.keys()), set(sd.keys()) ^ set(ref_sd.keys())
+    for k in ref_sd:
+        assert torch.equal(sd[k], ref_sd[k]), k
+    model.load_state_dict(ref_sd)
+
+
+def test_oracle_wav2vec2_model_and_criterion():
+    """wav2vec 2.0 end to end: extractor, Gumbel quantiser in TRAIN mode (noise from the torch CPU
+    generator, as the reference draws it), sampled negatives, InfoNCE, diversity + features penalties, against the golden
+    generated from the reference's Wav2Vec2Model + Wav2vecCriterion: logits, perplexities, loss, every gradient."""
+    from conftest import Cfg
+    z = load_golden("tiny_w2v2.npz")
+    cfg = Cfg(**W2V2)
+    sd = golden_state_dict(z, as_param=True)
+    wav = torch.from_numpy(z["in/source"])
+    m = torch.from_numpy(z["out/mask_seed77"])
+    torch.manual_seed(31)
+    res = O.wav2vec2_forward(sd, cfg, wav, torch.zeros(3, 16000, dtype=torch.bool), m, training=True)
+    assert abs(res["prob_perplexity"].item() - float(z["out/prob_perplexity"])) < RTOL * float(z["out/prob_perplexity"])
+    assert abs(res["code_perplexity"].item() - float(z["out/code_perplexity"])) < RTOL * float(z["out/code_perplexity"])
+    loss, ss, log = O.wav2vec_criterion(res, [0.1, 10.0])
+    l2 = res["x"].detach().transpose(0, 2).reshape(-1, res["x"].size(0))
+    ref = torch.from_numpy(z["out/logits"])
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(l2), fin) and rel_err(l2[fin], ref[fin]) < RTOL
+    assert ss == int(z["out/sample_size"]) and log["correct"] == int(z["log/correct"])
+    assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
+    loss.backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+    for k, p in sd.items():
+        if not p.is_floating_point() or ("grad/" + k) not in z.files:
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        ref = torch.from_numpy(z["grad/" + k])
+        if k.startswith("feature_extractor."):
+            g = g * cfg.feature_grad_mult
+        assert (g - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-6 * gmax) + 1e-8, k

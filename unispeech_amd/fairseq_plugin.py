@@ -10,7 +10,9 @@ built-ins in fairseq's registries instead, for drop-in use of unmodified recipes
 Registered:
   models     wavlm_mi355x  (WavLMPretrainModel  <- src/fairseq/models/wavlm/wavlm.py:255  @register_model("wavlm"))
              hubert_mi355x, unispeech_sat_mi355x, ils_hubert_mi355x  (same class; structure / heads selected by config fields)
+             wav2vec2_mi355x  (Wav2Vec2Model  <- src/fairseq/models/wav2vec/wav2vec2.py:274  @register_model("wav2vec2"))
   criterions wavlm_mi355x, hubert_mi355x  (WavLMCriterion  <- criterions/wavlm_criterion.py:38, hubert_criterion.py:39)
+             wav2vec_mi355x  (Wav2vecCriterion  <- criterions/wav2vec_criterion.py:36)
 Tasks (`hubert_pretraining`, `utterance_mixing_pretraining`) are the reference's own: they are the *caller* of this
 path; the sample dict they collate is consumed unchanged.
 
@@ -69,6 +71,40 @@ def _classes():
     return _CLASSES
 
 
+def _w2v_classes():
+    """wav2vec 2.0 / UniSpeech: Wav2Vec2Model <- models/wav2vec/wav2vec2.py:274 @register_model("wav2vec2"),
+    Wav2vecCriterion <- criterions/wav2vec_criterion.py:36 @register_criterion("wav2vec")"""
+    from fairseq.criterions import FairseqCriterion
+    from fairseq.dataclass import FairseqDataclass
+    from fairseq.models import BaseFairseqModel
+    from .wav2vec2 import Wav2Vec2Config, Wav2Vec2Model, Wav2vecCriterion
+    fields_ = [(n, f.type, field(default=f.default)) for n, f in Wav2Vec2Config.__dataclass_fields__.items()]
+    W2VCfg = make_dataclass("Wav2Vec2MI355XConfig", fields_, bases=(FairseqDataclass,))
+
+    @dataclass
+    class W2VCritCfg(FairseqDataclass):
+        infonce: bool = field(default=False, metadata={"help": "cross entropy over (positive, negatives) instead of BCE"})
+        loss_weights: Optional[List[float]] = field(default=None, metadata={"help": "weights of extra losses"})
+        log_keys: List[str] = field(default_factory=lambda: [], metadata={"help": "output keys to log"})
+
+    class W2VModel(Wav2Vec2Model, BaseFairseqModel):
+        @classmethod
+        def build_model(cls, cfg, task=None):
+            return cls(cfg)
+
+    class W2VCriterion(Wav2vecCriterion, FairseqCriterion):
+        def __init__(self, task, infonce=False, loss_weights=None, log_keys=None):
+            FairseqCriterion.__init__(self, task)
+            Wav2vecCriterion.__init__(self, task, infonce, loss_weights, log_keys)
+
+        @staticmethod
+        def reduce_metrics(logging_outputs) -> None:
+            from fairseq import metrics
+            Wav2vecCriterion.reduce_metrics(logging_outputs, log_scalar=lambda k, v: metrics.log_scalar(k, v, round=3))
+
+    return W2VModel, W2VCriterion, W2VCfg, W2VCritCfg
+
+
 def register(override: bool = False):
     """Call once per mode (importing the package via --user-dir does the default one).  Returns (model_cls,
     criterion_cls).  override=False registers the `*_mi355x` names; override=True ALSO replaces the built-in
@@ -105,5 +141,8 @@ def register(override: bool = False):
         register_model("ils_hubert_mi355x", dataclass=ModelCfg)(type("ILSHubertMI355X", (Model,), {}))
         register_criterion("wavlm_mi355x", dataclass=CritCfg)(Criterion)
         register_criterion("hubert_mi355x", dataclass=CritCfg)(type("HubertCriterionMI355X", (Criterion,), {}))
+        W2VModel, W2VCriterion, W2VCfg, W2VCritCfg = _w2v_classes()
+        register_model("wav2vec2_mi355x", dataclass=W2VCfg)(W2VModel)
+        register_criterion("wav2vec_mi355x", dataclass=W2VCritCfg)(W2VCriterion)
         _REGISTERED.add("names")
     return Model, Criterion

@@ -912,3 +912,59 @@ def sample_negatives_indices(bsz, tsz, num, n_negatives, cross_sample_negatives,
     if cross_sample_negatives > 0 and n_negatives > 0:
         neg = torch.cat([neg, cross], dim=1)
     return neg
+
+
+# ------------------------------------------------------------------------------------- Gumbel vector quantiser
+class GumbelVQFn(torch.autograd.Function):
+    """Per-row part of GumbelVectorQuantizer.forward (src/fairseq/modules/gumbel_vector_quantizer.py:157-213) on the
+    projected logits [n, G*V]: hard / soft code statistics, Gumbel-softmax with the straight-through estimator, codebook
+    product.  Returns (x [n, G*var_dim], prob_perplexity[1], code_perplexity[1]).  `noise`: the Gumbel draws [n*G, V]
+    (host-drawn for RNG parity with the reference's F.gumbel_softmax) or None = drawn on the device from `seed`.
+    The reference's [n, G, V] one-hot times codebook product is a gather of G code vectors per row; its backward a
+    batched GEMM (d one-hot = dx . vars^T), the softmax backward kernel and a segmented row sum into the codebook."""
+
+    @staticmethod
+    def forward(ctx, logits, vars_, G, V, tau, training, noise, seed):
+        n = logits.shape[0]
+        lc = logits.contiguous()
+        vd = vars_.shape[-1]
+        idx, ysoft, ppl, dA = ops.gumbel_vq_fwd(lc, G, V, tau, training, noise, seed)
+        codes = vars_.reshape(G * V, vd).contiguous()
+        x = ops.gather_rows(codes, idx, n * G).view(n, G * vd)
+        ctx.save_for_backward(lc, ysoft, idx, dA, codes)
+        ctx.cfg = (n, G, V, vd, tau, training, vars_.shape)
+        prob, code = ppl[0:1].clone(), ppl[1:2].clone()
+        ctx.mark_non_differentiable(code)
+        return x, prob, code
+
+    @staticmethod
+    def backward(ctx, dx, dprob, _dcode):
+        lc, ysoft, idx, dA, codes = ctx.saved_tensors
+        n, G, V, vd, tau, training, vshape = ctx.cfg
+        dev = lc.device
+        dret = None
+        dvars = None
+        if dx is not None:
+            dxc = dx.contiguous()
+            if training:
+                # d one-hot[row, g, v] = <dx[row, g], vars[g, v]>  (fp32: feeds the softmax backward)
+                dret = torch.empty((n, G * V), dtype=torch.float32, device=dev)
+                ops.gemm(dxc, codes.to(dxc.dtype), dret, n, V, vd, lda=G * vd, ldb=vd, ldc=G * V, batch=(1, G),
+                         sA=(0, vd), sB=(0, V * vd), sC=(0, V))
+            # d vars[c] = sum of dx[row, g] over the (row, g) that selected code c (the one-hot's forward value is 1)
+            flat = idx.view(-1)
+            src_t, _order, off_t = _csr_by_target(flat, G * V, 1)
+            ones = torch.ones(n * G, dtype=torch.float32, device=dev)
+            dv = ops.rows_wsum(dxc.view(n * G, vd), src_t, ones, off_t, G * V)
+            dvars = dv.to(codes.dtype).view(vshape)
+        dppl = dprob.reshape(1).to(torch.float32).contiguous() if dprob is not None else None
+        if dret is None and dppl is None:
+            return None, dvars, None, None, None, None, None, None
+        dl = ops.gumbel_vq_bwd(lc, ysoft if dret is not None else None, dret, dA, dppl, G, V, tau)
+        return dl, dvars, None, None, None, None, None, None
+
+
+def host_gumbel_noise(n_rows, V):
+    """the draws of F.gumbel_softmax on the CPU generator (torch/nn/functional.py gumbel_softmax:
+    -empty_like(logits).exponential_().log()), for RNG parity with the reference's CPU run"""
+    return -torch.empty((n_rows, V), dtype=torch.float32).exponential_().log()

@@ -589,3 +589,34 @@ def bce_logits(logits, targets_u8, gscale, want_grad=True):
     check(L.wavlm_bce_logits(ptr(logits), ptr(targets_u8), ptr(dl), ptr(out), n, float(gscale), ptr(ws), need, stream()),
           "wavlm_bce_logits")
     return out, dl
+
+
+# ------------------------------------------------------------------------------- Gumbel vector quantiser
+def gumbel_vq_fwd(logits, G, V, tau, training, noise=None, seed=0):
+    """logits [n, G*V] -> (idx int32 [n*G] (global code index g*V + k), ysoft fp32 [n*G, V] or None, out[2] =
+    (prob_perplexity, code_perplexity), dA [G*V] = d prob_perplexity / d avg_probs)"""
+    dev = _dev(logits); _contig(logits); _contig(noise)
+    n = logits.shape[0]
+    L = _lib.lib()
+    rows = int(L.wavlm_gumbel_vq_partial_rows(n))
+    part = torch.empty((rows, 2 * G * V), dtype=torch.float32, device=dev)
+    idx = torch.empty(n * G, dtype=torch.int32, device=dev)
+    ysoft = torch.empty((n * G, V), dtype=torch.float32, device=dev) if training else None
+    check(L.wavlm_gumbel_vq_fwd(ptr(logits), dt(logits), ptr(noise), int(seed) & 0xFFFFFFFFFFFFFFFF, float(tau),
+                                int(bool(training)), n, int(G), int(V), ptr(ysoft), ptr(idx), ptr(part), stream()),
+          "wavlm_gumbel_vq_fwd")
+    sums = colsum(part, torch.float32)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    dA = torch.empty(G * V, dtype=torch.float32, device=dev)
+    check(L.wavlm_vq_perplexity(ptr(sums), n, int(G), int(V), ptr(out), ptr(dA), stream()), "wavlm_vq_perplexity")
+    return idx, ysoft, out, dA
+
+
+def gumbel_vq_bwd(logits, ysoft, dret, dA, dppl, G, V, tau):
+    """dlogits [n, G*V] (dtype of logits); ysoft / dret None in eval mode, dppl None when the perplexity carries no gradient"""
+    _dev(logits); _contig(dret)
+    n = logits.shape[0]
+    dl = torch.empty_like(logits)
+    check(_lib.lib().wavlm_gumbel_vq_bwd(ptr(logits), dt(logits), ptr(ysoft), ptr(dret), ptr(dA), ptr(dppl), float(tau), n,
+                                         int(G), int(V), ptr(dl), stream()), "wavlm_gumbel_vq_bwd")
+    return dl

@@ -127,7 +127,9 @@ class WavLMPretrainModel(WavLM):
         self.separate_label_embeds = self.separate_layer_targets = self.weighted_sum = False
         if self.predict_layers is not None:
             if cfg.layer_norm_first:
-                raise NotImplementedError("pre-LN ILS (post_layer_norm on the tapped layers) is not supported by the HIP path")
+                # pre-LN ILS (ils_hubert.py:73-76, 186-187): the encoder's final LayerNorm is skipped when layers are tapped
+                # (wavlm.py:699-701 `layer is None`), every tapped output gets its own LayerNorm instead
+                self.post_layer_norm = nn.Sequential(*[nn.LayerNorm(cfg.encoder_embed_dim) for _ in self.predict_layers])
             # ils_hubert.py:70-107, same creation order (seeded-init parity): final_proj module(s), `weights`, label embeddings
             self.separate_label_embeds = bool(getattr(cfg, "separate_label_embeds", False))
             self.separate_layer_targets = bool(getattr(cfg, "separate_layer_targets", False))
@@ -266,6 +268,9 @@ class WavLMPretrainModel(WavLM):
                                                       fairseq_layer_results=True, prezeroed=True)
         result = {"x": x, "padding_mask": padding_mask, "features": conv_sum, "layer_results": layer_results}
         if features_only:
+            if output_layer is not None and getattr(self, "post_layer_norm", None) is not None:
+                ln = self.post_layer_norm[-1]  # ils_hubert.py:176-178
+                result["x"] = F.layer_norm(x, ln.weight, ln.bias, ln.eps)[0]
             return result
         self._check_targets(target_list)
 
@@ -284,7 +289,10 @@ class WavLMPretrainModel(WavLM):
         n = B * T
         if self.predict_layers is not None:
             # ILS: the head runs on every collected layer output ([T, B, C] views -> [B, T, C])
-            sources = [lx.transpose(0, 1).reshape(B * T, -1) for lx, _ in layer_results]
+            taps = [lx.transpose(0, 1) for lx, _ in layer_results]
+            if hasattr(self, "post_layer_norm") and self.post_layer_norm is not None:
+                taps = [F.layer_norm(t, ln.weight, ln.bias, ln.eps)[0] for t, ln in zip(taps, self.post_layer_norm)]
+            sources = [t.reshape(B * T, -1) for t in taps]
         else:
             sources = [x.reshape(B * T, -1)]
 
