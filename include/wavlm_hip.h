@@ -243,6 +243,20 @@ int wavlm_adam_step(float* p, float* m, float* v, const void* grad, int32_t grad
                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Utterance / noise mixing of a collated batch (replaces the per-sample numpy loop of
+ * src/fairseq/data/audio/utterance_mixing_dataset.py:373-438 mixing_collated_audios; all random draws stay on the host).
+ * dst[B, T] (fp32, != src) = src with `ops` applied in the reference's in-place row order; ops: n_ops x 8 int32
+ * (row, kind 0 = batch row / 1 = noise segment, src row | noise offset, c_start, s_start, c_len, src length, float32
+ * bits of 10^(snr/10)), sorted by row; op_begin[B + 1].  scale = sqrt(mean(dst_row^2) / (mean(src^2) * gain)), 0 if the
+ * source power is 0.  normalize: rows that were mixed get (x - mean) / sqrt(var + eps) over the whole row (F.layer_norm).
+ * dst_lowp (optional): bf16 copy of the result (the Trainer's waveform cast, trainer.py:1141-1152).
+ * ------------------------------------------------------------------------------------------ */
+uint64_t wavlm_mix_workspace_bytes(int32_t B, int64_t T);
+int wavlm_mix_utterances(const float* src, float* dst, void* dst_lowp, int32_t B, int64_t T, const int32_t* ops,
+                         int32_t n_ops, const int32_t* op_begin, const float* noise, int32_t normalize, float eps,
+                         void* workspace, uint64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Gumbel-softmax vector quantiser on projected logits [n, G*V] (replaces the per-row part of
  * src/fairseq/modules/gumbel_vector_quantizer.py:157-213; the weight projection is a wavlm_gemm, the codebook product a
  * wavlm_gather_rows with the returned indices).

@@ -254,7 +254,7 @@ def gen_tiny_chanmask():
     gen_tiny_pretrain({"mask_channel_prob": 0.25, "mask_channel_length": 4}, "tiny_chanmask.npz")
 
 
-def gen_tiny_sat(overrides=None, fname="tiny_sat.npz"):
+def gen_tiny_sat(overrides=None, fname="tiny_sat.npz", loss_weights=(10.0, 5.0, 0.0)):
     """UniSpeech-SAT at tiny size (fairseq UniSpeechSATModel, utterance_contrastive_loss with 2 in-utterance and 5
     cross-utterance instances tapped after layer 1 of 2) + HubertCriterion with loss_weights [10, 5, 0]: loss, the
     speaker logits statistics and every parameter gradient."""
@@ -280,7 +280,7 @@ def gen_tiny_sat(overrides=None, fname="tiny_sat.npz"):
     torch.manual_seed(0)
     model = us.UniSpeechSATModel(cfg, SimpleNamespace(sample_rate=16000), [_Dict(V)])
     model.train()
-    crit = HubertCriterion(SimpleNamespace(), 1.0, 0.0, loss_weights=[10.0, 5.0, 0.0])
+    crit = HubertCriterion(SimpleNamespace(), 1.0, 0.0, loss_weights=list(loss_weights))
     out = sd_to_np(model.state_dict())
     g = torch.Generator().manual_seed(99)
     wav = torch.randn(3, 16000, generator=g)
@@ -299,6 +299,8 @@ def gen_tiny_sat(overrides=None, fname="tiny_sat.npz"):
     out["out/loss"] = np.float64(loss.item())
     out["out/sample_size"] = np.int64(sample_size)
     out["out/loss_spk_m"] = np.float64(net["loss_spk_m"].item())
+    if "prob_perplexity" in net:
+        out["out/prob_perplexity"] = np.float64(net["prob_perplexity"].item())
     out["out/mean_targets"] = np.float64(float(net["mean_targets"]))
     out["out/contrastive_acc"] = np.float64(float(net["contrastive_acc"]))
     out["out/x"] = net["x"].detach().numpy()
@@ -380,6 +382,9 @@ def gen_tiny_sat_variants():
     gen_tiny_sat({"relative_position_embedding": True, "gru_rel_pos": True}, "tiny_sat_relpos.npz")
     gen_tiny_sat({"relative_position_embedding": True, "gru_rel_pos": True, "extractor_mode": "layer_norm",
                   "layer_norm_first": True}, "tiny_sat_large.npz")
+    # Gumbel-quantised speaker targets (unispeech_sat.py:391-404, 702-705) + codebook-diversity extra loss (820-825)
+    gen_tiny_sat({"quantize_targets": True, "latent_vars": 20, "latent_groups": 2, "latent_dim": 0,
+                  "latent_temp": (2.0, 0.5, 0.999995)}, "tiny_sat_quant.npz", loss_weights=(10.0, 5.0, 0.0, 0.1))
 
 
 def gen_adam_clip():
@@ -532,6 +537,67 @@ def gen_tiny_w2v2():
     np.savez_compressed(os.path.join(OUT, "tiny_w2v2.npz"), **out)
 
 
+def gen_mixing():
+    """UtteranceMixingDataset.collater of the reference (data/audio/utterance_mixing_dataset.py:323-438) on 6 synthetic
+    utterances of different lengths (one all-zero) with frame labels: crop to the shortest (random_crop), utterance mixing
+    with mixing_prob 0.7 / mixing_num 2 / normalize, and a second run with pad_audio + noise mixing from an in-memory noise
+    list.  The dataset object is created without __init__ (which reads manifests from disk); every attribute collater()
+    touches is set by hand.  Stored: inputs, collated source / padding mask / labels, and the next numpy draw (pins the RNG
+    consumption of the host-side plan)."""
+    ref_shim.fairseq_wavlm()
+    from fairseq.data.audio import utterance_mixing_dataset as um
+    g = torch.Generator().manual_seed(606)
+    lens = [5200, 4800, 6100, 4100, 5000, 4500]
+    audios = [torch.randn(n, generator=g) * (0.05 + 0.02 * i) for i, n in enumerate(lens)]
+    audios[3] = torch.zeros(lens[3])   # digital silence: the reference then skips the SNR draw for partners == 3
+    labels = [torch.randint(4, 23, (n // 320 + 1,), generator=g) for n in lens]
+    noise_bank = [(torch.randn(n, generator=g) * 0.1).numpy().astype(np.float32) for n in (3000, 7000, 2500)]
+    noise_bank[1][:] = 0.0
+    out = {"in/lens": np.array(lens, dtype=np.int64)}
+    for i, (a, l) in enumerate(zip(audios, labels)):
+        out["in/audio%d" % i] = a.numpy()
+        out["in/label%d" % i] = l.numpy()
+    for i, nz in enumerate(noise_bank):
+        out["in/noise%d" % i] = nz
+
+    def make(**kw):
+        ds = object.__new__(um.UtteranceMixingDataset)
+        base = dict(sample_rate=16000, label_rates=[50], pad_list=[1], eos_list=[2], num_labels=1, max_sample_size=4600,
+                    pad_audio=False, normalize=True, random_crop=True, single_target=False, multitask=False,
+                    mixing_max_len=-1, mixing_prob=0.7, mixing_num=2, mixing_noise=False, mixing_noise_prob=0.0,
+                    mixing_noise_num=1, noise_list=[], noise_container={})
+        base.update(kw)
+        for k, v in base.items():
+            setattr(ds, k, v)
+        return ds
+
+    def run(tag, seed, ds):
+        samples = [{"id": i, "source": a.clone(), "label_list": [l.clone()], "boundary": []}
+                   for i, (a, l) in enumerate(zip(audios, labels))]
+        np.random.seed(seed)
+        b = ds.collater(samples)
+        out[tag + "/next"] = np.float64(np.random.random())
+        out[tag + "/source"] = b["net_input"]["source"].numpy()
+        out[tag + "/padding_mask"] = b["net_input"]["padding_mask"].numpy()
+        out[tag + "/target"] = b["target_list"][0].numpy()
+        out[tag + "/target_lengths"] = b["target_lengths_list"][0].numpy()
+        out[tag + "/ntokens"] = np.int64(b["ntokens_list"][0])
+
+    run("utt", 4711, make())
+    # noise mixing: the reference reads int16 segments from an h5 file and divides by 32767; here the container is a
+    # dict of in-memory int16 arrays addressed by the same "path\tkey\tstart\tend" strings
+    i16 = [np.round(nz * 32767).astype(np.int16) for nz in noise_bank]
+    cat = np.concatenate(i16)
+    offs = np.cumsum([0] + [len(x) for x in i16])
+    nlist = [{"loc": "bank\tk%d\t%d\t%d" % (i, offs[i], offs[i + 1])} for i in range(3)]
+    out["in/noise_i16"] = cat
+    out["in/noise_offs"] = offs.astype(np.int64)
+    run("noise", 1213, make(pad_audio=True, max_sample_size=5600, normalize=False, mixing_prob=0.9, mixing_num=1,
+                            mixing_noise=True, mixing_noise_prob=0.6, mixing_noise_num=2, noise_list=nlist,
+                            noise_container={"bank": cat}))
+    np.savez_compressed(os.path.join(OUT, "mixing.npz"), **out)
+
+
 def gen_sampled_negatives():
     """wav2vec 2.0 head at function level: the reference's Wav2Vec2Model.sample_negatives and
     compute_preds called as unbound functions (they only read n_negatives / cross_sample_negatives / logit_temp), then the
@@ -581,5 +647,6 @@ if __name__ == "__main__":
     gen_tiny_ils_variants()
     gen_sampled_negatives()
     gen_tiny_w2v2()
+    gen_mixing()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

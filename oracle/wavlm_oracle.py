@@ -334,7 +334,12 @@ def utterance_contrastive(sd, cfg, spk_x, masked_indices):
     proj = F.linear(spk_x_m, sd["spk_proj.weight"], sd["spk_proj.bias"])         # [B, num, C]
     num = proj.size(1)
     b_pos = torch.arange(B).unsqueeze(1).expand(B, num)
-    yflat = proj.reshape(-1, proj.size(-1))
+    q = None
+    ytgt = proj
+    if getattr(cfg, "quantize_targets", False):  # unispeech_sat.py:702-705: targets = project_q(quantizer(tapped frames))
+        q = gumbel_vq(sd, "quantizer.", spk_x_m, cfg.latent_groups, cfg.latent_vars, cfg.latent_temp[0], True)
+        ytgt = F.linear(q["x"], sd["project_q.weight"], sd["project_q.bias"])
+    yflat = ytgt.reshape(-1, ytgt.size(-1))
     idx = sample_instances(B, num, num, cfg.num_instances, cfg.cross_sample_instances)
     samples = yflat[idx.view(-1)].view(B, N, num, -1).permute(1, 0, 2, 3)         # [N, B, num, C]
     samples_b = b_pos.reshape(-1)[idx.view(-1)].view(B, N, num).permute(1, 0, 2)
@@ -343,11 +348,14 @@ def utterance_contrastive(sd, cfg, spk_x, masked_indices):
     px = proj.reshape(-1, proj.size(-1))
     inst = samples.reshape(N, -1, px.size(-1))
     tg = targets.reshape(N + 1, -1).transpose(0, 1)
-    cand = torch.cat([px.unsqueeze(0), inst], dim=0)
+    cand = torch.cat([yflat.unsqueeze(0), inst], dim=0)
     logits = (torch.cosine_similarity(px.float(), cand.float(), dim=-1) / cfg.logit_temp).transpose(0, 1)
     loss = F.binary_cross_entropy_with_logits(logits, tg.type_as(logits), reduction="none").mean()
-    return {"loss_spk_m": loss, "mean_targets": tg.float().mean(), "contrastive_acc": ((logits >= 0.0) == tg).float().mean(),
-            "spk_logits": logits}
+    out = {"loss_spk_m": loss, "mean_targets": tg.float().mean(), "contrastive_acc": ((logits >= 0.0) == tg).float().mean(),
+           "spk_logits": logits}
+    if q is not None:
+        out.update(prob_perplexity=q["prob_perplexity"], num_vars=q["num_vars"])
+    return out
 
 
 def sampled_negatives_logits(x, y, neg_idxs, n_neg, logit_temp):
@@ -402,6 +410,11 @@ def criterion(net_output, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_w
             q = w * net_output["loss_spk_m"].float() * sample_size
             loss = loss + q
             log["loss_loss_spk_m"] = q
+        if "prob_perplexity" in net_output and len(loss_weights) > 3 and loss_weights[3] != 0:
+            # get_extra_losses order: features_pen, loss_spk_m, loss_spk_u (None), prob_perplexity (unispeech_sat.py:803-825)
+            d = loss_weights[3] * ((net_output["num_vars"] - net_output["prob_perplexity"]) / net_output["num_vars"]).float() * sample_size
+            loss = loss + d
+            log["loss_prob_perplexity"] = d
     for name, ls in (("m", lm), ("u", lu)):
         for i, l in enumerate(ls):
             if l.numel() == 0:
@@ -565,3 +578,34 @@ def wav2vec_criterion(res, loss_weights=None):
     log["correct"] = int(mx.long().sum().item() - (mx & mn).long().sum().item())
     log["count"] = int(mx.numel())
     return loss, sample_size, log
+
+
+# ------------------------------------------------------------------------- utterance mixing
+def mix_collated_audios(source, ops, op_begin, noise=None, normalize=False):
+    """The arithmetic of UtteranceMixingDataset.mixing_collated_audios (src/fairseq/data/audio/utterance_mixing_dataset.py:
+    373-438) for a given list of mixing ops (the random draws, made by unispeech_amd.data.UtteranceMixingCollater.
+    draw_mixing_plan from the reference's numpy stream): in place, in row order, numpy float32 powers, the reference's
+    expression for the scale, `.clone()` of the added span, per-row F.layer_norm when `normalize`."""
+    import numpy as np
+    source = source.clone()
+    B = source.shape[0]
+    for i in range(B):
+        for k in range(int(op_begin[i]), int(op_begin[i + 1])):
+            row, kind, src, c_start, s_start, c_len, src_len, gbits = [int(v) for v in ops[k]]
+            gain = np.array([gbits], dtype=np.int32).view(np.float32)[0]
+            assert row == i
+            ref_pow = np.mean(source[i].numpy() ** 2)
+            if kind == 1:
+                nz = noise[src:src + src_len]
+                noise_pow = np.mean(nz ** 2)
+                scale = 0 if noise_pow == 0 else (ref_pow / (noise_pow * gain)) ** 0.5
+                seg = torch.from_numpy(np.asarray(scale * nz, dtype=np.float32))
+                source[i, s_start:s_start + c_len] += seg[c_start:c_start + c_len]
+            else:
+                noise_pow = np.mean(source[src].numpy() ** 2)
+                scale = 0 if noise_pow == 0 else (ref_pow / (noise_pow * gain)) ** 0.5
+                source[i, s_start:s_start + c_len] += source[src, c_start:c_start + c_len].clone() * scale
+        if normalize and op_begin[i + 1] > op_begin[i]:
+            with torch.no_grad():
+                source[i] = F.layer_norm(source[i], source[i].shape)
+    return source

@@ -1,0 +1,111 @@
+"""Utterance / noise mixing + collation against tests/golden/mixing.npz, which oracle/gen_golden.py
+produced by calling the reference's `UtteranceMixingDataset.collater` (src/fairseq/data/audio/utterance_mixing_dataset.py:
+323-438) under fixed numpy seeds.
+
+CPU: the host side of the product (unispeech_amd.data.UtteranceMixingCollater: crops, mixing plan, label collation) consumes
+the numpy stream exactly as the reference (same next draw), padding mask and labels are bit-exact, and the oracle's
+restatement of the mixing arithmetic applied to that plan reproduces the reference's waveform batch to 1e-6.
+GPU: the device kernel (wavlm_mix_utterances) applied to the same plan matches the golden to 1e-6 of the batch scale
+(float32 power reductions are summed in a different order than numpy's pairwise sum; everything else is the same
+arithmetic), and its bf16 output equals the bf16 rounding of its fp32 output.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def _inputs(z):
+    n = len(z["in/lens"])
+    audios = [torch.from_numpy(z["in/audio%d" % i]) for i in range(n)]
+    labels = [torch.from_numpy(z["in/label%d" % i]) for i in range(n)]
+    return [{"id": i, "source": a.clone(), "label_list": [l.clone()], "boundary": []} for i, (a, l) in enumerate(zip(audios, labels))]
+
+
+def _collaters(z, device=None, out_dtype=torch.float32):
+    from unispeech_amd.data import UtteranceMixingCollater
+    offs = z["in/noise_offs"]
+    cat = z["in/noise_i16"]
+    nlist = [{"loc": "bank\tk%d\t%d\t%d" % (i, offs[i], offs[i + 1])} for i in range(3)]
+
+    def loader(entry):  # what the reference does with its h5 container (utterance_mixing_dataset.py:386-390)
+        _p, _k, s, e = entry["loc"].split("\t")
+        return cat[int(s):int(e)].astype(np.float32) / np.iinfo(np.int16).max
+
+    utt = UtteranceMixingCollater(label_rates=[50], pad_list=[1], max_sample_size=4600, pad_audio=False, normalize=True,
+                                  random_crop=True, mixing_prob=0.7, mixing_num=2, device=device, out_dtype=out_dtype)
+    noise = UtteranceMixingCollater(label_rates=[50], pad_list=[1], max_sample_size=5600, pad_audio=True, normalize=False,
+                                    random_crop=True, mixing_prob=0.9, mixing_num=1, mixing_noise=True,
+                                    mixing_noise_prob=0.6, mixing_noise_num=2, noise_list=nlist, noise_loader=loader,
+                                    device=device, out_dtype=out_dtype)
+    return {"utt": (utt, 4711), "noise": (noise, 1213)}
+
+
+@pytest.mark.parametrize("tag", ["utt", "noise"])
+def test_host_plan_labels_and_oracle_mixing_vs_reference_collater(tag):
+    from oracle import wavlm_oracle as O
+    z = load_golden("mixing.npz")
+    col, seed = _collaters(z)[tag]
+    np.random.seed(seed)
+    b = col.collater(_inputs(z))
+    assert np.random.random() == float(z[tag + "/next"]), "numpy stream consumption differs from the reference collater"
+    assert torch.equal(b["net_input"]["padding_mask"], torch.from_numpy(z[tag + "/padding_mask"]))
+    assert torch.equal(b["target_list"][0], torch.from_numpy(z[tag + "/target"]))
+    assert torch.equal(b["target_lengths_list"][0], torch.from_numpy(z[tag + "/target_lengths"]))
+    assert b["ntokens_list"][0] == int(z[tag + "/ntokens"])
+    ops, begin, noise = b["mixing_plan"]
+    assert ops.shape[0] >= 3
+    mixed = O.mix_collated_audios(b["net_input"]["source"], ops, begin, noise, normalize=col.normalize)
+    ref = torch.from_numpy(z[tag + "/source"])
+    assert mixed.shape == ref.shape
+    assert (mixed - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    assert (b["net_input"]["source"] - ref).abs().max().item() > 1e-3, "the fixture must actually mix something"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["utt", "noise"])
+def test_device_mixing_kernel_vs_reference_collater(tag):
+    z = load_golden("mixing.npz")
+    col, seed = _collaters(z, device="cuda")[tag]
+    np.random.seed(seed)
+    b = col.collater(_inputs(z))
+    src = b["net_input"]["source"]
+    assert src.is_cuda and src.dtype == torch.float32
+    ref = torch.from_numpy(z[tag + "/source"])
+    err = (src.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 1e-6, err
+    assert torch.equal(b["net_input"]["padding_mask"].cpu(), torch.from_numpy(z[tag + "/padding_mask"]))
+    assert torch.equal(b["target_list"][0], torch.from_numpy(z[tag + "/target"]))
+    col16, _ = _collaters(z, device="cuda", out_dtype=torch.bfloat16)[tag]
+    np.random.seed(seed)
+    b16 = col16.collater(_inputs(z))
+    assert b16["net_input"]["source"].dtype == torch.bfloat16
+    assert torch.equal(b16["net_input"]["source"], src.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+def test_device_mixing_at_batch_scale_dependency_chain():
+    """32 x 15 s (the bench batch): every row mixed twice, partners chosen so that long chains of "finished lower row"
+    dependencies and self-mixes occur; compared with the oracle's sequential restatement on the same plan."""
+    from oracle import wavlm_oracle as O
+    from unispeech_amd import ops as K
+    B, T = 32, 240000
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(B, T, generator=g) * 0.1
+    rs = np.random.RandomState(9)
+    plan, begin = [], [0]
+    for i in range(B):
+        for c in (max(i - 1, 0), int(rs.randint(0, B))):       # i-1: a chain through all rows; plus a random partner
+            c_len = int(rs.randint(0, T // 2 + 1))
+            c_end, s_end = int(rs.randint(c_len, T + 1)), int(rs.randint(c_len, T + 1))
+            gain = np.float32(10 ** (rs.uniform(-5, 5) / 10)).view(np.int32)
+            plan.append((i, 0, c, c_end - c_len, s_end - c_len, c_len, T, int(gain)))
+        begin.append(len(plan))
+    ops = np.asarray(plan, dtype=np.int32)
+    begin = np.asarray(begin, dtype=np.int32)
+    want = O.mix_collated_audios(src, ops, begin, None, normalize=True)
+    got = K.mix_utterances(src.cuda(), torch.from_numpy(ops.reshape(-1)).cuda(), ops.shape[0], torch.from_numpy(begin).cuda(),
+                           None, True)
+    err = (got.cpu() - want).abs().max().item() / want.abs().max().item()
+    assert err <= 2e-6, err

@@ -292,7 +292,10 @@ def test_large_structure_vs_reference_golden(golden, conv_bias):
 SAT_CASES = [("tiny_sat.npz", {}),
              ("tiny_sat_relpos.npz", {"relative_position_embedding": True, "gru_rel_pos": True}),
              ("tiny_sat_large.npz", {"relative_position_embedding": True, "gru_rel_pos": True,
-                                     "extractor_mode": "layer_norm", "layer_norm_first": True})]
+                                     "extractor_mode": "layer_norm", "layer_norm_first": True}),
+             ("tiny_sat_quant.npz", {"quantize_targets": True, "latent_vars": 20, "latent_groups": 2, "latent_dim": 0,
+                                     "latent_temp": (2.0, 0.5, 0.999995)})]
+SAT_LOSS_WEIGHTS = {"tiny_sat_quant.npz": [10.0, 5.0, 0.0, 0.1]}  # 4th: codebook diversity (prob_perplexity)
 
 
 @pytest.mark.parametrize("golden,overrides", SAT_CASES)
@@ -311,7 +314,9 @@ def test_unispeech_sat_head_vs_reference_golden(golden, overrides):
     m = WavLMPretrainModel(cfg, None, [range(23)])
     missing = m.load_state_dict(golden_state_dict(z), strict=True)
     m = m.to("cuda").train()
-    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0, 5.0, 0.0])
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=SAT_LOSS_WEIGHTS.get(golden, [10.0, 5.0, 0.0]))
+    if m.quantizer is not None:
+        m.quantizer.gumbel_noise = "host"  # the reference's own Gumbel draws (torch CPU generator)
     wav = torch.from_numpy(z["in/source"]).cuda()
     target = torch.from_numpy(z["in/target"]).cuda()
     pm = torch.zeros(3, 16000, dtype=torch.bool)

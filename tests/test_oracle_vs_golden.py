@@ -196,7 +196,10 @@ def _sat_cfg(**overrides):
 SAT_CASES = [("tiny_sat.npz", {}),
              ("tiny_sat_relpos.npz", {"relative_position_embedding": True, "gru_rel_pos": True}),
              ("tiny_sat_large.npz", {"relative_position_embedding": True, "gru_rel_pos": True,
-                                     "extractor_mode": "layer_norm", "layer_norm_first": True})]
+                                     "extractor_mode": "layer_norm", "layer_norm_first": True}),
+             ("tiny_sat_quant.npz", {"quantize_targets": True, "latent_vars": 20, "latent_groups": 2, "latent_dim": 0,
+                                     "latent_temp": (2.0, 0.5, 0.999995)})]
+SAT_LOSS_WEIGHTS = {"tiny_sat_quant.npz": [10.0, 5.0, 0.0, 0.1]}  # 4th: codebook diversity (prob_perplexity)
 
 
 @pytest.mark.parametrize("golden,overrides", SAT_CASES)
@@ -233,7 +236,9 @@ def test_oracle_unispeech_sat_head(golden, overrides):
     assert abs(net["loss_spk_m"].item() - float(z["out/loss_spk_m"])) < RTOL * abs(float(z["out/loss_spk_m"]))
     assert abs(float(net["mean_targets"]) - float(z["out/mean_targets"])) < 1e-6
     assert abs(float(net["contrastive_acc"]) - float(z["out/contrastive_acc"])) < 1e-6
-    loss, ss, _ = O.criterion(net, 1.0, 0.0, [10.0, 5.0, 0.0])
+    if "out/prob_perplexity" in z.files:
+        assert abs(net["prob_perplexity"].item() - float(z["out/prob_perplexity"])) < RTOL * float(z["out/prob_perplexity"])
+    loss, ss, _ = O.criterion(net, 1.0, 0.0, SAT_LOSS_WEIGHTS.get(golden, [10.0, 5.0, 0.0]))
     assert ss == int(z["out/sample_size"])
     assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"]))
     loss.backward()

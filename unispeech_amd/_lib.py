@@ -103,6 +103,8 @@ SIGNATURES = {
     "wavlm_sum_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_u64, c_vp]),
     "wavlm_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
                                 c_i64, c_f32, c_vp, c_vp, c_f32, c_vp]),
+    "wavlm_mix_workspace_bytes": (c_u64, [c_i32, c_i64]),
+    "wavlm_mix_utterances": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp]),
     "wavlm_gumbel_vq_partial_rows": (c_u64, [c_i64]),
     "wavlm_gumbel_vq_fwd": (c_i32, [c_vp, c_i32, c_vp, c_u64, c_f32, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "wavlm_vq_perplexity": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),

@@ -16,7 +16,7 @@ OBJ_DIR = os.path.join(HERE, "_build")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwavlm_hip.so")
 ARCH = "gfx950"
-SOURCES = ["gemm_bf16.hip", "gemm_pp.hip", "gemm_pp3.hip", "gemm_f32.hip", "rowops.hip", "conv0.hip", "attn.hip", "attn_fused.hip", "posconv.hip", "loss.hip", "vq.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_pp.hip", "gemm_pp3.hip", "gemm_f32.hip", "rowops.hip", "conv0.hip", "attn.hip", "attn_fused.hip", "posconv.hip", "loss.hip", "vq.hip", "mixing.hip",
            "optim.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", INCLUDE]
 

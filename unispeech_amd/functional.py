@@ -807,42 +807,46 @@ class FeaturesPenFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------ utterance-contrastive head (UniSpeech-SAT)
 class UttContrastiveLossFn(torch.autograd.Function):
-    """mean BCE-with-logits of cos(y_s, y_{idx[s, n]}) / temp against same-utterance indicators: compute_pred_spk of
+    """mean BCE-with-logits of cos(x_s, y_{idx[s, n]}) / temp against same-utterance indicators: compute_pred_spk of
     UniSpeech-SAT (src/fairseq/models/unispeech_sat/unispeech_sat.py:701-737) with compute_nce(replace_inf=False)
-    (545-557).  idx[:, 0] is the row itself (the reference's positive is the projection itself); the gathered
-    [N, S, C] instance tensor of the reference is never built.  Returns (loss[1], accuracy[1])."""
+    (545-557).  idx[:, 0] is the row itself; y = the (Gumbel-quantised, projected) targets, or None = the projections
+    themselves (no quantiser: the reference's positive is the projection itself).  The gathered [N, S, C] instance tensor
+    of the reference is never built.  Returns (loss[1], accuracy[1])."""
 
     @staticmethod
-    def forward(ctx, proj, idx, targets_u8, temp):
+    def forward(ctx, proj, idx, targets_u8, temp, y=None):
         S, N1 = idx.shape
-        yn, inv = ops.l2norm_fwd(proj.contiguous(), proj.dtype)
-        logits = ops.gather_dot(yn, yn, idx, 1.0 / temp)
+        xn, inv = ops.l2norm_fwd(proj.contiguous(), proj.dtype)
+        if y is not None:
+            yn, inv_y = ops.l2norm_fwd(y.contiguous(), y.dtype)
+        else:
+            yn, inv_y = xn, inv
+        logits = ops.gather_dot(xn, yn, idx, 1.0 / temp)
         out, dl = ops.bce_logits(logits, targets_u8, 1.0 / (temp * S * N1), want_grad=True)
-        ctx.save_for_backward(yn, inv, dl, idx, proj)
+        ctx.save_for_backward(xn, inv, yn, inv_y, dl, idx, proj, y if y is not None else proj)
+        ctx.has_y = y is not None
         loss, acc = out[0:1].clone(), out[1:2].clone()
         ctx.mark_non_differentiable(acc)
         return loss, acc
 
     @staticmethod
     def backward(ctx, dloss, _dacc):
-        yn, inv, dl, idx, proj = ctx.saved_tensors
+        xn, inv, yn, inv_y, dl, idx, proj, y = ctx.saved_tensors
         S, N1 = idx.shape
-        dev = yn.device
+        dev = xn.device
         w = (dl * dloss.reshape(1).to(torch.float32)).view(-1)      # d loss / d logits, already / temp / numel
         flat = idx.view(-1)
-        # direct half: d yn[s] += sum_n w[s, n] * yn[idx[s, n]]
+        # direct half: d xn[s] = sum_n w[s, n] * yn[idx[s, n]]
         off = torch.arange(0, (S + 1) * N1, N1, dtype=torch.int32, device=dev)
-        dyn = ops.rows_wsum(yn, flat, w, off, S)
-        # transposed half: d yn[j] += sum_{(s, n): idx[s, n] = j} w[s, n] * yn[s]   (entries sorted by gathered row)
-        order = torch.argsort(flat.long(), stable=True)
-        src_t = torch.div(order, N1, rounding_mode="floor").to(torch.int32)
+        dxn = ops.rows_wsum(yn, flat, w, off, S)
+        # transposed half: d yn[j] = sum_{(s, n): idx[s, n] = j} w[s, n] * xn[s]   (entries sorted by gathered row)
+        src_t, order, off_t = _csr_by_target(flat, S, N1)
         w_t = w.index_select(0, order)
-        counts = torch.bincount(flat.long(), minlength=S)
-        off_t = torch.zeros(S + 1, dtype=torch.int32, device=dev)
-        off_t[1:] = torch.cumsum(counts, 0).to(torch.int32)
-        ops.rows_wsum(yn, src_t, w_t, off_t, S, out=dyn, accumulate=True)
-        dproj = ops.l2norm_bwd(dyn, yn, inv, proj.dtype)
-        return dproj, None, None, None
+        if not ctx.has_y:
+            ops.rows_wsum(xn, src_t, w_t, off_t, S, out=dxn, accumulate=True)
+            return ops.l2norm_bwd(dxn, xn, inv, proj.dtype), None, None, None, None
+        dyn = ops.rows_wsum(xn, src_t, w_t, off_t, S)
+        return (ops.l2norm_bwd(dxn, xn, inv, proj.dtype), None, None, None, ops.l2norm_bwd(dyn, yn, inv_y, y.dtype))
 
 
 def _csr_by_target(flat_idx, n_rows, per_row):

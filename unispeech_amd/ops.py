@@ -620,3 +620,22 @@ def gumbel_vq_bwd(logits, ysoft, dret, dA, dppl, G, V, tau):
     check(_lib.lib().wavlm_gumbel_vq_bwd(ptr(logits), dt(logits), ptr(ysoft), ptr(dret), ptr(dA), ptr(dppl), float(tau), n,
                                          int(G), int(V), ptr(dl), stream()), "wavlm_gumbel_vq_bwd")
     return dl
+
+
+# ------------------------------------------------------------------------------------- utterance mixing
+def mix_utterances(src, ops_flat, n_ops, op_begin, noise, normalize, out_dtype=torch.float32, eps=1e-5):
+    """src fp32 [B, T] (left untouched) -> mixed batch [B, T] in out_dtype (fp32, or bf16 = the Trainer's waveform cast);
+    ops_flat int32 [n_ops * 8], op_begin int32 [B + 1], noise fp32 or None (see include/wavlm_hip.h)"""
+    dev = _dev(src); _contig(src)
+    if src.dtype != torch.float32:
+        raise TypeError("mix_utterances works on the fp32 collated waveform")
+    B, T = src.shape
+    dst = torch.empty_like(src)
+    low = torch.empty((B, T), dtype=torch.bfloat16, device=dev) if out_dtype == torch.bfloat16 else None
+    L = _lib.lib()
+    need = L.wavlm_mix_workspace_bytes(B, T)
+    ws = workspace(dev, need, "mix")
+    check(L.wavlm_mix_utterances(ptr(src), ptr(dst), ptr(low), B, T, ptr(ops_flat) if n_ops else None, int(n_ops),
+                                 ptr(op_begin), ptr(noise), int(bool(normalize)), float(eps), ptr(ws), need, stream()),
+          "wavlm_mix_utterances")
+    return low if low is not None else dst

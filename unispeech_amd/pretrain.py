@@ -77,6 +77,10 @@ class WavLMPretrainConfig:
     num_instances: int = 0
     cross_sample_instances: int = 100
     quantize_targets: bool = False
+    latent_vars: int = 320
+    latent_groups: int = 2
+    latent_dim: int = 0
+    latent_temp: tuple = (2, 0.5, 0.999995)
     # ILS-SSL (models/hubert/ils_hubert.py:44-58): the masked-prediction loss on several layers' outputs
     predict_layers: str = ""
     separate_label_embeds: bool = False
@@ -151,12 +155,20 @@ class WavLMPretrainModel(WavLM):
         self.utterance_contrastive_loss = getattr(cfg, "utterance_contrastive_loss", False)
         self.utterance_contrastive_layer = None
         if self.utterance_contrastive_loss:
-            if getattr(cfg, "quantize_targets", False):
-                raise NotImplementedError("quantize_targets (Gumbel quantiser) is not supported by the HIP path")
             self.utterance_contrastive_layer = cfg.utterance_contrastive_layer
             self.n_instances = cfg.num_instances
             self.cross_sample_instances = cfg.cross_sample_instances
-            self.project_q = nn.Linear(cfg.encoder_embed_dim, final_dim)  # unused without the quantiser; state-dict parity
+            self.quantizer = None
+            if getattr(cfg, "quantize_targets", False):
+                # Gumbel-quantised speaker targets (unispeech_sat.py:391-402): quantizer(tapped frames) -> project_q
+                from .wav2vec2 import GumbelVectorQuantizer
+                vq_dim = cfg.latent_dim if cfg.latent_dim > 0 else final_dim
+                self.quantizer = GumbelVectorQuantizer(dim=cfg.encoder_embed_dim, num_vars=cfg.latent_vars,
+                                                       temp=cfg.latent_temp, groups=cfg.latent_groups, combine_groups=False,
+                                                       vq_dim=vq_dim, time_first=True)
+                self.project_q = nn.Linear(vq_dim, final_dim)
+            else:
+                self.project_q = nn.Linear(cfg.encoder_embed_dim, final_dim)  # unused without the quantiser; state-dict parity
             self.spk_proj = nn.Linear(cfg.encoder_embed_dim, final_dim)
 
     @classmethod
@@ -168,6 +180,8 @@ class WavLMPretrainModel(WavLM):
 
     def set_num_updates(self, num_updates):
         self.num_updates = num_updates
+        if getattr(self, "quantizer", None) is not None:
+            self.quantizer.set_num_updates(num_updates)
 
     def max_positions(self):
         return None
@@ -344,8 +358,11 @@ class WavLMPretrainModel(WavLM):
             if self.skip_masked or spk_x is None:
                 result.update(loss_spk_m=None, mean_targets=None, contrastive_acc=None, loss_spk_u=None)
             else:
-                loss_spk, mean_t, acc = self._utterance_contrastive(spk_x, np.logical_and(~pad_np, m_np))
+                loss_spk, mean_t, acc, q = self._utterance_contrastive(spk_x, np.logical_and(~pad_np, m_np))
                 result.update(loss_spk_m=loss_spk, mean_targets=mean_t, contrastive_acc=acc, loss_spk_u=None)
+                if q is not None:  # unispeech_sat.py:753-757
+                    result.update(prob_perplexity=q["prob_perplexity"], code_perplexity=q["code_perplexity"],
+                                  num_vars=q["num_vars"], temp=q["temp"])
         return result
 
     def _sample_instances(self, bsz, tsz, num):
@@ -385,6 +402,10 @@ class WavLMPretrainModel(WavLM):
         inv_np[idx_np] = np.arange(S, dtype=np.int32)
         rows = F.GatherRowsFn.apply(spk_x.reshape(B * T, D), F.h2d(idx_np, dev), F.h2d(inv_np, dev))
         proj = F.LinearFn.apply(rows, self.spk_proj.weight, self.spk_proj.bias)         # [S, final_dim], row = b * num + t
+        q, y = None, None
+        if self.quantizer is not None:  # targets = project_q(quantizer(tapped frames)) instead of the projection itself
+            q = self.quantizer(rows.view(B, num, D))
+            y = F.LinearFn.apply(q["x"].reshape(S, -1), self.project_q.weight, self.project_q.bias)
         N = self.n_instances + self.cross_sample_instances
         samples_idx = self._sample_instances(B, num, num)                               # [B, N * num], CPU int64
         # instance n of frame (b, t) is samples_idx[b, n * num + t]; its utterance = index // num
@@ -394,8 +415,9 @@ class WavLMPretrainModel(WavLM):
         b_of = torch.arange(B).view(B, 1).expand(B, num).reshape(S, 1)
         targets = torch.cat([torch.ones(S, 1, dtype=torch.bool), torch.div(si, num, rounding_mode="floor") == b_of], dim=1)
         mean_targets = float(targets.float().mean())
-        loss, acc = F.UttContrastiveLossFn.apply(proj, F.h2d(idx_full, dev), F.h2d(targets.to(torch.uint8), dev), self.logit_temp)
-        return loss, mean_targets, acc
+        loss, acc = F.UttContrastiveLossFn.apply(proj, F.h2d(idx_full, dev), F.h2d(targets.to(torch.uint8), dev),
+                                                 self.logit_temp, y)
+        return loss, mean_targets, acc, q
 
     # gradient through the unmasked head is only needed when pred_nomask_weight > 0 (criterion sets this)
     training_nomask_grad = False
@@ -449,12 +471,16 @@ class WavLMPretrainModel(WavLM):
         if "loss_spk_u" in net_output:
             extra_losses.append(net_output["loss_spk_u"])
             names.append("loss_spk_u")
+        if "prob_perplexity" in net_output:  # codebook diversity (unispeech_sat.py:820-825)
+            extra_losses.append((net_output["num_vars"] - net_output["prob_perplexity"]) / net_output["num_vars"])
+            names.append("prob_perplexity")
         return extra_losses, names
 
     def remove_pretraining_modules(self):
         self.final_proj = None
         self.label_embs_concat = None
         if self.utterance_contrastive_loss:
+            self.quantizer = None
             self.project_q = None
             self.spk_proj = None
         if hasattr(self.encoder, "layer_norm_for_extract"):  # unispeech_sat.py:833-834
