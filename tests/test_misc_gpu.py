@@ -175,6 +175,50 @@ def test_fused_adam_checkpoint_roundtrip_and_rehoming():
         assert torch.equal(o4.exp_avg[o:o + p.numel()].view(p.shape), fsd["state"][i]["exp_avg"])
 
 
+def test_downstream_consumer_call_patterns():
+    """The two consumers SURVEY.md 8(f) rank 4 names, called the way the reference's own code calls them:
+    (a) s3prl's UpstreamExpert (downstreams/speaker_verification/models/utils.py:49-75): forward hooks on
+        model.encoder.layers[i] reading `input[0].transpose(0, 1)` and on model.encoder reading `output[0]`, then
+        model.extract_features(padded_wav, padding_mask=mask, mask=None);
+    (b) the k-means feature dump (src/examples/hubert/simple_kmeans/dump_hubert_feature.py:68-80):
+        model.extract_features(source=chunk, padding_mask=None, mask=False, output_layer=L) in chunks.
+    Checked against the CPU oracle's layer inputs / outputs (tiny golden weights)."""
+    from conftest import Cfg
+    from oracle import wavlm_oracle as O
+    model, z = _tiny()
+    model.eval()
+    sd = golden_state_dict(z)
+    cfg = Cfg(**TINY)
+    wavs = [torch.from_numpy(z["in/source"][0]), torch.from_numpy(z["in/source"][1][:12000])]
+    # ---- (a)
+    got = []
+    handles = [l.register_forward_hook(lambda m, inp, out: got.append(inp[0].transpose(0, 1))) for l in model.encoder.layers]
+    handles.append(model.encoder.register_forward_hook(lambda m, inp, out: got.append(out[0])))
+    lengths = torch.LongTensor([len(w) for w in wavs])
+    pmask = ~torch.lt(torch.arange(int(lengths.max())).unsqueeze(0), lengths.unsqueeze(1))
+    padded = torch.nn.utils.rnn.pad_sequence(wavs, batch_first=True)
+    with torch.no_grad():
+        feats, fpm = model.extract_features(padded.cuda(), padding_mask=pmask.cuda(), mask=None)
+    for h in handles:
+        h.remove()
+    ref = O.extract_features(sd, cfg, padded, padding_mask=pmask, output_layer=cfg.encoder_layers)
+    want = [t.transpose(0, 1) for t, _ in ref["layer_results"][:cfg.encoder_layers]] + [ref["x"]]
+    assert len(got) == len(want) == cfg.encoder_layers + 1
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        assert ((a.cpu() - b).abs().max() / b.abs().max()).item() < 1e-4
+    assert ((feats.cpu() - ref["x"]).abs().max() / ref["x"].abs().max()).item() < 1e-4
+    assert torch.equal(fpm.cpu(), ref["padding_mask"])
+    # ---- (b)
+    x = wavs[0].view(1, -1)
+    with torch.no_grad():
+        chunks = [model.extract_features(source=x[:, s:s + 8000].cuda(), padding_mask=None, mask=False, output_layer=1)[0]
+                  for s in range(0, x.size(1), 8000)]
+        feat = torch.cat(chunks, 1).squeeze(0)
+    refc = torch.cat([O.extract_features(sd, cfg, x[:, s:s + 8000], output_layer=1)["x"] for s in range(0, x.size(1), 8000)], 1)
+    assert ((feat.cpu() - refc.squeeze(0)).abs().max() / refc.abs().max()).item() < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ RCCL, world 2
 def _free_port():
     s = socket.socket()

@@ -306,7 +306,14 @@ class TransformerSentenceEncoderLayer(nn.Module):
             return None
         return F.WgradGroup(4 if self.self_attn._packed is not None else 3)
 
-    def forward(self, x, key_padding_u8=None, position_table=None):
+    def forward(self, x, key_padding_u8=None, position_table=None, tbc=False):
+        """x [B, T, D] -> (x, None, position_table).  tbc=True: x comes and goes as the reference's [T, B, D] (a transposed
+        VIEW of the channel-last tensor, no copy) -- the encoder calls the layer that way when forward hooks are registered
+        on it, so that hook-based consumers written for the reference (s3prl's UpstreamExpert:
+        downstreams/speaker_verification/models/utils.py:49-56 reads `input[0].transpose(0, 1)` of every layer) see the
+        shapes they expect."""
+        if tbc:
+            x = x.transpose(0, 1)
         ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
         p = self.dropout if self.training else 0.0
         if self.layer_norm_first:
@@ -329,7 +336,7 @@ class TransformerSentenceEncoderLayer(nn.Module):
             f = self._ffn(x, tf, wg)
             x, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps, residual=f, p_in=p, training=self.training,
                                 residual_bias_tok=tf)
-        return x, None, position_table
+        return (x.transpose(0, 1) if tbc else x), None, position_table
 
 
 class TransformerEncoder(nn.Module):
@@ -418,7 +425,11 @@ class TransformerEncoder(nn.Module):
             # one host draw per layer, training or not: keeps the numpy stream aligned with the reference
             dropout_probability = np.random.random()
             if not self.training or (dropout_probability > self.layerdrop):
-                x, z, table = layer(x, kpm, table)
+                if layer._forward_hooks or layer._forward_pre_hooks:
+                    xt, z, table = layer(x.transpose(0, 1), kpm, table, tbc=True)
+                    x = xt.transpose(0, 1)
+                else:
+                    x, z, table = layer(x, kpm, table)
             else:
                 z = None
             if extract_layer is not None and i == extract_layer:
