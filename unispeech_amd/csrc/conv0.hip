@@ -41,6 +41,49 @@ template <> __device__ __forceinline__ void V8<bf16_t>::st(bf16_t* p, const floa
   *reinterpret_cast<uint4*>(p) = o;
 }
 
+// ---- GELU / GELU' by table (bf16 activations only) ------------------------------------------------------------------
+// The erf evaluation (one v_rcp, one v_exp, six FMAs, sign handling: ~18 VALU slots) was more than half of the VALU work
+// per output of the apply pass, which is what kept this HBM-bound stage at 2.2 TB/s.  With bf16 output (relative
+// resolution 2^-9) a piecewise-linear table is indistinguishable: 2048 cells over [-8, 8), cell i holds (slope,
+// intercept) of the chord through the exact values at its ends -> |error| <= h^2/8 * max|f''| = 8e-6 absolute, and the
+// evaluation is fma + med3 + cvt + one 8-byte LDS read + fma.  Outside the range the end cells extrapolate (slope 1 /
+// 0 for gelu, 0 for gelu'), NaN and inf propagate through the final fma.  The fp32 (parity) instantiations keep the
+// exact erf path.
+#define GT_N 2048
+#define GT_LO (-8.0f)
+#define GT_INV_H (GT_N / 16.0f)
+__device__ float2 g_gelu_tab[2][GT_N];  // [0] gelu, [1] gelu'
+__global__ void gelu_tab_init_kernel() {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= GT_N) return;
+  const double h = 16.0 / GT_N, x0 = -8.0 + i * h, x1 = x0 + h;
+  auto f = [](double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752440)); };
+  auto d = [](double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)) + x * 0.39894228040143267794 * exp(-0.5 * x * x); };
+  const double s0 = (f(x1) - f(x0)) / h, s1 = (d(x1) - d(x0)) / h;
+  g_gelu_tab[0][i] = make_float2((float)s0, (float)(f(x0) - s0 * x0));
+  g_gelu_tab[1][i] = make_float2((float)s1, (float)(d(x0) - s1 * x0));
+}
+static int gelu_tab_ensure(hipStream_t st) {
+  static bool done = false;  // one process per GPU: the table lives in this device's copy of the module
+  if (!done) {
+    WL_LAUNCH(gelu_tab_init_kernel, dim3(GT_N / 256), dim3(256), 0, st);
+    done = true;
+  }
+  return WL_OK;
+}
+// copy one table (16 KiB) into LDS; the caller synchronises
+__device__ __forceinline__ void gelu_tab_to_lds(int which, float2* tab) {
+  const float4* src = reinterpret_cast<const float4*>(g_gelu_tab[which]);
+  float4* dst = reinterpret_cast<float4*>(tab);
+  for (int i = threadIdx.x; i < GT_N / 2; i += blockDim.x) dst[i] = src[i];
+}
+__device__ __forceinline__ float tab_eval(const float2* tab, float x) {
+  float u = fmaf(x, GT_INV_H, -GT_LO * GT_INV_H);
+  u = __builtin_amdgcn_fmed3f(u, 0.f, (float)(GT_N - 1));
+  const float2 sc = tab[(int)u];
+  return fmaf(sc.x, x, sc.y);
+}
+
 // stage the waveform samples feeding time steps [t0, t0 + nt) of batch row b into LDS (as f32)
 template <typename TW>
 __device__ __forceinline__ void stage_wave(const TW* __restrict__ wav, long T, int b, int t0, int nt, int stride,
@@ -74,49 +117,63 @@ __device__ __forceinline__ void conv_at(const float* seg, int tt, int stride, co
   }
 }
 
-// pass 1: per-(b, c) partial sums of y and y^2 over the block's time chunk -> part[(b*nchunk + chunk)][2][C]
-template <typename TW, typename TP>
-__global__ __launch_bounds__(256) void conv0_stats_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
-    float* __restrict__ part, long T, int T0, int C, int stride) {
+// pass 1: GroupNorm statistics WITHOUT evaluating the convolution.  mean_c = sum_k w[c][k] Q[k] / T0 and
+// E[y_c^2] = sum_{j,k} w[c][j] w[c][k] XX[j][k] / T0 with the waveform-only sums Q[k] = sum_t x[s t + k] and
+// XX[j][k] = sum_t x[s t + j] x[s t + k] (a 10 x 10 Gram matrix per batch row): O(110) instead of O(10 C) work per
+// frame -- the pass that used to recompute the conv for all C channels (0.19 ms at cfg2) is a few microseconds.
+// partx[(b * nchunk + chunk)][112]: Q[10], XX[10][10] of the chunk (fp32 partials over <= 512 frames).
+#define C0_NX 112
+template <typename TW>
+__global__ __launch_bounds__(256) void conv0_gram_kernel(const TW* __restrict__ wav, float* __restrict__ partx, long T,
+                                                         int T0, int stride) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* seg = sm;                                      // [(TCH-1)*stride + KW]
-  float* red = sm + ((C0_TCH - 1) * stride + C0_KW + 3) / 4 * 4;  // [4][2][512]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* seg = sm;
+  __shared__ float half[2][C0_NX];
   const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH;
   const int nt = min(C0_TCH, T0 - t0);
   stage_wave(wav, T, b, t0, nt, stride, seg);
-  float w[8][C0_KW];
-  load_w(W, lane, C, w);
   __syncthreads();
-  float s1[8], s2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  for (int tt = wave; tt < nt; tt += 4) {
-    float y[8];
-    conv_at(seg, tt, stride, w, y);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] += y[e]; s2[e] = fmaf(y[e], y[e], s2[e]); }
+  const int idx = threadIdx.x % 110, hf = threadIdx.x / 110;  // two halves of the chunk's frames, 110 sums each
+  if (hf < 2) {
+    const int ta = hf ? nt / 2 : 0, tb = hf ? nt : nt / 2;
+    float acc = 0.f;
+    if (idx < C0_KW) {
+      for (int tt = ta; tt < tb; ++tt) acc += seg[tt * stride + idx];
+    } else {
+      const int j = (idx - C0_KW) / C0_KW, k = (idx - C0_KW) % C0_KW;
+      for (int tt = ta; tt < tb; ++tt) acc = fmaf(seg[tt * stride + j], seg[tt * stride + k], acc);
+    }
+    half[hf][idx] = acc;
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { red[(wave * 2 + 0) * 512 + lane * 8 + e] = s1[e]; red[(wave * 2 + 1) * 512 + lane * 8 + e] = s2[e]; }
   __syncthreads();
-  float* out = part + ((long)b * gridDim.x + blockIdx.x) * 2 * C;
-  for (int i = threadIdx.x; i < 2 * 512; i += 256) {
-    const int which = i >> 9, c = i & 511;
-    if (c < C) out[which * C + c] = red[(0 * 2 + which) * 512 + c] + red[(1 * 2 + which) * 512 + c] +
-                                     red[(2 * 2 + which) * 512 + c] + red[(3 * 2 + which) * 512 + c];
-  }
+  if (threadIdx.x < 110) partx[((long)b * gridDim.x + blockIdx.x) * C0_NX + threadIdx.x] = half[0][threadIdx.x] + half[1][threadIdx.x];
 }
 
-// stats[b][c] = (mean, rstd) from the chunk partials (double accumulation)
-__global__ __launch_bounds__(256) void conv0_stats_finish_kernel(const float* __restrict__ part, float* __restrict__ stats,
-                                                                 int nchunk, int C, int T0, float eps) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+// stats[b][c] = (mean, rstd) from the chunk Gram partials (double); gram[b][112] = the reduced sums (backward reuses them)
+template <typename TP>
+__global__ __launch_bounds__(256) void conv0_stats_from_gram_kernel(const float* __restrict__ partx, const TP* __restrict__ W,
+    float* __restrict__ stats, int nchunk, int C, int T0, float eps) {
+  __shared__ double xs[C0_NX];
+  const int b = blockIdx.y;
+  if (threadIdx.x < 110) {
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += partx[((long)b * nchunk + k) * C0_NX + threadIdx.x];
+    xs[threadIdx.x] = s;
+  }
+  __syncthreads();
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  double wv[C0_KW];
+#pragma unroll
+  for (int j = 0; j < C0_KW; ++j) wv[j] = Elem<TP>::ld(W + (long)c * C0_KW + j);
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nchunk; ++k) {
-    const float* p = part + ((long)b * nchunk + k) * 2 * C;
-    s1 += p[c]; s2 += p[C + c];
+#pragma unroll
+  for (int j = 0; j < C0_KW; ++j) {
+    s1 += wv[j] * xs[j];
+    double r = 0.0;
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) r += wv[k] * xs[C0_KW + j * C0_KW + k];
+    s2 += wv[j] * r;
   }
   const double mean = s1 / T0;
   double var = s2 / T0 - mean * mean;
@@ -132,10 +189,13 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const TW* __restrict__
     long T, int T0, int C, int stride) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* seg = sm;
+  constexpr bool TAB = sizeof(TO) == 2;  // bf16 activations: table GELU
+  float2* tab = reinterpret_cast<float2*>(sm + ((C0_TCH - 1) * stride + C0_KW + 3) / 4 * 4);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH;
   const int nt = min(C0_TCH, T0 - t0);
   stage_wave(wav, T, b, t0, nt, stride, seg);
+  if constexpr (TAB) gelu_tab_to_lds(0, tab);
   float w[8][C0_KW];
   load_w(W, lane, C, w);
   float sc[8], sh[8];
@@ -154,7 +214,10 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const TW* __restrict__
     float y[8];
     conv_at(seg, tt, stride, w, y);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) y[e] = gelu_f(fmaf(y[e], sc[e], sh[e]));
+    for (int e = 0; e < 8; ++e) {
+      const float zz = fmaf(y[e], sc[e], sh[e]);
+      if constexpr (TAB) y[e] = tab_eval(tab, zz); else y[e] = gelu_f(zz);
+    }
     V8<TO>::st(out + ((long)b * T0 + t0 + tt) * C + lane * 8, y);
   }
 }
@@ -169,10 +232,11 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const TW* __restrict__
 //        R = sum_t xhat * x_k = rstd * ( sum_j w[c][j] * XX[b][j][k] - mean * Q[b,k] ),  XX = sum_t x_j x_k  (waveform only)
 // so the second sweep over g (and the second recomputation of conv + gelu') of a two-pass GroupNorm backward is
 // replaced by a 10 x 10 waveform Gram matrix per batch row.
-// part[(b * nchunk + chunk)][12][C]: A, Bq, P[0..9];  partx[(b * nchunk + chunk)][112]: Q[10], XX[10][10]
-#define C0_NQ (2 + C0_KW)
+// Bq needs no accumulation of its own either: sum_t dz * y = sum_k w[c][k] P[c][k], so
+//   Bq = sum_t dz * xhat = rstd * (sum_k w[c][k] P[b,c,k] - mean * A).
+// part[(b * nchunk + chunk)][11][C]: A, P[0..9];  partx[(b * nchunk + chunk)][112]: Q[10], XX[10][10]
+#define C0_NQ (1 + C0_KW)
 #define C0_LN_NQ (3 + C0_KW)  // layer_norm mode: dbeta, dgamma, dW[.][0..9], dbias (conv_bias=True; zero work otherwise)
-#define C0_NX 112
 template <typename TW, typename TP, typename TO>
 __global__ __launch_bounds__(256) void conv0_bwd_fused_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
     const TP* __restrict__ gamma, const TP* __restrict__ beta, const float* __restrict__ stats,
@@ -181,10 +245,13 @@ __global__ __launch_bounds__(256) void conv0_bwd_fused_kernel(const TW* __restri
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* seg = sm;
   float* red = sm + ((C0_TCH_BWD - 1) * stride + C0_KW + 3) / 4 * 4;  // [4 waves][512]
+  constexpr bool TAB = sizeof(TO) == 2;  // bf16 gradients: table gelu'
+  float2* tab = reinterpret_cast<float2*>(red + 4 * 512);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH_BWD;
   const int nt = min(C0_TCH_BWD, T0 - t0);
   stage_wave(wav, T, b, t0, nt, stride, seg);
+  if constexpr (TAB) gelu_tab_to_lds(1, tab);
   float w[8][C0_KW];
   load_w(W, lane, C, w);
   float mean[8], rstd[8], gm[8], bt[8];
@@ -207,10 +274,12 @@ __global__ __launch_bounds__(256) void conv0_bwd_fused_kernel(const TW* __restri
     }
     partx[((long)b * gridDim.x + blockIdx.x) * C0_NX + idx] = acc;
   }
-  float a1[8], a2[8], pw[8][C0_KW];
+  float a1[8], pw[8][C0_KW];
+  float zs[8], zb[8];  // z = y * zs + zb  (GroupNorm affine folded: one fma per output)
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    a1[e] = 0.f; a2[e] = 0.f;
+    a1[e] = 0.f;
+    zs[e] = rstd[e] * gm[e]; zb[e] = bt[e] - mean[e] * rstd[e] * gm[e];
 #pragma unroll
     for (int k = 0; k < C0_KW; ++k) pw[e][k] = 0.f;
   }
@@ -229,9 +298,11 @@ __global__ __launch_bounds__(256) void conv0_bwd_fused_kernel(const TW* __restri
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float xh = (y[e] - mean[e]) * rstd[e];
-        const float dz = gv[e] * gscale * gelu_grad_f(fmaf(xh, gm[e], bt[e]));
-        a1[e] += dz; a2[e] = fmaf(dz, xh, a2[e]);
+        const float zz = fmaf(y[e], zs[e], zb[e]);
+        float gp;
+        if constexpr (TAB) gp = tab_eval(tab, zz); else gp = gelu_grad_f(zz);
+        const float dz = gv[e] * gscale * gp;
+        a1[e] += dz;
 #pragma unroll
         for (int k = 0; k < C0_KW; ++k) pw[e][k] = fmaf(dz, xw[k], pw[e][k]);
       }
@@ -242,7 +313,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_fused_kernel(const TW* __restri
   for (int q = 0; q < C0_NQ; ++q) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[wave * 512 + lane * 8 + e] = q == 0 ? a1[e] : q == 1 ? a2[e] : pw[e][q >= 2 ? q - 2 : 0];
+    for (int e = 0; e < 8; ++e) red[wave * 512 + lane * 8 + e] = q == 0 ? a1[e] : pw[e][q >= 1 ? q - 1 : 0];
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) out[(long)q * C + c] = red[c] + red[512 + c] + red[1024 + c] + red[1536 + c];
   }
@@ -280,19 +351,23 @@ __global__ __launch_bounds__(256) void conv0_bwd_combine_kernel(const float* __r
     for (int q = 0; q < C0_NQ; ++q) acc[q] = red[0][q][col] + red[1][q][col] + red[2][q][col] + red[3][q][col];
     const double mean = stats[((long)b * C + c) * 2], rstd = stats[((long)b * C + c) * 2 + 1];
     const double gm = Elem<TP>::ld(gamma + c);
-    const double am = acc[0] / T0, bm = acc[1] / T0;
     double wv[C0_KW];
 #pragma unroll
     for (int j = 0; j < C0_KW; ++j) wv[j] = Elem<TP>::ld(W + (long)c * C0_KW + j);
+    double dzy = 0.0;  // sum_t dz * y = sum_k w[k] P[k]
+#pragma unroll
+    for (int j = 0; j < C0_KW; ++j) dzy += wv[j] * acc[1 + j];
+    const double bq = rstd * (dzy - mean * acc[0]);
+    const double am = acc[0] / T0, bm = bq / T0;
     ab[((long)b * C + c) * 2] = (float)acc[0];
-    ab[((long)b * C + c) * 2 + 1] = (float)acc[1];
+    ab[((long)b * C + c) * 2 + 1] = (float)bq;
 #pragma unroll
     for (int k = 0; k < C0_KW; ++k) {
       double r = -mean * xs[k];
 #pragma unroll
       for (int j = 0; j < C0_KW; ++j) r += wv[j] * xs[C0_KW + j * C0_KW + k];
       r *= rstd;
-      dwb[((long)b * C + c) * C0_KW + k] = (float)(rstd * gm * (acc[2 + k] - am * xs[k] - bm * r));
+      dwb[((long)b * C + c) * C0_KW + k] = (float)(rstd * gm * (acc[1 + k] - am * xs[k] - bm * r));
     }
   }
 }
@@ -479,7 +554,8 @@ extern "C" {
 uint64_t wavlm_conv0_gn_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride) {
   const long T0 = (T - C0_KW) / stride + 1;
   const uint64_t nchunk = (uint64_t)((T0 + C0_TCH - 1) / C0_TCH);
-  return (uint64_t)B * nchunk * 2 * C * sizeof(float);
+  (void)C;
+  return (uint64_t)B * nchunk * C0_NX * sizeof(float);
 }
 
 // forward: y0[B, T0, C] and stats[B, C, 2] (mean, rstd) which backward needs
@@ -494,28 +570,29 @@ int wavlm_conv0_gn_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
   const int T0 = (int)((T - kw) / stride + 1);
   const int nchunk = (T0 + C0_TCH - 1) / C0_TCH;
   const dim3 grid((unsigned)nchunk, (unsigned)B);
-  const size_t sm_stats = (seg_floats(C0_TCH, stride) + 4 * 2 * 512) * sizeof(float);
-  const size_t sm_apply = seg_floats(C0_TCH, stride) * sizeof(float);
-  float* part = (float*)workspace;
-#define ST(TW, TP) WL_LAUNCH((conv0_stats_kernel<TW, TP>), grid, dim3(256), sm_stats, st, (const TW*)wav, \
-    (const TP*)W, part, (long)T, T0, (int)C, (int)stride)
+  const size_t sm_gram = seg_floats(C0_TCH, stride) * sizeof(float);
+  const size_t sm_apply = seg_floats(C0_TCH, stride) * sizeof(float) + (out_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
+  float* partx = (float*)workspace;
+  if (out_dtype == WL_BF16) gelu_tab_ensure(st);
+  if (wav_dtype == WL_F32)
+    WL_LAUNCH((conv0_gram_kernel<float>), grid, dim3(256), sm_gram, st, (const float*)wav, partx, (long)T, T0, (int)stride);
+  else
+    WL_LAUNCH((conv0_gram_kernel<bf16_t>), grid, dim3(256), sm_gram, st, (const bf16_t*)wav, partx, (long)T, T0, (int)stride);
+  int rc = wl_check_launch();
+  if (rc != WL_OK) return rc;
+  const dim3 gs((unsigned)((C + 255) / 256), (unsigned)B);
+  if (param_dtype == WL_F32)
+    WL_LAUNCH((conv0_stats_from_gram_kernel<float>), gs, dim3(256), 0, st, partx, (const float*)W, stats, nchunk, (int)C, T0, eps);
+  else
+    WL_LAUNCH((conv0_stats_from_gram_kernel<bf16_t>), gs, dim3(256), 0, st, partx, (const bf16_t*)W, stats, nchunk, (int)C, T0, eps);
 #define AP(TW, TP, TO) WL_LAUNCH((conv0_apply_kernel<TW, TP, TO>), grid, dim3(256), sm_apply, st, (const TW*)wav, \
     (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (TO*)out, (long)T, T0, (int)C, (int)stride)
   const int key = wav_dtype * 100 + param_dtype * 10 + out_dtype;
-  if (key == 0) ST(float, float);
-  else if (key == 111) ST(bf16_t, bf16_t);
-  else if (key == 11) ST(float, bf16_t);
-  else if (key == 1) ST(float, float);
-  else return WL_EINVAL;
-  int rc = wl_check_launch();
-  if (rc != WL_OK) return rc;
-  WL_LAUNCH(conv0_stats_finish_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, st, part,
-                     stats, nchunk, (int)C, T0, eps);
   if (key == 0) AP(float, float, float);
   else if (key == 111) AP(bf16_t, bf16_t, bf16_t);
   else if (key == 11) AP(float, bf16_t, bf16_t);
-  else AP(float, float, bf16_t);
-#undef ST
+  else if (key == 1) AP(float, float, bf16_t);
+  else return WL_EINVAL;
 #undef AP
   return wl_check_launch();
 }
@@ -543,7 +620,8 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   float* partx = part + (long)B * nchunk * C0_NQ * C;
   float* dwb = partx + (long)B * nchunk * C0_NX;
   float* ab = dwb + (long)B * C * C0_KW;
-  const size_t sm1 = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float);
+  const size_t sm1 = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float) + (g_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
+  if (g_dtype == WL_BF16) gelu_tab_ensure(st);
 #define B1(TW, TP, TO) WL_LAUNCH((conv0_bwd_fused_kernel<TW, TP, TO>), grid, dim3(256), sm1, st, (const TW*)wav, \
     (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (const TO*)g, part, partx, (long)T, T0, (int)C, (int)stride, gscale)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
