@@ -40,6 +40,18 @@ typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
 __device__ __forceinline__ unsigned fa_row_word(unsigned s0, unsigned grow) { return hash32(grow ^ s0); }
 __device__ __forceinline__ unsigned fa_col_word(unsigned s1, unsigned jpair) { return hash32((jpair ^ s1) + 0x68E31DA4u); }
 __device__ __forceinline__ unsigned fa_mix(unsigned x) { return drop_mix(x); }
+// Keep decisions of the fused kernels: the two 16-bit halves of a word as SIGNED numbers >= ths = th - 32768 (the same
+// probability as the unsigned form).  Signed, because the forward applies the mask to the PACKED bf16 pair with three
+// packed-integer instructions and no compare / VCC / select:  d = sat(ths - 1 - half) is negative iff the half is kept,
+// d >> 15 (arithmetic) is the 0xffff / 0 keep mask of each half, one v_and_b32 applies both.
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned fa_keepmask2(unsigned w, unsigned k2) {
+  s16x2_t d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, k2), __builtin_bit_cast(s16x2_t, w));
+  d = d >> (short)15;
+  return __builtin_bit_cast(unsigned, d);
+}
+__device__ __forceinline__ bool fa_keep_lo(unsigned w, int ths) { return (int)(short)(w & 0xffffu) >= ths; }
+__device__ __forceinline__ bool fa_keep_hi(unsigned w, int ths) { return ((int)w >> 16) >= ths; }
 #define FA_LOG2E 1.4426950408889634f
 #define FA_LN2 0.6931471805599453f
 
@@ -94,6 +106,7 @@ struct FaP {
   const float* gate; const float* tab; const unsigned char* kpm;
   const bf16_t* dO; bf16_t* dqkv; float* delta; float* dgate; float* dtab_part;
   int B, H, T; float scale; float sc2; unsigned th; float sc, log2sc, inv_sc; unsigned s0, s1;  // th: 16-bit keep threshold (0 = no dropout)
+  int ths; unsigned k2;  // signed threshold th - 32768; (ths - 1) in both halves
   int Ltab, Tkb;  // LDS extents: rel table (zero padded) and key bias
 };
 
@@ -196,16 +209,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        float p0 = __builtin_amdgcn_exp2f(s[f][r] - msub);
-        float p1 = __builtin_amdgcn_exp2f(s[f][r + 1] - msub);
+        const float p0 = __builtin_amdgcn_exp2f(s[f][r] - msub);
+        const float p1 = __builtin_amdgcn_exp2f(s[f][r + 1] - msub);
         rs += p0 + p1;
+        unsigned pk = pack_bf16(p0, p1);
         if constexpr (DROP) {
           const int jp = (j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi) >> 1;
-          const unsigned w = fa_mix(roww + colw[jp]);
-          p0 = (w & 0xffffu) >= p.th ? p0 : 0.f;
-          p1 = (w >> 16) >= p.th ? p1 : 0.f;
+          pk &= fa_keepmask2(fa_mix(roww + colw[jp]), p.k2);
         }
-        pf[f][r >> 3].u[(r & 7) >> 1] = pack_bf16(p0, p1);
+        pf[f][r >> 3].u[(r & 7) >> 1] = pk;
       }
     rs += __shfl_xor(rs, 32, 64);
     l = l * alpha + rs;
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
             if constexpr (EDGE) x += kb[j];
             const float pe = __builtin_amdgcn_exp2f(x - lse2);  // 0 for masked keys (-inf) and rows past T (lse = +inf)
             float dpe = dp[rr];
-            if constexpr (DROP) dpe = (e ? (w >> 16) : (w & 0xffffu)) >= p.th ? dpe : 0.f;
+            if constexpr (DROP) dpe = (e ? fa_keep_hi(w, p.ths) : fa_keep_lo(w, p.ths)) ? dpe : 0.f;
             const float ds = pe * (dpe - dls);
             dv[e] = ds;
             dg = fmaf(ds, tv, dg);
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
           float pd = pe;
           if constexpr (DROP) {
             const unsigned w = fa_mix(roww[e] + cw);
-            const bool kp = ((w >> csh) & 0xffffu) >= p.th;
+            const bool kp = (int)(short)((w >> csh) & 0xffffu) >= p.ths;
             pd = kp ? pe : 0.f;
             dpe = kp ? dpe : 0.f;
           }
@@ -630,6 +642,8 @@ static FaP fa_params(int B, int H, int T, float scale, float p_drop, uint64_t se
   if (p_drop > 0.f && p.th == 0u) p.th = 1u;
   p.sc = p.th ? (float)(1.0 / (1.0 - (double)p.th / 65536.0)) : 1.f;  // unbiased for the quantised probability
   p.log2sc = log2f(p.sc); p.inv_sc = 1.f / p.sc;
+  p.ths = (int)p.th - 32768;
+  p.k2 = (unsigned)((p.ths - 1) & 0xffff) * 0x10001u;
   p.s0 = (unsigned)seed; p.s1 = (unsigned)(seed >> 32);
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
   p.Tkb = nkv * FA_BKV;
