@@ -165,7 +165,8 @@ uint64_t wavlm_gate_bwd_workspace_bytes(int32_t H, int32_t hd);
 int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void* grep_a, const float* ga,
                    const float* gb, void* dx, void* dW, void* dbias, void* dgrep_a, int32_t B, int32_t T, int32_t H,
                    int32_t hd, int32_t dtype, int32_t param_dtype, int32_t accumulate_params, void* workspace,
-                   uint64_t ws_bytes, void* stream);  /* accumulate_params: dW / dbias / dgrep_a (+)= (gradient sinks) */
+                   uint64_t ws_bytes, void* stream);  /* accumulate_params bit 0: dW / dbias / dgrep_a (+)= (gradient sinks);
+                                           bit 1: dx (+)= (dx already holds the gradient another consumer of x produced) */
 /* P = dropout(softmax_j(S + gate_i*rel[h, j-i] + keypad)); lse saved.  S: [B*H, T, ldS], P: [B*H, T, ldP]; T <= 1024 */
 int wavlm_attn_softmax_fwd(const void* S, void* P, float* lse, const float* gate, const float* tab, const uint8_t* kpm,
                            int32_t B, int32_t H, int32_t T, int64_t ldS, int64_t ldP, int32_t s_dtype, int32_t p_dtype,

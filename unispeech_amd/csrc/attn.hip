@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void gate_fwd64_kernel(const T* __restrict__ x
 template <typename T, typename TP>
 __global__ __launch_bounds__(256) void gate_bwd64_kernel(const float* __restrict__ dgate, const T* __restrict__ x,
     const TP* __restrict__ W, const TP* __restrict__ grep_a, const float* __restrict__ ga_i,
-    const float* __restrict__ gb_i, T* __restrict__ dx, float* __restrict__ part, int B, int Tn, int H) {
+    const float* __restrict__ gb_i, T* __restrict__ dx, float* __restrict__ part, int B, int Tn, int H, int accdx) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [128 + 2 + H], zeroed, accumulated with LDS atomics once per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long nbt = (long)B * Tn;
@@ -404,6 +404,12 @@ __global__ __launch_bounds__(256) void gate_bwd64_kernel(const float* __restrict
           dwa[e] = fmaf(dsa[i], xv[i][e], dwa[e]);
           dwb[e] = fmaf(dsb[i], xv[i][e], dwb[e]);
         }
+        if (accdx) {  // dx already holds another consumer's gradient of the same tensor: add instead of overwrite
+          float p8[8];
+          gate_ld8(dx + row * D + (q % CPR) * 8, p8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] += p8[e];
+        }
         gate_st8(dx + row * D + (q % CPR) * 8, o8);
       }
     }
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(256) void gate_bwd64_kernel(const float* __restrict
 template <typename T, typename TP>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dgate, const T* __restrict__ x,
     const TP* __restrict__ W, const TP* __restrict__ grep_a, const float* __restrict__ ga_i,
-    const float* __restrict__ gb_i, T* __restrict__ dx, float* __restrict__ part, int B, int Tn, int H, int hd) {
+    const float* __restrict__ gb_i, T* __restrict__ dx, float* __restrict__ part, int B, int Tn, int H, int hd, int accdx) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][2*hd + 2 + H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long nbt = (long)B * Tn;
@@ -466,7 +472,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
         const int c = lane + 64 * q;
         if (c < hd) {
           const float xv = Elem<T>::ld(x + bt * D + h * hd + c);
-          Elem<T>::st(dx + bt * D + h * hd + c, dsa * wa[q] + dsb * wb[q]);
+          const float prev = accdx ? Elem<T>::ld(dx + bt * D + h * hd + c) : 0.f;
+          Elem<T>::st(dx + bt * D + h * hd + c, prev + dsa * wa[q] + dsb * wb[q]);
           dwa[q] = fmaf(dsa, xv, dwa[q]);
           dwb[q] = fmaf(dsb, xv, dwb[q]);
         }
@@ -628,9 +635,9 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
   const size_t smem = 4 * (2 * (size_t)hd + 2 + H) * sizeof(float);
   const bool fast = hd == 64 && H <= 16 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)dx) & 15) == 0;
 #define GB(TT, TP) do { if (fast) WL_LAUNCH((gate_bwd64_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), smem, st, dgate, \
-    (const TT*)x, (const TP*)W, (const TP*)grep_a, ga, gb, (TT*)dx, (float*)workspace, (int)B, (int)T, (int)H); \
+    (const TT*)x, (const TP*)W, (const TP*)grep_a, ga, gb, (TT*)dx, (float*)workspace, (int)B, (int)T, (int)H, (int)(accumulate_params & 2)); \
   else WL_LAUNCH((gate_bwd_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), smem, st, dgate, \
-    (const TT*)x, (const TP*)W, (const TP*)grep_a, ga, gb, (TT*)dx, (float*)workspace, (int)B, (int)T, (int)H, (int)hd); } while (0)
+    (const TT*)x, (const TP*)W, (const TP*)grep_a, ga, gb, (TT*)dx, (float*)workspace, (int)B, (int)T, (int)H, (int)hd, (int)(accumulate_params & 2)); } while (0)
   if (dtype == WL_F32 && param_dtype == WL_F32) GB(float, float);
   else if (dtype == WL_BF16 && param_dtype == WL_BF16) GB(bf16_t, bf16_t);
   else if (dtype == WL_BF16 && param_dtype == WL_F32) GB(bf16_t, float);
@@ -639,7 +646,7 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   WL_LAUNCH(gate_bwd_finish_kernel, dim3((unsigned)((2 * hd + 2 + H + 15) / 16)), dim3(1024), 0, st, (const float*)workspace,
-                     (int)grid, (int)H, (int)hd, dW, dbias, dgrep_a, (int)param_dtype, (int)accumulate_params);
+                     (int)grid, (int)H, (int)hd, dW, dbias, dgrep_a, (int)param_dtype, (int)(accumulate_params & 1));
   return wl_check_launch();
 }
 

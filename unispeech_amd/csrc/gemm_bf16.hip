@@ -285,6 +285,28 @@ static double tile_efficiency(const wavlm_gemm_desc* d, int nbatch, int BM, int 
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// GELU / GELU' chord table of the fast GELU epilogue (gemm_common.hpp gelu_both_tab); filled once per process
+__device__ float4 g_gelu_tab4[GT4_N];
+__global__ void gelu_tab4_init_kernel() {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= GT4_N) return;
+  const double h = 16.0 / GT4_N, x0 = -8.0 + i * h, x1 = x0 + h;
+  auto f = [](double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752440)); };
+  auto d = [](double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)) + x * 0.39894228040143267794 * exp(-0.5 * x * x); };
+  const double s0 = (f(x1) - f(x0)) / h, s1 = (d(x1) - d(x0)) / h;
+  g_gelu_tab4[i] = make_float4((float)s0, (float)(f(x0) - s0 * x0), (float)s1, (float)(d(x0) - s1 * x0));
+}
+static const float4* gelu_tab4_get(hipStream_t st) {
+  static const float4* ptr = nullptr;
+  if (!ptr) {
+    void* a = nullptr;
+    if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_gelu_tab4)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(gelu_tab4_init_kernel, dim3(GT4_N / 256), dim3(256), 0, st);
+    ptr = (const float4*)a;
+  }
+  return ptr;
+}
+
 // ---- optional per-launch timing (bench.py roofline leg): HIP events recorded on the launch stream around every
 // wavlm_gemm call while enabled.  Single-threaded use only (one stream, one host thread).
 #define PROF_MAX 16384
@@ -382,8 +404,12 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   if ((g_gemm_variant == 4 && gemm_pp3_ok(d)) ||
       (g_gemm_variant == 0 && d->N >= 384 && gemm_pp3_ok(d) && gemm_pp_ok(d) &&
        tile_efficiency(d, nbatch, 192, 384) > 1.06 * tile_efficiency(d, nbatch, 256, 256)))  // measured at 24 k rows: N = 768 (+25 %), 2304 (+10 % at K = 768), 3072 (+6 %) go to 192 x 384; N = 2048 and the conv stack (N = 512) stay
-    rc = gemm_pp3_launch(p, nbatch, d->transA != 0, d->transB != 0, gemm_epilogue_class(d, vec), st);
-  else if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) rc = gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, gemm_epilogue_class(d, vec), st);
+    { const int ec = gemm_epilogue_class(d, vec); if (ec == 3) p.gtab = gelu_tab4_get(st);
+      rc = gemm_pp3_launch(p, nbatch, d->transA != 0, d->transB != 0, ec, st); }
+  else if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) {
+    const int ec = gemm_epilogue_class(d, vec); if (ec == 3) p.gtab = gelu_tab4_get(st);
+    rc = gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, ec, st);
+  }
   else if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, vec, st);
   else if (!d->transA && d->transB) rc = launch_t<false, true>(p, nbatch, vec, st);
   else if (d->transA && !d->transB) rc = launch_t<true, false>(p, nbatch, vec, st);

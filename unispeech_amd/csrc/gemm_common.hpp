@@ -22,6 +22,7 @@ struct GemmP {
   int vtotal, nbatch, skew;  // persistent launch (ping-pong kernels): virtual block count, batch count, start skew
   int patch_m;               // split-K work order: tile-row patch height (0: tiles only, split outermost)
   int ngrp;                  // > 0: grouped launch, the problems are grp[0 .. ngrp) (A/B/M/N/lda/ldb/ws above are unused)
+  const float4* gtab;        // GELU / GELU' chord table in global memory (fast epilogue 3 copies it to LDS), or null
   GemmGrp grp[4];
 };
 
@@ -35,6 +36,7 @@ static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
   p.alpha = d->alpha; p.epi = d->epi; p.c_dtype = d->c_dtype;
   p.bias = d->bias; p.bias_dtype = d->bias_dtype; p.sBias_o = d->sBias_o; p.sBias_i = d->sBias_i;
   p.aux = d->aux; p.aux_dtype = d->aux_dtype; p.ld_aux = d->ld_aux; p.sAux_o = d->sAux_o; p.sAux_i = d->sAux_i;
+  p.gtab = nullptr;
   p.res = d->res; p.res_dtype = d->res_dtype; p.ld_res = d->ld_res; p.sRes_o = d->sRes_o; p.sRes_i = d->sRes_i;
   p.accumulate = d->accumulate;
   p.split_k = d->split_k < 1 ? 1 : d->split_k;
@@ -160,13 +162,31 @@ __device__ __forceinline__ void gemm_store8(const GemmP& p, int zo, int zi, int 
   st8_dt(p.C, ci, p.c_dtype, v);
 }
 
-// Specialised 8-wide store for the cases that carry the step (bf16 C, bf16 bias / aux, no residual, no accumulate, no
+// Specialised 8-wide store for the cases that carry the step (bf16 C, bf16 bias / aux / residual, no accumulate, no
 // split-K): KIND 0 = alpha * acc (+ bias); 3 = + GELU with GELU'(pre-activation) stored to aux; 4 = * aux.
 // The generic gemm_store8 decides all of that per 8-element chunk at run time; with one block per CU the epilogue is
 // exposed, and the probe in tools/gemm_epi_probe.py showed it bound by the CU's own instruction stream (7.5 us per tile
 // even with 8 CUs active), not by the HBM write burst.
+// GELU and GELU' together from one 16-byte LDS read: cell i of the table holds the chords (slope, intercept) of gelu
+// and of gelu' over [x_i, x_i + h), h = 16 / GT4_N, x_0 = -8 (see conv0.hip for the error bound: 8e-6 absolute at 2048
+// cells; the outputs here are bf16).  The erf evaluation (v_rcp, v_exp, ~12 more VALU) on every element of fc1's and
+// the conv stack's outputs ran in the EXPOSED epilogue of one-block-per-CU GEMMs: ~45 us of a 199 us fc1 launch.
+#define GT4_N 2048
+__device__ __forceinline__ float gelu_both_tab(const float4* tab, float x, float& grad) {
+  float u = fmaf(x, GT4_N / 16.0f, 8.0f * (GT4_N / 16.0f));
+  u = __builtin_amdgcn_fmed3f(u, 0.f, (float)(GT4_N - 1));
+  const float4 t = tab[(int)u];
+  grad = fmaf(t.z, x, t.w);
+  return fmaf(t.x, x, t.y);
+}
+// every thread of the block: global table -> LDS (32 KiB); the caller synchronises before and after
+__device__ __forceinline__ void gelu_tab_stage(const float4* g, float4* lds) {
+  for (int i = threadIdx.x; i < GT4_N; i += blockDim.x) lds[i] = g[i];
+}
+
 template <int KIND>
-__device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi, int m, int n, const float (&acc)[8]) {
+__device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi, int m, int n, const float (&acc)[8],
+                                                 const float4* tab = nullptr) {
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = p.alpha * acc[e];
@@ -178,8 +198,13 @@ __device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi,
   }
   if constexpr (KIND == 3) {
     float gr[8];
+    if (tab) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_both_f(v[e], gr[e]);
+      for (int e = 0; e < 8; ++e) v[e] = gelu_both_tab(tab, v[e], gr[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_both_f(v[e], gr[e]);
+    }
     if (p.aux) st8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, WL_BF16, gr);
   } else if constexpr (KIND == 4) {
     float u[8];
@@ -187,13 +212,20 @@ __device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi,
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= u[e];
   }
+  if (p.res) {  // bf16 residual (uniform branch): the gradient another consumer of the same tensor produced
+    float r[8];
+    ld8_dt(p.res, (long)zo * p.sRes_o + (long)zi * p.sRes_i + (long)m * p.ld_res + n, WL_BF16, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += r[e];
+  }
   st8_dt(p.C, (long)zo * p.sC_o + (long)zi * p.sC_i + (long)m * p.ldc + n, WL_BF16, v);
 }
 
 // epilogue class of a launch: 0 scalar stores, 1 generic row vectors, 2 / 3 / 4 specialised for epi 0 / 3 / 4
 static inline int gemm_epilogue_class(const wavlm_gemm_desc* d, bool vec) {
   if (!vec) return 0;
-  const bool fast = d->split_k <= 1 && !d->res && !d->accumulate && d->c_dtype == WL_BF16 && d->N % 8 == 0 &&
+  const bool fast = d->split_k <= 1 && (!d->res || (d->res_dtype == WL_BF16 && d->ld_res % 8 == 0)) && !d->accumulate &&
+                    d->c_dtype == WL_BF16 && d->N % 8 == 0 &&
                     (!d->bias || d->bias_dtype == WL_BF16) &&
                     (d->epi == 0 || (d->epi == 3 && (!d->aux || d->aux_dtype == WL_BF16)) ||
                      (d->epi == 4 && d->aux && d->aux_dtype == WL_BF16));

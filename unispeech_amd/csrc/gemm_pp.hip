@@ -450,6 +450,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
   } else {
     constexpr int EP_LD = 64 + 4;
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    // GELU epilogue: the chord table sits behind the staging slices (8 x 8704 B = 68 KiB) at 96 KiB; the K loop is over
+    // (barrier above), the next tile's DMA only starts after the barrier that ends this epilogue
+    const float4* tab = nullptr;
+    if constexpr (EP == 3) {
+      if (P.gtab) {
+        float4* tl = reinterpret_cast<float4*>(smem + 98304);
+        gelu_tab_stage(P.gtab, tl);
+        __syncthreads();
+        tab = tl;
+      }
+    }
     auto stage_block = [&](const f32x16_t (&a)[2]) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
           const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           if constexpr (EP == 1) gemm_store8(P, zo, zi, z, split, mm, nn, v);
-          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(P, zo, zi, mm, nn, v);
+          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(P, zo, zi, mm, nn, v, tab);
         }
       }
     }

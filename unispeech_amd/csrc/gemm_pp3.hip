@@ -380,6 +380,16 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
   } else {
     constexpr int EP_LD = 96 + 4;
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    // GELU epilogue: chord table behind the staging slices (8 x 12800 B = 100 KiB) at 104 KiB of the 144 KiB
+    const float4* tab = nullptr;
+    if constexpr (EP == 3) {
+      if (p.gtab) {
+        float4* tl = reinterpret_cast<float4*>(smem + 106496);
+        gelu_tab_stage(p.gtab, tl);
+        __syncthreads();
+        tab = tl;
+      }
+    }
     auto stage_block = [&](const f32x16_t (&a)[3]) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
           const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           if constexpr (EP == 1) gemm_store8(p, zo, zi, z, split, mm, nn, v);
-          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(p, zo, zi, mm, nn, v);
+          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(p, zo, zi, mm, nn, v, tab);
         }
       }
     }

@@ -26,6 +26,9 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
+# chained consumers (LinearFn / GateFn / FFNFn pass_x): removes the torch add kernels autograd would launch for tensors
+# with several consumers (3 per post-LN encoder layer).  WAVLM_CHAIN_CONSUMERS=0 restores one Function per consumer.
+CHAIN_CONSUMERS = os.environ.get("WAVLM_CHAIN_CONSUMERS", "1") == "1"
 SINK_LISTENERS = []
 # Grouped weight-gradient launches (WgradGroup) are OFF by default: measured on one box, same build, 12 grouped launches
 # of 425 us against 48 single ones of ~100 us each (401 us per layer) -- the K loop of the K-strided form runs at
@@ -216,7 +219,11 @@ class LinearFn(torch.autograd.Function):
     sink_w / sink_b: explicit gradient sinks for W / b given as plain views (packed q|k|v projections)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, sink_w=None, sink_b=None, bias_tok=None, wgroup=None):
+    def forward(ctx, x, W, b, sink_w=None, sink_b=None, bias_tok=None, wgroup=None, pass_x=False):
+        """pass_x=True: also returns x itself (a view).  A tensor with several consumers costs one torch add kernel per
+        extra consumer in backward (autograd sums their gradients).  When the consumers are CHAINED instead -- each takes
+        x, hands it on, and the last one is the only real reader of the alias -- every consumer receives the gradient
+        accumulated so far and folds it into its own kernel: here as the residual operand of the dX GEMM's epilogue."""
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
@@ -230,20 +237,29 @@ class LinearFn(torch.autograd.Function):
             if b is not None:
                 _sink_use(b, sink_b)
         ctx.xshape = x.shape
-        return y.view(*x.shape[:-1], W.shape[0])
+        ctx.pass_x = pass_x
+        y = y.view(*x.shape[:-1], W.shape[0])
+        return (y, x.view_as(x)) if pass_x else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_pass=None):
         x2d, W, b = ctx.saved_tensors
+        dx = None
+        if dy is None:  # only the alias was used downstream
+            return dx_pass, None, None, None, None, None, None, None
         dy2d = dy.reshape(-1, dy.shape[-1])
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
-        dx = None
         if ctx.needs_input_grad[0]:
-            dx = _linear_bwd_x(dy2d, W).view(ctx.xshape)
+            res = None
+            if dx_pass is not None:
+                res = dx_pass.reshape(-1, dx_pass.shape[-1])
+                if not res.is_contiguous():
+                    res = res.contiguous()
+            dx = _linear_bwd_x(dy2d, W, res=res).view(ctx.xshape)
         dW, db = _param_grads(dy2d, x2d, W, b, b is not None, ctx.needs_input_grad[1], ctx.needs_input_grad[2],
                               ctx.sinks[0], ctx.sinks[1], ctx.bias_tok, ctx.wgroup)
-        return dx, dW, db, None, None, None, None
+        return dx, dW, db, None, None, None, None, None
 
 
 class FFNFn(torch.autograd.Function):
@@ -252,7 +268,7 @@ class FFNFn(torch.autograd.Function):
     input-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, p_act, seed, b2_tok=None, wgroup=None):
+    def forward(ctx, x, W1, b1, W2, b2, p_act, seed, b2_tok=None, wgroup=None, pass_x=False):
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
@@ -272,11 +288,14 @@ class FFNFn(torch.autograd.Function):
         ctx.p_act, ctx.seed, ctx.xshape = p_act, seed, x.shape
         ctx.b2_tok = b2_tok
         ctx.wgroup = wgroup
-        return y.view(*x.shape[:-1], W2.shape[0])
+        y = y.view(*x.shape[:-1], W2.shape[0])
+        return (y, x.view_as(x)) if pass_x else y   # pass_x: see LinearFn.forward
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_pass=None):
         x2d, W1, W2, u, hd, b1, b2 = ctx.saved_tensors
+        if dy is None:
+            return (dx_pass,) + (None,) * 9
         dy2d = dy.reshape(-1, dy.shape[-1])
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
@@ -290,8 +309,15 @@ class FFNFn(torch.autograd.Function):
         else:
             du = _linear_bwd_x(dy2d, W2, epi=4, aux=u)
         dW1, db1 = _param_grads(du, x2d, W1, b1, b1 is not None, True, True, wgroup=ctx.wgroup)
-        dx = _linear_bwd_x(du, W1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        return dx, dW1, db1, dW2, db2, None, None, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            res = None
+            if dx_pass is not None:
+                res = dx_pass.reshape(-1, dx_pass.shape[-1])
+                if not res.is_contiguous():
+                    res = res.contiguous()
+            dx = _linear_bwd_x(du, W1, res=res).view(ctx.xshape)
+        return dx, dW1, db1, dW2, db2, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------- LayerNorm
@@ -579,7 +605,7 @@ class GateFn(torch.autograd.Function):
     """gate[b,h,t] from the un-projected layer input (gru_rel_pos, WavLM/modules.py:523-533)"""
 
     @staticmethod
-    def forward(ctx, x, W, bias, grep_a, H):
+    def forward(ctx, x, W, bias, grep_a, H, pass_x=False):
         xc = x.contiguous()
         a = grep_a.contiguous().view(-1)
         gate, ga, gb = ops.gate_fwd(xc, W.contiguous(), bias.contiguous(), a, H)
@@ -588,21 +614,33 @@ class GateFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             for t in (W, bias, grep_a):
                 _sink_use(t)
-        return gate
+        return (gate, x.view_as(x)) if pass_x else gate   # pass_x: see LinearFn.forward
 
     @staticmethod
-    def backward(ctx, dgate):
+    def backward(ctx, dgate, dx_pass=None):
         xc, W, bias, grep_a, ga, gb = ctx.saved_tensors
+        if dgate is None:
+            return dx_pass, None, None, None, None, None
         sinks = (_sink(W), _sink(bias), _sink(grep_a))
         if any(t is None for t in sinks) or not (W.is_contiguous() and grep_a.is_contiguous()):
             sinks = None
+        # chained consumer: the gate's gradient of x is ADDED into the gradient the later consumers already produced (in
+        # place, inside the gate kernel).  The buffer may alias the LayerNorm's residual-branch gradient (dr is dx when
+        # there is no residual dropout): every reader of that gradient (out_proj's backward -> attention backward ->
+        # dgate) has been enqueued before this kernel by construction, so the in-place update is ordered after them.
+        acc = None
+        if dx_pass is not None and dx_pass.is_contiguous() and dx_pass.dtype == xc.dtype and ctx.needs_input_grad[0]:
+            acc = dx_pass
         dx, dW, dbias, da = ops.gate_bwd(dgate.contiguous(), xc, W.contiguous(), bias, grep_a.contiguous().view(-1),
-                                         ga, gb, ctx.H, sinks=None if sinks is None else tuple(t.view(-1) for t in sinks))
+                                         ga, gb, ctx.H, sinks=None if sinks is None else tuple(t.view(-1) for t in sinks),
+                                         dx_accumulate=acc)
+        if acc is None and dx_pass is not None:
+            dx = dx + dx_pass
         if sinks is not None:
             for t in sinks:
                 _sink_written(t)
-            return dx, None, None, None, None
-        return dx, dW, dbias, da.view_as(grep_a), None
+            return dx, None, None, None, None, None
+        return dx, dW, dbias, da.view_as(grep_a), None, None
 
 
 class AttnCoreFn(torch.autograd.Function):

@@ -376,12 +376,14 @@ def gate_fwd(x, W, bias, grep_a, H):
     return gate, ga, gb
 
 
-def gate_bwd(dgate, x, W, bias, grep_a, ga, gb, H, sinks=None):
-    """returns (dx, dW, dbias, da); sinks = (dW, dbias, da) gradient-sink views -> accumulated in place, returned as None"""
+def gate_bwd(dgate, x, W, bias, grep_a, ga, gb, H, sinks=None, dx_accumulate=None):
+    """returns (dx, dW, dbias, da); sinks = (dW, dbias, da) gradient-sink views -> accumulated in place, returned as None;
+    dx_accumulate: a [B, T, D] tensor already holding another consumer's gradient of x -> the gate's is added into it"""
     dev = _dev(x)
     B, T, D = x.shape
     hd = D // H
-    dx = torch.empty_like(x)
+    dx = dx_accumulate if dx_accumulate is not None else torch.empty_like(x)
+    _contig(dx)
     if sinks is not None:
         dW, dbias, da = sinks
     else:
@@ -392,7 +394,8 @@ def gate_bwd(dgate, x, W, bias, grep_a, ga, gb, H, sinks=None):
     need = L.wavlm_gate_bwd_workspace_bytes(H, hd)
     ws = workspace(dev, need)
     check(L.wavlm_gate_bwd(ptr(dgate), ptr(x), ptr(W), ptr(grep_a), ptr(ga), ptr(gb), ptr(dx), ptr(dW), ptr(dbias),
-                           ptr(da), B, T, H, hd, dt(x), dt(W), int(sinks is not None), ptr(ws), need, stream()),
+                           ptr(da), B, T, H, hd, dt(x), dt(W), int(sinks is not None) | (2 if dx_accumulate is not None else 0),
+                           ptr(ws), need, stream()),
           "wavlm_gate_bwd")
     if sinks is not None:
         return dx, None, None, None

@@ -225,31 +225,38 @@ class MultiheadAttention(nn.Module):
             cache[key] = bucket
         return F.RelPosTableFn.apply(self.relative_attention_bias.weight, bucket)
 
-    def forward(self, x, key_padding_u8=None, position_table=None, out_bias_tok=None, wgroup=None):
-        """x [B, T, D] -> (attn_out [B, T, D], position_table)"""
+    def forward(self, x, key_padding_u8=None, position_table=None, out_bias_tok=None, wgroup=None, chain=False):
+        """x [B, T, D] -> (attn_out [B, T, D], position_table).  chain=True: a third value, an alias of x that has passed
+        through the gate and the q|k|v projection (functional.LinearFn pass_x): the caller uses it wherever it would have
+        used x again (the residual), so that x has ONE consumer chain and backward needs no separate add kernels."""
         B, T, D = x.shape
         if self.has_relative_attention_bias and position_table is None:
             position_table = self.position_table(T, x.device)
         gate = None
         if position_table is not None:
             if self.gru_rel_pos:
-                gate = F.GateFn.apply(x, self.grep_linear.weight, self.grep_linear.bias, self.grep_a, self.num_heads)
+                if chain:
+                    gate, x = F.GateFn.apply(x, self.grep_linear.weight, self.grep_linear.bias, self.grep_a, self.num_heads, True)
+                else:
+                    gate = F.GateFn.apply(x, self.grep_linear.weight, self.grep_linear.bias, self.grep_a, self.num_heads)
             else:
                 gate = torch.ones((B, self.num_heads, T), dtype=torch.float32, device=x.device)
         pk = self._packed
         if (pk is not None and torch.is_grad_enabled() and pk[0].data_ptr() == self.q_proj.weight.data_ptr()
                 and pk[2].data_ptr() == self.q_proj.bias.data_ptr() and pk[0].dtype == x.dtype):
             # optimizer-bound packed views of q|k|v (no concatenation; the gradient lands packed in the arena)
-            qkv = F.LinearFn.apply(x, pk[0], pk[2], pk[1], pk[3], None, wgroup)
+            qkv = F.LinearFn.apply(x, pk[0], pk[2], pk[1], pk[3], None, wgroup, chain)
         else:
             w = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
             b = torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0)
-            qkv = F.LinearFn.apply(x, w, b)
+            qkv = F.LinearFn.apply(x, w, b, None, None, None, None, chain)
+        if chain:
+            qkv, x = qkv
         p = self.dropout_module.p if self.training else 0.0
         o = F.AttnCoreFn.apply(qkv, gate, position_table, key_padding_u8, self.num_heads, self.scaling, p,
                                F.next_seed() if p > 0 else 0)
         out = F.LinearFn.apply(o, self.out_proj.weight, self.out_proj.bias, None, None, out_bias_tok, wgroup)
-        return out, position_table
+        return (out, position_table, x) if chain else (out, position_table)
 
 
 class ResidualAddFn(torch.autograd.Function):
@@ -295,10 +302,10 @@ class TransformerSentenceEncoderLayer(nn.Module):
         self.fc2 = nn.Linear(ffn_embedding_dim, embedding_dim)
         self.final_layer_norm = nn.LayerNorm(embedding_dim)
 
-    def _ffn(self, x, b2_tok=None, wgroup=None):
+    def _ffn(self, x, b2_tok=None, wgroup=None, chain=False):
         p = self.activation_dropout if self.training else 0.0
         return F.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p,
-                             F.next_seed() if p > 0 else 0, b2_tok, wgroup)
+                             F.next_seed() if p > 0 else 0, b2_tok, wgroup, chain)
 
     def _wgrad_group(self):
         """the layer's weight gradients (q|k|v packed, out_proj, fc1, fc2) as one grouped launch in backward"""
@@ -329,11 +336,18 @@ class TransformerSentenceEncoderLayer(nn.Module):
             grad = torch.is_grad_enabled()
             wg = self._wgrad_group()
             ta = F.BiasGradToken(self.self_attn.out_proj.bias) if grad else None
-            a, position_table = self.self_attn(x, key_padding_u8, position_table, out_bias_tok=ta, wgroup=wg)
+            chain = grad and F.CHAIN_CONSUMERS  # x / the first LayerNorm's output: one consumer chain each (no add kernels)
+            if chain:
+                a, position_table, x = self.self_attn(x, key_padding_u8, position_table, out_bias_tok=ta, wgroup=wg, chain=True)
+            else:
+                a, position_table = self.self_attn(x, key_padding_u8, position_table, out_bias_tok=ta, wgroup=wg)
             x, _ = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps, residual=a, p_in=p, training=self.training,
                                 residual_bias_tok=ta)
             tf = F.BiasGradToken(self.fc2.bias) if grad else None
-            f = self._ffn(x, tf, wg)
+            if chain:
+                f, x = self._ffn(x, tf, wg, chain=True)
+            else:
+                f = self._ffn(x, tf, wg)
             x, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps, residual=f, p_in=p, training=self.training,
                                 residual_bias_tok=tf)
         return (x.transpose(0, 1) if tbc else x), None, position_table
