@@ -101,6 +101,24 @@ __device__ __forceinline__ void glds_tile64(const bf16_t* base, long ld, int row
   }
 }
 
+// block -> (tile along the sequence, batch*head).  The grid is one-dimensional: the dispatcher hands consecutive
+// workgroups to consecutive XCDs (private 4 MiB L2 each), so with the natural order the nqb tiles of one (b, h) -- the
+// only blocks that share K / V (Q / dO in the dK/dV kernel) -- landed on nqb DIFFERENT XCDs and every one of them pulled
+// its own copy from HBM: 483 MB fetched per forward launch against 150 MB algorithmic (PMC, profiles/r01).  Here XCD x
+// takes the heads bh = x (mod 8) and walks their tiles back to back, so a head's tiles run on one XCD at the same time
+// and share its L2.
+__device__ __forceinline__ void fa_block_map(int nqb, int BH, int& qb, int& bh) {
+  const int L = blockIdx.x;
+  if ((BH & 7) == 0) {
+    const int xcd = L & 7, idx = L >> 3;
+    bh = (idx / nqb) * 8 + xcd;
+    qb = idx - (idx / nqb) * nqb;
+  } else {
+    bh = L / nqb;
+    qb = L - bh * nqb;
+  }
+}
+
 struct FaP {
   const bf16_t* qkv; bf16_t* O; float* lse;
   const float* gate; const float* tab; const unsigned char* kpm;
@@ -108,6 +126,7 @@ struct FaP {
   int B, H, T; float scale; float sc2; unsigned th; float sc, log2sc, inv_sc; unsigned s0, s1;  // th: 16-bit keep threshold (0 = no dropout)
   int ths; unsigned k2;  // signed threshold th - 32768; (ths - 1) in both halves
   int Ltab, Tkb;  // LDS extents: rel table (zero padded) and key bias
+  int nqb;        // tiles along the sequence per (b, h) of the kernel being launched
 };
 
 // ------------------------------------------------------------------------------------------------- forward
@@ -120,11 +139,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
   float* kb = tabs + p.Ltab;
   unsigned* colw = reinterpret_cast<unsigned*>(kb + p.Tkb);  // [Tkb / 2] dropout column words
   const int T = p.T, H = p.H;
-  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  int qblk, bh;
+  fa_block_map(p.nqb, p.B * H, qblk, bh);
+  const int b = bh / H, h = bh % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int hi = lane >> 5, ql = lane & 31;
-  const int i = blockIdx.x * FA_BQ + 32 * wave + ql;
+  const int i = qblk * FA_BQ + 32 * wave + ql;
   const int ic = i < T ? i : T - 1;
   const long D3 = 3L * H * FA_HD;
   const bf16_t* base = p.qkv + (long)b * T * D3 + h * FA_HD;
@@ -286,15 +307,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   // 2T - 1 floats -- per-wave rows in HBM cost 4x the partial traffic, a memset, and a 4x longer reduction
   float* drow = reinterpret_cast<float*>(colw + (p.Tkb >> 1));
   const int T = p.T, H = p.H;
-  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  int qblk, bh;
+  fa_block_map(p.nqb, p.B * H, qblk, bh);
+  const int b = bh / H, h = bh % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int hi = lane >> 5, ql = lane & 31;
-  const int i = blockIdx.x * FA_BQ + 32 * wave + ql;
+  const int i = qblk * FA_BQ + 32 * wave + ql;
   const int ic = i < T ? i : T - 1;
   const bool valid_i = i < T;
   unsigned char* skew = smem + 32768 + wave_u * 6144;
-  const int ib = blockIdx.x * FA_BQ + 32 * wave_u;
+  const int ib = qblk * FA_BQ + 32 * wave_u;
   const int dlo0 = -ib - 31 + T - 1;  // diagonal of skew row 0 at tile 0 (negative for rows past the table)
   if constexpr (TAB)
     for (int d = threadIdx.x; d < 2 * T - 1; d += 256) drow[d] = 0.f;  // ordered before the first add by the tile loop's barriers
@@ -439,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   }
   if constexpr (TAB) {
     __syncthreads();
-    float* prow = p.dtab_part + ((long)bh * gridDim.x + blockIdx.x) * L;
+    float* prow = p.dtab_part + ((long)bh * p.nqb + qblk) * L;
     for (int d = threadIdx.x; d < L; d += 256) prow[d] = drow[d];
   }
   dg += __shfl_xor(dg, 32, 64);
@@ -474,11 +497,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   float* tabs = reinterpret_cast<float*>(smem + 32768);
   float* rowv = tabs + p.Ltab + 64;  // [2 stages][4][64]: lse * log2e, delta, gate * log2e, dropout row word of the query tile
   const int T = p.T, H = p.H;
-  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  int kblk, bh;
+  fa_block_map(p.nqb, p.B * H, kblk, bh);
+  const int b = bh / H, h = bh % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int hi = lane >> 5, kl = lane & 31;
-  const int j = blockIdx.x * FA_BK1 + 32 * wave + kl;
+  const int j = kblk * FA_BK1 + 32 * wave + kl;
   const int jc = j < T ? j : T - 1;
   const long D3 = 3L * H * FA_HD, D = (long)H * FA_HD;
   const bf16_t* base = p.qkv + (long)b * T * D3 + h * FA_HD;
@@ -670,7 +695,8 @@ int wavlm_attn_fused_fwd(const void* qkv, void* O, float* lse, const float* gate
   FaP p = fa_params(B, H, T, scale, p_drop, seed);
   p.qkv = (const bf16_t*)qkv; p.O = (bf16_t*)O; p.lse = lse; p.gate = gate; p.tab = tab; p.kpm = kpm;
   const size_t smem = 32768 + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float);
-  const dim3 grid((unsigned)((T + FA_BQ - 1) / FA_BQ), (unsigned)(B * H));
+  p.nqb = (T + FA_BQ - 1) / FA_BQ;
+  const dim3 grid((unsigned)(p.nqb * B * H));
   if (p.th) {
     if (fa_set_smem(attn_fwd_kernel<true>, smem) != WL_OK) return WL_ELAUNCH;
     WL_LAUNCH(attn_fwd_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, p);
@@ -705,16 +731,18 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
   p.dtab_part = (float*)workspace;
   p.delta = p.dtab_part + (long)B * H * nqt * L;
   const size_t smem1 = 32768 + 4 * 6144 + (size_t)(2 * p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float);
+  p.nqb = nqt;
   if (p.th) {
 #define FA_DQ(DR, TB) do { if (fa_set_smem(attn_bwd_dq_kernel<DR, TB>, smem1) != WL_OK) return WL_ELAUNCH; \
-    WL_LAUNCH((attn_bwd_dq_kernel<DR, TB>), dim3((unsigned)nqt, (unsigned)(B * H)), dim3(256), smem1, st, p); } while (0)
+    WL_LAUNCH((attn_bwd_dq_kernel<DR, TB>), dim3((unsigned)(nqt * B * H)), dim3(256), smem1, st, p); } while (0)
     if (tab) FA_DQ(true, true); else FA_DQ(true, false);
   } else {
     if (tab) FA_DQ(false, true); else FA_DQ(false, false);
   }
 #undef FA_DQ
   const size_t smem2 = 32768 + (size_t)(p.Ltab + 64 + 2 * 256) * sizeof(float);
-  const dim3 grid2((unsigned)((T + FA_BK1 - 1) / FA_BK1), (unsigned)(B * H));
+  p.nqb = (T + FA_BK1 - 1) / FA_BK1;
+  const dim3 grid2((unsigned)(p.nqb * B * H));
   if (p.th) {
     if (fa_set_smem(attn_bwd_dkv_kernel<true>, smem2) != WL_OK) return WL_ELAUNCH;
     WL_LAUNCH(attn_bwd_dkv_kernel<true>, grid2, dim3(256), smem2, st, p);
