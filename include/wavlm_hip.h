@@ -116,6 +116,9 @@ int wavlm_axpby(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_
 int wavlm_scale_dev(void* y, int32_t dtype, int64_t n, const float* scalar, float extra, void* stream);
 /* y = dropout(x; p, seed): counter-based (Philox4x32-10) mask, regenerated (not stored) for the backward. */
 int wavlm_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int32_t dtype, void* stream);
+/* y = x + dropout(r, p, seed): residual add of a pre-LN block (unispeech_sat.py:1088-1111 `x = residual + dropout(x)`);
+ * same mask as wavlm_dropout for the same seed (the backward of the dropped branch is wavlm_dropout(dy)) */
+int wavlm_dropout_add(const void* x, const void* r, void* y, int64_t n, float p, uint64_t seed, int32_t dtype, void* stream);
 /* out[0] = scale * sum(x^2): features_pen (wavlm.py:486) and the global gradient norm (utils.py:338-388). */
 uint64_t wavlm_sumsq_workspace_bytes(void);
 int wavlm_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out, void* workspace, uint64_t ws_bytes,

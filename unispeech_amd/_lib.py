@@ -55,6 +55,7 @@ SIGNATURES = {
     "wavlm_axpby": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_vp]),
     "wavlm_scale_dev": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_f32, c_vp]),
     "wavlm_dropout": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_u64, c_i32, c_vp]),
+    "wavlm_dropout_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_u64, c_i32, c_vp]),
     "wavlm_sumsq_workspace_bytes": (c_u64, []),
     "wavlm_sumsq": (c_i32, [c_vp, c_i32, c_i64, c_f32, c_vp, c_vp, c_u64, c_vp]),
     "wavlm_conv0_gn_workspace_bytes": (c_u64, [c_i32, c_i64, c_i32, c_i32]),

@@ -408,10 +408,13 @@ __global__ __launch_bounds__(256) void conv0_ln_fwd_kernel(const TW* __restrict_
     int T0, int C, int stride, float eps) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* seg = sm;
+  constexpr bool TAB = sizeof(TO) == 2;  // bf16 activations: table GELU (see gelu_tab_to_lds)
+  float2* tab = reinterpret_cast<float2*>(sm + ((C0_TCH - 1) * stride + C0_KW + 3) / 4 * 4);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH;
   const int nt = min(C0_TCH, T0 - t0);
   stage_wave(wav, T, b, t0, nt, stride, seg);
+  if constexpr (TAB) gelu_tab_to_lds(0, tab);
   float w[8][C0_KW];
   load_w(W, lane, C, w);
   float gm[8], bt[8], cb[8];
@@ -439,7 +442,10 @@ __global__ __launch_bounds__(256) void conv0_ln_fwd_kernel(const TW* __restrict_
     const float rstd = rsqrtf(wave_sum(q) * invC + eps);
     if (act) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = gelu_f(fmaf((y[e] - mean) * rstd, gm[e], bt[e]));
+      for (int e = 0; e < 8; ++e) {
+        const float zz = fmaf((y[e] - mean) * rstd, gm[e], bt[e]);
+        if constexpr (TAB) y[e] = tab_eval(tab, zz); else y[e] = gelu_f(zz);
+      }
       V8<TO>::st(out + ((long)b * T0 + t0 + tt) * C + lane * 8, y);
     }
   }
@@ -453,10 +459,13 @@ __global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict_
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* seg = sm;
   float* red = sm + ((C0_TCH_BWD - 1) * stride + C0_KW + 3) / 4 * 4;  // [4 waves][512]
+  constexpr bool TAB = sizeof(TO) == 2;  // bf16 gradients: table gelu'
+  float2* tab = reinterpret_cast<float2*>(red + 4 * 512);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, t0 = blockIdx.x * C0_TCH_BWD;
   const int nt = min(C0_TCH_BWD, T0 - t0);
   stage_wave(wav, T, b, t0, nt, stride, seg);
+  if constexpr (TAB) gelu_tab_to_lds(1, tab);
   float w[8][C0_KW];
   load_w(W, lane, C, w);
   float gm[8], bt[8], cb[8];
@@ -500,7 +509,10 @@ __global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       xh[e] = (y[e] - mean) * rstd;
-      const float dz = act ? gv[e] * gscale * gelu_grad_f(fmaf(xh[e], gm[e], bt[e])) : 0.f;
+      const float zz = fmaf(xh[e], gm[e], bt[e]);
+      float gp;
+      if constexpr (TAB) gp = tab_eval(tab, zz); else gp = gelu_grad_f(zz);
+      const float dz = act ? gv[e] * gscale * gp : 0.f;
       a1[e] += dz; a2[e] = fmaf(dz, xh[e], a2[e]);
       h[e] = dz * gm[e];
       s1 += h[e]; s2 = fmaf(h[e], xh[e], s2);
@@ -663,7 +675,8 @@ int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
   hipStream_t st = (hipStream_t)stream;
   const int T0 = (int)((T - kw) / stride + 1);
   const dim3 grid((unsigned)((T0 + C0_TCH - 1) / C0_TCH), (unsigned)B);
-  const size_t smem = seg_floats(C0_TCH, stride) * sizeof(float);
+  const size_t smem = seg_floats(C0_TCH, stride) * sizeof(float) + (out_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
+  if (out_dtype == WL_BF16) gelu_tab_ensure(st);
 #define FW(TW, TP, TO) WL_LAUNCH((conv0_ln_fwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
     (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (TO*)out, (long)T, T0, (int)C, (int)stride, eps)
   const int key = wav_dtype * 100 + param_dtype * 10 + out_dtype;
@@ -689,7 +702,8 @@ int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   const int nchunk = (T0 + C0_TCH_BWD - 1) / C0_TCH_BWD;
   const dim3 grid((unsigned)nchunk, (unsigned)B);
   float* part = (float*)workspace;
-  const size_t smem = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float);
+  const size_t smem = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float) + (g_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
+  if (g_dtype == WL_BF16) gelu_tab_ensure(st);
 #define BW(TW, TP, TO) WL_LAUNCH((conv0_ln_bwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
     (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (const TO*)g, part, (long)T, T0, (int)C, (int)stride, eps, gscale)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;

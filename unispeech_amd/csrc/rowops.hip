@@ -404,6 +404,26 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
   }
 }
 
+// y = x + dropout(r): the residual add of a pre-LN block (no LayerNorm follows the add to fuse it into), one pass
+// instead of clone + dropout + axpby (three kernels, 7 tensor passes).  Same mask as dropout_kernel for the same seed.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ y,
+                                                           long n8, unsigned th, float sc, unsigned long long seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8], a[8];
+    load8(r + i * 8, v);
+    load8(x + i * 8, a);
+    if (th) {
+      const unsigned k = keep8(seed, (unsigned long long)i * 8, th);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ((k >> e) & 1u) ? v[e] * sc : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += a[e];
+    store8(y + i * 8, v);
+  }
+}
+
 // block partial sums of x^2 (features_pen, global gradient norm) -> part[block] (double).  16-byte loads; eight fp32
 // running sums per thread (each over <= n / (8 * threads) terms) folded into a double per thread, doubles from there on.
 template <typename T>
@@ -595,6 +615,24 @@ int wavlm_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int
   else if (dtype == WL_BF16)
     WL_LAUNCH((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
                        (long)(n >> 3), th, sc, (unsigned long long)seed);
+  else return WL_EINVAL;
+  return wl_check_launch();
+}
+
+// y = x + dropout(r, p, seed)  (p = 0: plain add); n % 8 == 0, 16-byte aligned pointers
+int wavlm_dropout_add(const void* x, const void* r, void* y, int64_t n, float p, uint64_t seed, int32_t dtype, void* stream) {
+  if (!x || !r || !y || n < 0 || (n & 7) || p < 0.f || p >= 1.f) return WL_EINVAL;
+  if (n == 0) return WL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned th = p > 0.f ? drop_thresh(p) : 0u;
+  const float sc = 1.f / (1.f - p);
+  const unsigned grid = grid_for(n >> 3, 256, 8192);
+  if (dtype == WL_F32)
+    WL_LAUNCH((dropout_add_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (const float*)r, (float*)y,
+              (long)(n >> 3), th, sc, (unsigned long long)seed);
+  else if (dtype == WL_BF16)
+    WL_LAUNCH((dropout_add_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)r, (bf16_t*)y,
+              (long)(n >> 3), th, sc, (unsigned long long)seed);
   else return WL_EINVAL;
   return wl_check_launch();
 }

@@ -261,6 +261,15 @@ def dropout(x, p, seed):
     return y
 
 
+def dropout_add(x, r, p, seed):
+    """x + dropout(r, p, seed) in one pass (p = 0: plain add)"""
+    _dev(x); _contig(x); _contig(r)
+    y = torch.empty_like(x)
+    check(_lib.lib().wavlm_dropout_add(ptr(x), ptr(r), ptr(y), x.numel(), float(p), int(seed), dt(x), stream()),
+          "wavlm_dropout_add")
+    return y
+
+
 def sumsq(x, scale=1.0, out=None):
     """scale * sum(x^2) as a 1-element fp32 device tensor (no host sync)"""
     dev = _dev(x); _contig(x)

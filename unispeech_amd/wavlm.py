@@ -265,9 +265,12 @@ class ResidualAddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, r, p, seed):
         from . import ops
-        y = x.contiguous().clone()
-        rd = ops.dropout(r.contiguous(), p, seed) if p > 0 else r.contiguous()
-        ops.axpby_(y, rd, 1.0, 1.0)
+        xc, rc = x.contiguous(), r.contiguous()
+        if xc.numel() % 8 == 0:
+            y = ops.dropout_add(xc, rc, p, seed)   # one pass instead of clone + dropout + axpby
+        else:
+            y = xc.clone()
+            ops.axpby_(y, ops.dropout(rc, p, seed) if p > 0 else rc, 1.0, 1.0)
         ctx.p, ctx.seed = p, seed
         return y
 
@@ -326,7 +329,11 @@ class TransformerSentenceEncoderLayer(nn.Module):
         if self.layer_norm_first:
             wg = self._wgrad_group()
             h, _ = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps)
-            a, position_table = self.self_attn(h, key_padding_u8, position_table, wgroup=wg)
+            if torch.is_grad_enabled() and F.CHAIN_CONSUMERS:
+                # h feeds the gate and the q|k|v projection: chained (the alias that comes back is not needed here)
+                a, position_table, _h = self.self_attn(h, key_padding_u8, position_table, wgroup=wg, chain=True)
+            else:
+                a, position_table = self.self_attn(h, key_padding_u8, position_table, wgroup=wg)
             x = ResidualAddFn.apply(x, a, p, F.next_seed() if p > 0 else 0)
             h, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps)
             f = self._ffn(h, wgroup=wg)
