@@ -20,6 +20,10 @@ import os
 import sys
 import time
 
+# the host driver only supports dmabuf IPC: without this RCCL / cross-process device memory sharing fails with
+# `hipIpcGetMemHandle: invalid argument` (set before torch / HIP initialise; a no-op when the launcher exported it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -42,6 +46,12 @@ CONFIGS = {
                  name="WavLM-Base (12L, d=768)", baseline="BASELINE.json configs[1]", fgm=0.1),
     "large": dict(L=24, D=1024, F=4096, H=16, mode="layer_norm", pre_ln=True, seconds=20.0,
                   name="WavLM-Large (24L, d=1024)", baseline="per-GPU slice of BASELINE.json configs[3]", fgm=1.0),
+    # configs[4]: UniSpeech-SAT Large = the Large structure + utterance mixing of the batch (task defaults: mixing_prob 0.5,
+    # mixing_num 1, utterance_mixing_pretraining.py:103-114) + the utterance-contrastive head on layer 6 (model defaults:
+    # unispeech_sat.py:248-262).  The mixing kernel runs INSIDE the timed step (the un-mixed collated batch is resident).
+    "sat_large": dict(L=24, D=1024, F=4096, H=16, mode="layer_norm", pre_ln=True, seconds=20.0,
+                      name="UniSpeech-SAT Large (24L, d=1024, utterance mixing + contrastive head)",
+                      baseline="per-GPU slice of BASELINE.json configs[4]", fgm=1.0, sat=True),
 }
 
 
@@ -55,6 +65,7 @@ def base_cfg(training_dropouts=True, config="base"):
         dropout_features=d, feature_grad_mult=c["fgm"], mask_prob=0.80, mask_length=10, final_dim=256 if config == "base" else 768,
         logit_temp=0.1, relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True,
         label_rate=50, extractor_mode=c["mode"], layer_norm_first=c["pre_ln"],
+        utterance_contrastive_loss=bool(c.get("sat")), utterance_contrastive_layer=6, num_instances=0, cross_sample_instances=100,
         conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2")
 
 
@@ -145,7 +156,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="base",
-                    help="base = BASELINE.json configs[1] (the headline); large = WavLM-Large, 20 s utterances")
+                    help="base = BASELINE.json configs[1] (the headline); large = WavLM-Large, 20 s utterances; "
+                         "sat_large = UniSpeech-SAT Large with utterance mixing + contrastive head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -190,8 +202,10 @@ def main():
     torch.manual_seed(0)
     model = WavLMPretrainModel(cfg, None, [range(V)]).to(dev).to(torch.bfloat16).train()
     opt = FusedAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=10.0, model=model)
+    model.instance_sampling = "device"   # UniSpeech-SAT head: draw the instance indices on the GPU (no host work per step)
     net = DataParallelWavLM(model, opt) if world > 1 else model
-    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0], defer_logging=True)
+    sat = bool(CONFIGS[args.config].get("sat"))
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0, 10.0, 0.0] if sat else [10.0], defer_logging=True)
 
     B, T = args.batch, int(SECONDS * SR)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -202,9 +216,20 @@ def main():
               "target_list": [torch.randint(4, V, (B, int(50 * SECONDS)), generator=g).to(dev)]}
     np.random.seed(1337 + rank)
     torch.manual_seed(1337)
+    mixer = None
+    if sat:
+        # utterance mixing of the collated batch, as UtteranceMixingDataset.collater does it (host draws, device arithmetic)
+        from unispeech_amd.data import UtteranceMixingCollater
+        mixer = UtteranceMixingCollater(mixing_prob=0.5, mixing_num=1, normalize=True, device=dev)
+        raw = torch.randn(B, T, generator=g).to(dev)          # fp32 un-mixed batch, resident before the timed region
+        zero_rows = [False] * B
 
     def step():
         opt.zero_grad()
+        if mixer is not None:
+            ops_np, begin_np, _ = mixer.draw_mixing_plan(B, T, zero_rows)
+            sample["net_input"]["source"] = ops.mix_utterances(raw, WF.h2d(ops_np.reshape(-1), dev), ops_np.shape[0],
+                                                                WF.h2d(begin_np, dev), None, True, torch.bfloat16)
         loss, ss, _ = crit(net, sample)
         loss.backward()
         if world > 1:

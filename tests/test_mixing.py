@@ -109,3 +109,29 @@ def test_device_mixing_at_batch_scale_dependency_chain():
                            None, True)
     err = (got.cpu() - want).abs().max().item() / want.abs().max().item()
     assert err <= 2e-6, err
+
+
+@pytest.mark.gpu
+def test_collater_feeds_the_pretraining_step():
+    """the batch dict of UtteranceMixingCollater goes into the criterion unchanged (the reference's
+    `utterance_mixing_pretraining` task -> `wavlm` criterion hand-over): device waveform already mixed and bf16-cast,
+    host copy of the padding mask, boundary list, label tensors; one forward + backward of the tiny model."""
+    from conftest import TINY, golden_state_dict
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
+    z = load_golden("mixing.npz")
+    zt = load_golden("tiny_pretrain.npz")
+    cfg = WavLMPretrainConfig(**{k: v for k, v in TINY.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    model = WavLMPretrainModel(cfg, None, [range(23)])
+    model.load_state_dict(golden_state_dict(zt))
+    model = model.cuda().to(torch.bfloat16).train()
+    col, seed = _collaters(z, device="cuda", out_dtype=torch.bfloat16)["noise"]
+    np.random.seed(seed)
+    batch = col.collater(_inputs(z))
+    assert batch["net_input"]["source"].dtype == torch.bfloat16 and batch["net_input"]["padding_mask"].any()
+    batch["target_list"] = [t.cuda() for t in batch["target_list"]]
+    batch.pop("mixing_plan")
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0])
+    loss, ss, log = crit(model, batch)
+    loss.backward()
+    assert torch.isfinite(loss) and ss > 0 and log["nsentences"] == 6
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)

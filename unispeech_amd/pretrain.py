@@ -365,7 +365,13 @@ class WavLMPretrainModel(WavLM):
                                   num_vars=q["num_vars"], temp=q["temp"])
         return result
 
-    def _sample_instances(self, bsz, tsz, num):
+    # "host": the index draws of sample_instances are made with the reference's own torch.randint calls on the CPU generator
+    # (RNG-stream parity; ~1.3 M draws + index arithmetic per step at the Large batch: 20-30 ms of launch-thread time that
+    # the GPU ends up waiting for).  "device": the same draws and the same index arithmetic on the GPU (torch's device
+    # generator: a different stream, the same law) -- no host work, nothing uploaded.
+    instance_sampling = "host"
+
+    def _sample_instances(self, bsz, tsz, num, device=None):
         """Row indices into the flattened [bsz * tsz] projections, [bsz, (n_instances + cross) * num], drawn with the
         reference's torch.randint calls (unispeech_sat.py:487-543) so the host RNG stream stays aligned."""
         n_in, n_cr = self.n_instances, self.cross_sample_instances
@@ -373,12 +379,12 @@ class WavLMPretrainModel(WavLM):
         assert high > 1
         idxs = cross = None
         if n_in > 0:
-            tszs = torch.arange(num).unsqueeze(-1).expand(-1, n_in).flatten()
-            idxs = torch.randint(low=0, high=high - 1, size=(bsz, n_in * num))
+            tszs = torch.arange(num, device=device).unsqueeze(-1).expand(-1, n_in).flatten()
+            idxs = torch.randint(low=0, high=high - 1, size=(bsz, n_in * num), device=device)
             idxs[idxs >= tszs] += 1
         if n_cr > 0:
-            tszs = torch.arange(num).unsqueeze(-1).expand(-1, n_cr).flatten()
-            cross = torch.randint(low=0, high=cross_high - 1, size=(bsz, n_cr * num))
+            tszs = torch.arange(num, device=device).unsqueeze(-1).expand(-1, n_cr).flatten()
+            cross = torch.randint(low=0, high=cross_high - 1, size=(bsz, n_cr * num), device=device)
             cross[cross >= tszs] += 1
         if n_in > 0:
             for i in range(1, bsz):
@@ -407,16 +413,22 @@ class WavLMPretrainModel(WavLM):
             q = self.quantizer(rows.view(B, num, D))
             y = F.LinearFn.apply(q["x"].reshape(S, -1), self.project_q.weight, self.project_q.bias)
         N = self.n_instances + self.cross_sample_instances
-        samples_idx = self._sample_instances(B, num, num)                               # [B, N * num], CPU int64
+        sdev = dev if self.instance_sampling == "device" else None
+        samples_idx = self._sample_instances(B, num, num, sdev)                         # [B, N * num] int64 (CPU | device)
         # instance n of frame (b, t) is samples_idx[b, n * num + t]; its utterance = index // num
         si = samples_idx.view(B, N, num).permute(0, 2, 1).reshape(S, N)                 # [S, N]
-        own = torch.arange(S).view(S, 1)
+        own = torch.arange(S, device=sdev).view(S, 1)
         idx_full = torch.cat([own, si], dim=1).to(torch.int32)                          # column 0: the frame itself
-        b_of = torch.arange(B).view(B, 1).expand(B, num).reshape(S, 1)
-        targets = torch.cat([torch.ones(S, 1, dtype=torch.bool), torch.div(si, num, rounding_mode="floor") == b_of], dim=1)
-        mean_targets = float(targets.float().mean())
-        loss, acc = F.UttContrastiveLossFn.apply(proj, F.h2d(idx_full, dev), F.h2d(targets.to(torch.uint8), dev),
-                                                 self.logit_temp, y)
+        b_of = torch.arange(B, device=sdev).view(B, 1).expand(B, num).reshape(S, 1)
+        targets = torch.cat([torch.ones(S, 1, dtype=torch.bool, device=sdev),
+                             torch.div(si, num, rounding_mode="floor") == b_of], dim=1)
+        if sdev is None:
+            mean_targets = float(targets.float().mean())
+            idx_full, t8 = F.h2d(idx_full, dev), F.h2d(targets.to(torch.uint8), dev)
+        else:
+            mean_targets = targets.float().mean()   # stays on the device (logging converts it when it logs)
+            t8 = targets.to(torch.uint8)
+        loss, acc = F.UttContrastiveLossFn.apply(proj, idx_full, t8, self.logit_temp, y)
         return loss, mean_targets, acc, q
 
     # gradient through the unmasked head is only needed when pred_nomask_weight > 0 (criterion sets this)
@@ -508,7 +520,9 @@ class WavLMCriterion(nn.Module):
         self.defer_logging = defer_logging
 
     def forward(self, model, sample, reduce=True, log_pred=False):
-        model.training_nomask_grad = self.pred_nomask_weight > 0
+        # set on the model itself, not on a data-parallel wrapper around it (nn.Module.__setattr__ would keep the flag on
+        # the wrapper and the wrapped forward would never see it)
+        getattr(model, "module", model).training_nomask_grad = self.pred_nomask_weight > 0
         net_output = model(target_list=sample["target_list"], **sample["net_input"])
         return self.get_loss(model, sample, net_output, reduce)
 
