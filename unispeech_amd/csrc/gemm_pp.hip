@@ -238,32 +238,47 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 
   // ---- fragment side ---------------------------------------------------------------------------------------------
   // K-contiguous image: lane -> row (l & 31), chunk 2 s + (l >> 5), swizzle ((l >> 1) & 7)
-  unsigned kc_a[4], kc_b[4];
+  // Two copies of every per-lane fragment address, one per LDS stage: with ONE copy the stage-1 reads need
+  // "register + 65536 + ..." and the 16-bit offset field of ds_read cannot hold that, so the compiler spent a v_add_u32 on
+  // every fragment read (48 per two K steps, all in the read interval that decides when the wave reaches its barrier).
+  // The asm barrier keeps the second copy a register instead of a rematerialised add.
+  unsigned kc_a[2][4], kc_b[2][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const unsigned lo = (unsigned)((lane & 31) * 128 + (((2 * s + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
-    kc_a[s] = lo + wm * 8192;
-    kc_b[s] = lo + wn * 4096;
+    kc_a[0][s] = lo + wm * 8192;
+    kc_b[0][s] = lo + wn * 4096;
+    kc_a[1][s] = kc_a[0][s] + PP_STAGE;
+    kc_b[1][s] = kc_b[0][s] + PP_STAGE;
+    if constexpr (!TA) asm volatile("" : "+v"(kc_a[1][s]));
+    if constexpr (!TB) asm volatile("" : "+v"(kc_b[1][s]));
   }
   // K-strided image: 16-lane group g reads the [4 k][16 rows] block of k octet (l >> 5), rows 16 (g & 1) + ..;
   // lane i of the group supplies the address of k row (i >> 2), rows 4 (i & 3) .. +4
-  unsigned tr_a[2], tr_b;
+  unsigned tr_a[2][2], tr_b[2];
   {
     const int i = lane & 15, g1 = (lane >> 4) & 1;
     const unsigned kpart = (unsigned)((8 * (lane >> 5) + (i >> 2)) * 256 + (i & 3) * 8);
 #pragma unroll
-    for (int f = 0; f < 2; ++f) tr_a[f] = kpart + (unsigned)(((wm * 4 + f * 2 + g1) ^ (2 * (i >> 2))) << 5);
-    tr_b = kpart + (unsigned)(((wn * 2 + g1) ^ (2 * (i >> 2))) << 5);
+    for (int f = 0; f < 2; ++f) {
+      tr_a[0][f] = kpart + (unsigned)(((wm * 4 + f * 2 + g1) ^ (2 * (i >> 2))) << 5);
+      tr_a[1][f] = tr_a[0][f] + PP_STAGE;
+      if constexpr (TA) asm volatile("" : "+v"(tr_a[1][f]));
+    }
+    tr_b[0] = kpart + (unsigned)(((wn * 2 + g1) ^ (2 * (i >> 2))) << 5);
+    tr_b[1] = tr_b[0] + PP_STAGE;
+    if constexpr (TB) asm volatile("" : "+v"(tr_b[1]));
   }
   auto rd_a = [&](int base, int f, int s) __attribute__((always_inline)) -> bf16x8_t {  // base: byte offset of the half-tile buffer
 #if PP_PROBE & 1
     bf16x8_t z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)(float)(base + f + s); return z;
 #endif
+    const int st = base >= PP_STAGE ? 1 : 0, ib = base - st * PP_STAGE;  // `base` is a constant at every call site
     if constexpr (!TA) {
-      return *reinterpret_cast<const bf16x8_t*>(smem + base + f * 4096 + kc_a[s]);
+      return *reinterpret_cast<const bf16x8_t*>(smem + kc_a[st][s] + (ib + f * 4096));
     } else {
-      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 4096 + tr_a[f]));
-      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 4096 + 1024 + tr_a[f]));
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + tr_a[st][f] + (ib + s * 4096)));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + tr_a[st][f] + (ib + s * 4096 + 1024)));
       return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
   };
@@ -271,11 +286,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 #if PP_PROBE & 1
     bf16x8_t z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)(float)(base + s); return z;
 #endif
+    const int st = base >= PP_STAGE ? 1 : 0, ib = base - st * PP_STAGE;
     if constexpr (!TB) {
-      return *reinterpret_cast<const bf16x8_t*>(smem + base + kc_b[s]);
+      return *reinterpret_cast<const bf16x8_t*>(smem + kc_b[st][s] + ib);
     } else {
-      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 4096 + tr_b));
-      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 4096 + 1024 + tr_b));
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + tr_b[st] + (ib + s * 4096)));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + tr_b[st] + (ib + s * 4096 + 1024)));
       return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
   };

@@ -176,38 +176,50 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
   using I5 = std::integral_constant<int, 5>;
 
   // ---- fragment side ---------------------------------------------------------------------------------------------
-  unsigned kc_a[4], kc_b[4];
+  // one copy of every per-lane fragment address per LDS stage (gemm_pp.hip: a stage-1 read otherwise needs an offset
+  // beyond the 16-bit field of ds_read and costs a v_add_u32 per fragment)
+  unsigned kc_a[2][4], kc_b[2][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const unsigned lo = (unsigned)((lane & 31) * 128 + (((2 * s + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
-    kc_a[s] = lo + wm * 4096;
-    kc_b[s] = lo + wn * 12288;
+    kc_a[0][s] = lo + wm * 4096;
+    kc_b[0][s] = lo + wn * 12288;
+    kc_a[1][s] = kc_a[0][s] + P3_STAGE;
+    kc_b[1][s] = kc_b[0][s] + P3_STAGE;
+    if constexpr (!TA) asm volatile("" : "+v"(kc_a[1][s]));
+    if constexpr (!TB) asm volatile("" : "+v"(kc_b[1][s]));
   }
-  unsigned tr_a, tr_b[3];
+  unsigned tr_a[2], tr_b[2][3];
   {
     const int i = lane & 15, g1 = (lane >> 4) & 1, o = lane >> 5;
-    tr_a = (unsigned)((8 * o + (i >> 2)) * 128 + (((wm * 2 + g1) ^ (2 * ((i >> 3) & 1))) << 5) + (i & 3) * 8);
+    tr_a[0] = (unsigned)((8 * o + (i >> 2)) * 128 + (((wm * 2 + g1) ^ (2 * ((i >> 3) & 1))) << 5) + (i & 3) * 8);
+    tr_a[1] = tr_a[0] + P3_STAGE;
+    if constexpr (TA) asm volatile("" : "+v"(tr_a[1]));
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int gB = wn * 6 + j * 2 + g1;
-      tr_b[j] = (unsigned)((8 * o + (i >> 2)) * 768 + (((gB & ~7) | ((gB & 7) ^ (2 * (i >> 2)))) << 5) + (i & 3) * 8);
+      tr_b[0][j] = (unsigned)((8 * o + (i >> 2)) * 768 + (((gB & ~7) | ((gB & 7) ^ (2 * (i >> 2)))) << 5) + (i & 3) * 8);
+      tr_b[1][j] = tr_b[0][j] + P3_STAGE;
+      if constexpr (TB) asm volatile("" : "+v"(tr_b[1][j]));
     }
   }
   auto rd_a = [&](int base, int s) __attribute__((always_inline)) -> bf16x8_t {  // base: byte offset of the A unit
+    const int st = base >= P3_STAGE ? 1 : 0, ib = base - st * P3_STAGE;  // `base` is a constant at every call site
     if constexpr (!TA) {
-      return *reinterpret_cast<const bf16x8_t*>(smem + base + kc_a[s]);
+      return *reinterpret_cast<const bf16x8_t*>(smem + kc_a[st][s] + ib);
     } else {
-      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 2048 + tr_a));
-      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 2048 + 512 + tr_a));
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + tr_a[st] + (ib + s * 2048)));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + tr_a[st] + (ib + s * 2048 + 512)));
       return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
   };
   auto rd_b = [&](int base, int j, int s) __attribute__((always_inline)) -> bf16x8_t {  // base: byte offset of B
+    const int st = base >= P3_STAGE ? 1 : 0, ib = base - st * P3_STAGE;
     if constexpr (!TB) {
-      return *reinterpret_cast<const bf16x8_t*>(smem + base + j * 4096 + kc_b[s]);
+      return *reinterpret_cast<const bf16x8_t*>(smem + kc_b[st][s] + (ib + j * 4096));
     } else {
-      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 12288 + tr_b[j]));
-      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + base + s * 12288 + 3072 + tr_b[j]));
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + tr_b[st][j] + (ib + s * 12288)));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(smem + tr_b[st][j] + (ib + s * 12288 + 3072)));
       return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
   };
