@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libwavlm_hip.so")
 ARCH = "gfx950"
 SOURCES = ["gemm_bf16.hip", "gemm_pp.hip", "gemm_pp3.hip", "gemm_f32.hip", "rowops.hip", "conv0.hip", "attn.hip", "attn_fused.hip", "posconv.hip", "loss.hip", "vq.hip", "mixing.hip",
            "optim.hip"]
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", INCLUDE]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm", "-I", INCLUDE]
 
 
 def _hipcc():

@@ -185,6 +185,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
   }
   // issue half-tile `which` (0 A-top, 1 A-bot, 2 B-left, 3 B-right) of the stream's current K tile into `stage`,
   // then advance the stream by one K tile
+  // LDS-DMA of one 1 KiB piece: M0 = LDS destination, address = SGPR base + 32-bit VGPR offset.  EVERY DMA of this kernel
+  // goes through here, so the compiler never tracks M0 itself (it would not see these writes).
+  auto dma16 = [&](const char* sbase, unsigned voff32, unsigned char* ldst) __attribute__((always_inline)) {
+    const unsigned lds_dst = (unsigned)(unsigned long)(las_ptr)ldst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_dst), "v"(voff32), "s"(sbase) : "memory", "m0");  // m0: so that the K-tail's builtin DMA re-initialises it
+  };
   auto issue_gen = [&](auto which_c, int stage) __attribute__((always_inline)) {
     constexpr int W = decltype(which_c)::value;
     constexpr int OP = W >> 1;
@@ -198,12 +205,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     if (kv >= 64) {
 #endif
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_global_load_lds((gas_ptr)(src + voff[W][j]), (las_ptr)(dst + j * 1024), 16, 0, 0);
+      for (int j = 0; j < 2; ++j) dma16(src, voff[W][j], dst + j * 1024);
     } else if (!(PP_PROBE & 2)) {
+      // K tail: lanes whose k position lies past the end read the zero page instead (per-lane choice of the OFFSET from
+      // the uniform base: the zero page's distance from `src` does not fit 32 bits in general, so those lanes use the
+      // zero page as base through a second, fully predicated instruction)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const char* s = (kidx[OP][j] < kv) ? src + voff[W][j] : (const char*)g_pp_zero;
+        const bool in = kidx[OP][j] < kv;
+        const char* s = in ? src + voff[W][j] : (const char*)g_pp_zero;
         __builtin_amdgcn_global_load_lds((gas_ptr)s, (las_ptr)(dst + j * 1024), 16, 0, 0);
       }
     }
@@ -224,7 +234,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     src = Ab + W * 16384 + wave * 2048 + j * 1024 - voff[W][j] + lane * 16;  // hot, contiguous window
 #endif
 #if !(PP_PROBE & 2)
-    __builtin_amdgcn_global_load_lds((gas_ptr)(src + voff[W][j]), (las_ptr)(dst + j * 1024), 16, 0, 0);
+    // the per-lane offset stays a 32-bit register and the address is formed as "SGPR base + VGPR offset" by the
+    // instruction itself (global_load_lds ... v, s[base]): without the barrier the zero-extension is hoisted out of
+    // the loop as eight 64-bit register pairs and every DMA costs a v_lshl_add_u64 between two MFMAs
+    // (written as asm: through the builtin the zero-extension of the offset is hoisted out of the loop as eight 64-bit
+    // register pairs and every DMA costs a v_lshl_add_u64 -- or, with the offset hidden from the optimiser, a v_mov_b32
+    // -- between two MFMAs.  M0 = LDS destination of the wave's 1 KiB piece; one wait state after writing it.)
+    dma16(src, voff[W][j], dst + j * 1024);
 #endif
     if (j == 1) {  // scalar cursor work hides behind the MFMAs around it
       c.off += OP ? stepB : stepA;
