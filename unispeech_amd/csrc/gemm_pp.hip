@@ -333,8 +333,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 #else
 #define PP_STAMP(K_)
 #endif
-#define PP_MFMA_SECTION(FA, I0_, BF, J_) PP_MFMA_SECTION_H(FA, I0_, BF, J_, (void)0, (void)0)
-#define PP_MFMA_SECTION_H(FA, I0_, BF, J_, H0_, H1_)                                                \
+#define PP_MFMA_SECTION(FA, I0_, BF, J_) PP_MFMA_SECTION_H4(FA, I0_, BF, J_, (void)0, (void)0, (void)0, (void)0, (void)0)
+#define PP_MFMA_SECTION_H(FA, I0_, BF, J_, H0_, H1_) PP_MFMA_SECTION_H4(FA, I0_, BF, J_, H0_, (void)0, H1_, (void)0, (void)0)
+#define PP_MFMA_SECTION_H4(FA, I0_, BF, J_, H0_, H1_, H2_, H3_, TAIL_)                              \
   __builtin_amdgcn_sched_barrier(0);                                                                \
   PP_STAMP(4 * (I0_ + (I0_ ? 1 - J_ : J_)) + 0);                                                     \
   __builtin_amdgcn_s_barrier();                                                                     \
@@ -346,8 +347,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     acc[I0_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][s], BF[s], acc[I0_][J_], 0, 0, 0);  \
     acc[I0_ + 1][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][s], BF[s], acc[I0_ + 1][J_], 0, 0, 0); \
     if (s == 0) { H0_; }                                                                            \
-    if (s == 2) { H1_; }                                                                            \
+    if (s == 1) { H1_; }                                                                            \
+    if (s == 2) { H2_; }                                                                            \
+    if (s == 3) { H3_; }                                                                            \
   }                                                                                                 \
+  TAIL_;                                                                                            \
   PP_STAMP(4 * (I0_ + (I0_ ? 1 - J_ : J_)) + 2);                                                     \
   __builtin_amdgcn_s_setprio(0);                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -355,10 +359,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
   PP_STAMP(4 * (I0_ + (I0_ ? 1 - J_ : J_)) + 3);                                                     \
   __builtin_amdgcn_sched_barrier(0);
 
-  auto k_step = [&](auto stage_c, auto steady_c, int t) __attribute__((always_inline)) {
+  constexpr bool EARLY = (TA && TB) && !(PP_PROBE & 128);
+  auto k_step = [&](auto stage_c, auto steady_c, int t, auto first_c) __attribute__((always_inline)) {
     constexpr int ST = decltype(stage_c)::value;
     constexpr int SB = ST * PP_STAGE;
     constexpr bool SD = decltype(steady_c)::value;  // steady: tiles t+1 and t+2 exist, are full, and share the K batch
+    constexpr bool FIRST = decltype(first_c)::value;
     const bool more1 = SD || t + 1 < nt, more2 = SD || t + 2 < nt;
     auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) { issue_gen(which_c, stage); };
     if constexpr (SD) {
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) bl[s] = rd_b(SB + 2 * PP_HB, s);
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int f = (EARLY && !FIRST) ? 1 : 0; f < 2; ++f)
 #pragma unroll
         for (int s = 0; s < 4; ++s) at[f][s] = rd_a(SB, f, s);
       PP_VMWAIT(6);
@@ -381,9 +387,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int s = 0; s < 4; ++s) ab[f][s] = rd_a(SB + PP_HB, f, s);
-      PP_MFMA_SECTION_H(ab, 2, br, 1, issue_one(I0{}, ST, 0), issue_one(I0{}, ST, 1))
-      PP_VMWAIT(6);
-      PP_MFMA_SECTION_H(ab, 2, bl, 0, issue_one(I2{}, ST, 0), issue_one(I2{}, ST, 1))
+      if constexpr (EARLY) {
+        PP_MFMA_SECTION_H4(ab, 2, br, 1, issue_one(I0{}, ST, 0), (void)0, issue_one(I0{}, ST, 1), (void)0, PP_VMWAIT(8))
+        PP_VMWAIT(6);
+        constexpr int NB = (ST ^ 1) * PP_STAGE;
+#define PP_RD_AT(S_) { at[0][S_] = rd_a(NB, 0, S_); }
+        PP_MFMA_SECTION_H4(ab, 2, bl, 0, { issue_one(I2{}, ST, 0); PP_RD_AT(0) }, PP_RD_AT(1),
+                           { issue_one(I2{}, ST, 1); PP_RD_AT(2) }, PP_RD_AT(3), (void)0)
+#undef PP_RD_AT
+      } else {
+        PP_MFMA_SECTION_H(ab, 2, br, 1, issue_one(I0{}, ST, 0), issue_one(I0{}, ST, 1))
+        PP_VMWAIT(6);
+        PP_MFMA_SECTION_H(ab, 2, bl, 0, issue_one(I2{}, ST, 0), issue_one(I2{}, ST, 1))
+      }
       return;
     }
     // ---- P1: A-top, B-left -> quadrant (0,0)
@@ -445,18 +461,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     // (K batches without a K tail are steady too: the in-section issue carries the cursor wrap)
     const int n_steady = (kv_last == 64 || P.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
     int t = 0;
+    if (n_steady > 0) {
+      k_step(I0{}, std::true_type{}, 0, std::true_type{});
+      k_step(I1{}, std::true_type{}, 1, std::false_type{});
+      t = 2;
+    }
     for (; t < n_steady; t += 2) {
-      k_step(I0{}, std::true_type{}, t);
-      k_step(I1{}, std::true_type{}, t + 1);
+      k_step(I0{}, std::true_type{}, t, std::false_type{});
+      k_step(I1{}, std::true_type{}, t + 1, std::false_type{});
     }
     for (; t < nt; t += 2) {
-      k_step(I0{}, std::false_type{}, t);
-      if (t + 1 < nt) k_step(I1{}, std::false_type{}, t + 1);
+      k_step(I0{}, std::false_type{}, t, std::false_type{});
+      if (t + 1 < nt) k_step(I1{}, std::false_type{}, t + 1, std::false_type{});
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
   }
 #undef PP_MFMA_SECTION
 #undef PP_MFMA_SECTION_H
+#undef PP_MFMA_SECTION_H4
 #undef PP_VMWAIT
 #undef PP_STAMP
 #if PP_PROBE & 16
