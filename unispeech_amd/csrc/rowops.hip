@@ -463,7 +463,12 @@ static inline unsigned grid_for(long work_items, int per_block, unsigned cap) {
   return (unsigned)g;
 }
 
+#ifndef LN_BWD_BLOCKS
 #define LN_BWD_BLOCKS 1024
+#endif
+#ifndef LN_FWD_DROP_BLOCKS
+#define LN_FWD_DROP_BLOCKS 1024
+#endif
 #define CS_BLOCKS 512
 
 extern "C" {
@@ -478,7 +483,7 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   hipStream_t st = (hipStream_t)stream;
   const unsigned ti = drop_thresh16(p_in), to = drop_thresh16(p_out);
   const float si = drop_scale16(ti), so = drop_scale16(to);
-  const unsigned grid = grid_for(rows, 4, (ti | to) ? 1024 : 8192);  // with dropout: several rows per wave amortise the column words
+  const unsigned grid = grid_for(rows, 4, (ti | to) ? LN_FWD_DROP_BLOCKS : 8192);  // with dropout: several rows per wave amortise the column words
   // chunk slots per lane are a template parameter: registers (and occupancy) follow the actual row width
 #define LN_FWD_N(T, TP, NCS) WL_LAUNCH((layernorm_fwd_kernel<T, TP, NCS>), dim3(grid), dim3(256), 0, st, (const T*)x, \
     (const T*)r, (T*)y, (T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (long)rows, (int)D, eps, (int)act, ti, si, \
