@@ -316,6 +316,23 @@ def check_layernorm():
         dx_, dr_, _, _, _ = ops.layernorm_bwd(dyb, sv, mean, rstd, g.detach(), b.detach(), p_in=p, seed_in=999, need_dr=True,
                                               dgamma=dg, dbeta=db_, dr_colsum=dc)
         out.append((f"layernorm[{dtype}] dr colsum accumulated", err(dc, dg0.double() + dr_.double().sum(0)), tol * 4))
+        # residual-stream gradient added inside the backward kernel (pre-LN blocks): dx gains dx_add, dr / colsum do not
+        extra = gen(rows, D, seed=23).to(dtype).to(DEV)
+        dx0, dr0, _, _, cs0 = ops.layernorm_bwd(dyb, sv, mean, rstd, g.detach(), b.detach(), p_in=p, seed_in=999,
+                                                need_dr=True, dr_colsum=True)
+        dx1, dr1, _, _, cs1 = ops.layernorm_bwd(dyb, sv, mean, rstd, g.detach(), b.detach(), p_in=p, seed_in=999,
+                                                need_dr=True, dr_colsum=True, dx_add=extra)
+        out.append((f"layernorm[{dtype}] dx_add", err(dx1, dx0.double() + extra.double()), tol))
+        out.append((f"layernorm[{dtype}] dx_add leaves dr", err(dr1, dr0), 0.0))
+        out.append((f"layernorm[{dtype}] dx_add leaves colsum", err(cs1, cs0), tol))
+        # the same through autograd: y = LN(x) + x with x handed through as an alias
+        xa = gen(rows, D, seed=31).to(dtype).to(DEV).requires_grad_(True)
+        ya, _s, xal = F.LayerNormFn.apply(xa, None, g.detach(), b.detach(), 1e-5, 0, 0.0, 0, 0.0, 0, 1.0, None, True)
+        (ya.float() * dyb.float() + xal.float() * extra.float()).sum().backward()
+        xb = xa.detach().clone().requires_grad_(True)
+        yb, _s = F.LayerNormFn.apply(xb, None, g.detach(), b.detach(), 1e-5, 0, 0.0, 0, 0.0, 0, 1.0)
+        (yb.float() * dyb.float() + xb.float() * extra.float()).sum().backward()
+        out.append((f"layernorm[{dtype}] pass_x autograd", err(xa.grad, xb.grad), tol))
     return out
 
 

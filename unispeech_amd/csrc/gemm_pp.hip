@@ -131,12 +131,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  const char* Ab = (const char*)((const bf16_t*)P.A + (long)zo * P.sA_o + (long)zi * P.sA_i + (TA ? (long)m0 : (long)m0 * P.lda));
-  const char* Bb = (const char*)((const bf16_t*)P.B + (long)zo * P.sB_o + (long)zi * P.sB_i + (TB ? (long)n0 : (long)n0 * P.ldb));
+  // The DMA asm below takes its base address in an SGPR pair: pin the (wave-uniform) panel bases and the K range to
+  // scalar registers here, once per tile -- in some instantiations the work-item decode above runs on the VALU and the
+  // compiler would otherwise hand the asm a VGPR pair (an assembler error, not a slow path).
+  auto uni_ptr = [](const char* q_) __attribute__((always_inline)) {
+    const unsigned long v = (unsigned long)q_;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long)hi << 32) | lo);
+  };
+  const char* Ab = uni_ptr((const char*)((const bf16_t*)P.A + (long)zo * P.sA_o + (long)zi * P.sA_i + (TA ? (long)m0 : (long)m0 * P.lda)));
+  const char* Bb = uni_ptr((const char*)((const bf16_t*)P.B + (long)zo * P.sB_o + (long)zi * P.sB_i + (TB ? (long)n0 : (long)n0 * P.ldb)));
   const int kt_per = (P.K + 63) >> 6;
   const int kv_last = P.K - (kt_per - 1) * 64;
   int t0, t1;
   gemm_split_range(P.KB * kt_per, P.split_k, split, t0, t1);
+  t0 = __builtin_amdgcn_readfirstlane(t0); t1 = __builtin_amdgcn_readfirstlane(t1);
   const int nt = t1 - t0;
 
   // ---- DMA side: per-lane byte offsets of the two pieces (j) this lane fetches of each half-tile ------------------

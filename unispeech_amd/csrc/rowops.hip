@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 template <typename T, typename TP, int NC, bool CS>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
     const float* __restrict__ mean_i, const float* __restrict__ rstd_i, const TP* __restrict__ gamma,
-    const TP* __restrict__ beta, T* __restrict__ dx, T* __restrict__ dr, float* __restrict__ part, long rows, int D,
-    int act, unsigned th_in, float sc_in, unsigned long long seed_in, unsigned th_out, float sc_out,
+    const TP* __restrict__ beta, T* __restrict__ dx, T* __restrict__ dr, const T* __restrict__ dx_add,
+    float* __restrict__ part, long rows, int D, int act, unsigned th_in, float sc_in, unsigned long long seed_in, unsigned th_out, float sc_out,
     unsigned long long seed_out, float grad_scale) {
   constexpr int NA = CS ? 3 : 2;
   __shared__ float red[4][NA][512];  // cross-wave reduce of one chunk slot (64 lanes x 8 columns) at a time
@@ -207,7 +207,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = grad_scale * rstd * (h[c][e] - s1 - xh[c][e] * s2);  // grad_scale: input gradient only, not dgamma/dbeta
-        store8(dx + off, o);
+        if (dx_add) {  // gradient that reaches x past the LayerNorm (the residual stream of a pre-LN block)
+          float a[8], t[8];
+          load8(dx_add + off, a);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] = o[e] + a[e];
+          store8(dx + off, t);
+        } else store8(dx + off, o);
         if (dr || CS) {
           if (th_in) ln_drop_apply(o, rw_in, cw[c], th_in, sc_in);
           if (dr) store8(dr + off, o);
@@ -501,10 +507,10 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
 uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D) { return (uint64_t)LN_BWD_BLOCKS * 3 * D * sizeof(float); }
 
 int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd, const void* gamma,
-                        const void* beta, void* dx, void* dr, void* dgamma, void* dbeta, void* dr_colsum, int64_t rows,
-                        int32_t D, int32_t dtype, int32_t param_dtype, int32_t act, float p_in, uint64_t seed_in,
-                        float p_out, uint64_t seed_out, float grad_scale, int32_t accumulate_params, void* workspace,
-                        uint64_t ws_bytes, void* stream) {
+                        const void* beta, void* dx, void* dr, const void* dx_add, void* dgamma, void* dbeta,
+                        void* dr_colsum, int64_t rows, int32_t D, int32_t dtype, int32_t param_dtype, int32_t act,
+                        float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float grad_scale,
+                        int32_t accumulate_params, void* workspace, uint64_t ws_bytes, void* stream) {
   if (!dy || !s || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return WL_EINVAL;
   if (rows <= 0 || D <= 0 || (D & 7) || D > LN_MAXC * 512) return WL_EINVAL;
   if (act && !beta) return WL_EINVAL;
@@ -515,7 +521,7 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   const unsigned grid = grid_for(rows, 4, LN_BWD_BLOCKS);
   float* part = (float*)workspace;
 #define LN_BWD_C(T, TP, NCS, CSF) WL_LAUNCH((layernorm_bwd_kernel<T, TP, NCS, CSF>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
-    (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, part, (long)rows, (int)D, (int)act, ti, si, \
+    (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, (const T*)dx_add, part, (long)rows, (int)D, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale)
 #define LN_BWD_N(T, TP, NCS) do { if (dr_colsum) LN_BWD_C(T, TP, NCS, true); else LN_BWD_C(T, TP, NCS, false); } while (0)
 #define LN_BWD(T, TP) do { if (D <= 512) LN_BWD_N(T, TP, 1); else if (D <= 1024) LN_BWD_N(T, TP, 2); else LN_BWD_N(T, TP, 4); } while (0)

@@ -323,10 +323,13 @@ class FFNFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------- LayerNorm
 class LayerNormFn(torch.autograd.Function):
     """y = dropout_out(act(LN(x + dropout_in(r)))); returns (y, s) with s = the pre-norm sum (not differentiable).
-    grad_scale multiplies the incoming gradient (GradMultiply at the extractor output)."""
+    grad_scale multiplies the incoming gradient (GradMultiply at the extractor output).
+    pass_x: also return an alias of x; the gradient that arrives at the alias (the residual stream of a pre-LN block) is
+    added to dx inside the backward kernel instead of by an autograd add."""
 
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, eps, act, p_in, seed_in, p_out, seed_out, grad_scale, rbias_tok=None):
+    def forward(ctx, x, r, gamma, beta, eps, act, p_in, seed_in, p_out, seed_out, grad_scale, rbias_tok=None,
+                pass_x=False):
         xc = x.contiguous()
         rc = r.contiguous() if r is not None else None
         y, s, mean, rstd = ops.layernorm_fwd(xc, rc, gamma, beta, eps, act=act, p_in=p_in, seed_in=seed_in,
@@ -344,12 +347,18 @@ class LayerNormFn(torch.autograd.Function):
         s_out = s.detach()
         ctx.mark_non_differentiable(s_out)
         ctx.set_materialize_grads(False)  # no zero-filled [rows, D] gradient for the second output
+        if pass_x:
+            return y, s_out, x.view_as(x)
         return y, s_out
 
     @staticmethod
-    def backward(ctx, dy, _ds):
+    def backward(ctx, dy, _ds, dx_pass=None):
         if dy is None:
-            return (None,) * 12
+            return (dx_pass,) + (None,) * 12
+        if dx_pass is not None:
+            dx_pass = dx_pass.contiguous()
+            if dx_pass.dtype != dy.dtype:
+                dx_pass = dx_pass.to(dy.dtype)
         s, mean, rstd, gamma, beta = ctx.saved_tensors
         act, p_in, seed_in, p_out, seed_out, grad_scale, has_r = ctx.cfg
         sg, sb = _sink(gamma), _sink(beta)
@@ -362,7 +371,8 @@ class LayerNormFn(torch.autograd.Function):
                                                      seed_in=seed_in, p_out=p_out, seed_out=seed_out,
                                                      grad_scale=grad_scale, need_dr=has_r and p_in > 0,
                                                      dgamma=sg, dbeta=sb,
-                                                     dr_colsum=sc.view(-1) if sc is not None else None)
+                                                     dr_colsum=sc.view(-1) if sc is not None else None,
+                                                     dx_add=dx_pass)
         if sg is not None:
             dgamma = dbeta = None  # accumulated in place
             _sink_written(sg); _sink_written(sb)
@@ -370,15 +380,15 @@ class LayerNormFn(torch.autograd.Function):
             _sink_written(sc)
         if has_r and dr is None:
             dr = dx
-        return dx, (dr if has_r else None), dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, (dr if has_r else None), dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, *, residual=None, act=0, p_in=0.0, p_out=0.0, training=True,
-               grad_scale=1.0, residual_bias_tok=None):
+               grad_scale=1.0, residual_bias_tok=None, pass_x=False):
     p_in = p_in if training else 0.0
     p_out = p_out if training else 0.0
     return LayerNormFn.apply(x, residual, gamma, beta, eps, act, p_in, next_seed() if p_in > 0 else 0, p_out,
-                             next_seed() if p_out > 0 else 0, grad_scale, residual_bias_tok)
+                             next_seed() if p_out > 0 else 0, grad_scale, residual_bias_tok, pass_x)
 
 
 # ------------------------------------------------------------------------------------- feature extractor

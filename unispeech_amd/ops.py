@@ -172,12 +172,16 @@ def layernorm_fwd(x, r, gamma, beta, eps, *, act=0, p_in=0.0, seed_in=0, p_out=0
 
 
 def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0,
-                  grad_scale=1.0, need_dr=False, dgamma=None, dbeta=None, dr_colsum=None):
+                  grad_scale=1.0, need_dr=False, dgamma=None, dbeta=None, dr_colsum=None, dx_add=None):
     """returns (dx, dr, dgamma, dbeta, dr_colsum); given dgamma / dbeta (/ dr_colsum) tensors are accumulated into (+=).
     dr_colsum: True -> also return the column sums of dr (fresh tensor); a tensor -> accumulate into it (only together
-    with dgamma / dbeta tensors: the three share the accumulate flag)."""
+    with dgamma / dbeta tensors: the three share the accumulate flag).  dx_add: added into dx (not into dr)."""
     dev = _dev(dy)
     _contig(dy); _contig(s)
+    if dx_add is not None:
+        _contig(dx_add)
+        if dx_add.shape != dy.shape or dx_add.dtype != dy.dtype:
+            raise ValueError("dx_add must match dy in shape and dtype")
     D = dy.shape[-1]
     rows = dy.numel() // D
     dx = torch.empty_like(dy)
@@ -194,7 +198,7 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0,
     need = L.wavlm_layernorm_bwd_workspace_bytes(D)
     ws = workspace(dev, need)
     check(L.wavlm_layernorm_bwd(ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dr),
-                                ptr(dgamma), ptr(dbeta), ptr(dr_colsum), rows, D, dt(dy), dt(gamma), int(act),
+                                ptr(dx_add), ptr(dgamma), ptr(dbeta), ptr(dr_colsum), rows, D, dt(dy), dt(gamma), int(act),
                                 float(p_in), int(seed_in), float(p_out), int(seed_out), float(grad_scale), int(acc),
                                 ptr(ws), need, stream()), "wavlm_layernorm_bwd")
     return dx, dr, dgamma, dbeta, dr_colsum

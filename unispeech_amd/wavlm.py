@@ -328,14 +328,21 @@ class TransformerSentenceEncoderLayer(nn.Module):
         p = self.dropout if self.training else 0.0
         if self.layer_norm_first:
             wg = self._wgrad_group()
-            h, _ = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps)
-            if torch.is_grad_enabled() and F.CHAIN_CONSUMERS:
-                # h feeds the gate and the q|k|v projection: chained (the alias that comes back is not needed here)
+            chain = torch.is_grad_enabled() and F.CHAIN_CONSUMERS
+            if chain:
+                # x feeds the LayerNorm and the residual add: the LayerNorm hands back an alias and adds the residual
+                # stream's gradient inside its backward kernel.  h feeds the gate and the q|k|v projection: chained too
+                # (the alias of h that comes back is not needed here)
+                h, _, x = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps, pass_x=True)
                 a, position_table, _h = self.self_attn(h, key_padding_u8, position_table, wgroup=wg, chain=True)
             else:
+                h, _ = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps)
                 a, position_table = self.self_attn(h, key_padding_u8, position_table, wgroup=wg)
             x = ResidualAddFn.apply(x, a, p, F.next_seed() if p > 0 else 0)
-            h, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps)
+            if chain:
+                h, _, x = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps, pass_x=True)
+            else:
+                h, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps)
             f = self._ffn(h, wgroup=wg)
             x = ResidualAddFn.apply(x, f, p, F.next_seed() if p > 0 else 0)
         else:
