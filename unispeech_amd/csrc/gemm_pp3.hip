@@ -50,12 +50,26 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  const char* Ab = (const char*)((const bf16_t*)p.A + (long)zo * p.sA_o + (long)zi * p.sA_i + (TA ? (long)m0 : (long)m0 * p.lda));
-  const char* Bb = (const char*)((const bf16_t*)p.B + (long)zo * p.sB_o + (long)zi * p.sB_i + (TB ? (long)n0 : (long)n0 * p.ldb));
+  // panel bases and K range pinned to scalar registers: the DMA asm below takes "SGPR base + 32-bit VGPR offset"
+  auto uni_ptr = [](const char* q_) __attribute__((always_inline)) {
+    const unsigned long v = (unsigned long)q_;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long)hi << 32) | lo);
+  };
+  const char* Ab = uni_ptr((const char*)((const bf16_t*)p.A + (long)zo * p.sA_o + (long)zi * p.sA_i + (TA ? (long)m0 : (long)m0 * p.lda)));
+  const char* Bb = uni_ptr((const char*)((const bf16_t*)p.B + (long)zo * p.sB_o + (long)zi * p.sB_i + (TB ? (long)n0 : (long)n0 * p.ldb)));
   const int kt_per = (p.K + 63) >> 6;
   const int kv_last = p.K - (kt_per - 1) * 64;
   int t0, t1;
   gemm_split_range(p.KB * kt_per, p.split_k, split, t0, t1);
+  t0 = __builtin_amdgcn_readfirstlane(t0); t1 = __builtin_amdgcn_readfirstlane(t1);
+  // LDS-DMA of one 1 KiB piece of a full tile (gemm_pp.hip): M0 = LDS destination, one wait state, then the load with
+  // its address formed by the instruction itself -- no 64-bit address VALU between MFMAs
+  auto dma16 = [&](const char* sbase, unsigned voff32, unsigned char* ldst) __attribute__((always_inline)) {
+    const unsigned lds_dst = (unsigned)(unsigned long)(las_ptr)ldst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_dst), "v"(voff32), "s"(sbase) : "memory", "m0");
+  };
   const int nt = t1 - t0;
 
   // ---- DMA side -------------------------------------------------------------------------------------------------
@@ -155,13 +169,12 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
     constexpr int W = decltype(which_c)::value;
     P3Cursor& c = cur[W];
     if constexpr (W < 3) {
-      __builtin_amdgcn_global_load_lds((gas_ptr)(Ab + c.off * 2 + voffA[W]), (las_ptr)(smem + stage * P3_STAGE + W * P3_AU + wave * 1024), 16, 0, 0);
+      dma16(Ab + c.off * 2, voffA[W], smem + stage * P3_STAGE + W * P3_AU + wave * 1024);
       c.off += stepA;
       if (++c.kt == kt_per) { c.kt = 0; c.off += jumpA; }
     } else {
       constexpr int J0 = 2 * (W - 3);
-      __builtin_amdgcn_global_load_lds((gas_ptr)(Bb + c.off * 2 + voffB[J0 + j]),
-                                       (las_ptr)(smem + stage * P3_STAGE + 3 * P3_AU + (wave * 6 + J0 + j) * 1024), 16, 0, 0);
+      dma16(Bb + c.off * 2, voffB[J0 + j], smem + stage * P3_STAGE + 3 * P3_AU + (wave * 6 + J0 + j) * 1024);
       if (j == 1) {
         c.off += stepB;
         if (++c.kt == kt_per) { c.kt = 0; c.off += jumpB; }
