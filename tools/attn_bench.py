@@ -38,3 +38,11 @@ O, lse = ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234)
 timeit(lambda: ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234), "attention fwd (p=%.2f)" % p, fl)
 timeit(lambda: ops.attn_fused_bwd(qkv, O, dO, lse, gate, tab, None, H, hd ** -0.5, p, 1234), "attention bwd (dq+dkv+red)", 2.5 * fl)
 timeit(lambda: ops.attn_fused_fwd(qkv, None, None, None, H, hd ** -0.5, 0.0, 0), "fwd, no bias, no dropout", fl)
+
+# backward variants: which part of the dQ / dK-dV kernels costs what (per-kernel times: rocprofv3 --kernel-trace --stats,
+# the template arguments in the kernel names are <DROP, TAB> / <DROP>)
+for (use_tab, pp) in ((True, 0.0), (False, p), (False, 0.0)):
+    g_, t_ = (gate, tab) if use_tab else (None, None)
+    O2, lse2 = ops.attn_fused_fwd(qkv, g_, t_, None, H, hd ** -0.5, pp, 1234)
+    timeit(lambda: ops.attn_fused_bwd(qkv, O2, dO, lse2, g_, t_, None, H, hd ** -0.5, pp, 1234),
+           "bwd tab=%d p=%.2f" % (use_tab, pp), 2.5 * fl)

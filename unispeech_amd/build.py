@@ -16,8 +16,10 @@ OBJ_DIR = os.path.join(HERE, "_build")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwavlm_hip.so")
 ARCH = "gfx950"
-SOURCES = ["gemm_bf16.hip", "gemm_pp.hip", "gemm_pp3.hip", "gemm_f32.hip", "rowops.hip", "conv0.hip", "attn.hip", "attn_fused.hip", "posconv.hip", "loss.hip", "vq.hip", "mixing.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_pp.hip", "gemm_pp3.hip", "gemm_f32.hip", "rowops.hip", "conv0.hip", "attn.hip", "attn_fused.hip", "attn_fused_dkv.hip", "posconv.hip", "loss.hip", "vq.hip", "mixing.hip",
            "optim.hip"]
+# per-file extra flags (attn_fused_dkv.hip: see its header)
+EXTRA_FLAGS = {"attn_fused_dkv.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm", "-I", INCLUDE]
 
 
@@ -43,7 +45,7 @@ def _compile(src, force):
     newest = max(os.path.getmtime(srcp), _deps_mtime())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
-    cmd = [_hipcc()] + FLAGS + ["-c", srcp, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

@@ -1,0 +1,143 @@
+// Shared pieces of the fused attention kernels (attn_fused.hip: forward, dQ kernel, launchers; attn_fused_dkv.hip: the
+// dK/dV kernel, a translation unit of its own because it is compiled with -fno-slp-vectorize, see build.py).
+#pragma once
+// Fused gated-relative-position attention for gfx950 (bf16, head_dim 64): QK^T + Toeplitz bias + key padding +
+// online softmax + dropout + PV in one kernel, and a two-kernel backward that recomputes the probabilities from
+// the saved log-sum-exp.  Nothing of size [B*H, T, T] ever reaches HBM (the reference writes the bias, the scores
+// and the probabilities, 862 MB each at B=32: WavLM/modules.py:504-563 + SDPA with a float mask).
+//
+// Layout choice (all three kernels): scores are produced TRANSPOSED, S^T = K.Q^T, with v_mfma_f32_32x32x16_bf16.
+// In the C/D layout (col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) a lane then owns ONE query row and 16
+// keys per 32x32 block, so
+//   * row max / row sum are 15 in-register ops + one exchange with lane ^ 32 (no LDS, no 32-lane shuffles),
+//   * the per-row scalars (gate, running max, normaliser, lse, delta) are plain per-lane registers,
+//   * the probabilities feed the next MFMA directly as its B operand: registers r = 8s .. 8s+7 of a block ARE the
+//     eight k-slots of k-step s.  The A operand (V^T or K^T rows from LDS) is read with the matching key
+//     permutation k-slot (hi, e) <-> key 16s + 4hi + (e&3) + 8(e>>2): two 8-byte LDS reads instead of one 16-byte.
+// The key-contraction products (O = P V, dQ = dS K) therefore need no cross-lane data movement at all.  The
+// query-contraction products (dV = P^T dO, dK = dS^T Q) use the untransposed layout in their own kernel.
+//
+// Bias: bias[i, j] = gate[b,h,i] * rel[h, j - i] is Toeplitz; rel[h, :] (2T-1 floats) is staged in LDS once per
+// block.  Dropout: stateless hash of the element index (b,h,i,j) -> identical mask in all three kernels
+// regardless of which lane holds the element.
+#include "tile_loaders.hpp"
+#include "../../include/wavlm_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
+
+#define FA_HD 64
+#define FA_BQ 128   // query rows per block (forward, dQ kernel): 4 waves x 32
+#define FA_BKV 64   // keys per iteration
+#define FA_BK1 128  // key rows per block (dK/dV kernel): 4 waves x 32
+#define FA_BQ1 64   // query rows per iteration (dK/dV kernel)
+
+// Dropout mask: stateless, identical in all three kernels whichever lane holds element (i, j).
+//   word(i, j >> 1) = mix(row_word(b, h, i) + col_word(j >> 1));  keep(i, j) = 16-bit half (j & 1) of it >= th16
+// row_word / col_word are strong multiplicative hashes (3 x v_mul_lo_u32 each, quarter rate) evaluated once per
+// query row / key pair; the per-element work is only the multiply-free mix (xor-shift / shift-add, full rate) --
+// the previous per-element multiplicative hash was ~1/3 of the forward kernel's VALU time.  The 1/(1-p) factor is
+// never applied per element: forward folds it into the final 1/l, backward into the exponent (lse - log2 sc) and
+// into delta / sc.
+__device__ __forceinline__ unsigned fa_row_word(unsigned s0, unsigned grow) { return hash32(grow ^ s0); }
+__device__ __forceinline__ unsigned fa_col_word(unsigned s1, unsigned jpair) { return hash32((jpair ^ s1) + 0x68E31DA4u); }
+__device__ __forceinline__ unsigned fa_mix(unsigned x) { return drop_mix(x); }
+// Keep decisions of the fused kernels: the two 16-bit halves of a word as SIGNED numbers >= ths = th - 32768 (the same
+// probability as the unsigned form).  Signed, because the forward applies the mask to the PACKED bf16 pair with three
+// packed-integer instructions and no compare / VCC / select:  d = sat(ths - 1 - half) is negative iff the half is kept,
+// d >> 15 (arithmetic) is the 0xffff / 0 keep mask of each half, one v_and_b32 applies both.
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned fa_keepmask2(unsigned w, unsigned k2) {
+  s16x2_t d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, k2), __builtin_bit_cast(s16x2_t, w));
+  d = d >> (short)15;
+  return __builtin_bit_cast(unsigned, d);
+}
+__device__ __forceinline__ bool fa_keep_lo(unsigned w, int ths) { return (int)(short)(w & 0xffffu) >= ths; }
+__device__ __forceinline__ bool fa_keep_hi(unsigned w, int ths) { return ((int)w >> 16) >= ths; }
+#define FA_LOG2E 1.4426950408889634f
+#define FA_LN2 0.6931471805599453f
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return pack_bf16x2(a, b); }
+
+// A-operand fragment for a contraction over the tile's 64 "k" positions stored along LDS rows ([rows][64 k]):
+// k-slot (hi, e) of k-step (f, s) <-> position 32f + 16s + 4hi + (e&3) + 8(e>>2)
+__device__ __forceinline__ bf16x8_t frag_perm(const unsigned char* lds, int row, int f, int s, int hi) {
+  const int c0 = 4 * f + 2 * s;
+  const uint2 lo = *reinterpret_cast<const uint2*>(lds + lds_off(row, c0) + 8 * hi);
+  const uint2 hi2 = *reinterpret_cast<const uint2*>(lds + lds_off(row, c0 + 1) + 8 * hi);
+  U4 u; u.v = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+  return u.b;
+}
+// plain fragment (row, 8 consecutive k at 16kk + 8hi)
+__device__ __forceinline__ bf16x8_t frag_plain(const unsigned char* lds, int row, int kk, int hi) {
+  U4 u; u.v = *reinterpret_cast<const uint4*>(lds + lds_off(row, 2 * kk + hi));
+  return u.b;
+}
+
+// Transposed A-operand fragment straight from a K-contiguous [64 keys][64 hd] tile (no separately staged transpose):
+// rows = head-dim 32 f2 + (l & 31), k-slot (hi, e) of k-step (f, s) <-> key 32f + 16s + 4hi + (e&3) + 8(e>>2), the
+// order in which a lane holds P / dS.  ds_read_b64_tr_b16: lane i of a 16-lane group supplies the address of key
+// (i >> 2), head-dim columns 4 (i & 3) .. +4 and receives column i of the 4 x 16 block.  `tr_base` is the per-lane
+// part of the (swizzled) address, fa_tr_base(); everything else is an immediate.
+__device__ __forceinline__ unsigned fa_tr_base(int lane) {
+  const int hi = lane >> 5, li = lane & 15, g1 = (lane >> 4) & 1;
+  return (unsigned)((4 * hi + (li >> 2)) * 128 + ((((g1 ^ hi) << 1) | (((li >> 1) & 1) ^ (li >> 3))) << 4) + (li & 1) * 8);
+}
+__device__ __forceinline__ bf16x8_t frag_tr(const unsigned char* tile, unsigned tr_base, int f2, int f, int s) {
+  const unsigned char* kt = tile + tr_base + (32 * f + 16 * s) * 128;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(kt + (f2 << 6)));
+  const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(kt + 8 * 128 + ((f2 ^ 1) << 6)));
+  return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// K-contiguous [64 rows][64] tile -> LDS through LDS-DMA; rows past `nrows` are clamped (results unused/masked)
+__device__ __forceinline__ void glds_tile64(const bf16_t* base, long ld, int row0, int nrows, unsigned char* lds,
+                                            int wave_u) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int rr = (t >> 3) + 32 * ps;
+    int row = row0 + rr; if (row > nrows - 1) row = nrows - 1;
+    const bf16_t* src = base + (long)row * ld + (((t & 7) ^ ((rr >> 1) & 7)) << 3);
+    __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(lds + (ps * 32 + wave_u * 8) * 128), 16, 0, 0);
+  }
+}
+
+// block -> (tile along the sequence, batch*head).  The grid is one-dimensional: the dispatcher hands consecutive
+// workgroups to consecutive XCDs (private 4 MiB L2 each), so with the natural order the nqb tiles of one (b, h) -- the
+// only blocks that share K / V (Q / dO in the dK/dV kernel) -- landed on nqb DIFFERENT XCDs and every one of them pulled
+// its own copy from HBM: 483 MB fetched per forward launch against 150 MB algorithmic (PMC, profiles/r01).  Here XCD x
+// takes the heads bh = x (mod 8) and walks their tiles back to back, so a head's tiles run on one XCD at the same time
+// and share its L2.
+__device__ __forceinline__ void fa_block_map(int nqb, int BH, int& qb, int& bh) {
+  const int L = blockIdx.x;
+  if ((BH & 7) == 0) {
+    const int xcd = L & 7, idx = L >> 3;
+    bh = (idx / nqb) * 8 + xcd;
+    qb = idx - (idx / nqb) * nqb;
+  } else {
+    bh = L / nqb;
+    qb = L - bh * nqb;
+  }
+}
+
+struct FaP {
+  const bf16_t* qkv; bf16_t* O; float* lse;
+  const float* gate; const float* tab; const unsigned char* kpm;
+  const bf16_t* dO; bf16_t* dqkv; float* delta; float* dgate; float* dtab_part;
+  int B, H, T; float scale; float sc2; unsigned th; float sc, log2sc, inv_sc; unsigned s0, s1;  // th: 16-bit keep threshold (0 = no dropout)
+  int ths; unsigned k2;  // signed threshold th - 32768; (ths - 1) in both halves
+  int Ltab, Tkb;  // LDS extents: rel table (zero padded) and key bias
+  int nqb;        // tiles along the sequence per (b, h) of the kernel being launched
+};
+
+
+// launcher of the dK/dV kernel (attn_fused_dkv.hip); returns a WL_* code
+int fa_launch_dkv(const FaP& p, unsigned grid, size_t smem, hipStream_t st);
+
+template <typename K> static int fa_set_smem(K kernel, size_t bytes) {
+  if (bytes <= 65536) return WL_OK;
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess
+             ? WL_OK : WL_ELAUNCH;
+}
