@@ -170,6 +170,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 // ds_read_b64_tr_b16 (lane i of a 16-lane group addresses key (i >> 2), head-dim columns 4 (i & 3) .. +4).
 // TAB: relative-position table present (a uniform `if (p.tab)` per element pair inside the score loop cost one basic
 // block, its waits and hazard nops per pair: 34 branches and 92 s_nop per tile iteration)
+// Structure switches of the dQ kernel's tile loop, both measured on the same box against the plain order (227 us):
+// FA_DQ_DEFER (diagonal sums of tile t at the top of tile t + 1) 240 us, FA_DQ_BOTH (both 32-key blocks' score MFMAs
+// before the element passes) 230-235 us.  Neither pays: off.
+#ifndef FA_DQ_DEFER
+#define FA_DQ_DEFER 0
+#endif
+#ifndef FA_DQ_BOTH
+#define FA_DQ_BOTH 0
+#endif
 template <bool DROP, bool TAB>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -264,6 +273,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   glds_tile64(base + 2 * D, D3, 0, T, vbuf(0), wave_u);
   __syncthreads();
 
+  // diagonal sums of a finished tile (first key j0p): six B-operand reads of the skew buffer, six small MFMAs; blocks
+  // 4, 5 of the tile before carry into blocks 0, 1.  FA_DQ_DEFER: run for tile jt - 1 at the top of tile jt, so that
+  // its LDS round trip and MFMA chain sit under this tile's score MFMAs instead of in front of the barrier (the skew
+  // buffer is private to the wave and LDS operations of one wave execute in order: the reads precede this tile's
+  // skew writes).
+  auto skew_sums = [&](int j0p) __attribute__((always_inline)) {
+    f32x4_t nacc[6];
+#pragma unroll
+    for (int cb = 0; cb < 6; ++cb) {
+      U4 bfr; bfr.v = *reinterpret_cast<const uint4*>(sk_r + cb * 1024);
+      const f32x4_t cin = cb < 2 ? dacc[cb + 4] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      nacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfrag.b, bfr.b, cin, 0, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 6; ++cb) dacc[cb] = nacc[cb];
+    const int gsel = lane >> 4;
+    // (a chain of selects on scalars: written as one nested conditional over dacc[.][0] the compiler builds a
+    // dynamically indexed array in scratch)
+    const float a0 = dacc[0][0], a1 = dacc[1][0], a2 = dacc[2][0], a3 = dacc[3][0];
+    float v = a0;
+    v = gsel == 1 ? a1 : v;
+    v = gsel == 2 ? a2 : v;
+    v = gsel == 3 ? a3 : v;
+    const int d = dlo0 + j0p + lane;
+    if (d >= 0 && d < L) prow[d] = v;
+  };
   int cur = 0;
   for (int jt = 0; jt < nkv; ++jt) {
     const int j0 = jt * FA_BKV;
@@ -272,77 +307,84 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
       glds_tile64(base + D, D3, j0 + FA_BKV, T, kbuf(cur ^ 1), wave_u);
       glds_tile64(base + 2 * D, D3, j0 + FA_BKV, T, vbuf(cur ^ 1), wave_u);
     }
+    if constexpr (TAB && FA_DQ_DEFER) {
+      if (jt > 0) skew_sums(j0 - FA_BKV);
+    }
+    U4 dsf0[2], dsf1[2];  // (two arrays, not dsf[2][2]: the 2-D array of unions is not split into registers)
+    f32x16_t s[2], dp[2];
+    // (block index as a type: a run-time index into s / dp / dsf would put the arrays into scratch)
+    using F0 = std::integral_constant<int, 0>;
+    using F1 = std::integral_constant<int, 1>;
+    auto scores = [&](auto fc) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value;
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      // one 32-key block at a time keeps only one (S, dP) accumulator pair live (computing both pairs up front, so that
-      // block 0's element pass runs under block 1's MFMAs, measured no gain: the pass is VALU-bound either way)
-      U4 dsf[2];
-      f32x16_t s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { s[f][r] = 0.f; dp[f][r] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(vbuf(cur), 32 * f + ql, kk, hi), dof[kk].b, dp, 0, 0, 0);
+        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s[f], 0, 0, 0);
+        dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(vbuf(cur), 32 * f + ql, kk, hi), dof[kk].b, dp[f], 0, 0, 0);
       }
-      auto elem_pass = [&](auto edge_c) __attribute__((always_inline)) {
-        constexpr bool EDGE = decltype(edge_c)::value;
+    };
+    auto elem_pass = [&](auto fc, auto edge_c) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value;
+      constexpr bool EDGE = decltype(edge_c)::value;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          float dv[2];
-          unsigned w = 0;
-          if constexpr (DROP) w = fa_mix(roww + colw[(j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi) >> 1]);
+      for (int r = 0; r < 16; r += 2) {
+        float dv[2];
+        unsigned w = 0;
+        if constexpr (DROP) w = fa_mix(roww + colw[(j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi) >> 1]);
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int rr = r + e;
-            const int j = j0 + 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-            const float tv = trow[j];
-            float x = fmaf(s[rr], p.sc2, fmaf(g2, tv, nlse2));  // x - lse as two fmas (the -lse rides in the bias term)
-            if constexpr (EDGE) x += kb[j];
-            const float pe = __builtin_amdgcn_exp2f(x);  // 0 for masked keys (-inf) and rows past T (nlse2 = -inf)
-            float dpe = dp[rr];
-            if constexpr (DROP) dpe = (e ? fa_keep_hi(w, p.ths) : fa_keep_lo(w, p.ths)) ? dpe : 0.f;
-            const float ds = pe * (dpe - dls);
-            dv[e] = ds;
-            dg = fmaf(ds, tv, dg);
-          }
-          const unsigned u2 = pack_bf16(dv[0], dv[1]);
-          dsf[r >> 3].u[(r & 7) >> 1] = u2;
-          if constexpr (TAB) {  // the skew buffer takes dS itself; the gate multiplies inside the diagonal-sum MFMA
-            const int dd = 32 * f + (r & 3) + 8 * (r >> 2);  // + 4 hi is in sk_w
-            sk_w[dd * 32] = (unsigned short)u2;
-            sk_w[(dd + 1) * 32] = (unsigned short)(u2 >> 16);
-          }
+        for (int e = 0; e < 2; ++e) {
+          const int rr = r + e;
+          const int j = j0 + 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+          const float tv = trow[j];
+          float x = fmaf(s[f][rr], p.sc2, fmaf(g2, tv, nlse2));  // x - lse as two fmas (the -lse rides in the bias term)
+          if constexpr (EDGE) x += kb[j];
+          const float pe = __builtin_amdgcn_exp2f(x);  // 0 for masked keys (-inf) and rows past T (nlse2 = -inf)
+          float dpe = dp[f][rr];
+          if constexpr (DROP) dpe = (e ? fa_keep_hi(w, p.ths) : fa_keep_lo(w, p.ths)) ? dpe : 0.f;
+          const float ds = pe * (dpe - dls);
+          dv[e] = ds;
+          dg = fmaf(ds, tv, dg);
         }
-      };
-      if ((p.kpm != nullptr) || (j0 + FA_BKV > T)) elem_pass(std::true_type{}); else elem_pass(std::false_type{});
-      // dQ^T += K^T dS^T (this 32-key block); K^T fragments by transposing reads of the K tile
+        const unsigned u2 = pack_bf16(dv[0], dv[1]);
+        if constexpr (f == 0) dsf0[r >> 3].u[(r & 7) >> 1] = u2; else dsf1[r >> 3].u[(r & 7) >> 1] = u2;
+        if constexpr (TAB) {  // the skew buffer takes dS itself; the gate multiplies inside the diagonal-sum MFMA
+          const int dd = 32 * f + (r & 3) + 8 * (r >> 2);  // + 4 hi is in sk_w
+          sk_w[dd * 32] = (unsigned short)u2;
+          sk_w[(dd + 1) * 32] = (unsigned short)(u2 >> 16);
+        }
+      }
+    };
+    // dQ^T += K^T dS^T (one 32-key block); K^T fragments by transposing reads of the K tile
+    auto dq_acc = [&](auto fc) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value;
 #pragma unroll
       for (int f2 = 0; f2 < 2; ++f2)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          dq[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kbuf(cur), ktr, f2, f, s2), dsf[s2].b, dq[f2], 0, 0, 0);
-        }
-    }
-    if constexpr (TAB) {
-      // diagonal sums of this tile; blocks 4, 5 of the previous tile carry into blocks 0, 1
-      f32x4_t nacc[6];
-#pragma unroll
-      for (int cb = 0; cb < 6; ++cb) {
-        U4 bfr; bfr.v = *reinterpret_cast<const uint4*>(sk_r + cb * 1024);
-        const f32x4_t cin = cb < 2 ? dacc[cb + 4] : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        nacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfrag.b, bfr.b, cin, 0, 0, 0);
-      }
-#pragma unroll
-      for (int cb = 0; cb < 6; ++cb) dacc[cb] = nacc[cb];
-      const int gsel = lane >> 4;
-      const float v = gsel == 0 ? dacc[0][0] : gsel == 1 ? dacc[1][0] : gsel == 2 ? dacc[2][0] : dacc[3][0];
-      const int d = dlo0 + j0 + lane;
-      if (d >= 0 && d < L) prow[d] = v;
-    }
+        for (int s2 = 0; s2 < 2; ++s2)
+          dq[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kbuf(cur), ktr, f2, f, s2), (f == 0 ? dsf0[s2] : dsf1[s2]).b, dq[f2], 0, 0, 0);
+    };
+    const bool edge = (p.kpm != nullptr) || (j0 + FA_BKV > T);
+#if FA_DQ_BOTH
+    // both 32-key blocks' score MFMAs first: 16 independent MFMAs in flight, then 32 elements of VALU, then 8 MFMAs
+    scores(F0{}); scores(F1{});
+    if (edge) { elem_pass(F0{}, std::true_type{}); elem_pass(F1{}, std::true_type{}); }
+    else { elem_pass(F0{}, std::false_type{}); elem_pass(F1{}, std::false_type{}); }
+    dq_acc(F0{}); dq_acc(F1{});
+#else
+    scores(F0{});
+    if (edge) elem_pass(F0{}, std::true_type{}); else elem_pass(F0{}, std::false_type{});
+    dq_acc(F0{});
+    scores(F1{});
+    if (edge) elem_pass(F1{}, std::true_type{}); else elem_pass(F1{}, std::false_type{});
+    dq_acc(F1{});
+#endif
+    if constexpr (TAB && !FA_DQ_DEFER) skew_sums(j0);
     __syncthreads();
     cur ^= 1;
   }
+  if constexpr (TAB && FA_DQ_DEFER) skew_sums((nkv - 1) * FA_BKV);
   if (TAB && lane < 32) {
     // the 31 diagonals past the last tile's first 64 (blocks 4, 5)
     const float v = lane < 16 ? dacc[4][0] : dacc[5][0];
