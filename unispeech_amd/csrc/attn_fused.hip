@@ -179,6 +179,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 #ifndef FA_DQ_BOTH
 #define FA_DQ_BOTH 0
 #endif
+// FA_DQ_PREFETCH: bias-table entries and dropout column words of a tile are read into registers before its score MFMAs
+// (the compiler cannot move those LDS reads above the skew writes of the block before): 229 -> 220 us.
+#ifndef FA_DQ_PREFETCH
+#define FA_DQ_PREFETCH 1
+#endif
+#ifndef FA_DQ_NOSKEW
+#define FA_DQ_NOSKEW 0
+#endif
 template <bool DROP, bool TAB>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -273,6 +281,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
   glds_tile64(base + 2 * D, D3, 0, T, vbuf(0), wave_u);
   __syncthreads();
 
+  float pend_v = 0.f;
+  int pend_d = -1;
   // diagonal sums of a finished tile (first key j0p): six B-operand reads of the skew buffer, six small MFMAs; blocks
   // 4, 5 of the tile before carry into blocks 0, 1.  FA_DQ_DEFER: run for tile jt - 1 at the top of tile jt, so that
   // its LDS round trip and MFMA chain sit under this tile's score MFMAs instead of in front of the barrier (the skew
@@ -296,8 +306,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
     v = gsel == 1 ? a1 : v;
     v = gsel == 2 ? a2 : v;
     v = gsel == 3 ? a3 : v;
-    const int d = dlo0 + j0p + lane;
-    if (d >= 0 && d < L) prow[d] = v;
+    // the store is issued at the top of the NEXT tile: gfx950's vmcnt counts stores, so the s_waitcnt vmcnt(0) that
+    // guards the K/V prefetch in front of the tile barrier would otherwise wait for this store's round trip
+    // (measured neutral: the round trip is not what the relative-position part costs)
+    pend_v = v;
+    pend_d = dlo0 + j0p + lane;
+  };
+  auto flush_pending = [&]() __attribute__((always_inline)) {
+    if (pend_d >= 0 && pend_d < L) prow[pend_d] = pend_v;
+    pend_d = -1;
   };
   int cur = 0;
   for (int jt = 0; jt < nkv; ++jt) {
@@ -307,9 +324,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
       glds_tile64(base + D, D3, j0 + FA_BKV, T, kbuf(cur ^ 1), wave_u);
       glds_tile64(base + 2 * D, D3, j0 + FA_BKV, T, vbuf(cur ^ 1), wave_u);
     }
+    if constexpr (TAB) flush_pending();
     if constexpr (TAB && FA_DQ_DEFER) {
       if (jt > 0) skew_sums(j0 - FA_BKV);
     }
+#if FA_DQ_PREFETCH
+    // bias-table entries and dropout column words of the whole tile, read before the score MFMAs are issued
+    float tvv[2][16];
+    unsigned cww[2][8];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        tvv[f][r] = trow[j];
+        if (DROP && !(r & 1)) cww[f][r >> 1] = colw[j >> 1];
+      }
+#endif
     U4 dsf0[2], dsf1[2];  // (two arrays, not dsf[2][2]: the 2-D array of unions is not split into registers)
     f32x16_t s[2], dp[2];
     // (block index as a type: a run-time index into s / dp / dsf would put the arrays into scratch)
@@ -332,12 +363,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
       for (int r = 0; r < 16; r += 2) {
         float dv[2];
         unsigned w = 0;
+#if FA_DQ_PREFETCH
+        if constexpr (DROP) w = fa_mix(roww + cww[f][r >> 1]);
+#else
         if constexpr (DROP) w = fa_mix(roww + colw[(j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi) >> 1]);
+#endif
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int rr = r + e;
           const int j = j0 + 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+#if FA_DQ_PREFETCH
+          const float tv = tvv[f][rr];
+#else
           const float tv = trow[j];
+#endif
           float x = fmaf(s[f][rr], p.sc2, fmaf(g2, tv, nlse2));  // x - lse as two fmas (the -lse rides in the bias term)
           if constexpr (EDGE) x += kb[j];
           const float pe = __builtin_amdgcn_exp2f(x);  // 0 for masked keys (-inf) and rows past T (nlse2 = -inf)
@@ -351,8 +390,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
         if constexpr (f == 0) dsf0[r >> 3].u[(r & 7) >> 1] = u2; else dsf1[r >> 3].u[(r & 7) >> 1] = u2;
         if constexpr (TAB) {  // the skew buffer takes dS itself; the gate multiplies inside the diagonal-sum MFMA
           const int dd = 32 * f + (r & 3) + 8 * (r >> 2);  // + 4 hi is in sk_w
+#if !FA_DQ_NOSKEW  // (probe: wrong d(rel), prices the skew writes)
           sk_w[dd * 32] = (unsigned short)u2;
           sk_w[(dd + 1) * 32] = (unsigned short)(u2 >> 16);
+#endif
         }
       }
     };
@@ -385,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
     cur ^= 1;
   }
   if constexpr (TAB && FA_DQ_DEFER) skew_sums((nkv - 1) * FA_BKV);
+  if constexpr (TAB) flush_pending();
   if (TAB && lane < 32) {
     // the 31 diagonals past the last tile's first 64 (blocks 4, 5)
     const float v = lane < 16 ? dacc[4][0] : dacc[5][0];
