@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 6
+#define WAVLM_HIP_ABI_VERSION 7
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -208,6 +208,18 @@ int wavlm_posconv_weight_bwd(const float* dWf, const void* v, const void* g, con
 /* x[B,T,D] (optionally * gelu'(aux)) -> group-major, time-padded out[B,G,Tp,D/G]; nat_out optional natural copy */
 int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* nat_out, int32_t B, int32_t T, int32_t D,
                               int32_t G, int32_t left_pad, int32_t Tp, int32_t dtype, int32_t aux_is_grad, void* stream);
+
+/* The grouped convolution itself as a direct convolution (bf16; Cg = 48 or 64; K % 4 == 0): one workgroup per (batch,
+ * group, frame segment) keeps its input window in LDS, the group's weights stream through it.
+ *   out[b, t, g*Cg + n] = res[b, t, g*Cg + n] + f( sum_{tap, ci} xg[b, g, t + tap, ci] * W[g, n, tap*Cg + ci] + bias[g*Cg + n] )
+ * xg [B, G, Tp, Cg] is wavlm_posconv_group_major's output (Tp >= T + K - 1), W one of wavlm_posconv_weight_fwd's images.
+ * gelu != 0: f = GELU and aux (optional, [B, T, G*Cg]) receives the pre-activation for the backward pass -- the
+ * forward, nn.Conv1d(groups=16, k=128) + SamePad + GELU + the residual add of WavLM/WavLM.py:577-579; gelu == 0 with
+ * W = Wb over the group-major dy * gelu': the gradient of x.  bias / res / aux may be NULL.
+ * wavlm_posconv_direct_supported tells whether the shape is covered (otherwise: wavlm_gemm, overlapping-row form). */
+int wavlm_posconv_direct_supported(int32_t Cg, int32_t K, int32_t T);
+int wavlm_posconv_direct(const void* xg, const void* W, const void* bias, const void* res, void* out, void* aux,
+                         int32_t B, int32_t G, int32_t T, int32_t Tp, int32_t Cg, int32_t K, int32_t gelu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Masked-prediction loss (src/fairseq/models/wavlm/wavlm.py:426-438; criterions/wavlm_criterion.py:52-138)

@@ -591,7 +591,12 @@ def check_posconv():
     out = []
     for dtype in (torch.float32, torch.bfloat16):
         tol = tol_for(dtype)
-        for (B, T, D, K, G) in [(2, 49, 64, 16, 4), (2, 75, 768, 128, 16)]:
+        # (.., 768, 128, 16) / (.., 1024, 128, 16) in bf16 run the direct-convolution kernel (Cg = 48 / 64), at one, two
+        # frame segments and every tile height; the rest the overlapping-row GEMM form
+        cases = [(2, 49, 64, 16, 4), (2, 75, 768, 128, 16)]
+        if dtype == torch.bfloat16:
+            cases += [(1, 749, 768, 128, 16), (2, 400, 768, 128, 16), (1, 999, 1024, 128, 16), (2, 330, 1024, 128, 16)]
+        for (B, T, D, K, G) in cases:
             Cg = D // G
             x = q(gen(B, T, D, seed=1), dtype)
             v = q(gen(D, Cg, K, seed=2, scale=math.sqrt(4.0 / (K * D))), dtype)
@@ -612,6 +617,17 @@ def check_posconv():
             out.append((tag + " dv", err(vd.grad, vr.grad), tol * 3))
             out.append((tag + " dg", err(gd.grad, gr.grad), tol * 3))
             out.append((tag + " dbias", err(bd.grad, br.grad), tol * 2))
+            if dtype == torch.bfloat16 and ops.posconv_direct_supported(dtype, Cg, K, T):
+                # the two activation-side implementations against each other (same bf16 inputs, fp32 accumulation)
+                F.POSCONV_DIRECT = False
+                try:
+                    x2 = xd.detach().clone().requires_grad_(True)
+                    y2 = F.PosConvFn.apply(x2, vd.detach(), gd.detach(), bd.detach(), G)
+                    y2.backward(dy.to(dtype).to(DEV))
+                finally:
+                    F.POSCONV_DIRECT = True
+                out.append((tag + " direct vs gemm y", err(yd, y2), 1.0e-2))
+                out.append((tag + " direct vs gemm dx", err(xd.grad, x2.grad), 1.0e-2))
     return out
 
 

@@ -307,6 +307,9 @@ static const float4* gelu_tab4_get(hipStream_t st) {
   return ptr;
 }
 
+// the same table for the other translation units of the library (posconv_direct.hip)
+const float4* wl_gelu_tab4(hipStream_t st) { return gelu_tab4_get(st); }
+
 // ---- optional per-launch timing (bench.py roofline leg): HIP events recorded on the launch stream around every
 // wavlm_gemm call while enabled.  Single-threaded use only (one stream, one host thread).
 #define PROF_MAX 16384

@@ -179,6 +179,7 @@ __device__ __forceinline__ float gelu_both_tab(const float4* tab, float x, float
   grad = fmaf(t.z, x, t.w);
   return fmaf(t.x, x, t.y);
 }
+const float4* wl_gelu_tab4(hipStream_t st);  // device address of the table (gemm_bf16.hip; filled on first use)
 // every thread of the block: global table -> LDS (32 KiB); the caller synchronises before and after
 __device__ __forceinline__ void gelu_tab_stage(const float4* g, float4* lds) {
   for (int i = threadIdx.x; i < GT4_N; i += blockDim.x) lds[i] = g[i];

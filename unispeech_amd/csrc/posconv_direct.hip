@@ -1,0 +1,291 @@
+// Convolutional position embedding, activation side, as a DIRECT grouped convolution on the matrix cores
+// (WavLM/WavLM.py:514-527, 577-579: x + gelu(pos_conv(x))[:, :T]).
+//
+// Round 1 ran it as G*B "overlapping-row" GEMMs: A row t = the K*Cg contiguous elements of the group-major, time-padded
+// activation copy starting at frame t.  That form re-fetches every activation element once per tap: 4.7 GB of
+// L2 -> LDS fill per launch at the Base step shape for 75 MB of distinct data, and the launch ran at the L2 rate
+// (519 us, 0.43 PF/s).  Here one workgroup owns a (batch, group, frame-segment): its whole input window
+// ((BM + K - 1) frames x Cg channels, <= 100 KB) is loaded into LDS ONCE and every tap reads its A fragments from
+// there at a shifted row; only the weights (K*Cg x Cg per group, shared by all batches of the group and L2-resident:
+// workgroup index -> XCD keeps a group on one XCD) stream through a double-buffered LDS chunk.
+//
+// MFMA: v_mfma_f32_16x16x32_bf16, because Cg = 48 (Base) is 3 x 16: no padded output columns (the 128 x 64 tile of
+// the GEMM form wasted 25 %).  A (16 frames x 32 k): lane l holds frame (l & 15), k = 8 (l >> 4) .. +8; the flat
+// k = tap * Cg + ci runs channel-fastest and Cg is a multiple of 8, so a lane's 8 k values are 8 consecutive channels
+// of ONE tap: one ds_read_b128 at row (frame + tap).  B (32 k x 16 columns): lane holds column (l & 15), same k.
+// A wave owns RW = 16 MT frames x all Cg columns: per 32-k slice MT A reads + NT B reads feed MT * NT MFMAs.
+// LDS rows are padded by 8 elements (row stride 112 B at Cg = 48, 144 B at Cg = 64; weight rows 400 B / 272 B): the
+// 16 lanes of a fragment read then touch 16 distinct 16-byte bank groups.
+//
+// Epilogue: accumulators -> the wave's own LDS slice (same padded rows) -> 16-byte row vectors, so that bias,
+// GELU / GELU' (chord table, gemm_common.hpp), the residual and the two outputs move as 96 / 128-byte row segments.
+// Serves the forward (W = Wf, gelu, aux = pre-activation, res = x) and the backward-data pass (W = Wb over the
+// group-major dy * gelu', res = dy) -- the same calls PosConvFn made to wavlm_gemm.
+#include "tile_loaders.hpp"
+#include "gemm_common.hpp"
+#include "../../include/wavlm_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+struct PcdP {
+  const bf16_t* xg; const bf16_t* W; const bf16_t* bias; const bf16_t* res; bf16_t* out; bf16_t* aux;
+  const float4* gtab;
+  int B, G, T, Tp, D, K, nseg, gelu;
+};
+
+template <int CG, int MT, int TC>
+__global__ __launch_bounds__(256, 1) void posconv_direct_kernel(PcdP p) {
+  constexpr int NT = CG / 16;        // 16-column blocks
+  constexpr int C8 = CG / 8;         // 16-byte vectors per activation row
+  constexpr int XR = CG + 8;         // padded LDS row (elements)
+  constexpr int XRB = XR * 2;
+  constexpr int RW = 16 * MT;        // frames per wave
+  constexpr int BM = 4 * RW;         // frames per workgroup
+  constexpr int KC = TC * CG;        // k per weight chunk
+  constexpr int SL = KC / 32;        // 32-k slices per chunk
+  constexpr int VPR = KC / 8;        // 16-byte vectors per weight row of a chunk
+  constexpr int WRB = (KC + 8) * 2;  // padded weight row (bytes)
+  constexpr int NV = CG * VPR;       // vectors per chunk
+  constexpr int NVT = (NV + 255) / 256;
+  static_assert(KC % 32 == 0 && CG % 16 == 0, "chunk must be whole 32-k slices");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int WIN = BM + p.K - 1;
+  unsigned char* xs = smem;
+  unsigned char* wbuf = smem + (size_t)WIN * XRB;  // 2 x CG x WRB
+
+  const int blk = blockIdx.x;
+  const int seg = blk % p.nseg, bg = blk / p.nseg;
+  const int g = bg % p.G, b = bg / p.G;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lm = lane & 15, q = lane >> 4;
+  const int t0 = seg * BM;  // first output frame of the workgroup (= first window row in padded coordinates)
+
+  // ---- input window -> LDS (rows past the padded length are zero)
+  {
+    const bf16_t* src = p.xg + (long)bg * p.Tp * CG;
+    const int nv = WIN * C8;
+    for (int v0 = threadIdx.x; v0 < nv; v0 += 256 * 8) {
+      uint4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + 256 * u;
+        const int row = v / C8, c8 = v - row * C8;
+        r[u] = make_uint4(0, 0, 0, 0);
+        if (v < nv && t0 + row < p.Tp) r[u] = *reinterpret_cast<const uint4*>(src + (long)(t0 + row) * CG + c8 * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + 256 * u;
+        const int row = v / C8, c8 = v - row * C8;
+        if (v < nv) *reinterpret_cast<uint4*>(xs + (size_t)row * XRB + c8 * 16) = r[u];
+      }
+    }
+  }
+  // ---- weight chunks: global -> registers -> LDS
+  const bf16_t* wsrc = p.W + (long)g * CG * ((long)p.K * CG);
+  const long wld = (long)p.K * CG;
+  // (macros, not lambdas: with the register array captured by reference the compiler keeps it in scratch)
+  u32x4_t wr[NVT];
+#define PCD_WLOAD(C)                                                                              \
+  _Pragma("unroll") for (int u = 0; u < NVT; ++u) {                                               \
+    int v = threadIdx.x + 256 * u;                                                                \
+    if (v > NV - 1) v = NV - 1;                                                                   \
+    const int n = v / VPR, kv = v - n * VPR;                                                      \
+    wr[u] = *reinterpret_cast<const u32x4_t*>(wsrc + n * wld + (long)(C) * KC + kv * 8);          \
+  }
+#define PCD_WSTORE(ST)                                                                            \
+  _Pragma("unroll") for (int u = 0; u < NVT; ++u) {                                               \
+    const int v = threadIdx.x + 256 * u;                                                          \
+    const int n = v / VPR, kv = v - n * VPR;                                                      \
+    if (v < NV) *reinterpret_cast<u32x4_t*>(wbuf + (size_t)(ST) * CG * WRB + (size_t)n * WRB + kv * 16) = wr[u]; \
+  }
+  PCD_WLOAD(0)
+  PCD_WSTORE(0)
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane A offsets of the SL slices of a chunk: 16-byte vector index c8i = 4 s + q -> (tap, channel block)
+  unsigned offA[SL];
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    const int c8i = 4 * s + q;
+    const int tap = c8i / C8, cb = c8i - tap * C8;
+    offA[s] = (unsigned)((tap * XR + cb * 8) * 2);
+  }
+  const unsigned char* abase = xs + (size_t)(wave * RW + lm) * XRB;
+  const unsigned boff = (unsigned)(lm * WRB + q * 16);
+  __syncthreads();
+
+  const int NC = p.K / TC;
+  for (int c = 0; c < NC; ++c) {
+    const bool more = c + 1 < NC;
+    if (more) { PCD_WLOAD(c + 1) }
+    const unsigned char* wb = wbuf + (size_t)(c & 1) * CG * WRB + boff;
+    const unsigned char* ab = abase + (size_t)c * TC * XRB;
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      U4 bf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt].v = *reinterpret_cast<const uint4*>(wb + nt * 16 * WRB + s * 64);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        U4 af; af.v = *reinterpret_cast<const uint4*>(ab + offA[s] + mt * 16 * XRB);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.b, bf[nt].b, acc[mt][nt], 0, 0, 0);
+      }
+      // the scheduler would hoist every fragment read of the chunk to its top (MT = 12: 512 VGPRs and spills); fence
+      // every FENCE slices -- the reads of the next group still issue under the tail of this group's MFMAs
+      if constexpr (MT * NT >= 36) { if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0); }
+    }
+    if (more) { PCD_WSTORE((c + 1) & 1) }  // that buffer was last read in chunk c - 1: every wave has passed the barrier since
+    __syncthreads();
+  }
+
+  // ---- epilogue.  The loop's last barrier has passed: the window and the weight buffers are dead.
+  float4* tabL = reinterpret_cast<float4*>(smem + (size_t)BM * XRB);
+  if (p.gelu) {
+    gelu_tab_stage(p.gtab, tabL);
+    __syncthreads();
+  }
+  unsigned char* st = smem + (size_t)wave * RW * XRB;
+  float bias_n[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bias_n[nt] = p.bias ? bf2f(p.bias[g * CG + 16 * nt + lm]) : 0.f;
+  const int tw = t0 + wave * RW;  // first frame of the wave
+  // D[m][n] of a 16 x 16 block: lane holds rows 4 q + i (i = 0..3), column lm
+  auto stage = [&](auto second_c) __attribute__((always_inline)) {
+    constexpr bool SECOND = decltype(second_c)::value;  // false: pre-activation (or the plain result); true: gelu value
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[mt][nt][i];
+          if constexpr (!SECOND) {
+            v += bias_n[nt];
+            if (p.gelu) {  // aux takes the pre-activation itself (what epi = 1 of wavlm_gemm stores)
+              float gr;
+              acc[mt][nt][i] = gelu_both_tab(tabL, v, gr);
+            }
+          }
+          *reinterpret_cast<bf16_t*>(st + (size_t)(16 * mt + 4 * q + i) * XRB + (16 * nt + lm) * 2) = f2bf(v);
+        }
+  };
+  auto flush = [&](bf16_t* dst, const bf16_t* res) __attribute__((always_inline)) {
+    for (int v = lane; v < RW * C8; v += 64) {
+      const int row = v / C8, c8 = v - row * C8;
+      const int t = tw + row;
+      if (t < p.T) {
+        U4 o; o.v = *reinterpret_cast<const uint4*>(st + (size_t)row * XRB + c8 * 16);
+        const long gi = ((long)b * p.T + t) * p.D + g * CG + c8 * 8;
+        if (res) {
+          U4 r; r.v = *reinterpret_cast<const uint4*>(res + gi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(o.u[e] << 16) + __uint_as_float(r.u[e] << 16);
+            const float hi = __uint_as_float(o.u[e] & 0xffff0000u) + __uint_as_float(r.u[e] & 0xffff0000u);
+            o.u[e] = pack_bf16x2(lo, hi);
+          }
+        }
+        *reinterpret_cast<uint4*>(dst + gi) = o.v;
+      }
+    }
+  };
+  // LDS operations of one wave execute in order, so the wave's private slice needs no barrier -- but the COMPILER must
+  // not move the 2-byte stores across the 16-byte loads of the same bytes (different access types: type-based alias
+  // analysis sees no conflict)
+#define PCD_FENCE() asm volatile("" ::: "memory")
+  if (p.gelu) {
+    stage(std::false_type{});          // pre-activation -> aux; the accumulators now hold gelu(pre-activation)
+    PCD_FENCE();
+    if (p.aux) flush(p.aux, nullptr);
+    PCD_FENCE();
+    stage(std::true_type{});
+    PCD_FENCE();
+    flush(p.out, p.res);
+  } else {
+    stage(std::false_type{});
+    PCD_FENCE();
+    flush(p.out, p.res);
+  }
+}
+
+template <int CG, int MT, int TC>
+static int pcd_launch(const PcdP& p, hipStream_t st) {
+  constexpr int BM = 64 * MT;
+  const size_t win = (size_t)(BM + p.K - 1) * (CG + 8) * 2;
+  const size_t wb = (size_t)2 * CG * (TC * CG + 8) * 2;
+  size_t smem = win + wb;
+  const size_t epi = (size_t)BM * (CG + 8) * 2 + (size_t)GT4_N * sizeof(float4);
+  if (smem < epi) smem = epi;
+  if (smem > 160 * 1024) return WL_EINVAL;
+  static size_t allowed = 0;  // per instantiation
+  if (smem > allowed) {
+    if (hipFuncSetAttribute((const void*)posconv_direct_kernel<CG, MT, TC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+      return WL_ELAUNCH;
+    allowed = smem;
+  }
+  WL_LAUNCH((posconv_direct_kernel<CG, MT, TC>), dim3((unsigned)(p.B * p.G * p.nseg)), dim3(256), smem, st, p);
+  return wl_check_launch();
+}
+
+extern "C" {
+
+int wavlm_posconv_direct_supported(int32_t Cg, int32_t K, int32_t T) {
+  if (T <= 0 || K <= 0 || (K & 3)) return 0;
+  return (Cg == 48 || Cg == 64) ? 1 : 0;
+}
+
+// out[b, t, g*Cg + n] = (res) + f(sum_{tap, ci} xg[b, g, t + tap, ci] * W[g, n, tap*Cg + ci] (+ bias)),  f = gelu or id
+int wavlm_posconv_direct(const void* xg, const void* W, const void* bias, const void* res, void* out, void* aux,
+                         int32_t B, int32_t G, int32_t T, int32_t Tp, int32_t Cg, int32_t K, int32_t gelu, void* stream) {
+  if (!xg || !W || !out || B <= 0 || G <= 0 || T <= 0 || Tp < T + K - 1) return WL_EINVAL;
+  if (!wavlm_posconv_direct_supported(Cg, K, T)) return WL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  PcdP p;
+  p.xg = (const bf16_t*)xg; p.W = (const bf16_t*)W; p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)res;
+  p.out = (bf16_t*)out; p.aux = (bf16_t*)aux; p.gtab = nullptr;
+  p.B = B; p.G = G; p.T = T; p.Tp = Tp; p.D = G * Cg; p.K = K; p.gelu = gelu ? 1 : 0;
+  if (p.gelu) {
+    p.gtab = wl_gelu_tab4(st);
+    if (!p.gtab) return WL_ELAUNCH;
+  }
+  // frames per workgroup: the candidate (64 MT) that wastes the fewest padded frames, larger tiles first on ties
+  if (Cg == 48) {
+    const int cand[3] = {12, 8, 6};
+    int best = 0; long bw = -1;
+    for (int i = 0; i < 3; ++i) {
+      const int bm = 64 * cand[i];
+      const long tot = (long)((T + bm - 1) / bm) * bm;
+      if (bw < 0 || tot < bw) { bw = tot; best = i; }
+    }
+    const int mt = cand[best];
+    p.nseg = (T + 64 * mt - 1) / (64 * mt);
+    if (mt == 12) return pcd_launch<48, 12, 4>(p, st);
+    if (mt == 8) return pcd_launch<48, 8, 4>(p, st);
+    return pcd_launch<48, 6, 4>(p, st);
+  } else {
+    const int cand[2] = {8, 6};
+    int best = 0; long bw = -1;
+    for (int i = 0; i < 2; ++i) {
+      const int bm = 64 * cand[i];
+      const long tot = (long)((T + bm - 1) / bm) * bm;
+      if (bw < 0 || tot < bw) { bw = tot; best = i; }
+    }
+    const int mt = cand[best];
+    p.nseg = (T + 64 * mt - 1) / (64 * mt);
+    if (mt == 8) return pcd_launch<64, 8, 2>(p, st);
+    return pcd_launch<64, 6, 2>(p, st);
+  }
+}
+
+}  // extern "C"

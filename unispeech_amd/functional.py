@@ -545,6 +545,9 @@ class ConvStackFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------- pos_conv
+POSCONV_DIRECT = os.environ.get("WAVLM_POSCONV_DIRECT", "1") != "0"
+
+
 class PosConvFn(torch.autograd.Function):
     """out = x + gelu(weight_norm_conv1d(x) + bias)[:, :T]  (WavLM/WavLM.py:514-527, 577-579; SamePad drops the last
     frame).  G*B overlapping-row GEMMs over a group-major, time-padded copy of x; bias, GELU and the residual add
@@ -561,11 +564,16 @@ class PosConvFn(torch.autograd.Function):
         xg, _ = ops.group_major(xc, None, groups, K // 2, Tp)
         out = torch.empty_like(xc)
         u = torch.empty_like(xc)
-        ops.gemm(xg, Wf, out, T, Cg, K * Cg, lda=Cg, ldb=K * Cg, ldc=D, batch=(B, groups),
-                 sA=(groups * Tp * Cg, Tp * Cg), sB=(0, Cg * K * Cg), sC=(T * D, Cg), bias=bias, sBias=(0, Cg), epi=1,
-                 aux=u, ld_aux=D, sAux=(T * D, Cg), res=xc, ld_res=D, sRes=(T * D, Cg))
+        direct = POSCONV_DIRECT and ops.posconv_direct_supported(xc.dtype, Cg, K, T) and bias.dtype == xc.dtype
+        if direct:  # direct convolution: the input window stays in LDS (csrc/posconv_direct.hip)
+            ops.posconv_direct(xg, Wf, out, T, K, bias=bias.contiguous(), res=xc, aux=u, gelu=True)
+        else:
+            ops.gemm(xg, Wf, out, T, Cg, K * Cg, lda=Cg, ldb=K * Cg, ldc=D, batch=(B, groups),
+                     sA=(groups * Tp * Cg, Tp * Cg), sB=(0, Cg * K * Cg), sC=(T * D, Cg), bias=bias, sBias=(0, Cg), epi=1,
+                     aux=u, ld_aux=D, sAux=(T * D, Cg), res=xc, ld_res=D, sRes=(T * D, Cg))
         ctx.save_for_backward(xg, u, Wb, norm, v, g)
         ctx.dims = (B, T, D, K, Cg, groups, Tp)
+        ctx.direct = direct
         return out
 
     @staticmethod
@@ -587,9 +595,12 @@ class PosConvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(dyc)
-            ops.gemm(dug, Wb, dx, T, Cg, K * Cg, lda=Cg, ldb=K * Cg, ldc=D, batch=(B, G),
-                     sA=(G * Tp * Cg, Tp * Cg), sB=(0, Cg * K * Cg), sC=(T * D, Cg), res=dyc, ld_res=D,
-                     sRes=(T * D, Cg))
+            if ctx.direct:
+                ops.posconv_direct(dug, Wb, dx, T, K, res=dyc)
+            else:
+                ops.gemm(dug, Wb, dx, T, Cg, K * Cg, lda=Cg, ldb=K * Cg, ldc=D, batch=(B, G),
+                         sA=(G * Tp * Cg, Tp * Cg), sB=(0, Cg * K * Cg), sC=(T * D, Cg), res=dyc, ld_res=D,
+                         sRes=(T * D, Cg))
         return dx, dv, dg.view_as(g), dbias, None
 
 

@@ -503,6 +503,20 @@ def group_major(x, aux, G, left_pad, Tp, want_nat=False, aux_is_grad=False):
     return out, nat
 
 
+def posconv_direct_supported(x_dtype, Cg, K, T):
+    return x_dtype == torch.bfloat16 and bool(_lib.lib().wavlm_posconv_direct_supported(int(Cg), int(K), int(T)))
+
+
+def posconv_direct(xg, W, out, T, K, *, bias=None, res=None, aux=None, gelu=False):
+    """grouped convolution over the group-major, time-padded copy xg [B, G, Tp, Cg] with the weight image W [G, Cg, K*Cg]:
+    out[B, T, G*Cg] = res + f(conv + bias), f = GELU (aux receives the pre-activation) or identity"""
+    _dev(xg); _contig(xg); _contig(W); _contig(out); _contig(res); _contig(aux)
+    B, G, Tp, Cg = xg.shape
+    check(_lib.lib().wavlm_posconv_direct(ptr(xg), ptr(W), ptr(bias), ptr(res), ptr(out), ptr(aux), B, G, T, Tp, Cg, K,
+                                          int(bool(gelu)), stream()), "wavlm_posconv_direct")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- loss
 def l2norm_fwd(x, out_dtype, eps=1e-8):
     dev = _dev(x); _contig(x)
