@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 7
+#define WAVLM_HIP_ABI_VERSION 8
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -199,9 +199,13 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
  * pos_conv weight side: weight_norm(dim=2) -> GEMM weight images, and its backward (WavLM/WavLM.py:514-527)
  * ------------------------------------------------------------------------------------------ */
 uint64_t wavlm_posconv_weight_workspace_bytes(int32_t D, int32_t Cg, int32_t K);
+/* w[co, ci, k] = g[k] * v[co, ci, k] / ||v[:, :, k]|| as the two operand images of the convolution (Wf: forward; Wb:
+ * gradient of x, taps flipped, channels / columns swapped), G * Cg * K * Cg elements each.  layout 0: [g][column][tap][channel]
+ * (B operand of the overlapping-row GEMM form); layout 1 (K % 16 == 0, Cg % 8 == 0): the image wavlm_posconv_direct
+ * streams, [g][channel / 8][(tap % 16) / 4][tap / 16][tap % 4][column][channel % 8]. */
 int wavlm_posconv_weight_fwd(const void* v, const void* g, int32_t param_dtype, void* Wf, void* Wb, int32_t out_dtype,
-                             float* norm, int32_t D, int32_t Cg, int32_t K, void* workspace, uint64_t ws_bytes,
-                             void* stream);
+                             float* norm, int32_t D, int32_t Cg, int32_t K, int32_t layout, void* workspace,
+                             uint64_t ws_bytes, void* stream);
 int wavlm_posconv_weight_bwd(const float* dWf, const void* v, const void* g, const float* norm, int32_t param_dtype,
                              void* dv, void* dg, int32_t D, int32_t Cg, int32_t K, void* workspace, uint64_t ws_bytes,
                              void* stream);
@@ -209,10 +213,10 @@ int wavlm_posconv_weight_bwd(const float* dWf, const void* v, const void* g, con
 int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* nat_out, int32_t B, int32_t T, int32_t D,
                               int32_t G, int32_t left_pad, int32_t Tp, int32_t dtype, int32_t aux_is_grad, void* stream);
 
-/* The grouped convolution itself as a direct convolution (bf16; Cg = 48 or 64; K % 4 == 0): one workgroup per (batch,
+/* The grouped convolution itself as a direct convolution (bf16; Cg = 48 or 64; K = 128): one workgroup per (batch,
  * group, frame segment) keeps its input window in LDS, the group's weights stream through it.
- *   out[b, t, g*Cg + n] = res[b, t, g*Cg + n] + f( sum_{tap, ci} xg[b, g, t + tap, ci] * W[g, n, tap*Cg + ci] + bias[g*Cg + n] )
- * xg [B, G, Tp, Cg] is wavlm_posconv_group_major's output (Tp >= T + K - 1), W one of wavlm_posconv_weight_fwd's images.
+ *   out[b, t, g*Cg + n] = res[b, t, g*Cg + n] + f( sum_{tap, ci} xg[b, g, t + tap, ci] * w[g, n, tap, ci] + bias[g*Cg + n] )
+ * xg [B, G, Tp, Cg] is wavlm_posconv_group_major's output (Tp >= T + K - 1), W one of wavlm_posconv_weight_fwd's LAYOUT-1 images.
  * gelu != 0: f = GELU and aux (optional, [B, T, G*Cg]) receives the pre-activation for the backward pass -- the
  * forward, nn.Conv1d(groups=16, k=128) + SamePad + GELU + the residual add of WavLM/WavLM.py:577-579; gelu == 0 with
  * W = Wb over the group-major dy * gelu': the gradient of x.  bias / res / aux may be NULL.

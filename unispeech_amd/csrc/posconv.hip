@@ -52,8 +52,16 @@ __global__ __launch_bounds__(1024) void pc_finish_kernel(const float* __restrict
 // one thread per (co, ci, k): writes both GEMM images and norm[k]
 template <typename TP, typename TO>
 __global__ __launch_bounds__(256) void pc_weight_kernel(const TP* __restrict__ v, const TP* __restrict__ g,
-    const float* __restrict__ norm, TO* __restrict__ Wf, TO* __restrict__ Wb, int D, int Cg, int K) {
+    const float* __restrict__ norm, TO* __restrict__ Wf, TO* __restrict__ Wb, int D, int Cg, int K, int layout) {
   const long total = (long)D * Cg * K;
+  const long KC = (long)K * Cg;
+  // element (column n, tap, channel c) of group grp: layout 0 = [n][tap][c] (B operand of the GEMM form); layout 1 = the
+  // direct convolution's image [c / 8][(tap % 16) / 4][tap / 16][tap % 4][n][c % 8] (posconv_direct.hip)
+  auto off = [&](int grp, int n, int tap, int c) -> long {
+    if (layout == 0) return ((long)grp * Cg + n) * KC + (long)tap * Cg + c;
+    const int J = K >> 4;
+    return (long)grp * Cg * KC + (((((long)(c >> 3) * 4 + ((tap & 15) >> 2)) * J + (tap >> 4)) * 4 + (tap & 3)) * Cg + n) * 8 + (c & 7);
+  };
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i % K);
     const long r = i / K;
@@ -61,9 +69,8 @@ __global__ __launch_bounds__(256) void pc_weight_kernel(const TP* __restrict__ v
     const int grp = co / Cg, col = co % Cg;
     const float nrm = norm[k];
     const float w = Elem<TP>::ld(g + k) * Elem<TP>::ld(v + i) / nrm;
-    const long KC = (long)K * Cg;
-    Elem<TO>::st(Wf + ((long)grp * Cg + col) * KC + (long)k * Cg + ci, w);
-    Elem<TO>::st(Wb + ((long)grp * Cg + ci) * KC + (long)(K - 1 - k) * Cg + col, w);
+    Elem<TO>::st(Wf + off(grp, col, k, ci), w);
+    Elem<TO>::st(Wb + off(grp, ci, K - 1 - k, col), w);
   }
 }
 
@@ -144,9 +151,10 @@ uint64_t wavlm_posconv_weight_workspace_bytes(int32_t D, int32_t Cg, int32_t K) 
 }
 
 int wavlm_posconv_weight_fwd(const void* v, const void* g, int32_t param_dtype, void* Wf, void* Wb, int32_t out_dtype,
-                             float* norm, int32_t D, int32_t Cg, int32_t K, void* workspace, uint64_t ws_bytes,
-                             void* stream) {
+                             float* norm, int32_t D, int32_t Cg, int32_t K, int32_t layout, void* workspace,
+                             uint64_t ws_bytes, void* stream) {
   if (!v || !g || !Wf || !Wb || !norm || !workspace || D <= 0 || Cg <= 0 || K <= 0 || K > 1024 || D % Cg) return WL_EINVAL;
+  if (layout != 0 && (layout != 1 || (K & 15) || (Cg & 7))) return WL_EINVAL;
   if (ws_bytes < wavlm_posconv_weight_workspace_bytes(D, Cg, K)) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
@@ -160,16 +168,16 @@ int wavlm_posconv_weight_fwd(const void* v, const void* g, int32_t param_dtype, 
     WL_LAUNCH(pc_finish_kernel, dim3((unsigned)((K + 15) / 16)), dim3(1024), 0, st, part, PC_BLOCKS, (int)K, norm, 1);
     if (out_dtype == WL_F32)
       WL_LAUNCH((pc_weight_kernel<float, float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)v,
-                         (const float*)g, norm, (float*)Wf, (float*)Wb, (int)D, (int)Cg, (int)K);
+                         (const float*)g, norm, (float*)Wf, (float*)Wb, (int)D, (int)Cg, (int)K, (int)layout);
     else
       WL_LAUNCH((pc_weight_kernel<float, bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)v,
-                         (const float*)g, norm, (bf16_t*)Wf, (bf16_t*)Wb, (int)D, (int)Cg, (int)K);
+                         (const float*)g, norm, (bf16_t*)Wf, (bf16_t*)Wb, (int)D, (int)Cg, (int)K, (int)layout);
   } else if (param_dtype == WL_BF16 && out_dtype == WL_BF16) {
     WL_LAUNCH((pc_rowdot_partial_kernel<bf16_t, bf16_t>), dim3(PC_BLOCKS), dim3(th), 0, st, (const bf16_t*)v,
                        (const bf16_t*)v, rows, (int)K, part);
     WL_LAUNCH(pc_finish_kernel, dim3((unsigned)((K + 15) / 16)), dim3(1024), 0, st, part, PC_BLOCKS, (int)K, norm, 1);
     WL_LAUNCH((pc_weight_kernel<bf16_t, bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)v,
-                       (const bf16_t*)g, norm, (bf16_t*)Wf, (bf16_t*)Wb, (int)D, (int)Cg, (int)K);
+                       (const bf16_t*)g, norm, (bf16_t*)Wf, (bf16_t*)Wb, (int)D, (int)Cg, (int)K, (int)layout);
   } else return WL_EINVAL;
   return wl_check_launch();
 }

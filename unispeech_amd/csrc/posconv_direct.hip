@@ -10,12 +10,21 @@
 // workgroup index -> XCD keeps a group on one XCD) stream through a double-buffered LDS chunk.
 //
 // MFMA: v_mfma_f32_16x16x32_bf16, because Cg = 48 (Base) is 3 x 16: no padded output columns (the 128 x 64 tile of
-// the GEMM form wasted 25 %).  A (16 frames x 32 k): lane l holds frame (l & 15), k = 8 (l >> 4) .. +8; the flat
-// k = tap * Cg + ci runs channel-fastest and Cg is a multiple of 8, so a lane's 8 k values are 8 consecutive channels
-// of ONE tap: one ds_read_b128 at row (frame + tap).  B (32 k x 16 columns): lane holds column (l & 15), same k.
-// A wave owns RW = 16 MT frames x all Cg columns: per 32-k slice MT A reads + NT B reads feed MT * NT MFMAs.
-// LDS rows are padded by 8 elements (row stride 112 B at Cg = 48, 144 B at Cg = 64; weight rows 400 B / 272 B): the
-// 16 lanes of a fragment read then touch 16 distinct 16-byte bank groups.
+// the GEMM form wasted 25 %).  The contraction index (tap, channel) is cut into 32-wide slices of FOUR CONSECUTIVE TAPS
+// x one block of 8 channels: lane l of the A fragment (16 frames x 32 k) holds frame (l & 15) at tap tau4 + (l >> 4),
+// channels 8 cb .. +8 -- one ds_read_b128 at window row (frame + tap); the B fragment (32 k x 16 columns) holds column
+// (l & 15) at the same (tap, channels).
+// The convolution is Toeplitz in (frame, tap): the A fragment of frame block mt at taps tau4 + 16 is the fragment of
+// block mt + 1 at taps tau4.  So the slices are walked in groups (cb, rho = tau4 mod 16) of J = K / 16 slices
+// tau4 = rho + 16 j: the group needs only MT + J - 1 distinct A fragments (row block rb = mt + j) for its MT * J
+// (fragment, slice) pairs -- 19 reads instead of 96 at MT = 12.  (The first version read every pair: LDS-bound,
+// 288 us per launch against 125 us of MFMA time.)  Per group a wave reads MT + J - 1 A and J * NT B fragments for
+// MT * J * NT MFMAs.
+// Weights arrive in a matching image (wavlm_posconv_weight_fwd layout 1): per (group of channels g, cb, rho) one
+// contiguous blob [j][tap - tau4][column][8 channels], which is exactly the order the B fragments are read in, so it
+// moves global -> LDS as plain 1 KiB LDS-DMA pieces (double buffered) and is read back without bank conflicts.
+// Activation rows in LDS are padded by 8 elements (row stride 112 B at Cg = 48, 144 B at Cg = 64): the 16 lanes of an A
+// fragment read touch 16 distinct 16-byte bank groups.
 //
 // Epilogue: accumulators -> the wave's own LDS slice (same padded rows) -> 16-byte row vectors, so that bias,
 // GELU / GELU' (chord table, gemm_common.hpp), the residual and the two outputs move as 96 / 128-byte row segments.
@@ -34,25 +43,22 @@ struct PcdP {
   int B, G, T, Tp, D, K, nseg, gelu;
 };
 
-template <int CG, int MT, int TC>
+template <int CG, int MT, int J>
 __global__ __launch_bounds__(256, 1) void posconv_direct_kernel(PcdP p) {
   constexpr int NT = CG / 16;        // 16-column blocks
-  constexpr int C8 = CG / 8;         // 16-byte vectors per activation row
+  constexpr int C8 = CG / 8;         // 16-byte vectors per activation row = channel blocks
   constexpr int XR = CG + 8;         // padded LDS row (elements)
   constexpr int XRB = XR * 2;
   constexpr int RW = 16 * MT;        // frames per wave
   constexpr int BM = 4 * RW;         // frames per workgroup
-  constexpr int KC = TC * CG;        // k per weight chunk
-  constexpr int SL = KC / 32;        // 32-k slices per chunk
-  constexpr int VPR = KC / 8;        // 16-byte vectors per weight row of a chunk
-  constexpr int WRB = (KC + 8) * 2;  // padded weight row (bytes)
-  constexpr int NV = CG * VPR;       // vectors per chunk
-  constexpr int NVT = (NV + 255) / 256;
-  static_assert(KC % 32 == 0 && CG % 16 == 0, "chunk must be whole 32-k slices");
+  constexpr int NA = MT + J - 1;     // distinct A fragments of a group
+  constexpr int GB = J * 4 * CG * 16;  // bytes of one weight blob: [j][4 taps][CG columns][8 channels]
+  constexpr int NG = C8 * 4;         // groups (channel block, rho / 4)
+  static_assert(GB % 4096 == 0, "a blob is whole 1 KiB pieces per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int WIN = BM + p.K - 1;
+  const int WIN = BM + 16 * J - 1;
   unsigned char* xs = smem;
-  unsigned char* wbuf = smem + (size_t)WIN * XRB;  // 2 x CG x WRB
+  unsigned char* wbuf = smem + (size_t)((WIN * XRB + 1023) & ~1023);  // 2 x GB
 
   const int blk = blockIdx.x;
   const int seg = blk % p.nseg, bg = blk / p.nseg;
@@ -62,6 +68,17 @@ __global__ __launch_bounds__(256, 1) void posconv_direct_kernel(PcdP p) {
   const int lm = lane & 15, q = lane >> 4;
   const int t0 = seg * BM;  // first output frame of the workgroup (= first window row in padded coordinates)
 
+  // ---- weight blobs: LDS-DMA, 1 KiB per wave-instruction
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.W) + (size_t)g * NG * GB;
+  auto wdma = [&](int grp, int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < GB / 4096; ++i) {
+      const int piece = wave * (GB / 4096) + i;
+      __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc + (size_t)grp * GB + piece * 1024 + lane * 16),
+                                       (las_ptr)(wbuf + (size_t)st * GB + piece * 1024), 16, 0, 0);
+    }
+  };
+  wdma(0, 0);
   // ---- input window -> LDS (rows past the padded length are zero)
   {
     const bf16_t* src = p.xg + (long)bg * p.Tp * CG;
@@ -83,26 +100,6 @@ __global__ __launch_bounds__(256, 1) void posconv_direct_kernel(PcdP p) {
       }
     }
   }
-  // ---- weight chunks: global -> registers -> LDS
-  const bf16_t* wsrc = p.W + (long)g * CG * ((long)p.K * CG);
-  const long wld = (long)p.K * CG;
-  // (macros, not lambdas: with the register array captured by reference the compiler keeps it in scratch)
-  u32x4_t wr[NVT];
-#define PCD_WLOAD(C)                                                                              \
-  _Pragma("unroll") for (int u = 0; u < NVT; ++u) {                                               \
-    int v = threadIdx.x + 256 * u;                                                                \
-    if (v > NV - 1) v = NV - 1;                                                                   \
-    const int n = v / VPR, kv = v - n * VPR;                                                      \
-    wr[u] = *reinterpret_cast<const u32x4_t*>(wsrc + n * wld + (long)(C) * KC + kv * 8);          \
-  }
-#define PCD_WSTORE(ST)                                                                            \
-  _Pragma("unroll") for (int u = 0; u < NVT; ++u) {                                               \
-    const int v = threadIdx.x + 256 * u;                                                          \
-    const int n = v / VPR, kv = v - n * VPR;                                                      \
-    if (v < NV) *reinterpret_cast<u32x4_t*>(wbuf + (size_t)(ST) * CG * WRB + (size_t)n * WRB + kv * 16) = wr[u]; \
-  }
-  PCD_WLOAD(0)
-  PCD_WSTORE(0)
 
   f32x4_t acc[MT][NT];
 #pragma unroll
@@ -110,42 +107,30 @@ __global__ __launch_bounds__(256, 1) void posconv_direct_kernel(PcdP p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // per-lane A offsets of the SL slices of a chunk: 16-byte vector index c8i = 4 s + q -> (tap, channel block)
-  unsigned offA[SL];
-#pragma unroll
-  for (int s = 0; s < SL; ++s) {
-    const int c8i = 4 * s + q;
-    const int tap = c8i / C8, cb = c8i - tap * C8;
-    offA[s] = (unsigned)((tap * XR + cb * 8) * 2);
-  }
-  const unsigned char* abase = xs + (size_t)(wave * RW + lm) * XRB;
-  const unsigned boff = (unsigned)(lm * WRB + q * 16);
+  const unsigned char* abase = xs + (size_t)(wave * RW + lm + q) * XRB;  // + (4 r4) rows + cb * 16 bytes per group
+  const unsigned boff = (unsigned)((q * CG + lm) * 16);                   // + ((j * 4) * CG + 16 nt) * 16
   __syncthreads();
 
-  const int NC = p.K / TC;
-  for (int c = 0; c < NC; ++c) {
-    const bool more = c + 1 < NC;
-    if (more) { PCD_WLOAD(c + 1) }
-    const unsigned char* wb = wbuf + (size_t)(c & 1) * CG * WRB + boff;
-    const unsigned char* ab = abase + (size_t)c * TC * XRB;
+  for (int grp = 0; grp < NG; ++grp) {
+    if (grp + 1 < NG) wdma(grp + 1, (grp + 1) & 1);  // that buffer was last read in group grp - 1: every wave has passed the barrier since
+    const int cb = grp >> 2, r4 = grp & 3;
+    const unsigned char* ab = abase + (size_t)(4 * r4) * XRB + cb * 16;
+    const unsigned char* wb = wbuf + (size_t)(grp & 1) * GB + boff;
+    U4 af[NA];
 #pragma unroll
-    for (int s = 0; s < SL; ++s) {
+    for (int rb = 0; rb < NA; ++rb) af[rb].v = *reinterpret_cast<const uint4*>(ab + rb * 16 * XRB);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
       U4 bf[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[nt].v = *reinterpret_cast<const uint4*>(wb + nt * 16 * WRB + s * 64);
+      for (int nt = 0; nt < NT; ++nt) bf[nt].v = *reinterpret_cast<const uint4*>(wb + (j * 4 * CG + 16 * nt) * 16);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        U4 af; af.v = *reinterpret_cast<const uint4*>(ab + offA[s] + mt * 16 * XRB);
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.b, bf[nt].b, acc[mt][nt], 0, 0, 0);
-      }
-      // the scheduler would hoist every fragment read of the chunk to its top (MT = 12: 512 VGPRs and spills); fence
-      // every FENCE slices -- the reads of the next group still issue under the tail of this group's MFMAs
-      if constexpr (MT * NT >= 36) { if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0); }
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt + j].b, bf[nt].b, acc[mt][nt], 0, 0, 0);
     }
-    if (more) { PCD_WSTORE((c + 1) & 1) }  // that buffer was last read in chunk c - 1: every wave has passed the barrier since
-    __syncthreads();
+    __syncthreads();  // (waits for this wave's DMA pieces of the next blob, then for everybody's)
   }
 
   // ---- epilogue.  The loop's last barrier has passed: the window and the weight buffers are dead.
@@ -218,34 +203,35 @@ __global__ __launch_bounds__(256, 1) void posconv_direct_kernel(PcdP p) {
   }
 }
 
-template <int CG, int MT, int TC>
+template <int CG, int MT, int J>
 static int pcd_launch(const PcdP& p, hipStream_t st) {
   constexpr int BM = 64 * MT;
-  const size_t win = (size_t)(BM + p.K - 1) * (CG + 8) * 2;
-  const size_t wb = (size_t)2 * CG * (TC * CG + 8) * 2;
+  const size_t win = ((size_t)(BM + 16 * J - 1) * (CG + 8) * 2 + 1023) & ~(size_t)1023;
+  const size_t wb = (size_t)2 * J * 4 * CG * 16;
   size_t smem = win + wb;
   const size_t epi = (size_t)BM * (CG + 8) * 2 + (size_t)GT4_N * sizeof(float4);
   if (smem < epi) smem = epi;
   if (smem > 160 * 1024) return WL_EINVAL;
   static size_t allowed = 0;  // per instantiation
   if (smem > allowed) {
-    if (hipFuncSetAttribute((const void*)posconv_direct_kernel<CG, MT, TC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)posconv_direct_kernel<CG, MT, J>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)
       return WL_ELAUNCH;
     allowed = smem;
   }
-  WL_LAUNCH((posconv_direct_kernel<CG, MT, TC>), dim3((unsigned)(p.B * p.G * p.nseg)), dim3(256), smem, st, p);
+  WL_LAUNCH((posconv_direct_kernel<CG, MT, J>), dim3((unsigned)(p.B * p.G * p.nseg)), dim3(256), smem, st, p);
   return wl_check_launch();
 }
 
 extern "C" {
 
 int wavlm_posconv_direct_supported(int32_t Cg, int32_t K, int32_t T) {
-  if (T <= 0 || K <= 0 || (K & 3)) return 0;
+  if (T <= 0 || K != 128) return 0;  // J = K / 16 = 8 slices per group is a template argument
   return (Cg == 48 || Cg == 64) ? 1 : 0;
 }
 
-// out[b, t, g*Cg + n] = (res) + f(sum_{tap, ci} xg[b, g, t + tap, ci] * W[g, n, tap*Cg + ci] (+ bias)),  f = gelu or id
+// out[b, t, g*Cg + n] = (res) + f(sum_{tap, ci} xg[b, g, t + tap, ci] * w[g, n, tap, ci] (+ bias)),  f = gelu or id;
+// W = the layout-1 image of w (wavlm_posconv_weight_fwd)
 int wavlm_posconv_direct(const void* xg, const void* W, const void* bias, const void* res, void* out, void* aux,
                          int32_t B, int32_t G, int32_t T, int32_t Tp, int32_t Cg, int32_t K, int32_t gelu, void* stream) {
   if (!xg || !W || !out || B <= 0 || G <= 0 || T <= 0 || Tp < T + K - 1) return WL_EINVAL;
@@ -270,9 +256,9 @@ int wavlm_posconv_direct(const void* xg, const void* W, const void* bias, const 
     }
     const int mt = cand[best];
     p.nseg = (T + 64 * mt - 1) / (64 * mt);
-    if (mt == 12) return pcd_launch<48, 12, 4>(p, st);
-    if (mt == 8) return pcd_launch<48, 8, 4>(p, st);
-    return pcd_launch<48, 6, 4>(p, st);
+    if (mt == 12) return pcd_launch<48, 12, 8>(p, st);
+    if (mt == 8) return pcd_launch<48, 8, 8>(p, st);
+    return pcd_launch<48, 6, 8>(p, st);
   } else {
     const int cand[2] = {8, 6};
     int best = 0; long bw = -1;
@@ -283,8 +269,8 @@ int wavlm_posconv_direct(const void* xg, const void* W, const void* bias, const 
     }
     const int mt = cand[best];
     p.nseg = (T + 64 * mt - 1) / (64 * mt);
-    if (mt == 8) return pcd_launch<64, 8, 2>(p, st);
-    return pcd_launch<64, 6, 2>(p, st);
+    if (mt == 8) return pcd_launch<64, 8, 8>(p, st);
+    return pcd_launch<64, 6, 8>(p, st);
   }
 }
 

@@ -559,12 +559,12 @@ class PosConvFn(torch.autograd.Function):
         K = v.shape[2]
         Cg = D // groups
         xc = x.contiguous()
-        Wf, Wb, norm = ops.posconv_weight_fwd(v.contiguous(), g.contiguous().view(-1), xc.dtype)
+        direct = POSCONV_DIRECT and ops.posconv_direct_supported(xc.dtype, Cg, K, T) and bias.dtype == xc.dtype
+        Wf, Wb, norm = ops.posconv_weight_fwd(v.contiguous(), g.contiguous().view(-1), xc.dtype, layout=1 if direct else 0)
         Tp = T + K - 1
         xg, _ = ops.group_major(xc, None, groups, K // 2, Tp)
         out = torch.empty_like(xc)
         u = torch.empty_like(xc)
-        direct = POSCONV_DIRECT and ops.posconv_direct_supported(xc.dtype, Cg, K, T) and bias.dtype == xc.dtype
         if direct:  # direct convolution: the input window stays in LDS (csrc/posconv_direct.hip)
             ops.posconv_direct(xg, Wf, out, T, K, bias=bias.contiguous(), res=xc, aux=u, gelu=True)
         else:

@@ -463,7 +463,8 @@ def attn_fused_bwd(qkv, O, dO, lse, gate, tab, kpm, H, scale, p_drop, seed):
 
 
 # ------------------------------------------------------------------------------------------ pos_conv
-def posconv_weight_fwd(v, g, out_dtype):
+def posconv_weight_fwd(v, g, out_dtype, layout=0):
+    """layout 0: operand images of the GEMM form; 1: of the direct convolution (posconv_direct)"""
     dev = _dev(v); _contig(v)
     D, Cg, K = v.shape
     G = D // Cg
@@ -473,8 +474,8 @@ def posconv_weight_fwd(v, g, out_dtype):
     L = _lib.lib()
     need = L.wavlm_posconv_weight_workspace_bytes(D, Cg, K)
     ws = workspace(dev, need)
-    check(L.wavlm_posconv_weight_fwd(ptr(v), ptr(g), dt(v), ptr(Wf), ptr(Wb), dt(Wf), ptr(norm), D, Cg, K, ptr(ws),
-                                     need, stream()), "wavlm_posconv_weight_fwd")
+    check(L.wavlm_posconv_weight_fwd(ptr(v), ptr(g), dt(v), ptr(Wf), ptr(Wb), dt(Wf), ptr(norm), D, Cg, K, int(layout),
+                                     ptr(ws), need, stream()), "wavlm_posconv_weight_fwd")
     return Wf, Wb, norm
 
 
