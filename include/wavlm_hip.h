@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 8
+#define WAVLM_HIP_ABI_VERSION 9
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -206,9 +206,11 @@ uint64_t wavlm_posconv_weight_workspace_bytes(int32_t D, int32_t Cg, int32_t K);
 int wavlm_posconv_weight_fwd(const void* v, const void* g, int32_t param_dtype, void* Wf, void* Wb, int32_t out_dtype,
                              float* norm, int32_t D, int32_t Cg, int32_t K, int32_t layout, void* workspace,
                              uint64_t ws_bytes, void* stream);
+/* dWf: fp32 gradient of the layout-0 forward image, as `nsplit` slabs of G*Cg*K*Cg elements that are summed first
+ * (1 slab from the GEMM form, wavlm_posconv_dw_direct_splits() from the direct kernel) -> dv, dg in param dtype */
 int wavlm_posconv_weight_bwd(const float* dWf, const void* v, const void* g, const float* norm, int32_t param_dtype,
-                             void* dv, void* dg, int32_t D, int32_t Cg, int32_t K, void* workspace, uint64_t ws_bytes,
-                             void* stream);
+                             void* dv, void* dg, int32_t D, int32_t Cg, int32_t K, int32_t nsplit, void* workspace,
+                             uint64_t ws_bytes, void* stream);
 /* x[B,T,D] (optionally * gelu'(aux)) -> group-major, time-padded out[B,G,Tp,D/G]; nat_out optional natural copy */
 int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* nat_out, int32_t B, int32_t T, int32_t D,
                               int32_t G, int32_t left_pad, int32_t Tp, int32_t dtype, int32_t aux_is_grad, void* stream);
@@ -224,6 +226,13 @@ int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* n
 int wavlm_posconv_direct_supported(int32_t Cg, int32_t K, int32_t T);
 int wavlm_posconv_direct(const void* xg, const void* W, const void* bias, const void* res, void* out, void* aux,
                          int32_t B, int32_t G, int32_t T, int32_t Tp, int32_t Cg, int32_t K, int32_t gelu, void* stream);
+/* The weight gradient of the same convolution, directly from the two group-major copies (bf16; Cg = 48 / 64; K = 128):
+ *   part[s][g][n][tap][ci] = sum over the s-th part of the batch and all t of xg[b, g, t + tap, ci] * dug[b, g, du_off + t, n]
+ * fp32, wavlm_posconv_dw_direct_splits(Cg, G) slabs (0: shape not covered) for wavlm_posconv_weight_bwd to add up.
+ * Replaces the weight-gradient pass of nn.Conv1d(groups=16, k=128) in WavLM/WavLM.py:514-527's backward. */
+int wavlm_posconv_dw_direct_splits(int32_t Cg, int32_t G);
+int wavlm_posconv_dw_direct(const void* xg, const void* dug, float* part, int32_t B, int32_t G, int32_t T, int32_t Tp,
+                            int32_t du_off, int32_t Cg, int32_t K, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Masked-prediction loss (src/fairseq/models/wavlm/wavlm.py:426-438; criterions/wavlm_criterion.py:52-138)

@@ -622,12 +622,14 @@ def check_posconv():
                 F.POSCONV_DIRECT = False
                 try:
                     x2 = xd.detach().clone().requires_grad_(True)
-                    y2 = F.PosConvFn.apply(x2, vd.detach(), gd.detach(), bd.detach(), G)
+                    v2 = vd.detach().clone().requires_grad_(True)
+                    y2 = F.PosConvFn.apply(x2, v2, gd.detach(), bd.detach(), G)
                     y2.backward(dy.to(dtype).to(DEV))
                 finally:
                     F.POSCONV_DIRECT = True
                 out.append((tag + " direct vs gemm y", err(yd, y2), 1.0e-2))
                 out.append((tag + " direct vs gemm dx", err(xd.grad, x2.grad), 1.0e-2))
+                out.append((tag + " direct vs gemm dv", err(vd.grad, v2.grad), 1.0e-2))
     return out
 
 

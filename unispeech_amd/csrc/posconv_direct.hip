@@ -36,6 +36,8 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
 
 struct PcdP {
   const bf16_t* xg; const bf16_t* W; const bf16_t* bias; const bf16_t* res; bf16_t* out; bf16_t* aux;
@@ -225,6 +227,156 @@ static int pcd_launch(const PcdP& p, hipStream_t st) {
   return wl_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------- weight gradient
+// dw[g][n][tap][ci] = sum_{b, t} xg[b, g, t + tap, ci] * du[b, t, g*Cg + n]  (du = dy * gelu'(pre-activation), read from its
+// group-major copy).  The GEMM form (M = K*Cg, N = Cg, contraction over B*T, 128 x 64 tiles) ran at 0.27 PF/s: 830 us at
+// the Base step shape, 1.9 ms at the Large one -- the same per-tap re-fetch of the activations as the forward had.
+//
+// Here the contraction index t is the MFMA's k: D[ci][n] (16 x 16) += A[ci][32 t] * B[32 t][n] for one tap, with both
+// operands "k-strided" in LDS ([frame][channel] rows) and read with the transposing ds_read_b64_tr_b16.  Toeplitz again:
+// the A fragment of tap + 32 at frames t0.. is the fragment of tap at frames t0 + 32.., so a wave owns the FOUR taps
+// rho, rho + 32, rho + 64, rho + 96 of one residue and walks t in steps of 32: each step reads one new A fragment set
+// (NCI of them) and keeps three from the steps before -- 4x fewer activation reads than taps x steps -- plus NT B
+// fragments, for 4 * NCI * NT MFMAs.  A workgroup = NW / NH residues of one channel group (at Cg = 64 the 256
+// accumulator registers of a residue are split over NH = 2 waves by output column); 32 / (NW / NH) workgroups cover
+// the residues, BS of them split the batch: every CU gets one workgroup.  The BS partial sums leave as fp32 slabs and are
+// added by wavlm_posconv_weight_bwd's first kernel (deterministic, no atomics).
+// Frames stream through LDS in chunks of TCH (activation rows TCH + 127, gradient rows TCH), double buffered through
+// registers (rows are padded to Cg + 8 elements, which a DMA image cannot be).
+struct PdwP {
+  const bf16_t* xg; const bf16_t* dug; float* part;
+  int B, G, T, Tp, du_off, K, BS, bchunk;
+};
+
+template <int CG, int NW, int TCH, int NH>
+__global__ __launch_bounds__(NW * 64, 1) void posconv_dw_kernel(PdwP p) {
+  constexpr int NTH = NW * 64;
+  constexpr int NCI = CG / 16, NT = CG / 16 / NH, C8 = CG / 8;  // NH waves share a residue, each takes NT of the column blocks
+  constexpr int NRES = NW / NH;                                // residues per workgroup
+  constexpr int XR = CG + 8, XRB = XR * 2;
+  constexpr int XROWS = TCH + 127;
+  constexpr int STG = (XROWS + TCH) * XRB;       // bytes of one stage: activation rows, then gradient rows
+  constexpr int NVX = XROWS * C8, NVS = (XROWS + TCH) * C8;
+  constexpr int NVT = (NVS + NTH - 1) / NTH;
+  constexpr int NST = TCH / 32;                  // steps per chunk
+  constexpr int RQ = 32 / NRES;                  // workgroups per (channel group, batch split)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int gbs = blockIdx.x % (p.G * p.BS), rq = blockIdx.x / (p.G * p.BS);  // the RQ workgroups that share the same
+  const int bs = gbs % p.BS, g = gbs / p.BS;                                  // data sit on one XCD (G * BS % 8 == 0)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, q = lane >> 4;
+  const int rho = rq * NRES + wave / NH, nh = wave % NH;
+  const int b0 = bs * p.bchunk, b1 = min(p.B, b0 + p.bchunk);
+  const int nch = (p.T + TCH - 1) / TCH;
+  const int nwork = (b1 - b0) * nch;
+
+  f32x4_t acc[4][NCI][NT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < NCI; ++c)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[j][c][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t sr[NVT];
+  // work item w = (batch, frame chunk) -> registers (rows past the padded length / past T are zero)
+#define PDW_LOAD(W)                                                                                   \
+  {                                                                                                   \
+    const int bb = b0 + (W) / nch, tc = (W) - ((W) / nch) * nch;                                       \
+    const bf16_t* xsrc = p.xg + ((long)bb * p.G + g) * p.Tp * CG;                                      \
+    const bf16_t* dsrc = p.dug + (((long)bb * p.G + g) * p.Tp + p.du_off) * CG;                        \
+    _Pragma("unroll") for (int u = 0; u < NVT; ++u) {                                                  \
+      const int v = threadIdx.x + NTH * u;                                                            \
+      const bool isx = v < NVX;                                                                       \
+      const int vv = isx ? v : v - NVX;                                                               \
+      const int row = vv / C8, c8 = vv - row * C8;                                                    \
+      const int fr = tc * TCH + row;                                                                  \
+      const bool ok = v < NVS && (isx ? fr < p.Tp : fr < p.T);                                        \
+      const bf16_t* src = (isx ? xsrc : dsrc) + (long)(ok ? fr : 0) * CG + c8 * 8;                     \
+      u32x4_t val = *reinterpret_cast<const u32x4_t*>(src);                                           \
+      if (!ok) val = u32x4_t{0u, 0u, 0u, 0u};                                                         \
+      sr[u] = val;                                                                                    \
+    }                                                                                                 \
+  }
+#define PDW_STORE(ST)                                                                                 \
+  _Pragma("unroll") for (int u = 0; u < NVT; ++u) {                                                    \
+    const int v = threadIdx.x + NTH * u;                                                              \
+    const int row = v / C8, c8 = v - row * C8;                                                        \
+    if (v < NVS) *reinterpret_cast<u32x4_t*>(smem + (size_t)(ST) * STG + (size_t)row * XRB + c8 * 16) = sr[u]; \
+  }
+  // lane's part of a transposing fragment read: frame row 8 q + (li >> 2), channels 4 (li & 3) .. +4
+  const unsigned troff = (unsigned)((8 * q + (li >> 2)) * XRB + (li & 3) * 8);
+  auto frag = [&](const unsigned char* base) __attribute__((always_inline)) -> bf16x8_t {
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(base));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(base + 4 * XRB));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  if (nwork > 0) {
+    PDW_LOAD(0)
+    PDW_STORE(0)
+  }
+  __syncthreads();
+  for (int w = 0; w < nwork; ++w) {
+    const bool more = w + 1 < nwork;
+    if (more) PDW_LOAD(w + 1)
+    const unsigned char* xb = smem + (size_t)(w & 1) * STG + troff + (size_t)rho * XRB;  // activation frame 0 of tap rho
+    const unsigned char* db = smem + (size_t)(w & 1) * STG + (size_t)XROWS * XRB + troff;
+    bf16x8_t F[4][NCI];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int c = 0; c < NCI; ++c) F[u][c] = frag(xb + (size_t)(32 * u) * XRB + c * 32);
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+#pragma unroll
+      for (int c = 0; c < NCI; ++c) F[(s + 3) & 3][c] = frag(xb + (size_t)(32 * (s + 3)) * XRB + c * 32);
+      bf16x8_t Bf[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) Bf[n] = frag(db + (size_t)(32 * s) * XRB + (nh * NT + n) * 32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < NCI; ++c)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[j][c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(s + j) & 3][c], Bf[n], acc[j][c][n], 0, 0, 0);
+    }
+    if (more) PDW_STORE((w + 1) & 1)  // that stage was last read for work item w - 1: every wave has passed the barrier since
+    __syncthreads();
+  }
+  // D[m][n] of a 16 x 16 block: lane holds rows (channels) 4 q + i, column (output column) li
+  float* out = p.part + ((long)bs * p.G + g) * CG * ((long)p.K * CG);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < NCI; ++c)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int col = 16 * (nh * NT + n) + li, tap = rho + 32 * j;
+        *reinterpret_cast<f32x4_t*>(out + ((long)col * p.K + tap) * CG + 16 * c + 4 * q) = acc[j][c][n];
+      }
+#undef PDW_LOAD
+#undef PDW_STORE
+}
+
+template <int CG, int NW, int TCH, int NH>
+static int pdw_launch(const PdwP& p, hipStream_t st) {
+  const size_t smem = (size_t)2 * (TCH + 127 + TCH) * (CG + 8) * 2;
+  if (smem > 160 * 1024) return WL_EINVAL;
+  static size_t allowed = 0;
+  if (smem > allowed) {
+    if (hipFuncSetAttribute((const void*)posconv_dw_kernel<CG, NW, TCH, NH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+      return WL_ELAUNCH;
+    allowed = smem;
+  }
+  WL_LAUNCH((posconv_dw_kernel<CG, NW, TCH, NH>), dim3((unsigned)(p.G * p.BS * (32 / (NW / NH)))), dim3(NW * 64), smem, st, p);
+  return wl_check_launch();
+}
+
 extern "C" {
 
 int wavlm_posconv_direct_supported(int32_t Cg, int32_t K, int32_t T) {
@@ -278,4 +430,26 @@ int wavlm_posconv_direct(const void* xg, const void* W, const void* bias, const 
   }
 }
 
+
+// number of fp32 slabs wavlm_posconv_dw_direct writes (the batch is split that many ways)
+int wavlm_posconv_dw_direct_splits(int32_t Cg, int32_t G) {
+  if (Cg == 48) return (G * 4) % 8 == 0 ? 4 : 0;
+  if (Cg == 64) return (G * 2) % 8 == 0 ? 2 : 0;
+  return 0;
+}
+
+// part[split][g][n][tap][ci] (fp32, `splits` slabs of G*Cg*K*Cg) = partial sums over the batch of
+// sum_t xg[b, g, t + tap, ci] * dug[b, g, du_off + t, n];  K = 128, Cg = 48 or 64
+int wavlm_posconv_dw_direct(const void* xg, const void* dug, float* part, int32_t B, int32_t G, int32_t T, int32_t Tp,
+                            int32_t du_off, int32_t Cg, int32_t K, void* stream) {
+  if (!xg || !dug || !part || B <= 0 || G <= 0 || T <= 0 || K != 128 || Tp < T + K - 1 || du_off < 0 || du_off + T > Tp)
+    return WL_EINVAL;
+  const int bs = wavlm_posconv_dw_direct_splits(Cg, G);
+  if (bs == 0) return WL_EINVAL;
+  PdwP p;
+  p.xg = (const bf16_t*)xg; p.dug = (const bf16_t*)dug; p.part = part;
+  p.B = B; p.G = G; p.T = T; p.Tp = Tp; p.du_off = du_off; p.K = K; p.BS = bs; p.bchunk = (B + bs - 1) / bs;
+  if (Cg == 48) return pdw_launch<48, 8, 256, 1>(p, (hipStream_t)stream);
+  return pdw_launch<64, 8, 128, 2>(p, (hipStream_t)stream);  // 256 accumulator registers per residue: two waves share it
+}
 }  // extern "C"

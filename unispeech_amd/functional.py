@@ -583,15 +583,19 @@ class PosConvFn(torch.autograd.Function):
         dyc = dy.contiguous()
         dug, du = ops.group_major(dyc, u, G, K // 2 - 1, Tp, want_nat=True)
         dbias = ops.colsum(du.view(B * T, D), v.dtype)
-        # weight gradient in the forward GEMM layout, fp32: dWf[g][col][(tap, ci)]
-        # computed transposed ([(tap, ci)][col]: M = 6144 rows, N = 48): the 48-wide side sits on the 64-column tile
-        # edge (75 % MFMA use) instead of on a 128-row tile edge (37 %) -- 1.26 -> ~0.5 ms at cfg2
-        dWfT = torch.empty((G, K * Cg, Cg), dtype=torch.float32, device=dy.device)
-        ops.gemm(xg, dug, dWfT, K * Cg, Cg, T, lda=Cg, ldb=Cg, ldc=Cg, transA=True, transB=True,
-                 b_off=(K // 2 - 1) * Cg, KB=B, sA_kb=G * Tp * Cg, sB_kb=G * Tp * Cg, batch=(1, G),
-                 sA=(0, Tp * Cg), sB=(0, Tp * Cg), sC=(0, Cg * K * Cg))
-        dWf = dWfT.transpose(1, 2).contiguous()
-        dv, dg = ops.posconv_weight_bwd(dWf, v.contiguous(), g.contiguous().view(-1), norm)
+        if ctx.direct and ops._lib.lib().wavlm_posconv_dw_direct_splits(Cg, G) > 0:
+            # direct form: fp32 partial sums over parts of the batch, added up by the weight-norm backward
+            dWf, nsplit = ops.posconv_dw_direct(xg, dug, K // 2 - 1, T, K)
+        else:
+            # weight gradient in the forward GEMM layout, fp32: dWf[g][col][(tap, ci)]
+            # computed transposed ([(tap, ci)][col]: M = 6144 rows, N = 48): the 48-wide side sits on the 64-column tile
+            # edge (75 % MFMA use) instead of on a 128-row tile edge (37 %) -- 1.26 -> ~0.5 ms at cfg2
+            dWfT = torch.empty((G, K * Cg, Cg), dtype=torch.float32, device=dy.device)
+            ops.gemm(xg, dug, dWfT, K * Cg, Cg, T, lda=Cg, ldb=Cg, ldc=Cg, transA=True, transB=True,
+                     b_off=(K // 2 - 1) * Cg, KB=B, sA_kb=G * Tp * Cg, sB_kb=G * Tp * Cg, batch=(1, G),
+                     sA=(0, Tp * Cg), sB=(0, Tp * Cg), sC=(0, Cg * K * Cg))
+            dWf, nsplit = dWfT.transpose(1, 2).contiguous(), 1
+        dv, dg = ops.posconv_weight_bwd(dWf, v.contiguous(), g.contiguous().view(-1), norm, nsplit=nsplit)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(dyc)

@@ -479,7 +479,8 @@ def posconv_weight_fwd(v, g, out_dtype, layout=0):
     return Wf, Wb, norm
 
 
-def posconv_weight_bwd(dWf, v, g, norm):
+def posconv_weight_bwd(dWf, v, g, norm, nsplit=1):
+    """dWf: fp32 [nsplit, G, Cg, K*Cg] (slabs are summed)"""
     dev = _dev(v)
     D, Cg, K = v.shape
     dv = torch.empty_like(v)
@@ -487,8 +488,8 @@ def posconv_weight_bwd(dWf, v, g, norm):
     L = _lib.lib()
     need = L.wavlm_posconv_weight_workspace_bytes(D, Cg, K)
     ws = workspace(dev, need)
-    check(L.wavlm_posconv_weight_bwd(ptr(dWf), ptr(v), ptr(g), ptr(norm), dt(v), ptr(dv), ptr(dg), D, Cg, K, ptr(ws),
-                                     need, stream()), "wavlm_posconv_weight_bwd")
+    check(L.wavlm_posconv_weight_bwd(ptr(dWf), ptr(v), ptr(g), ptr(norm), dt(v), ptr(dv), ptr(dg), D, Cg, K, int(nsplit),
+                                     ptr(ws), need, stream()), "wavlm_posconv_weight_bwd")
     return dv, dg
 
 
@@ -502,6 +503,20 @@ def group_major(x, aux, G, left_pad, Tp, want_nat=False, aux_is_grad=False):
     check(_lib.lib().wavlm_posconv_group_major(ptr(x), ptr(aux), ptr(out), ptr(nat), B, T, D, G, left_pad, Tp, dt(x),
                                                int(bool(aux_is_grad)), stream()), "wavlm_posconv_group_major")
     return out, nat
+
+
+def posconv_dw_direct(xg, dug, du_off, T, K):
+    """weight gradient of the grouped convolution from the two group-major copies -> (fp32 slabs [S, G, Cg, K*Cg], S)"""
+    dev = _dev(xg); _contig(xg); _contig(dug)
+    B, G, Tp, Cg = xg.shape
+    L = _lib.lib()
+    S = L.wavlm_posconv_dw_direct_splits(Cg, G)
+    if S <= 0:
+        raise ValueError("posconv_dw_direct: shape not covered")
+    part = torch.empty((S, G, Cg, K * Cg), dtype=torch.float32, device=dev)
+    check(L.wavlm_posconv_dw_direct(ptr(xg), ptr(dug), ptr(part), B, G, T, Tp, int(du_off), Cg, K, stream()),
+          "wavlm_posconv_dw_direct")
+    return part, S
 
 
 def posconv_direct_supported(x_dtype, Cg, K, T):
