@@ -19,6 +19,9 @@ bt = torch.zeros(C, device=dev, dtype=torch.bfloat16, requires_grad=True)
 y = F.Conv0Fn.apply(wav, W, gm, bt, 5, 1e-5, torch.bfloat16)
 dy = torch.randn_like(y)
 y.backward(dy)
+for _ in range(2):  # (first calls load the code objects and set the LDS attributes: tens of milliseconds)
+    y = F.Conv0Fn.apply(wav, W, gm, bt, 5, 1e-5, torch.bfloat16)
+    y.backward(dy)
 torch.cuda.synchronize()
 e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 tf = tb = 0.0

@@ -9,11 +9,9 @@
 // time steps of the wave, so every store is one 16-byte (bf16) / 2 x 16-byte (f32) vector and a wave writes a
 // full contiguous 1 KiB / 2 KiB row.  Backward recomputes the same way (conv0 has no input gradient).
 #include "common.hpp"
+#include "conv0_shared.hpp"
 #include "../../include/wavlm_hip.h"
 
-#define C0_KW 10
-#define C0_TCH 512      // time steps per block (forward passes)
-#define C0_TCH_BWD 1024 // time steps per block (backward passes)
 
 template <typename T> struct V8 {
   static __device__ __forceinline__ void ld(const T* p, float (&v)[8]);
@@ -49,9 +47,6 @@ template <> __device__ __forceinline__ void V8<bf16_t>::st(bf16_t* p, const floa
 // evaluation is fma + med3 + cvt + one 8-byte LDS read + fma.  Outside the range the end cells extrapolate (slope 1 /
 // 0 for gelu, 0 for gelu'), NaN and inf propagate through the final fma.  The fp32 (parity) instantiations keep the
 // exact erf path.
-#define GT_N 2048
-#define GT_LO (-8.0f)
-#define GT_INV_H (GT_N / 16.0f)
 __device__ float2 g_gelu_tab[2][GT_N];  // [0] gelu, [1] gelu'
 __global__ void gelu_tab_init_kernel() {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -122,7 +117,6 @@ __device__ __forceinline__ void conv_at(const float* seg, int tt, int stride, co
 // XX[j][k] = sum_t x[s t + j] x[s t + k] (a 10 x 10 Gram matrix per batch row): O(110) instead of O(10 C) work per
 // frame -- the pass that used to recompute the conv for all C channels (0.19 ms at cfg2) is a few microseconds.
 // partx[(b * nchunk + chunk)][112]: Q[10], XX[10][10] of the chunk (fp32 partials over <= 512 frames).
-#define C0_NX 112
 template <typename TW>
 __global__ __launch_bounds__(256) void conv0_gram_kernel(const TW* __restrict__ wav, float* __restrict__ partx, long T,
                                                          int T0, int stride) {
@@ -235,7 +229,6 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const TW* __restrict__
 // Bq needs no accumulation of its own either: sum_t dz * y = sum_k w[c][k] P[c][k], so
 //   Bq = sum_t dz * xhat = rstd * (sum_k w[c][k] P[b,c,k] - mean * A).
 // part[(b * nchunk + chunk)][11][C]: A, P[0..9];  partx[(b * nchunk + chunk)][112]: Q[10], XX[10][10]
-#define C0_NQ (1 + C0_KW)
 #define C0_LN_NQ (3 + C0_KW)  // layer_norm mode: dbeta, dgamma, dW[.][0..9], dbias (conv_bias=True; zero work otherwise)
 template <typename TW, typename TP, typename TO>
 __global__ __launch_bounds__(256) void conv0_bwd_fused_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
@@ -559,6 +552,9 @@ __global__ __launch_bounds__(256) void conv0_ln_bwd_finish_kernel(const float* _
   }
 }
 
+// WAVLM_CONV0_BWD_MFMA=0 keeps the VALU form of the GroupNorm-mode backward (A/B and fallback)
+static const bool g_conv0_bwd_mfma = [] { const char* e = getenv("WAVLM_CONV0_BWD_MFMA"); return !(e && e[0] == '0'); }();
+
 static inline size_t seg_floats(int tch, int stride) { return (size_t)(((tch - 1) * stride + C0_KW + 3) / 4 * 4); }
 
 extern "C" {
@@ -637,7 +633,18 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
 #define B1(TW, TP, TO) WL_LAUNCH((conv0_bwd_fused_kernel<TW, TP, TO>), grid, dim3(256), sm1, st, (const TW*)wav, \
     (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (const TO*)g, part, partx, (long)T, T0, (int)C, (int)stride, gscale)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
-  if (key == 0) B1(float, float, float);
+  if (key == 111 && C == 512 && g_conv0_bwd_mfma) {
+    static const float2* tab1 = nullptr;
+    if (!tab1) {
+      void* a = nullptr;
+      if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_gelu_tab)) != hipSuccess) return WL_ELAUNCH;
+      tab1 = (const float2*)a + GT_N;  // [1] = gelu'
+    }
+    const int rc1 = conv0_bwd_mfma_launch(wav, W, gamma, beta, stats, g, part, partx, (long)T, T0, (int)stride, gscale, nchunk,
+                                          (int)B, tab1, st);
+    if (rc1 != WL_OK) return rc1;
+  }
+  else if (key == 0) B1(float, float, float);
   else if (key == 111) B1(bf16_t, bf16_t, bf16_t);
   else if (key == 11) B1(float, bf16_t, bf16_t);
   else if (key == 1) B1(float, float, bf16_t);

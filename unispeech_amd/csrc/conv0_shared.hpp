@@ -1,0 +1,17 @@
+// Constants shared by conv0.hip and conv0_bwd_mfma.hip (the latter is a translation unit of its own: build.py compiles it
+// with -fno-slp-vectorize).
+#pragma once
+#define C0_KW 10
+#define C0_TCH 512      // time steps per block (forward passes)
+#define C0_TCH_BWD 1024 // time steps per block (backward passes)
+// GELU / GELU' chord tables (conv0.hip): 2048 cells over [-8, 8), cell = (slope, intercept)
+#define GT_N 2048
+#define GT_LO (-8.0f)
+#define GT_INV_H (GT_N / 16.0f)
+#define C0_NQ (1 + C0_KW)   // chunk partials of the GroupNorm-mode backward: A, P[0..9]
+#define C0_NX 112           // waveform partials: Q[10], XX[10][10]
+// GroupNorm-mode backward on the matrix cores (bf16 waveform / parameters / gradient, C = 512); tab1 = device address of the
+// GELU' table; returns a WL_* code
+int conv0_bwd_mfma_launch(const void* wav, const void* W, const void* gamma, const void* beta, const float* stats, const void* g,
+                          float* part, float* partx, long T, int T0, int stride, float gscale, int nchunk, int B,
+                          const float2* tab1, hipStream_t st);
