@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 9
+#define WAVLM_HIP_ABI_VERSION 10
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -190,10 +190,14 @@ int wavlm_attn_fused_fwd(const void* qkv, void* O, float* lse, const float* gate
                          int32_t B, int32_t H, int32_t T, int32_t head_dim, float scale, float p_drop, uint64_t seed,
                          void* stream);
 uint64_t wavlm_attn_fused_bwd_workspace_bytes(int32_t B, int32_t H, int32_t T);
+/* dqkv [B, T, 3*H*64], dgate [B, H, T], dtab [H, 2T-1] from dO and the forward's (qkv, O, lse).
+ * dbias (optional, [3*H*64], dbias_dtype, (+)= if dbias_accumulate): column sums of dqkv over all B*T rows, i.e. the bias
+ * gradient of the packed q|k|v projection (WavLM/modules.py:504-520 in_proj_bias) -- it falls out of the kernels that produce
+ * dq / dk / dv (per-block column sums + one finishing launch) instead of a separate pass over dqkv. */
 int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
-                         const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, int32_t B,
-                         int32_t H, int32_t T, int32_t head_dim, float scale, float p_drop, uint64_t seed,
-                         void* workspace, uint64_t ws_bytes, void* stream);
+                         const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, void* dbias,
+                         int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T, int32_t head_dim,
+                         float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * pos_conv weight side: weight_norm(dim=2) -> GEMM weight images, and its backward (WavLM/WavLM.py:514-527)

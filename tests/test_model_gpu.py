@@ -258,6 +258,13 @@ def test_gradient_sink_matches_autograd_accumulation():
     for b in grads[1:]:
         assert a.keys() == b.keys()
         for n in a:
+            if n.endswith("k_proj.bias"):
+                # mathematically zero (a constant added to every key shifts each softmax row by a constant): what is left
+                # is rounding noise of the order 1e-5, which the two paths round differently (the sink path sums the fp32
+                # dk before it is rounded to bf16).  Bounded against the q bias of the same layer instead.
+                qn = n.replace("k_proj", "q_proj")
+                assert b[n].abs().max().item() < 2e-2 * max(a[qn].abs().max().item(), 1e-3), n
+                continue
             scale = a[n].abs().max().clamp_min(1e-6)
             assert ((a[n] - b[n]).abs().max() / scale).item() < 2e-2, n
 

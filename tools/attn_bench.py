@@ -37,6 +37,10 @@ fl = 4.0 * B * H * T * T * hd
 O, lse = ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234)
 timeit(lambda: ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234), "attention fwd (p=%.2f)" % p, fl)
 timeit(lambda: ops.attn_fused_bwd(qkv, O, dO, lse, gate, tab, None, H, hd ** -0.5, p, 1234), "attention bwd (dq+dkv+red)", 2.5 * fl)
+if os.environ.get("ATTN_BENCH_DBIAS", "0") == "1":  # with the q|k|v bias gradient delivered by the backward kernels
+    db = torch.zeros(3 * D, device=dev)
+    timeit(lambda: ops.attn_fused_bwd(qkv, O, dO, lse, gate, tab, None, H, hd ** -0.5, p, 1234, dbias=db, dbias_accumulate=True),
+           "attention bwd + dbias", 2.5 * fl)
 timeit(lambda: ops.attn_fused_fwd(qkv, None, None, None, H, hd ** -0.5, 0.0, 0), "fwd, no bias, no dropout", fl)
 
 # backward variants: which part of the dQ / dK-dV kernels costs what (per-kernel times: rocprofv3 --kernel-trace --stats,

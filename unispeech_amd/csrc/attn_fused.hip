@@ -434,6 +434,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
     if (d >= 0 && d < L) prow[d] = v;
   }
   dg += __shfl_xor(dg, 32, 64);
+  if (p.dbias_part)  // rows past T carry dS = 0, i.e. dq = 0
+    fa_wave_colsum(dq, p.scale, reinterpret_cast<float*>(smem),
+                   p.dbias_part + (((long)b * p.nqb + qblk) * 4 + wave_u) * D3 + h * FA_HD, lane, wave_u);
   if (valid_i) {
     bf16_t* dst = p.dqkv + ((long)b * T + i) * D3 + h * FA_HD;
 #pragma unroll
@@ -523,7 +526,7 @@ static FaP fa_params(int B, int H, int T, float scale, float p_drop, uint64_t se
   p.Tkb = nkv * FA_BKV;
   p.Ltab = (T + p.Tkb + 3) & ~3;  // index j - i + T - 1 with j < Tkb, i >= 0
   p.qkv = nullptr; p.O = nullptr; p.lse = nullptr; p.gate = nullptr; p.tab = nullptr; p.kpm = nullptr;
-  p.dO = nullptr; p.dqkv = nullptr; p.delta = nullptr; p.dgate = nullptr; p.dtab_part = nullptr;
+  p.dO = nullptr; p.dqkv = nullptr; p.delta = nullptr; p.dgate = nullptr; p.dtab_part = nullptr; p.dbias_part = nullptr;
   return p;
 }
 
@@ -553,14 +556,15 @@ int wavlm_attn_fused_fwd(const void* qkv, void* O, float* lse, const float* gate
 uint64_t wavlm_attn_fused_bwd_workspace_bytes(int32_t B, int32_t H, int32_t T) {
   const uint64_t nqt = (uint64_t)((T + FA_BQ - 1) / FA_BQ);
   const uint64_t Lp = (2 * (uint64_t)T - 1 + 3) & ~(uint64_t)3;
-  return ((uint64_t)B * H * nqt * 4 * Lp + (uint64_t)B * H * T) * sizeof(float);  // per-wave d(rel) rows + delta
+  // per-wave d(rel) rows + delta + per-wave column sums of dq | dk | dv
+  return ((uint64_t)B * H * nqt * 4 * Lp + (uint64_t)B * H * T + (uint64_t)B * nqt * 4 * 3 * H * FA_HD) * sizeof(float);
 }
 
 // dqkv[B,T,3*H*64], dgate[B,H,T], dtab[H,2T-1] from dO and the forward's (qkv, O, lse)
 int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
-                         const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, int32_t B,
-                         int32_t H, int32_t T, int32_t head_dim, float scale, float p_drop, uint64_t seed,
-                         void* workspace, uint64_t ws_bytes, void* stream) {
+                         const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, void* dbias,
+                         int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T, int32_t head_dim,
+                         float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes, void* stream) {
   if (!qkv || !O || !dO || !lse || !dqkv || !workspace || B <= 0 || H <= 0 || T <= 0 || head_dim != FA_HD)
     return WL_EINVAL;
   if ((gate == nullptr) != (tab == nullptr)) return WL_EINVAL;
@@ -575,7 +579,9 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
   p.dtab_part = (float*)workspace;
   const int Lp = (L + 3) & ~3;
   p.delta = p.dtab_part + (long)B * H * nqt * 4 * Lp;
-  const size_t smem1 = 32768 + 4 * 6144 + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float) + 256;  // + gate fragments
+  if (dbias) p.dbias_part = p.delta + (long)B * H * T;
+  size_t smem1 = 32768 + 4 * 6144 + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float) + 256;  // + gate fragments
+  if (smem1 < FA_CS_FLOATS * sizeof(float)) smem1 = FA_CS_FLOATS * sizeof(float);
   p.nqb = nqt;
   if (p.th) {
 #define FA_DQ(DR, TB) do { if (fa_set_smem(attn_bwd_dq_kernel<DR, TB>, smem1) != WL_OK) return WL_ELAUNCH; \
@@ -585,12 +591,17 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
     if (tab) FA_DQ(false, true); else FA_DQ(false, false);
   }
 #undef FA_DQ
-  const size_t smem2 = 32768 + (size_t)(p.Ltab + 64 + 2 * 256) * sizeof(float);
+  size_t smem2 = 32768 + (size_t)(p.Ltab + 64 + 2 * 256) * sizeof(float);
+  if (smem2 < FA_CS_FLOATS * sizeof(float)) smem2 = FA_CS_FLOATS * sizeof(float);
   p.nqb = (T + FA_BK1 - 1) / FA_BK1;
   const dim3 grid2((unsigned)(p.nqb * B * H));
   {
     const int rc = fa_launch_dkv(p, grid2.x, smem2, st);
     if (rc != WL_OK) return rc;
+  }
+  if (dbias) {  // [B * nqt * 4] partial rows x 3 * H * 64 columns -> the bias gradient ((+)= in its own dtype)
+    const int rcb = wl_colsum_finish(p.dbias_part, B * nqt * 4, 3 * H * FA_HD, dbias, dbias_dtype, dbias_accumulate, st);
+    if (rcb != WL_OK) return rcb;
   }
   if (tab)
     WL_LAUNCH(fa_dtab_reduce_kernel, dim3((unsigned)((Lp / 4 + 15) / 16), (unsigned)H), dim3(1024), 0, st,

@@ -126,12 +126,45 @@ struct FaP {
   const bf16_t* qkv; bf16_t* O; float* lse;
   const float* gate; const float* tab; const unsigned char* kpm;
   const bf16_t* dO; bf16_t* dqkv; float* delta; float* dgate; float* dtab_part;
+  float* dbias_part;  // optional [B * nqb * 4][3 * H * 64]: per-wave column sums of dq | dk | dv (the q|k|v bias gradient)
   int B, H, T; float scale; float sc2; unsigned th; float sc, log2sc, inv_sc; unsigned s0, s1;  // th: 16-bit keep threshold (0 = no dropout)
   int ths; unsigned k2;  // signed threshold th - 32768; (ths - 1) in both halves
   int Ltab, Tkb;  // LDS extents: rel table (zero padded) and key bias
   int nqb;        // tiles along the sequence per (b, h) of the kernel being launched
 };
 
+
+// Column sums of a wave's gradient rows (the packed q|k|v projection's bias gradient falls out of the kernels that
+// produce dq / dk / dv instead of a separate pass over dqkv).  The wave's 32 x 64 fp32 block goes through its own LDS
+// slice (rows padded to 68 floats: 16-byte row-vector writes, conflict-free column reads), lane c adds up column c and
+// writes it to the wave's own partial row -- no barrier, every (row, column) of the partial matrix has one writer.
+// `red`: 4 * 32 * 68 floats of LDS, free after the tile loop's last barrier.
+// (History: a butterfly of 160 ds_bpermute per wave cost 28-58 us per launch; a block-level sum with two barriers per call
+// 20 us per launch -- 2300 blocks pay the barrier latency four and a half deep per CU.)
+#define FA_CS_LD 68
+#define FA_CS_FLOATS (4 * 32 * FA_CS_LD)
+__device__ __forceinline__ void fa_wave_colsum(const f32x16_t (&a)[2], float scale, float* red, float* dst, int lane,
+                                               int wave) {
+  const int hi = lane >> 5, ql = lane & 31;
+  float* buf = red + wave * (32 * FA_CS_LD);
+#pragma unroll
+  for (int f2 = 0; f2 < 2; ++f2)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 v = make_float4(a[f2][4 * q4] * scale, a[f2][4 * q4 + 1] * scale, a[f2][4 * q4 + 2] * scale,
+                                   a[f2][4 * q4 + 3] * scale);
+      *reinterpret_cast<float4*>(buf + ql * FA_CS_LD + 32 * f2 + 8 * q4 + 4 * hi) = v;
+    }
+  asm volatile("" ::: "memory");  // same wave, LDS executes in order; the compiler must keep the order too
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 32; r += 4) {
+    s0 += buf[r * FA_CS_LD + lane]; s1 += buf[(r + 1) * FA_CS_LD + lane];
+    s2 += buf[(r + 2) * FA_CS_LD + lane]; s3 += buf[(r + 3) * FA_CS_LD + lane];
+  }
+  dst[lane] = (s0 + s1) + (s2 + s3);
+  asm volatile("" ::: "memory");  // the slice is reused by the wave's next call
+}
 
 // launcher of the dK/dV kernel (attn_fused_dkv.hip); returns a WL_* code
 int fa_launch_dkv(const FaP& p, unsigned grid, size_t smem, hipStream_t st);

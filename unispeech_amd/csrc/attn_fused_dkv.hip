@@ -139,13 +139,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
     __syncthreads();
     cur ^= 1;
   }
+  if (!key_ok) {  // padded keys and keys past T
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[f][r] = 0.f; dv[f][r] = 0.f; }
+  }
+  if (p.dbias_part) {
+    float* drow = p.dbias_part + (((long)b * p.nqb + kblk) * 4 + wave_u) * D3 + h * FA_HD;
+    fa_wave_colsum(dk, p.scale, reinterpret_cast<float*>(smem), drow + D, lane, wave_u);
+    fa_wave_colsum(dv, 1.f, reinterpret_cast<float*>(smem), drow + 2 * D, lane, wave_u);
+  }
   if (j < T) {
-    if (!key_ok) {
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[f][r] = 0.f; dv[f][r] = 0.f; }
-    }
     bf16_t* dst = p.dqkv + ((long)b * T + j) * D3 + h * FA_HD;
 #pragma unroll
     for (int f2 = 0; f2 < 2; ++f2)

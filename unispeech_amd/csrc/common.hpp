@@ -176,3 +176,6 @@ static inline int wl_check_launch() {
   wl_launch_failed = 0;
   return e ? WL_ELAUNCH : WL_OK;
 }
+
+// rowops.hip: out[c] (+)= sum over nblk rows of part[nblk][n]
+int wl_colsum_finish(const float* part, int nblk, int n, void* out, int out_dtype, int accumulate, hipStream_t st);

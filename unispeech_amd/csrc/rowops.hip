@@ -541,6 +541,16 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   return wl_check_launch();
 }
 
+}  // extern "C"
+// out[c] (+)= sum over nblk partial rows of n floats (row stride n): the finishing launch on its own, for kernels that
+// produce the partial rows themselves (attention backward: q|k|v bias gradient)
+int wl_colsum_finish(const float* part, int nblk, int n, void* out, int out_dtype, int accumulate, hipStream_t st) {
+  WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, st, part, nblk, (long)n, n, out, out_dtype,
+            accumulate, 0L, (void*)nullptr, (void*)nullptr);
+  return wl_check_launch();
+}
+extern "C" {
+
 uint64_t wavlm_colsum_workspace_bytes(int32_t N) { return (uint64_t)CS_BLOCKS * N * sizeof(float); }
 
 int wavlm_colsum(const void* x, int64_t rows, int32_t N, int64_t ld, int32_t dtype, const uint8_t* include_mask,

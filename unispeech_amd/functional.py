@@ -674,13 +674,20 @@ class AttnCoreFn(torch.autograd.Function):
     [B*H, T, T] bias tensor of the reference is never built); S (fp32) and P are kept for backward."""
 
     @staticmethod
-    def forward(ctx, qkv, gate, tab, kpm, H, scale, p_drop, seed):
+    def forward(ctx, qkv, gate, tab, kpm, H, scale, p_drop, seed, qkv_bias_tok=None, qkv_bias_sink=None):
+        """qkv_bias_tok / qkv_bias_sink: hand-over of the packed q|k|v projection's bias gradient (BiasGradToken): the fused
+        backward kernels deliver it (column sums of dq | dk | dv per block + one finishing launch) and the projection skips
+        its own pass over dqkv."""
         B, T, D3 = qkv.shape
         D = D3 // 3
         hd = D // H
         dev = qkv.device
         qkvc = qkv.contiguous()
         ctx.fused = USE_FUSED_ATTENTION and qkv.dtype == torch.bfloat16 and hd == 64
+        ctx.bias_sink = None
+        if ctx.fused and qkv_bias_tok is not None and qkv_bias_sink is not None and ctx.needs_input_grad[0]:
+            qkv_bias_tok.taken = True
+            ctx.bias_sink = qkv_bias_sink
         if ctx.fused:
             O, lse = ops.attn_fused_fwd(qkvc, gate, tab, kpm, H, scale, p_drop, seed)
             ctx.save_for_backward(qkvc, O, lse, gate, tab, kpm)
@@ -705,8 +712,12 @@ class AttnCoreFn(torch.autograd.Function):
         if ctx.fused:
             qkvc, O, lse, gate, tab, kpm = ctx.saved_tensors
             B, T, D, H, hd, _, scale, p_drop, seed = ctx.cfg
-            dqkv, dgate, dtab = ops.attn_fused_bwd(qkvc, O, dO.contiguous(), lse, gate, tab, kpm, H, scale, p_drop, seed)
-            return dqkv, dgate, dtab, None, None, None, None, None
+            sb = ctx.bias_sink
+            dqkv, dgate, dtab = ops.attn_fused_bwd(qkvc, O, dO.contiguous(), lse, gate, tab, kpm, H, scale, p_drop, seed,
+                                                   dbias=sb.view(-1) if sb is not None else None, dbias_accumulate=True)
+            if sb is not None:
+                _sink_written(sb)
+            return dqkv, dgate, dtab, None, None, None, None, None, None, None
         qkvc, S, P, lse, gate, tab, kpm = ctx.saved_tensors
         B, T, D, H, hd, ld, scale, p_drop, seed = ctx.cfg
         D3 = 3 * D
@@ -729,7 +740,7 @@ class AttnCoreFn(torch.autograd.Function):
                  sA=(H * T * ld, T * ld), sB=(T * D3, hd), b_off=0, sC=(T * D3, hd), c_off=D, alpha=scale)
         ops.gemm(P, dOc, dqkv, T, hd, T, lda=ld, ldb=D, ldc=D3, transA=True, transB=True, batch=(B, H),
                  sA=(H * T * ld, T * ld), sB=(T * D, hd), sC=(T * D3, hd), c_off=2 * D)
-        return dqkv, dgate, dtab, None, None, None, None, None
+        return dqkv, dgate, dtab, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------ masking / rows

@@ -443,8 +443,8 @@ def attn_fused_fwd(qkv, gate, tab, kpm, H, scale, p_drop, seed):
     return O, lse
 
 
-def attn_fused_bwd(qkv, O, dO, lse, gate, tab, kpm, H, scale, p_drop, seed):
-    """returns (dqkv, dgate, dtab)"""
+def attn_fused_bwd(qkv, O, dO, lse, gate, tab, kpm, H, scale, p_drop, seed, dbias=None, dbias_accumulate=False):
+    """returns (dqkv, dgate, dtab); dbias [3D] (optional, any float dtype): (+)= column sums of dqkv (q|k|v bias gradient)"""
     dev = _dev(qkv); _contig(dO)
     B, T, D3 = qkv.shape
     D = D3 // 3
@@ -457,7 +457,8 @@ def attn_fused_bwd(qkv, O, dO, lse, gate, tab, kpm, H, scale, p_drop, seed):
     need = L.wavlm_attn_fused_bwd_workspace_bytes(B, H, T)
     ws = workspace(dev, need, "attn")
     check(L.wavlm_attn_fused_bwd(ptr(qkv), ptr(O), ptr(dO), ptr(lse), ptr(gate), ptr(tab), ptr(kpm), ptr(dqkv),
-                                 ptr(dgate), ptr(dtab), B, H, T, D // H, float(scale), float(p_drop), int(seed),
+                                 ptr(dgate), ptr(dtab), ptr(dbias), dt(dbias) if dbias is not None else 0,
+                                 int(bool(dbias_accumulate)), B, H, T, D // H, float(scale), float(p_drop), int(seed),
                                  ptr(ws), need, stream()), "wavlm_attn_fused_bwd")
     return dqkv, dgate, dtab
 

@@ -245,8 +245,11 @@ class MultiheadAttention(nn.Module):
         if (pk is not None and torch.is_grad_enabled() and pk[0].data_ptr() == self.q_proj.weight.data_ptr()
                 and pk[2].data_ptr() == self.q_proj.bias.data_ptr() and pk[0].dtype == x.dtype):
             # optimizer-bound packed views of q|k|v (no concatenation; the gradient lands packed in the arena)
-            qkv = F.LinearFn.apply(x, pk[0], pk[2], pk[1], pk[3], None, wgroup, chain)
+            # the fused attention backward delivers the packed bias gradient (it produces dq | dk | dv anyway)
+            tq = F.BiasGradToken(pk[2])
+            qkv = F.LinearFn.apply(x, pk[0], pk[2], pk[1], pk[3], tq, wgroup, chain)
         else:
+            tq = None
             w = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
             b = torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0)
             qkv = F.LinearFn.apply(x, w, b, None, None, None, None, chain)
@@ -254,7 +257,7 @@ class MultiheadAttention(nn.Module):
             qkv, x = qkv
         p = self.dropout_module.p if self.training else 0.0
         o = F.AttnCoreFn.apply(qkv, gate, position_table, key_padding_u8, self.num_heads, self.scaling, p,
-                               F.next_seed() if p > 0 else 0)
+                               F.next_seed() if p > 0 else 0, tq, pk[3] if tq is not None else None)
         out = F.LinearFn.apply(o, self.out_proj.weight, self.out_proj.bias, None, None, out_bias_tok, wgroup)
         return (out, position_table, x) if chain else (out, position_table)
 
