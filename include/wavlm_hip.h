@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 10
+#define WAVLM_HIP_ABI_VERSION 11
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -63,6 +63,11 @@ typedef struct wavlm_gemm_desc {
   int32_t accumulate;
   int32_t split_k;
   void* workspace; uint64_t ws_bytes;
+  /* optional: colsum[n] (+)= sum_m C[m][n] over the rows of the (un-batched, un-split) result, in colsum_dtype -- the bias
+   * gradient of the linear whose output gradient C is (fc1's from fc2's GELU'-multiplying dX GEMM, WavLM/WavLM.py:732-737).
+   * Computed inside the GEMM's epilogue where the kernel supports it (per-tile partial rows in `workspace` + one finishing
+   * launch), otherwise by a column-sum pass over C; either way `workspace` must hold wavlm_gemm_workspace_bytes(). */
+  void* colsum; int32_t colsum_dtype; int32_t colsum_accumulate;
 } wavlm_gemm_desc;
 
 uint64_t wavlm_gemm_workspace_bytes(const wavlm_gemm_desc* d);

@@ -633,6 +633,32 @@ def check_posconv():
     return out
 
 
+def check_gemm_colsum():
+    """column sums of C out of the GEMM epilogue (192 x 384 and 256 x 256 ping-pong kernels) and by the fall-back pass
+    (128-wide kernel, fp32), against an explicit sum over the rows of the C the same call stored"""
+    out = []
+    bf = torch.bfloat16
+    for (n, N, K, epi, dtype) in [(1000, 3072, 768, 4, bf), (1000, 768, 3072, 0, bf), (777, 2048, 512, 4, bf),
+                                  (300, 2048, 512, 0, bf), (500, 48, 256, 0, bf), (300, 256, 128, 0, torch.float32)]:
+        # dx[n, K'] = dy[n, N'] @ W[N', K'] in the dX form the model uses (B K-strided); here N plays K'
+        dy = q(gen(n, K, seed=1), dtype).to(dtype).to(DEV)
+        W = q(gen(K, N, seed=2, scale=1.0 / math.sqrt(K)), dtype).to(dtype).to(DEV)
+        aux = q(gen(n, N, seed=3), dtype).to(dtype).to(DEV) if epi == 4 else None
+        Cc = torch.empty((n, N), dtype=dtype, device=DEV)
+        base = q(gen(N, seed=4), torch.float32).to(DEV)
+        cs = base.clone()
+        ops.gemm(dy, W, Cc, n, N, K, lda=K, ldb=N, ldc=N, transB=True, epi=epi, aux=aux, ld_aux=N, colsum=cs,
+                 colsum_accumulate=True)
+        ref = dy.double() @ W.double()
+        if epi == 4:
+            ref = ref * aux.double()
+        tag = f"gemm colsum[{dtype}] n={n} N={N} K={K} epi={epi}"
+        out.append((tag + " C", err(Cc, ref), tol_for(dtype)))
+        out.append((tag + " colsum vs stored C", err(cs - base, Cc.double().sum(0)), 2e-3 if dtype == bf else 1e-5))
+        out.append((tag + " colsum vs exact", err(cs - base, ref.sum(0)), 5e-3 if dtype == bf else 1e-5))
+    return out
+
+
 def check_linear_ffn():
     out = []
     for dtype in (torch.float32, torch.bfloat16):
@@ -749,7 +775,7 @@ def check_adam():
 
 GROUPS = {
     "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
-    "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv,
+    "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv, "gemm_colsum": check_gemm_colsum,
     "linear_ffn": check_linear_ffn, "loss": check_loss, "adam": check_adam,
 }
 

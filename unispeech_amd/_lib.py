@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVLM_HIP_LIB") or os.path.join(_HERE, "lib", "libwavlm_hip.so")
 
 _lib = None
-ABI_VERSION = 10  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 11  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
 
 F32, BF16 = 0, 1
 
@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("res", c_vp), ("res_dtype", c_i32), ("ld_res", c_i64), ("sRes_o", c_i64), ("sRes_i", c_i64),
         ("accumulate", c_i32), ("split_k", c_i32),
         ("workspace", c_vp), ("ws_bytes", c_u64),
+        ("colsum", c_vp), ("colsum_dtype", c_i32), ("colsum_accumulate", c_i32),
     ]
 
 

@@ -376,9 +376,18 @@ extern "C" double wavlm_prof_collect_bytes(int dtype) {
 }
 
 extern "C" uint64_t wavlm_gemm_workspace_bytes(const wavlm_gemm_desc* d) {
-  if (!d || d->split_k <= 1) return 0;
-  const uint64_t nb = (uint64_t)(d->batch_o < 1 ? 1 : d->batch_o) * (d->batch_i < 1 ? 1 : d->batch_i);
-  return nb * (uint64_t)d->split_k * (uint64_t)d->M * (uint64_t)d->N * sizeof(float);
+  if (!d) return 0;
+  uint64_t need = 0;
+  if (d->split_k > 1) {
+    const uint64_t nb = (uint64_t)(d->batch_o < 1 ? 1 : d->batch_o) * (d->batch_i < 1 ? 1 : d->batch_i);
+    need = nb * (uint64_t)d->split_k * (uint64_t)d->M * (uint64_t)d->N * sizeof(float);
+  }
+  if (d->colsum) {  // per-tile partial rows of the fused form (at most ceil(M / 192) of them) or the stand-alone pass
+    const uint64_t fused = (uint64_t)((d->M + 191) / 192) * (uint64_t)d->N * sizeof(float);
+    const uint64_t pass = wavlm_colsum_workspace_bytes(d->N);
+    need += fused > pass ? fused : pass;
+  }
+  return need;
 }
 
 extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
@@ -386,12 +395,16 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return WL_EINVAL;
   if ((d->epi == 2 || d->epi == 4) && !d->aux) return WL_EINVAL;
   if (d->epi < 0 || d->epi > 4) return WL_EINVAL;
-  if (d->split_k > 1 && (!d->workspace || d->ws_bytes < wavlm_gemm_workspace_bytes(d))) return WL_EINVAL;
+  if ((d->split_k > 1 || d->colsum) && (!d->workspace || d->ws_bytes < wavlm_gemm_workspace_bytes(d))) return WL_EINVAL;
+  if (d->colsum && (d->split_k > 1 || d->batch_o > 1 || d->batch_i > 1 || d->sC_o || d->sC_i)) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == WL_F32) {
     const int pi = prof_begin(d, st);
-    const int r = gemm_f32_launch(d, st);
+    int r = gemm_f32_launch(d, st);
     prof_end(pi, st);
+    if (r == WL_OK && d->colsum)
+      r = wavlm_colsum(d->C, d->M, d->N, d->ldc, d->c_dtype, nullptr, nullptr, d->colsum, d->colsum_dtype,
+                       d->colsum_accumulate, d->workspace, d->ws_bytes, stream);
     return r;
   }
   if (d->dtype != WL_BF16) return WL_EINVAL;
@@ -403,14 +416,17 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   const int nbatch = (d->batch_o < 1 ? 1 : d->batch_o) * p.batch_i;
   const int pi = prof_begin(d, st);
   int rc;
+  int csum_rows = 0;  // > 0: the kernel left that many partial rows of column sums in the workspace
   const bool vec = vec_epilogue_ok(d);
   if ((g_gemm_variant == 4 && gemm_pp3_ok(d)) ||
       (g_gemm_variant == 0 && d->N >= 384 && gemm_pp3_ok(d) && gemm_pp_ok(d) &&
        tile_efficiency(d, nbatch, 192, 384) > 1.06 * tile_efficiency(d, nbatch, 256, 256)))  // measured at 24 k rows: N = 768 (+25 %), 2304 (+10 % at K = 768), 3072 (+6 %) go to 192 x 384; N = 2048 and the conv stack (N = 512) stay
     { const int ec = gemm_epilogue_class(d, vec); if (ec == 3) p.gtab = gelu_tab4_get(st);
+      if (d->colsum && (ec == 2 || ec == 4)) { p.colsum_part = (float*)d->workspace; csum_rows = (d->M + 191) / 192; }
       rc = gemm_pp3_launch(p, nbatch, d->transA != 0, d->transB != 0, ec, st); }
   else if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) {
     const int ec = gemm_epilogue_class(d, vec); if (ec == 3) p.gtab = gelu_tab4_get(st);
+    if (d->colsum && (ec == 2 || ec == 4)) { p.colsum_part = (float*)d->workspace; csum_rows = (d->M + 255) / 256; }
     rc = gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, ec, st);
   }
   else if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, vec, st);
@@ -427,6 +443,11 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
       WL_LAUNCH(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, nbatch);
     }
     rc = wl_check_launch();
+  }
+  if (rc == WL_OK && d->colsum) {
+    if (csum_rows > 0) rc = wl_colsum_finish((const float*)d->workspace, csum_rows, d->N, d->colsum, d->colsum_dtype, d->colsum_accumulate, st);
+    else rc = wavlm_colsum(d->C, d->M, d->N, d->ldc, d->c_dtype, nullptr, nullptr, d->colsum, d->colsum_dtype,
+                           d->colsum_accumulate, d->workspace, d->ws_bytes, stream);
   }
   prof_end(pi, st);
   return rc;

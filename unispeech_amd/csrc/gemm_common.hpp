@@ -23,6 +23,7 @@ struct GemmP {
   int patch_m;               // split-K work order: tile-row patch height (0: tiles only, split outermost)
   int ngrp;                  // > 0: grouped launch, the problems are grp[0 .. ngrp) (A/B/M/N/lda/ldb/ws above are unused)
   const float4* gtab;        // GELU / GELU' chord table in global memory (fast epilogue 3 copies it to LDS), or null
+  float* colsum_part;        // fused column sums of C (ping-pong kernels, fast epilogues): partial rows [tiles_m][N], or null
   GemmGrp grp[4];
 };
 
@@ -37,6 +38,7 @@ static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
   p.bias = d->bias; p.bias_dtype = d->bias_dtype; p.sBias_o = d->sBias_o; p.sBias_i = d->sBias_i;
   p.aux = d->aux; p.aux_dtype = d->aux_dtype; p.ld_aux = d->ld_aux; p.sAux_o = d->sAux_o; p.sAux_i = d->sAux_i;
   p.gtab = nullptr;
+  p.colsum_part = nullptr;
   p.res = d->res; p.res_dtype = d->res_dtype; p.ld_res = d->ld_res; p.sRes_o = d->sRes_o; p.sRes_i = d->sRes_i;
   p.accumulate = d->accumulate;
   p.split_k = d->split_k < 1 ? 1 : d->split_k;
@@ -185,9 +187,10 @@ __device__ __forceinline__ void gelu_tab_stage(const float4* g, float4* lds) {
   for (int i = threadIdx.x; i < GT4_N; i += blockDim.x) lds[i] = g[i];
 }
 
+// vout (optional): receives the eight final values as stored (before rounding to bf16) -- fused column sums
 template <int KIND>
 __device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi, int m, int n, const float (&acc)[8],
-                                                 const float4* tab = nullptr) {
+                                                 const float4* tab = nullptr, float* vout = nullptr) {
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = p.alpha * acc[e];
@@ -220,6 +223,46 @@ __device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi,
     for (int e = 0; e < 8; ++e) v[e] += r[e];
   }
   st8_dt(p.C, (long)zo * p.sC_o + (long)zi * p.sC_i + (long)m * p.ldc + n, WL_BF16, v);
+  if (vout) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vout[e] = v[e];
+  }
+}
+
+// Fused column sums of C (the bias gradient of the linear whose output gradient this GEMM produces, e.g. fc1's from the
+// GELU'-multiplying dX GEMM of fc2: WavLM/WavLM.py:732-737): the row-vector epilogue writes each final 8-vector back into
+// the wave's staging slice (zeros for rows / columns past the edge); after a 32-row block lane c adds up column c of the
+// slice.  NCOL = columns per wave (64 or 96), LD = slice row stride in floats.
+template <int NCOL, int LD>
+__device__ __forceinline__ void gemm_colsum_block(const float* ep, int lane, float (&cs)[2]) {
+  asm volatile("" ::: "memory");  // same wave: LDS executes in order, the compiler must keep the order too
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 32; r += 2) { a0 += ep[r * LD + lane]; a1 += ep[(r + 1) * LD + lane]; }
+  cs[0] += a0 + a1;
+  if constexpr (NCOL > 64) {
+    if (lane < NCOL - 64) {
+#pragma unroll
+      for (int r = 0; r < 32; r += 2) { b0 += ep[r * LD + 64 + lane]; b1 += ep[(r + 1) * LD + 64 + lane]; }
+      cs[1] += b0 + b1;
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+// the two waves that share a column range (wm = 0, 1) meet in LDS; wm = 0 writes the tile's partial row segment
+template <int NCOL>
+__device__ __forceinline__ void gemm_colsum_finish(const GemmP& p, float* xch, int wave, int wm, int lane, int tm, int nw,
+                                                   const float (&cs)[2]) {
+  float* mine = xch + wave * 128;
+  mine[lane] = cs[0];
+  if (NCOL > 64 && lane < NCOL - 64) mine[64 + lane] = cs[1];
+  __syncthreads();
+  if (wm == 0) {
+    const float* other = xch + (wave + 4) * 128;  // waves are numbered wm * 4 + wn
+    float* dst = p.colsum_part + (long)tm * p.N;
+    if (nw + lane < p.N) dst[nw + lane] = cs[0] + other[lane];
+    if (NCOL > 64 && lane < NCOL - 64 && nw + 64 + lane < p.N) dst[nw + 64 + lane] = cs[1] + other[64 + lane];
+  }
 }
 
 // epilogue class of a launch: 0 scalar stores, 1 generic row vectors, 2 / 3 / 4 specialised for epi 0 / 3 / 4

@@ -422,6 +422,9 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
         for (int r = 0; r < 16; ++r)
           ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] = a[j][r];
     };
+    constexpr bool CSUM = EP == 2 || EP == 4;  // fused column sums of C: plain and aux-multiplying fast epilogues
+    const bool csum = CSUM && p.colsum_part != nullptr;
+    float cs[2] = {0.f, 0.f};
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {
       switch (i) {
@@ -435,14 +438,27 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
         const int rl = id / 12, ch = id - rl * 12;
         const int mm = mw + i * 32 + rl;
         const int nn = nw + ch * 8;
+        float vo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (mm < p.M && nn < p.N) {
           const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
           const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           if constexpr (EP == 1) gemm_store8(p, zo, zi, z, split, mm, nn, v);
-          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(p, zo, zi, mm, nn, v, tab);
+          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(p, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr);
+        }
+        if constexpr (CSUM) {
+          if (csum) {
+            *reinterpret_cast<float4*>(ep + rl * EP_LD + ch * 8) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+            *reinterpret_cast<float4*>(ep + rl * EP_LD + ch * 8 + 4) = make_float4(vo[4], vo[5], vo[6], vo[7]);
+          }
         }
       }
+      if constexpr (CSUM) {
+        if (csum) gemm_colsum_block<96, EP_LD>(ep, lane, cs);
+      }
+    }
+    if constexpr (CSUM) {
+      if (csum) gemm_colsum_finish<96>(p, reinterpret_cast<float*>(smem + 106496), wave, wm, lane, tm, nw, cs);
     }
   }
 }

@@ -101,14 +101,17 @@ def _linear_fwd(x2d, W, b, *, epi=0, aux=None, res=None, out_dtype=None):
     return y
 
 
-def _linear_bwd_x(dy2d, W, *, epi=0, aux=None, res=None):
-    """dx[n, K] = dy[n, N] @ W[N, K]  (W consumed K-strided: no transposed weight copy)"""
+def _linear_bwd_x(dy2d, W, *, epi=0, aux=None, res=None, colsum=None):
+    """dx[n, K] = dy[n, N] @ W[N, K]  (W consumed K-strided: no transposed weight copy).
+    colsum [K] (optional): += column sums of dx -- the bias gradient of the linear that produced this layer's input, out of
+    the GEMM's epilogue"""
     n, N = dy2d.shape
     K = W.shape[1]
     dx = torch.empty((n, K), dtype=dy2d.dtype, device=dy2d.device)
     if n == 0:
         return dx
-    ops.gemm(dy2d, W, dx, n, K, N, lda=N, ldb=K, ldc=K, transB=True, epi=epi, aux=aux, ld_aux=K, res=res, ld_res=K)
+    ops.gemm(dy2d, W, dx, n, K, N, lda=N, ldb=K, ldc=K, transB=True, epi=epi, aux=aux, ld_aux=K, res=res, ld_res=K,
+             colsum=colsum, colsum_accumulate=colsum is not None)
     return dx
 
 
@@ -300,6 +303,7 @@ class FFNFn(torch.autograd.Function):
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
         dW2, db2 = _param_grads(dy2d, hd, W2, b2, b2 is not None, True, True, bias_tok=ctx.b2_tok, wgroup=ctx.wgroup)
+        fused_b1 = False
         if ctx.p_act > 0:
             dh = _linear_bwd_x(dy2d, W2)
             dh = ops.dropout(dh, ctx.p_act, ctx.seed)
@@ -307,8 +311,13 @@ class FFNFn(torch.autograd.Function):
             du, _ = ops.group_major(dh.view(1, n, F), u.view(1, n, F), 1, 0, n)
             du = du.view(n, F)
         else:
-            du = _linear_bwd_x(dy2d, W2, epi=4, aux=u)
-        dW1, db1 = _param_grads(du, x2d, W1, b1, b1 is not None, True, True, wgroup=ctx.wgroup)
+            # fc1's bias gradient = column sums of du: out of the epilogue of the GEMM that produces du
+            sb1 = _sink(b1) if (b1 is not None and FUSE_BIAS_COLSUM) else None
+            du = _linear_bwd_x(dy2d, W2, epi=4, aux=u, colsum=sb1.view(-1) if sb1 is not None else None)
+            if sb1 is not None:
+                _sink_written(sb1)
+                fused_b1 = True
+        dW1, db1 = _param_grads(du, x2d, W1, b1, b1 is not None and not fused_b1, True, True, wgroup=ctx.wgroup)
         dx = None
         if ctx.needs_input_grad[0]:
             res = None
@@ -546,6 +555,7 @@ class ConvStackFn(torch.autograd.Function):
 
 # ---------------------------------------------------------------------------------------------- pos_conv
 POSCONV_DIRECT = os.environ.get("WAVLM_POSCONV_DIRECT", "1") != "0"
+FUSE_BIAS_COLSUM = os.environ.get("WAVLM_FUSE_BIAS_COLSUM", "1") != "0"  # fc1 bias gradient out of fc2's dX GEMM epilogue
 
 
 class PosConvFn(torch.autograd.Function):

@@ -66,8 +66,9 @@ def _contig(t):
 def gemm(A, B, Cc, M, N, K, *, lda, ldb, ldc, transA=False, transB=False, KB=1, sA_kb=0, sB_kb=0, batch=(1, 1),
          sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0, bias=None, bias_off=0, sBias=(0, 0),
          epi=0, aux=None, aux_off=0, ld_aux=0, sAux=(0, 0), res=None, res_off=0, ld_res=0, sRes=(0, 0),
-         accumulate=False, split_k=1):
-    """C = epi(alpha * sum_kb A.B^T + bias) (+res) (+C); see include/wavlm_hip.h for the addressing rules."""
+         accumulate=False, split_k=1, colsum=None, colsum_accumulate=False):
+    """C = epi(alpha * sum_kb A.B^T + bias) (+res) (+C); see include/wavlm_hip.h for the addressing rules.
+    colsum [N] (optional): (+)= column sums of C over its rows (a bias gradient), fused into the epilogue where possible."""
     dev = _dev(A)
     if A.dtype != B.dtype:
         raise TypeError("A and B must share a dtype")
@@ -94,8 +95,11 @@ def gemm(A, B, Cc, M, N, K, *, lda, ldb, ldc, transA=False, transB=False, KB=1, 
     d.ld_res, d.sRes_o, d.sRes_i = int(ld_res), int(sRes[0]), int(sRes[1])
     d.accumulate = int(bool(accumulate))
     d.split_k = int(split_k)
+    d.colsum = ptr(colsum)
+    d.colsum_dtype = dt(colsum) if colsum is not None else 0
+    d.colsum_accumulate = int(bool(colsum_accumulate))
     L = _lib.lib()
-    if d.split_k > 1:
+    if d.split_k > 1 or colsum is not None:
         need = L.wavlm_gemm_workspace_bytes(C.byref(d))
         ws = workspace(dev, need, "gemm")
         d.workspace, d.ws_bytes = ptr(ws), need
