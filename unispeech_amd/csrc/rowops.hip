@@ -469,8 +469,11 @@ static inline unsigned grid_for(long work_items, int per_block, unsigned cap) {
   return (unsigned)g;
 }
 
+// Grid caps of the LayerNorm kernels, measured at 23 968 x 768 bf16 (tools/ln_bench.py, same-box A/B of builds): backward
+// (+ finish) 256 blocks 52 us, 512: 36 us, 768: 43 us, 1024: 41 us, 2048: 42 us, 4096: 55 us -- two blocks per CU halve the
+// partial-sum traffic of 1024 and still fill the memory pipeline; forward with dropout 512: 54 us, 1024: 42 us.
 #ifndef LN_BWD_BLOCKS
-#define LN_BWD_BLOCKS 1024
+#define LN_BWD_BLOCKS 512
 #endif
 #ifndef LN_FWD_DROP_BLOCKS
 #define LN_FWD_DROP_BLOCKS 1024
