@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
       glds_tile64(base + FA_HD * H, D3, j0 + FA_BKV, T, kbuf(cur ^ 1), wave_u);
       glds_tile64(base + 2 * FA_HD * H, D3, j0 + FA_BKV, T, vbuf(cur ^ 1), wave_u);
     }
+    const unsigned* cwp = colw + ((j0 + 4 * hi) >> 1);  // j0 + 4 hi is even, r walks in pairs
     // S^T = K Q^T
     f32x16_t s[2];
 #pragma unroll
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
         rs += p0 + p1;
         unsigned pk = pack_bf16(p0, p1);
         if constexpr (DROP) {
-          const int jp = (j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi) >> 1;
-          pk &= fa_keepmask2(fa_mix(roww + colw[jp]), p.k2);
+          // (lane / tile part of the pair index as a base pointer: the rest is an immediate offset of the LDS read)
+          pk &= fa_keepmask2(fa_mix(roww + cwp[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]), p.k2);
         }
         pf[f][r >> 3].u[(r & 7) >> 1] = pk;
       }
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
       for (int r = 0; r < 16; ++r) {
         const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
         tvv[f][r] = trow[j];
-        if (DROP && !(r & 1)) cww[f][r >> 1] = colw[j >> 1];
+        if (DROP && !(r & 1)) cww[f][r >> 1] = (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1];
       }
 #endif
     U4 dsf0[2], dsf1[2];  // (two arrays, not dsf[2][2]: the 2-D array of unions is not split into registers)
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
 #if FA_DQ_PREFETCH
         if constexpr (DROP) w = fa_mix(roww + cww[f][r >> 1]);
 #else
-        if constexpr (DROP) w = fa_mix(roww + colw[(j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi) >> 1]);
+        if constexpr (DROP) w = fa_mix(roww + (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]);
 #endif
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
