@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 11
+#define WAVLM_HIP_ABI_VERSION 12
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -97,12 +97,14 @@ uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D);
  * out of the pass that already reduces dgamma / dbeta over rows.
  * dx_add (optional, same shape / dtype as dx): added into dx -- the gradient that reaches x past the LayerNorm, i.e. the
  * residual stream of a layer_norm_first block (WavLM/WavLM.py:702-724: `residual = x; x = layer_norm(x); ...; x =
- * residual + x`), so the two contributions never meet in a separate add kernel.  dr / dr_colsum do not include it. */
+ * residual + x`), so the two contributions never meet in a separate add kernel.  dr / dr_colsum do not include it unless
+ * dr_incl_add != 0: then the SUM s = x + dropout(r) is itself the residual stream (a pre-LN block whose residual add is
+ * fused into the following LayerNorm) and the gradient arriving at s reaches r as well (through the dropout mask). */
 int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd, const void* gamma,
                         const void* beta, void* dx, void* dr, const void* dx_add, void* dgamma, void* dbeta,
                         void* dr_colsum, int64_t rows, int32_t D, int32_t dtype, int32_t param_dtype, int32_t act,
                         float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float grad_scale,
-                        int32_t accumulate_params, void* workspace, uint64_t ws_bytes, void* stream);
+                        int32_t accumulate_params, int32_t dr_incl_add, void* workspace, uint64_t ws_bytes, void* stream);
 
 /* out[c] (+)= sum over rows of x[row, c]; a row counts iff (!include || include[row]) && (!exclude || !exclude[row]).
  * Bias gradients of every nn.Linear / conv bias, and d(mask_emb) (src/fairseq/models/wavlm/wavlm.py:401). */

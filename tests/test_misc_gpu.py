@@ -304,3 +304,43 @@ def test_dp_world2_rccl_gradients_sum_over_ranks():
         assert tb is None, tb
         assert err < 1e-2, (rank, err)
         assert early >= nb // 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_preln_fused_residuals_match_the_unfused_blocks(dtype, tol):
+    """Pre-LN encoder (WavLM-Large structure): the training path that fuses both residual adds of a block into the
+    LayerNorm that follows them (forward_preln_fused; the LayerNorm backward also delivers the out_proj / fc2 bias
+    gradients) against the block-by-block form, same weights and input, dropout 0: output and every gradient."""
+    from unispeech_amd import wavlm as W
+    from unispeech_amd.wavlm import WavLM, WavLMConfig
+    d = dict(encoder_layers=3, encoder_embed_dim=256, encoder_ffn_embed_dim=512, encoder_attention_heads=4,
+             conv_feature_layers="[(64,10,5)] + [(64,3,2)] * 2", extractor_mode="layer_norm", layer_norm_first=True,
+             normalize=True, conv_bias=True, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+             encoder_layerdrop=0.0, relative_position_embedding=True, gru_rel_pos=True, num_buckets=32, max_distance=64,
+             conv_pos=16, conv_pos_groups=4)
+    torch.manual_seed(3)
+    m = WavLM(WavLMConfig(d)).cuda().to(dtype).train()
+    wav = torch.randn(2, 8000, device="cuda").to(dtype)
+    probe = None
+    res = []
+    for fused in (True, False):
+        W.PRELN_FUSED = fused
+        try:
+            m.zero_grad(set_to_none=True)
+            np.random.seed(1)
+            x, _ = m.extract_features(wav)
+            if probe is None:
+                probe = torch.randn_like(x)
+            (x.float() * probe.float()).sum().backward()
+            res.append((x.detach().float().clone(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters()
+                                                      if p.grad is not None}))
+        finally:
+            W.PRELN_FUSED = True
+    (xa, ga), (xb, gb) = res
+    assert ((xa - xb).abs().max() / xb.abs().max()).item() < tol
+    assert ga.keys() == gb.keys()
+    gmax = max(v.abs().max().item() for v in gb.values())
+    for n in ga:
+        scale = max(gb[n].abs().max().item(), 1e-3 * gmax)
+        assert ((ga[n] - gb[n]).abs().max().item() / scale) < tol, n

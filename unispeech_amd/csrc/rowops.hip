@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     const float* __restrict__ mean_i, const float* __restrict__ rstd_i, const TP* __restrict__ gamma,
     const TP* __restrict__ beta, T* __restrict__ dx, T* __restrict__ dr, const T* __restrict__ dx_add,
     float* __restrict__ part, long rows, int D, int act, unsigned th_in, float sc_in, unsigned long long seed_in, unsigned th_out, float sc_out,
-    unsigned long long seed_out, float grad_scale) {
+    unsigned long long seed_out, float grad_scale, int dr_incl_add) {
   constexpr int NA = CS ? 3 : 2;
   __shared__ float red[4][NA][512];  // cross-wave reduce of one chunk slot (64 lanes x 8 columns) at a time
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -213,6 +213,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
           for (int e = 0; e < 8; ++e) t[e] = o[e] + a[e];
           store8(dx + off, t);
+          if (dr_incl_add) {  // the sum x + dropout(r) itself continues as the residual stream: r sees the total too
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = t[e];
+          }
         } else store8(dx + off, o);
         if (dr || CS) {
           if (th_in) ln_drop_apply(o, rw_in, cw[c], th_in, sc_in);
@@ -513,7 +517,8 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
                         const void* beta, void* dx, void* dr, const void* dx_add, void* dgamma, void* dbeta,
                         void* dr_colsum, int64_t rows, int32_t D, int32_t dtype, int32_t param_dtype, int32_t act,
                         float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float grad_scale,
-                        int32_t accumulate_params, void* workspace, uint64_t ws_bytes, void* stream) {
+                        int32_t accumulate_params, int32_t dr_incl_add, void* workspace, uint64_t ws_bytes,
+                        void* stream) {
   if (!dy || !s || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return WL_EINVAL;
   if (rows <= 0 || D <= 0 || (D & 7) || D > LN_MAXC * 512) return WL_EINVAL;
   if (act && !beta) return WL_EINVAL;
@@ -525,7 +530,7 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   float* part = (float*)workspace;
 #define LN_BWD_C(T, TP, NCS, CSF) WL_LAUNCH((layernorm_bwd_kernel<T, TP, NCS, CSF>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
     (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, (const T*)dx_add, part, (long)rows, (int)D, (int)act, ti, si, \
-    (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale)
+    (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale, (int)dr_incl_add)
 #define LN_BWD_N(T, TP, NCS) do { if (dr_colsum) LN_BWD_C(T, TP, NCS, true); else LN_BWD_C(T, TP, NCS, false); } while (0)
 #define LN_BWD(T, TP) do { if (D <= 512) LN_BWD_N(T, TP, 1); else if (D <= 1024) LN_BWD_N(T, TP, 2); else LN_BWD_N(T, TP, 4); } while (0)
   if (dtype == WL_F32 && param_dtype == WL_F32) LN_BWD(float, float);

@@ -338,13 +338,17 @@ class LayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, r, gamma, beta, eps, act, p_in, seed_in, p_out, seed_out, grad_scale, rbias_tok=None,
-                pass_x=False):
+                pass_x=False, s_grad=False):
+        """s_grad (with a residual r): the second output s = x + dropout(r) is differentiable -- it IS the residual stream
+        of a pre-LN block whose residual add is fused into this LayerNorm; the gradient that arrives at s is added inside
+        the backward kernel and reaches r through the dropout mask as well."""
         xc = x.contiguous()
         rc = r.contiguous() if r is not None else None
         y, s, mean, rstd = ops.layernorm_fwd(xc, rc, gamma, beta, eps, act=act, p_in=p_in, seed_in=seed_in,
                                              p_out=p_out, seed_out=seed_out, save=True)
         ctx.save_for_backward(s, mean, rstd, gamma, beta)
         ctx.cfg = (act, p_in, seed_in, p_out, seed_out, grad_scale, r is not None)
+        ctx.s_grad = bool(s_grad and r is not None)
         ctx.rbias = None
         if (rbias_tok is not None and r is not None and _sink(rbias_tok.param) is not None
                 and _sink(gamma) is not None and _sink(beta) is not None):
@@ -353,17 +357,23 @@ class LayerNormFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             _sink_use(gamma)
             _sink_use(beta)
+        ctx.set_materialize_grads(False)  # no zero-filled [rows, D] gradient for the second output
+        if ctx.s_grad:
+            return y, s
         s_out = s.detach()
         ctx.mark_non_differentiable(s_out)
-        ctx.set_materialize_grads(False)  # no zero-filled [rows, D] gradient for the second output
         if pass_x:
             return y, s_out, x.view_as(x)
         return y, s_out
 
     @staticmethod
     def backward(ctx, dy, _ds, dx_pass=None):
+        if ctx.s_grad:
+            dx_pass = _ds  # the residual stream's gradient arrives at s
+            if dy is None:
+                raise NotImplementedError("fused pre-LN residual: the normalised output must be used")
         if dy is None:
-            return (dx_pass,) + (None,) * 12
+            return (dx_pass,) + (None,) * 13
         if dx_pass is not None:
             dx_pass = dx_pass.contiguous()
             if dx_pass.dtype != dy.dtype:
@@ -381,7 +391,7 @@ class LayerNormFn(torch.autograd.Function):
                                                      grad_scale=grad_scale, need_dr=has_r and p_in > 0,
                                                      dgamma=sg, dbeta=sb,
                                                      dr_colsum=sc.view(-1) if sc is not None else None,
-                                                     dx_add=dx_pass)
+                                                     dx_add=dx_pass, dr_incl_add=ctx.s_grad)
         if sg is not None:
             dgamma = dbeta = None  # accumulated in place
             _sink_written(sg); _sink_written(sb)
@@ -389,15 +399,15 @@ class LayerNormFn(torch.autograd.Function):
             _sink_written(sc)
         if has_r and dr is None:
             dr = dx
-        return dx, (dr if has_r else None), dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, (dr if has_r else None), dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, *, residual=None, act=0, p_in=0.0, p_out=0.0, training=True,
-               grad_scale=1.0, residual_bias_tok=None, pass_x=False):
+               grad_scale=1.0, residual_bias_tok=None, pass_x=False, s_grad=False):
     p_in = p_in if training else 0.0
     p_out = p_out if training else 0.0
     return LayerNormFn.apply(x, residual, gamma, beta, eps, act, p_in, next_seed() if p_in > 0 else 0, p_out,
-                             next_seed() if p_out > 0 else 0, grad_scale, residual_bias_tok, pass_x)
+                             next_seed() if p_out > 0 else 0, grad_scale, residual_bias_tok, pass_x, s_grad)
 
 
 # ------------------------------------------------------------------------------------- feature extractor

@@ -176,7 +176,7 @@ def layernorm_fwd(x, r, gamma, beta, eps, *, act=0, p_in=0.0, seed_in=0, p_out=0
 
 
 def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0,
-                  grad_scale=1.0, need_dr=False, dgamma=None, dbeta=None, dr_colsum=None, dx_add=None):
+                  grad_scale=1.0, need_dr=False, dgamma=None, dbeta=None, dr_colsum=None, dx_add=None, dr_incl_add=False):
     """returns (dx, dr, dgamma, dbeta, dr_colsum); given dgamma / dbeta (/ dr_colsum) tensors are accumulated into (+=).
     dr_colsum: True -> also return the column sums of dr (fresh tensor); a tensor -> accumulate into it (only together
     with dgamma / dbeta tensors: the three share the accumulate flag).  dx_add: added into dx (not into dr)."""
@@ -204,7 +204,7 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0,
     check(L.wavlm_layernorm_bwd(ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dr),
                                 ptr(dx_add), ptr(dgamma), ptr(dbeta), ptr(dr_colsum), rows, D, dt(dy), dt(gamma), int(act),
                                 float(p_in), int(seed_in), float(p_out), int(seed_out), float(grad_scale), int(acc),
-                                ptr(ws), need, stream()), "wavlm_layernorm_bwd")
+                                int(bool(dr_incl_add)), ptr(ws), need, stream()), "wavlm_layernorm_bwd")
     return dx, dr, dgamma, dbeta, dr_colsum
 
 

@@ -13,6 +13,7 @@ Activations are [B, T, C]; where the reference API exposes [T, B, C] tensors (la
 returned.
 """
 import math
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -262,6 +263,9 @@ class MultiheadAttention(nn.Module):
         return (out, position_table, x) if chain else (out, position_table)
 
 
+PRELN_FUSED = os.environ.get("WAVLM_PRELN_FUSED", "1") != "0"  # pre-LN blocks: residual adds inside the LayerNorms
+
+
 class ResidualAddFn(torch.autograd.Function):
     """y = x + dropout(r) (pre-LN blocks, where no LayerNorm follows the add)"""
 
@@ -312,6 +316,30 @@ class TransformerSentenceEncoderLayer(nn.Module):
         p = self.activation_dropout if self.training else 0.0
         return F.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p,
                              F.next_seed() if p > 0 else 0, b2_tok, wgroup, chain)
+
+    def forward_preln_fused(self, x, pending, key_padding_u8=None, position_table=None):
+        """Pre-LN block with both residual adds fused into the LayerNorm that follows them (training path of the encoder,
+        no taps): `pending` = (f, bias_token) is the previous block's feed-forward output, still to be added to x.
+        LN1 computes x + dropout(f) and its normalisation in one kernel, LN2 does the same for the attention output; the
+        LayerNorm backward kernels deliver the gradients of both branches through the dropout mask AND the out_proj / fc2
+        bias gradients (column sums) -- the separate dropout-add, dropout and column-sum passes of the unfused form are
+        gone.  Returns (x, pending', position_table) with this block's own feed-forward output pending."""
+        ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
+        p = self.dropout if self.training else 0.0
+        wg = self._wgrad_group()
+        if pending is None:
+            h, _, x = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps, pass_x=True)
+        else:
+            f_prev, tok_prev = pending
+            h, x = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps, residual=f_prev, p_in=p, training=self.training,
+                                residual_bias_tok=tok_prev, s_grad=True)
+        ta = F.BiasGradToken(self.self_attn.out_proj.bias)
+        a, position_table, _h = self.self_attn(h, key_padding_u8, position_table, out_bias_tok=ta, wgroup=wg, chain=True)
+        h, x = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps, residual=a, p_in=p, training=self.training,
+                            residual_bias_tok=ta, s_grad=True)
+        tf = F.BiasGradToken(self.fc2.bias)
+        f = self._ffn(h, tf, wg)
+        return x, (f, tf), position_table
 
     def _wgrad_group(self):
         """the layer's weight gradients (q|k|v packed, out_proj, fc1, fc2) as one grouped launch in backward"""
@@ -413,10 +441,22 @@ class TransformerEncoder(nn.Module):
     def forward(self, x, padding_mask=None, layer=None, fairseq_layer_results=False, prezeroed=False, extract_layer=None):
         """extract_layer (0-based): also return that layer's output [B, T, D] (UniSpeech-SAT's speaker tap,
         models/unispeech_sat/unispeech_sat.py:1202-1255) as a 4th value"""
+        # pre-LN training path without taps: residual adds fused into the LayerNorms (forward_preln_fused); the last block's
+        # feed-forward output is added by the final LayerNorm
+        fuse = (self.layer_norm_first and layer is None  # (layer None: no per-layer results)
+                and torch.is_grad_enabled() and F.CHAIN_CONSUMERS and PRELN_FUSED
+                and not any(l._forward_hooks or l._forward_pre_hooks for l in self.layers))
         x, layer_results, pre_ln = self.extract_features(x, padding_mask, layer, fairseq_layer_results, prezeroed,
-                                                         extract_layer=extract_layer)
+                                                         extract_layer=extract_layer, fuse_preln=fuse)
         if self.layer_norm_first and layer is None:
-            x, _ = F.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+            pend = self._pending
+            self._pending = None
+            if pend is not None:
+                x, _ = F.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, residual=pend[0],
+                                    p_in=self.dropout if self.training else 0.0, training=self.training,
+                                    residual_bias_tok=pend[1])
+            else:
+                x, _ = F.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         if extract_layer is None:
             return x, layer_results, pre_ln
         er = self._extract_result
@@ -429,9 +469,10 @@ class TransformerEncoder(nn.Module):
         return x, layer_results, pre_ln, er
 
     _extract_result = None
+    _pending = None
 
     def extract_features(self, x, padding_mask=None, tgt_layer=None, fairseq_layer_results=False, prezeroed=False,
-                         extract_layer=None):
+                         extract_layer=None, fuse_preln=False):
         """x [B, T, D].  Returns (x, layer_results, conv_sum) where conv_sum = x + pos_conv(x): the tensor the
         reference's in-place `x += x_conv` leaves behind in `features` (WavLM/WavLM.py:579)."""
         kpm = None
@@ -452,11 +493,22 @@ class TransformerEncoder(nn.Module):
             layer_results.append((x.transpose(0, 1), None))
         r = None
         table = None
+        pending = None
+        self._pending = None
         for i, layer in enumerate(self.layers):
             # one host draw per layer, training or not: keeps the numpy stream aligned with the reference
             dropout_probability = np.random.random()
             if not self.training or (dropout_probability > self.layerdrop):
-                if layer._forward_hooks or layer._forward_pre_hooks:
+                if fuse_preln:
+                    x, pending, table = layer.forward_preln_fused(x, pending, kpm, table)
+                    z = None
+                    if extract_layer is not None and i == extract_layer:
+                        # the speaker tap needs this block's output itself: add the pending branch here (its bias
+                        # token stays untaken, fc2 computes its own bias gradient) and go on un-pended
+                        pd = layer.dropout if self.training else 0.0
+                        x = ResidualAddFn.apply(x, pending[0], pd, F.next_seed() if pd > 0 else 0)
+                        pending = None
+                elif layer._forward_hooks or layer._forward_pre_hooks:
                     xt, z, table = layer(x.transpose(0, 1), kpm, table, tbc=True)
                     x = xt.transpose(0, 1)
                 else:
@@ -479,6 +531,7 @@ class TransformerEncoder(nn.Module):
                     break
         if r is not None:
             x = r
+        self._pending = pending  # (fused pre-LN path: the caller adds it inside the final LayerNorm)
         return x, layer_results, xs
 
 
