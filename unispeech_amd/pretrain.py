@@ -264,7 +264,13 @@ class WavLMPretrainModel(WavLM):
         if mask:
             mask_np = self._mask_numpy(B, T, pad_cpu, boundary if self.boundary_mask else None)
         sel = F.h2d(mask_np.astype(np.uint8), dev).view(-1) if mask_np is not None else None
-        kpm = padding_mask.to(torch.uint8).contiguous().view(-1) if padding_mask is not None else None
+        # A padding mask with no padded frame is a no-op for the encoder (nothing to zero, no key to exclude): seen on the host
+        # copy (no synchronisation), it is not handed on, and the attention kernels skip their key-padding path -- every
+        # tile would otherwise read the key bias and add it to every score.
+        enc_pad = padding_mask
+        if padding_mask is not None and pad_cpu is not None and not bool(pad_cpu.any()):
+            enc_pad = None
+        kpm = enc_pad.to(torch.uint8).contiguous().view(-1) if enc_pad is not None else None
         if sel is not None or kpm is not None:
             x = F.SelectRowsFn.apply(x, sel, self.mask_emb if sel is not None else None, kpm)
         if mask:
@@ -274,11 +280,11 @@ class WavLMPretrainModel(WavLM):
             layer = list(self.predict_layers)
         spk_x = None
         if self.utterance_contrastive_layer is not None:
-            x, layer_results, conv_sum, spk_x = self.encoder(x, padding_mask=padding_mask, layer=layer,
+            x, layer_results, conv_sum, spk_x = self.encoder(x, padding_mask=enc_pad, layer=layer,
                                                              fairseq_layer_results=True, prezeroed=True,
                                                              extract_layer=self.utterance_contrastive_layer - 1)
         else:
-            x, layer_results, conv_sum = self.encoder(x, padding_mask=padding_mask, layer=layer,
+            x, layer_results, conv_sum = self.encoder(x, padding_mask=enc_pad, layer=layer,
                                                       fairseq_layer_results=True, prezeroed=True)
         result = {"x": x, "padding_mask": padding_mask, "features": conv_sum, "layer_results": layer_results}
         if features_only:
