@@ -188,13 +188,18 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 #ifndef FA_DQ_NOSKEW
 #define FA_DQ_NOSKEW 0
 #endif
+#ifndef FA_DQ_OCC
+#define FA_DQ_OCC 2
+#endif
 template <bool DROP, bool TAB>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
+__global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // per stage: K [kv][hd] 8 KB | V [kv][hd] 8 KB;  then the four waves' skew buffers (96 x 64 B each)
+  // per stage: K [kv][hd] 8 KB | V [kv][hd] 8 KB;  then (relative-position table present) the four waves' skew buffers
+  // (96 x 64 B each)
   auto kbuf = [&](int st) { return smem + st * 16384; };
   auto vbuf = [&](int st) { return smem + st * 16384 + 8192; };
-  float* tabs = reinterpret_cast<float*>(smem + 32768 + 4 * 6144);
+  constexpr int SKEW_BYTES = TAB ? 4 * 6144 : 0;
+  float* tabs = reinterpret_cast<float*>(smem + 32768 + SKEW_BYTES);
   float* kb = tabs + p.Ltab;
   unsigned* colw = reinterpret_cast<unsigned*>(kb + p.Tkb);
   // gate fragments of the four waves (64 B each) behind the dropout column words
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
     kb[j] = (j < T && !(p.kpm && p.kpm[(long)b * T + j])) ? 0.f : -INFINITY;
   if constexpr (DROP)
     for (int jp = threadIdx.x; jp < (p.Tkb >> 1); jp += 256) colw[jp] = fa_col_word(p.s1, (unsigned)jp);
-  for (int q = threadIdx.x; q < 4 * 6144 / 16; q += 256) reinterpret_cast<uint4*>(smem + 32768)[q] = make_uint4(0, 0, 0, 0);
+  for (int q = threadIdx.x; q < SKEW_BYTES / 16; q += 256) reinterpret_cast<uint4*>(smem + 32768)[q] = make_uint4(0, 0, 0, 0);
   const float g = p.gate ? p.gate[(long)bh * T + ic] : 0.f;
   const float g2 = g * FA_LOG2E;
   const float nlse2 = valid_i ? p.log2sc - p.lse[(long)bh * T + ic] * FA_LOG2E : -INFINITY;  // P * sc = 2^(x + nlse2)
@@ -329,19 +334,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
     if constexpr (TAB && FA_DQ_DEFER) {
       if (jt > 0) skew_sums(j0 - FA_BKV);
     }
-#if FA_DQ_PREFETCH
-    // bias-table entries and dropout column words of the whole tile, read before the score MFMAs are issued
-    float tvv[2][16];
-    unsigned cww[2][8];
+    // bias-table entries and dropout column words of the whole tile, read before the score MFMAs are issued.  Only with the
+    // relative-position table: without it the kernel needs 43 KB of LDS, and the 48 registers this costs are the
+    // difference between two and three workgroups per CU (160 -> 139 us).
+    constexpr bool PF = FA_DQ_PREFETCH && TAB;
+    float tvv[PF ? 2 : 1][16];
+    unsigned cww[PF ? 2 : 1][8];
+    if constexpr (PF) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+      for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        tvv[f][r] = trow[j];
-        if (DROP && !(r & 1)) cww[f][r >> 1] = (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1];
-      }
-#endif
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          tvv[f][r] = trow[j];
+          if (DROP && !(r & 1)) cww[f][r >> 1] = (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1];
+        }
+    }
     U4 dsf0[2], dsf1[2];  // (two arrays, not dsf[2][2]: the 2-D array of unions is not split into registers)
     f32x16_t s[2], dp[2];
     // (block index as a type: a run-time index into s / dp / dsf would put the arrays into scratch)
@@ -364,20 +372,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(FaP p) {
       for (int r = 0; r < 16; r += 2) {
         float dv[2];
         unsigned w = 0;
-#if FA_DQ_PREFETCH
-        if constexpr (DROP) w = fa_mix(roww + cww[f][r >> 1]);
-#else
-        if constexpr (DROP) w = fa_mix(roww + (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]);
-#endif
+        if constexpr (DROP) {
+          if constexpr (PF) w = fa_mix(roww + cww[f][r >> 1]);
+          else w = fa_mix(roww + (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]);
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int rr = r + e;
           const int j = j0 + 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-#if FA_DQ_PREFETCH
-          const float tv = tvv[f][rr];
-#else
-          const float tv = trow[j];
-#endif
+          float tv;
+          if constexpr (PF) tv = tvv[f][rr]; else tv = trow[j];
           float x = fmaf(s[f][rr], p.sc2, fmaf(g2, tv, nlse2));  // x - lse as two fmas (the -lse rides in the bias term)
           if constexpr (EDGE) x += kb[j];
           const float pe = __builtin_amdgcn_exp2f(x);  // 0 for masked keys (-inf) and rows past T (nlse2 = -inf)
@@ -581,7 +585,7 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
   const int Lp = (L + 3) & ~3;
   p.delta = p.dtab_part + (long)B * H * nqt * 4 * Lp;
   if (dbias) p.dbias_part = p.delta + (long)B * H * T;
-  size_t smem1 = 32768 + 4 * 6144 + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float) + 256;  // + gate fragments
+  size_t smem1 = 32768 + (tab ? 4 * 6144 : 0) + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float) + 256;  // + gate fragments
   if (smem1 < FA_CS_FLOATS * sizeof(float)) smem1 = FA_CS_FLOATS * sizeof(float);
   p.nqb = nqt;
   if (p.th) {
