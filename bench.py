@@ -295,7 +295,8 @@ def main():
                             traffic = None
             roof = {"bound": "mfma",
                     "kernel": "bf16 MFMA GEMM family (gemm_pp_kernel 256x256, gemm_pp3_kernel 192x384, gemm_bf16_kernel "
-                              "128-wide): every dense contraction of the step",
+                              "128-wide): every dense contraction of the step that goes through wavlm_gemm (all but the fused "
+                              "attention and the direct pos_conv kernels)",
                     "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (avg over the step's GEMM launches, PMC)",
