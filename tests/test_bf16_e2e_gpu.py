@@ -200,3 +200,46 @@ def test_bf16_loss_at_bench_batch_vs_fp32_hip_mode():
     print(msg)
     assert s16 == s32
     assert rel < 2e-3, msg
+
+
+def test_bf16_ragged_padded_batch_vs_fp32_hip_mode():
+    """A ragged batch (five utterances of 3.3 - 9.7 s, zero-padded, real key-padding mask, odd frame counts): loss and
+    global gradient norm of the bf16 path -- fused attention with the key-padding path, direct pos_conv kernels at a
+    non-multiple frame count, conv0 backward on the matrix cores with a partial last chunk, the fused bias gradients --
+    against the fp32 mode of the same HIP path (exact-FMA GEMMs, unfused attention, GEMM-form pos_conv) with identical
+    masks and bf16-rounded parameters.  Loss within 2e-3 relative as above, gradient norm within 2e-2."""
+    secs = [9.7, 3.3, 7.05, 5.5, 8.31]
+    B = len(secs)
+    g = torch.Generator().manual_seed(11)
+    Tmax = int(16000 * max(secs))
+    wav = torch.zeros(B, Tmax)
+    pm = torch.ones(B, Tmax, dtype=torch.bool)
+    for i, s in enumerate(secs):
+        n = int(16000 * s)
+        wav[i, :n] = torch.randn(n, generator=g)
+        pm[i, :n] = False
+    wav = wav.to(torch.bfloat16)
+    target = torch.randint(4, V, (B, int(50 * max(secs))), generator=g)
+    out = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        model, _, crit, _, _ = _build(dtype, with_opt=False)
+        if dtype == torch.float32:
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.copy_(p.to(torch.bfloat16).float())
+        sample = {"id": torch.arange(B),
+                  "net_input": {"source": wav.cuda().to(dtype), "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+                  "target_list": [target.cuda()]}
+        np.random.seed(99)
+        loss, ss, _ = crit(model, sample)
+        loss.backward()
+        gn = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)).item()
+        out[dtype] = (loss.item(), ss, gn)
+        del model
+        torch.cuda.empty_cache()
+    (l32, s32, g32), (l16, s16, g16) = out[torch.float32], out[torch.bfloat16]
+    msg = "ragged batch: loss bf16 %.4f vs fp32-HIP %.4f, gradient norm %.4f vs %.4f, sample_size %d" % (l16, l32, g16, g32, s16)
+    print(msg)
+    assert s16 == s32
+    assert abs(l16 - l32) <= 2e-3 * abs(l32), msg
+    assert abs(g16 - g32) <= 2e-2 * abs(g32), msg
