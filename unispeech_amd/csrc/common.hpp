@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
+
+#define WL_MAX_DEVICES 64  // per-device lazily initialised tables (one process may drive several GPUs)
 
 #define WL_OK 0
 #define WL_EINVAL (-1)

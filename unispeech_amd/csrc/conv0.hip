@@ -58,14 +58,23 @@ __global__ void gelu_tab_init_kernel() {
   g_gelu_tab[0][i] = make_float2((float)s0, (float)(f(x0) - s0 * x0));
   g_gelu_tab[1][i] = make_float2((float)s1, (float)(d(x0) - s1 * x0));
 }
-static int gelu_tab_ensure(hipStream_t st) {
-  static bool done = false;  // one process per GPU: the table lives in this device's copy of the module
-  if (!done) {
-    WL_LAUNCH(gelu_tab_init_kernel, dim3(GT_N / 256), dim3(256), 0, st);
-    done = true;
+// per device, thread-safe, and complete before the first user on ANY stream (same scheme as gelu_tab4_get, gemm_bf16.hip)
+static const float2* gelu_tab_get(hipStream_t st) {
+  static std::mutex mu;
+  static const float2* ptr[WL_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WL_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!ptr[dev]) {
+    void* a = nullptr;
+    if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_gelu_tab)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(gelu_tab_init_kernel, dim3(GT_N / 256), dim3(256), 0, st);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return nullptr;
+    ptr[dev] = (const float2*)a;
   }
-  return WL_OK;
+  return ptr[dev];
 }
+static int gelu_tab_ensure(hipStream_t st) { return gelu_tab_get(st) ? WL_OK : WL_ELAUNCH; }
 // copy one table (16 KiB) into LDS; the caller synchronises
 __device__ __forceinline__ void gelu_tab_to_lds(int which, float2* tab) {
   const float4* src = reinterpret_cast<const float4*>(g_gelu_tab[which]);
@@ -581,7 +590,7 @@ int wavlm_conv0_gn_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
   const size_t sm_gram = seg_floats(C0_TCH, stride) * sizeof(float);
   const size_t sm_apply = seg_floats(C0_TCH, stride) * sizeof(float) + (out_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
   float* partx = (float*)workspace;
-  if (out_dtype == WL_BF16) gelu_tab_ensure(st);
+  if (out_dtype == WL_BF16 && gelu_tab_ensure(st) != WL_OK) return WL_ELAUNCH;
   if (wav_dtype == WL_F32)
     WL_LAUNCH((conv0_gram_kernel<float>), grid, dim3(256), sm_gram, st, (const float*)wav, partx, (long)T, T0, (int)stride);
   else
@@ -629,17 +638,14 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   float* dwb = partx + (long)B * nchunk * C0_NX;
   float* ab = dwb + (long)B * C * C0_KW;
   const size_t sm1 = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float) + (g_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
-  if (g_dtype == WL_BF16) gelu_tab_ensure(st);
+  if (g_dtype == WL_BF16 && gelu_tab_ensure(st) != WL_OK) return WL_ELAUNCH;
 #define B1(TW, TP, TO) WL_LAUNCH((conv0_bwd_fused_kernel<TW, TP, TO>), grid, dim3(256), sm1, st, (const TW*)wav, \
     (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (const TO*)g, part, partx, (long)T, T0, (int)C, (int)stride, gscale)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
   if (key == 111 && C == 512 && g_conv0_bwd_mfma) {
-    static const float2* tab1 = nullptr;
-    if (!tab1) {
-      void* a = nullptr;
-      if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_gelu_tab)) != hipSuccess) return WL_ELAUNCH;
-      tab1 = (const float2*)a + GT_N;  // [1] = gelu'
-    }
+    const float2* tab0 = gelu_tab_get(st);
+    if (!tab0) return WL_ELAUNCH;
+    const float2* tab1 = tab0 + GT_N;  // [1] = gelu'
     const int rc1 = conv0_bwd_mfma_launch(wav, W, gamma, beta, stats, g, part, partx, (long)T, T0, (int)stride, gscale, nchunk,
                                           (int)B, tab1, st);
     if (rc1 != WL_OK) return rc1;
@@ -683,7 +689,7 @@ int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
   const int T0 = (int)((T - kw) / stride + 1);
   const dim3 grid((unsigned)((T0 + C0_TCH - 1) / C0_TCH), (unsigned)B);
   const size_t smem = seg_floats(C0_TCH, stride) * sizeof(float) + (out_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
-  if (out_dtype == WL_BF16) gelu_tab_ensure(st);
+  if (out_dtype == WL_BF16 && gelu_tab_ensure(st) != WL_OK) return WL_ELAUNCH;
 #define FW(TW, TP, TO) WL_LAUNCH((conv0_ln_fwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
     (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (TO*)out, (long)T, T0, (int)C, (int)stride, eps)
   const int key = wav_dtype * 100 + param_dtype * 10 + out_dtype;
@@ -710,7 +716,7 @@ int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   const dim3 grid((unsigned)nchunk, (unsigned)B);
   float* part = (float*)workspace;
   const size_t smem = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float) + (g_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
-  if (g_dtype == WL_BF16) gelu_tab_ensure(st);
+  if (g_dtype == WL_BF16 && gelu_tab_ensure(st) != WL_OK) return WL_ELAUNCH;
 #define BW(TW, TP, TO) WL_LAUNCH((conv0_ln_bwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
     (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (const TO*)g, part, (long)T, T0, (int)C, (int)stride, eps, gscale)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;

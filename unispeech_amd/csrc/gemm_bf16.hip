@@ -296,15 +296,23 @@ __global__ void gelu_tab4_init_kernel() {
   const double s0 = (f(x1) - f(x0)) / h, s1 = (d(x1) - d(x0)) / h;
   g_gelu_tab4[i] = make_float4((float)s0, (float)(f(x0) - s0 * x0), (float)s1, (float)(d(x0) - s1 * x0));
 }
+// Per device (hipGetSymbolAddress resolves against the CURRENT device's copy of the module), under a mutex, and the host
+// waits for the init kernel once: the table is then visible to every stream and thread that asks for it afterwards (a
+// pointer cached before the fill had run could be read unfilled by a first GELU-epilogue GEMM on another stream).
 static const float4* gelu_tab4_get(hipStream_t st) {
-  static const float4* ptr = nullptr;
-  if (!ptr) {
+  static std::mutex mu;
+  static const float4* ptr[WL_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WL_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!ptr[dev]) {
     void* a = nullptr;
     if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_gelu_tab4)) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(gelu_tab4_init_kernel, dim3(GT4_N / 256), dim3(256), 0, st);
-    ptr = (const float4*)a;
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return nullptr;
+    ptr[dev] = (const float4*)a;
   }
-  return ptr;
+  return ptr[dev];
 }
 
 // the same table for the other translation units of the library (posconv_direct.hip)

@@ -15,7 +15,8 @@ Division of labour:
             per mix), the scaled span additions in the reference's in-place row order, the optional per-row
             normalisation, and the bf16 cast of the waveform the Trainer would do afterwards.
 At 11 k audio-seconds/s per GPU (32 x 15 s every 43 ms) the reference's loop -- ~8 passes over a 240 000-sample row per
-mixed utterance in numpy -- cannot feed one GPU from one worker; here the host touches each sample once (the memcpy).
+mixed utterance in numpy -- cannot feed one GPU from one worker; here the host touches each sample twice (the memcpy into staging and, when mixing is
+on, the all-zero test of the staged row that decides whether the reference would draw an SNR).
 
 There is no CPU mixing path in this module: `device=None` returns the plan and the un-mixed batch (used by the CPU
 tests together with the oracle); with a device the HIP library does the arithmetic or the call raises.
@@ -58,7 +59,8 @@ class UtteranceMixingCollater:
         self.noise_list, self.noise_loader = noise_list, noise_loader
         self.device = torch.device(device) if device is not None else None
         self.out_dtype = out_dtype
-        self._stage = None
+        self._stages = [None, None, None]  # rotating pinned staging buffers: [tensor, event of the last H2D copy out of it]
+        self._stage_i = 0
 
     # ---------------------------------------------------------------------------------------------- host: audio
     def crop_to_max_size(self, n, target_size):
@@ -73,20 +75,40 @@ class UtteranceMixingCollater:
         return start, end
 
     def _staging(self, B, T):
+        """next pinned staging buffer of the rotation.  The H2D copy out of a staging buffer is asynchronous and the
+        training loop never synchronises (defer_logging), so the host can be a batch or two ahead of the copy engine: a
+        buffer is handed out again only after the event recorded behind its last copy has completed (`_staged_copy`).
+        PyTorch's pinned allocator guards a block against free + reuse only, not against host writes into a live tensor."""
         n = B * T
-        if self._stage is None or self._stage.numel() < n:
-            self._stage = torch.empty(max(n, 1), dtype=torch.float32)
+        self._stage_i = (self._stage_i + 1) % len(self._stages)
+        slot = self._stages[self._stage_i]
+        if slot is None or slot[0].numel() < n:
+            buf = torch.empty(max(n, 1), dtype=torch.float32)
             if self.device is not None and self.device.type == "cuda":
-                self._stage = self._stage.pin_memory()
-        return self._stage[:n].view(B, T)
+                buf = buf.pin_memory()
+            slot = self._stages[self._stage_i] = [buf, None]
+        if slot[1] is not None:
+            slot[1].synchronize()  # the copy engine has read the previous batch out of this buffer
+            slot[1] = None
+        return slot[0][:n].view(B, T)
+
+    def _staged_copy(self, staged):
+        """asynchronous H2D copy of the current staging buffer + the event that guards the buffer's reuse"""
+        dev_t = staged.to(self.device, non_blocking=True)
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._stages[self._stage_i][1] = ev
+        return dev_t
 
     def collater_audio(self, audios, audio_size):
         """utterance_mixing_dataset.py:440-462: crop / zero-pad into [B, audio_size]; returns (staging tensor, padding
-        mask, audio starts)"""
+        mask, audio starts, all-zero flag of every collated row)"""
         B = len(audios)
         out = self._staging(B, audio_size)
         padding_mask = torch.zeros(B, audio_size, dtype=torch.bool)
         starts = [0] * B
+        zero = [False] * B
         for i, a in enumerate(audios):
             diff = len(a) - audio_size
             if diff == 0:
@@ -100,7 +122,11 @@ class UtteranceMixingCollater:
                 s, e = self.crop_to_max_size(len(a), audio_size)
                 out[i].copy_(a[s:e])
                 starts[i] = s
-        return out, padding_mask, starts
+            if self.mixing_prob > 0:
+                # power of the COLLATED row (after crop / zero-pad), as mixing_collated_audios measures it
+                # (utterance_mixing_dataset.py:420-421): a crop can be silent although the utterance is not
+                zero[i] = not bool(out[i].any())
+        return out, padding_mask, starts, zero
 
     # ------------------------------------------------------------------------------------------- host: mix plan
     def draw_mixing_plan(self, B, T, row_is_zero=None):
@@ -111,7 +137,7 @@ class UtteranceMixingCollater:
         The reference draws the SNR only when the partner's power is non-zero.  That is data dependent, but decidable on
         the host without touching the waveform again: a row's power is zero iff the row is all zeros, and mixing never
         changes that (a zero row has ref_pow = 0 -> scale 0; a non-zero row stays non-zero) -- `row_is_zero[r]` of the
-        ORIGINAL rows (the dataset knows it when it decodes the audio) is enough."""
+        COLLATED rows before mixing (after crop / zero-pad: `collater_audio` tests the staged row) is enough."""
         mixing_max_len = T // 2 if self.mixing_max_len < 0 else T // self.mixing_max_len
         mixing_max_len = T if mixing_max_len > T else mixing_max_len
         zero = [False] * B if row_is_zero is None else list(row_is_zero)
@@ -191,12 +217,10 @@ class UtteranceMixingCollater:
         sizes = [len(a) for a in audios]
         bnds = [s.get("boundary", []) for s in samples]
         audio_size = min(max(sizes), self.max_sample_size) if self.pad_audio else min(min(sizes), self.max_sample_size)
-        staged, padding_mask, starts = self.collater_audio(audios, audio_size)
+        staged, padding_mask, starts, zero = self.collater_audio(audios, audio_size)
         B, T = staged.shape
         plan = None
         if self.mixing_prob > 0:
-            zero = [bool(s.get("is_zero", False)) if "is_zero" in s else not bool(torch.any(a != 0))
-                    for s, a in zip(samples, audios)]
             plan = self.draw_mixing_plan(B, T, zero)
         targets_by_label = [[s["label_list"][i] for s in samples] for i in range(self.num_labels)]
         targets_list, lengths_list, ntokens_list = self.collater_label(targets_by_label, audio_size, starts)
@@ -205,7 +229,7 @@ class UtteranceMixingCollater:
             source = staged.clone()
             pm_dev = padding_mask
         else:
-            src_dev = staged.to(self.device, non_blocking=True)
+            src_dev = self._staged_copy(staged)
             pm_dev = F.h2d(padding_mask, self.device)
             if plan is None:
                 source = src_dev if self.out_dtype == torch.float32 else src_dev.to(self.out_dtype)

@@ -503,6 +503,10 @@ class WavLMPretrainModel(WavLM):
             self.spk_proj = None
         if hasattr(self.encoder, "layer_norm_for_extract"):  # unispeech_sat.py:833-834
             self.encoder.layer_norm_for_extract = None
+        # unispeech_sat.py:828-832: fine-tuning / feature extraction must not request the speaker tap any more (a pre-LN
+        # encoder without layer_norm_for_extract would refuse it, a post-LN one would compute a tap nobody reads)
+        self.utterance_contrastive_loss = False
+        self.utterance_contrastive_layer = None
 
 
 class WavLMCriterion(nn.Module):

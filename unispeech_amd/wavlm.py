@@ -502,12 +502,6 @@ class TransformerEncoder(nn.Module):
                 if fuse_preln:
                     x, pending, table = layer.forward_preln_fused(x, pending, kpm, table)
                     z = None
-                    if extract_layer is not None and i == extract_layer:
-                        # the speaker tap needs this block's output itself: add the pending branch here (its bias
-                        # token stays untaken, fc2 computes its own bias gradient) and go on un-pended
-                        pd = layer.dropout if self.training else 0.0
-                        x = ResidualAddFn.apply(x, pending[0], pd, F.next_seed() if pd > 0 else 0)
-                        pending = None
                 elif layer._forward_hooks or layer._forward_pre_hooks:
                     xt, z, table = layer(x.transpose(0, 1), kpm, table, tbc=True)
                     x = xt.transpose(0, 1)
@@ -516,6 +510,14 @@ class TransformerEncoder(nn.Module):
             else:
                 z = None
             if extract_layer is not None and i == extract_layer:
+                if pending is not None:
+                    # fused pre-LN path: the last executed block's feed-forward branch is still pending.  The speaker tap
+                    # is the residual stream AFTER that whole block, whether layer i itself ran or was dropped
+                    # (unispeech_sat.py:1238-1247 records `x` after the layerdrop branch): add the branch here (its bias
+                    # token stays untaken, fc2 computes its own bias gradient) and go on un-pended
+                    pd = self.layers[0].dropout if self.training else 0.0
+                    x = ResidualAddFn.apply(x, pending[0], pd, F.next_seed() if pd > 0 else 0)
+                    pending = None
                 self._extract_result = x
             if fairseq_layer_results:
                 if isinstance(tgt_layer, list) and i + 1 in tgt_layer:
