@@ -233,12 +233,13 @@ def main():
         loss, ss, _ = crit(net, sample)
         loss.backward()
         if world > 1:
-            net.all_reduce_grads()
+            net.all_reduce_grads()   # AVERAGE over ranks (the wrapper folds 1/world into the optimizer's deferred factor)
             # pinned + asynchronous: torch.tensor(..., device=dev) is a blocking H2D copy, i.e. a stream synchronisation
             # that would cost the launch thread its run-ahead in every data-parallel step
             sst = WF.h2d(torch.tensor([float(ss)], dtype=torch.float32), dev)
             dist.all_reduce(sst)
-            opt.step(grad_mult=1.0, grad_mult_dev=sst.reciprocal())
+            # trainer.py:796-801: multiply_grads(world / sample_size summed over ranks)
+            opt.step(grad_mult=float(world), grad_mult_dev=sst.reciprocal())
         else:
             opt.step(grad_mult=1.0 / max(ss, 1))
         return loss

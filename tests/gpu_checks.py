@@ -496,7 +496,9 @@ def check_attention():
         Od = F.AttnCoreFn.apply(qkv.to(dtype).to(DEV), None, None, None, H, hd ** -0.5, 0.0, 0)
         out.append((f"attn[{dtype}] no bias O", err(Od, Or), tol))
     # fused kernels (bf16, head_dim 64) at the real frame count, with padding, vs the fp64 reference
-    for (B, T, H, use_pad) in [(2, 749, 3, True), (1, 300, 2, False)]:
+    # (1, 999, 16): WavLM-Large's frame count and head count (20 s utterances); (2, 1000, 2, 'ragged'): a full-length row next
+    # to one with 63 valid frames (937 padded keys: whole key tiles masked, dead query rows in the same block)
+    for (B, T, H, use_pad) in [(2, 749, 3, True), (1, 300, 2, False), (1, 999, 16, False), (2, 1000, 2, 'ragged')]:
         hd, D, dtype, tol = 64, 64 * H, torch.bfloat16, TOLBF
         qkv = q(gen(B, T, 3 * D, seed=11), dtype)
         gate = 1 + 0.5 * gen(B, H, T, seed=12)
@@ -504,7 +506,7 @@ def check_attention():
         kpm = None
         if use_pad:
             kpm = torch.zeros(B, T, dtype=torch.uint8)
-            kpm[1, T - 100:] = 1
+            kpm[1, (63 if use_pad == 'ragged' else T - 100):] = 1
         dO = q(gen(B, T, D, seed=14), dtype)
         qr, gr, tr = qkv.double().requires_grad_(True), gate.double().requires_grad_(True), tab.double().requires_grad_(True)
         Or = _ref_attention(qr, gr, tr, kpm, H, hd ** -0.5)
@@ -536,18 +538,7 @@ def check_attention():
     out.append(("attn[fused] dropout deterministic", float((O1 != O2).float().mean().item()), 0.0))
     out.append(("attn[fused] dropout seed changes mask", 0.0 if (O1 != O3).any().item() else 1.0, 0.0))
     out.append(("attn[fused] dropout E[kept mass] ~ 1", abs(O1.float().mean().item() - 1.0), 0.02))
-    R = gen(B, T, D, seed=22).to(torch.bfloat16).to(DEV)
-    x0 = qkv.clone().float()
-    delta = gen(B, T, 3 * D, seed=23).to(DEV)
-    xq = x0.to(torch.bfloat16).requires_grad_(True)
-    Od = F.AttnCoreFn.apply(xq, None, None, None, H, hd ** -0.5, 0.25, 99)
-    (Od.float() * R.float()).sum().backward()
-    lin = (xq.grad.float() * delta).sum().item()
-    eps = 0.05
-    Lp = (F.AttnCoreFn.apply((x0 + eps * delta).to(torch.bfloat16), None, None, None, H, hd ** -0.5, 0.25, 99).float() * R.float()).sum().item()
-    Lm = (F.AttnCoreFn.apply((x0 - eps * delta).to(torch.bfloat16), None, None, None, H, hd ** -0.5, 0.25, 99).float() * R.float()).sum().item()
-    fd = (Lp - Lm) / (2 * eps)
-    out.append(("attn[fused] dropout fwd/bwd mask consistency (finite difference)", abs(fd - lin) / max(abs(fd), 1e-6), 0.2))
+    # (forward / backward mask agreement and the numerics under dropout: check_dropout_exact -- exact, not statistical)
     # gate
     # (3, 64): 16-byte fast path with idle lanes, even row count; (12, 64) x 67 rows: Base geometry, odd row count (half
     # step at the end); (2, 32): generic kernel
@@ -583,6 +574,177 @@ def check_attention():
     td.backward(dt_.to(DEV))
     out.append(("relpos table", err(td, tr), 1e-6))
     out.append(("relpos table grad", err(ed.grad, emb.grad), 1e-5))
+    return out
+
+
+# ------------------------------------------------------------------------------------------- exact dropout parity
+def _attn_kernel_masks(B, H, T, p_drop, seed, gate, tab, kpm, qseed=41):
+    """The keep mask each of the three fused attention kernels ACTUALLY applies, read out of the kernels' own results
+    (no debug entry point, no re-implementation of the hash): bool [B, H, T, T] (query, key) each.
+      forward   V = one-hot over a 64-key chunk  ->  O[i, u] = P_drop[i, j0 + u]: kept iff non-zero;
+      dK/dV     dO = one-hot over a 64-query chunk  ->  dV[j, u] = P_drop[i0 + u, j]: kept iff non-zero;
+      dQ        K = one-hot over a 64-key chunk, V = dO = e_0 (so dP = 1 everywhere)  ->  dQ[i, u] = scale * dS[i, j0 + u]
+                with dS = P sc (keep - kappa_i), kappa_i = kept probability mass of row i in (0, 1): kept iff positive.
+    Padded keys (P = 0) carry no information and are reported as False by all three."""
+    hd = 64
+    D = H * hd
+    scale = hd ** -0.5
+    qv = (0.5 * gen(B, T, D, seed=qseed)).to(torch.bfloat16).to(DEV)
+    kv = (0.5 * gen(B, T, D, seed=qseed + 1)).to(torch.bfloat16).to(DEV)
+    keep_f = torch.zeros(B, H, T, T, dtype=torch.bool)
+    keep_q = torch.zeros(B, H, T, T, dtype=torch.bool)
+    keep_kv = torch.zeros(B, H, T, T, dtype=torch.bool)
+    hsel = torch.arange(H, device=DEV) * hd
+    for c0 in range(0, T, 64):
+        n = min(64, T - c0)
+        u = torch.arange(n, device=DEV)
+        onehot = torch.zeros(B, T, D, dtype=torch.bfloat16, device=DEV)
+        for h in range(H):
+            onehot[:, c0 + u, h * hd + u] = 1.0
+        # forward: V one-hot on the key chunk
+        qkv = torch.cat([qv, kv, onehot], dim=-1).contiguous()
+        O, lse = ops.attn_fused_fwd(qkv, gate, tab, kpm, H, scale, p_drop, seed)
+        keep_f[:, :, :, c0:c0 + n] = (O.view(B, T, H, hd)[..., :n] != 0).permute(0, 2, 1, 3).cpu()
+        # dK/dV: dO one-hot on the query chunk (any V)
+        qkv2 = torch.cat([qv, kv, kv], dim=-1).contiguous()
+        O2, lse2 = ops.attn_fused_fwd(qkv2, gate, tab, kpm, H, scale, p_drop, seed)
+        dqkv, _, _ = ops.attn_fused_bwd(qkv2, O2, onehot, lse2, gate, tab, kpm, H, scale, p_drop, seed)
+        dV = dqkv[..., 2 * D:].view(B, T, H, hd)[..., :n]                       # [b, j, h, u] = P_drop[i0 + u, j]
+        keep_kv[:, :, c0:c0 + n, :] = (dV != 0).permute(0, 2, 3, 1).cpu()
+        # dQ: K one-hot on the key chunk, V = dO = e_0
+        e0 = torch.zeros(B, T, D, dtype=torch.bfloat16, device=DEV)
+        e0[..., hsel] = 1.0
+        qkv3 = torch.cat([qv, onehot, e0], dim=-1).contiguous()
+        O3, lse3 = ops.attn_fused_fwd(qkv3, gate, tab, kpm, H, scale, p_drop, seed)
+        dqkv3, _, _ = ops.attn_fused_bwd(qkv3, O3, e0, lse3, gate, tab, kpm, H, scale, p_drop, seed)
+        dQ = dqkv3[..., :D].view(B, T, H, hd)[..., :n]
+        keep_q[:, :, :, c0:c0 + n] = (dQ > 0).permute(0, 2, 1, 3).cpu()
+    if kpm is not None:
+        valid = ~kpm.bool().cpu()[:, None, None, :]
+        keep_f, keep_q, keep_kv = keep_f & valid, keep_q & valid, keep_kv & valid
+    return keep_f, keep_q, keep_kv
+
+
+def _ref_attention_masked(qkv, gate, tab, kpm, H, scale, keep, sc):
+    """_ref_attention with an explicit dropout keep mask [B, H, T, T] and scale sc = 1 / (1 - p) on the probabilities"""
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // H
+    qh = qkv[..., :D].view(B, T, H, hd).permute(0, 2, 1, 3)
+    kh = qkv[..., D:2 * D].view(B, T, H, hd).permute(0, 2, 1, 3)
+    vh = qkv[..., 2 * D:].view(B, T, H, hd).permute(0, 2, 1, 3)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if tab is not None:
+        i = torch.arange(T)[:, None]
+        j = torch.arange(T)[None, :]
+        s = s + gate.unsqueeze(-1) * tab[:, (j - i) + T - 1].unsqueeze(0)
+    if kpm is not None:
+        s = s.masked_fill(kpm.bool()[:, None, None, :], float("-inf"))
+    pr = torch.softmax(s, dim=-1) * keep.to(s.dtype) * sc
+    return (pr @ vh).permute(0, 2, 1, 3).reshape(B, T, D)
+
+
+def check_dropout_exact():
+    """Dropout-on is the benchmarked mode: its parity must not be statistical.  (1) The keep masks the forward, dQ and dK/dV
+    attention kernels apply are read out of the kernels themselves and must be IDENTICAL (three kernels regenerate the mask
+    independently, the dK/dV one with a different word-sharing scheme).  (2) With that mask the fused forward and backward
+    are compared with the fp64 reference at the usual bf16 tolerance (multihead_attention.py:278-300 with
+    dropout_p = attention_dropout).  (3) The same for the dropouts fused into the LayerNorm kernels (residual-branch
+    dropout of post- and pre-LN blocks incl. the fused pre-LN residual stream, output dropout) and the dropout-add."""
+    out = []
+    p_drop = 0.25   # 16384 / 65536: the kernels' 16-bit threshold represents it exactly, sc = 4/3
+    sc = 1.0 / (1.0 - p_drop)
+    cases = [(1, 2, 256, False, False, 1234567), (2, 2, 200, True, True, 0x9E3779B97F4A7C15), (1, 16, 331, True, False, 77)]
+    for (B, H, T, use_tab, use_pad, seed) in cases:
+        gate = tab = kpm = None
+        if use_tab:
+            gate = (1 + 0.5 * gen(B, H, T, seed=2)).to(DEV)
+            tab = (0.5 * gen(H, 2 * T - 1, seed=3)).to(DEV)
+        if use_pad:
+            kpm = torch.zeros(B, T, dtype=torch.uint8)
+            kpm[1, T - 37:] = 1
+            kpm = kpm.to(DEV)
+        kf, kq, kkv = _attn_kernel_masks(B, H, T, p_drop, seed, gate, tab, kpm)
+        tag = f"dropout-exact attn B={B} H={H} T={T} tab={use_tab} pad={use_pad}"
+        nvalid = float((~kpm.bool().cpu()).float().mean().item()) if kpm is not None else 1.0
+        out.append((tag + " keep fraction", abs(kf.float().mean().item() / nvalid - (1 - p_drop)), 0.01))
+        out.append((tag + " mask fwd == dQ (mismatching elements)", float((kf != kq).sum().item()), 0.0))
+        out.append((tag + " mask fwd == dK/dV (mismatching elements)", float((kf != kkv).sum().item()), 0.0))
+        # (2) numerics with the forward's own mask
+        D = 64 * H
+        qkv = q(gen(B, T, 3 * D, seed=11), torch.bfloat16)
+        dO = q(gen(B, T, D, seed=14), torch.bfloat16)
+        gc, tc = (gate.cpu(), tab.cpu()) if use_tab else (None, None)
+        qr = qkv.double().requires_grad_(True)
+        gr = gc.double().requires_grad_(True) if use_tab else None
+        tr = tc.double().requires_grad_(True) if use_tab else None
+        Or = _ref_attention_masked(qr, gr, tr, kpm.cpu() if kpm is not None else None, H, 64 ** -0.5, kf, sc)
+        (Or * dO.double()).sum().backward()
+        qd = qkv.to(torch.bfloat16).to(DEV).requires_grad_(True)
+        gd = gate.clone().requires_grad_(True) if use_tab else None
+        td = tab.clone().requires_grad_(True) if use_tab else None
+        Od = F.AttnCoreFn.apply(qd, gd, td, kpm, H, 64 ** -0.5, p_drop, seed)
+        Od.backward(dO.to(torch.bfloat16).to(DEV))
+        out.append((tag + " O vs fp64 with the kernel's mask", err(Od, Or), TOLBF))
+        out.append((tag + " dqkv vs fp64 with the kernel's mask", err(qd.grad, qr.grad), TOLBF * 2))
+        if use_tab:
+            out.append((tag + " dgate", err(gd.grad, gr.grad), TOLBF * 2))
+            out.append((tag + " dtab", err(td.grad, tr.grad), TOLBF * 2))
+    # (3) LayerNorm-fused dropouts
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        for D in (768, 1024):
+            rows, p = 75, 0.25
+            x, r = q(gen(rows, D, seed=1), dtype), q(gen(rows, D, seed=2), dtype)
+            g, b = q(1 + 0.1 * gen(D, seed=3), dtype), q(0.1 * gen(D, seed=4), dtype)
+            dy, ds = q(gen(rows, D, seed=5), dtype), q(gen(rows, D, seed=6), dtype)
+            dev = lambda t: t.to(dtype).to(DEV)
+            # the forward's residual-dropout mask: x = 0, r = 1  ->  s = keep / (1 - p)
+            _, s_probe = F.LayerNormFn.apply(dev(torch.zeros(rows, D)), dev(torch.ones(rows, D)), dev(g), dev(b), 1e-5, 0, p, 4711,
+                                             0.0, 0, 1.0)
+            keep = (s_probe != 0).cpu()
+            tag = f"dropout-exact layernorm[{dtype}] D={D}"
+            out.append((tag + " residual-dropout keep fraction", abs(keep.float().mean().item() - (1 - p)), 0.02))
+            for s_grad in (False, True):
+                xr, rr, gr, br = [t.clone().double().requires_grad_(True) for t in (x, r, g, b)]
+                s_ref = xr + rr * keep.double() / (1 - p)
+                s_q = s_ref + (s_ref.detach().to(dtype).double() - s_ref.detach())  # the kernel rounds s to `dtype`
+                yr = TF.layer_norm(s_q, (D,), gr, br, 1e-5)
+                ((yr * dy.double()).sum() + ((s_q * ds.double()).sum() if s_grad else 0.0)).backward()
+                xd, rd, gd, bd = [dev(t).requires_grad_(True) for t in (x, r, g, b)]
+                res = F.LayerNormFn.apply(xd, rd, gd, bd, 1e-5, 0, p, 4711, 0.0, 0, 1.0, None, False, s_grad)
+                y, s_out = res[0], res[1]
+                if s_grad:
+                    (y.float() * dev(dy).float()).sum().add((s_out.float() * dev(ds).float()).sum()).backward()
+                else:
+                    y.backward(dev(dy))
+                t2 = tag + (" fused residual stream" if s_grad else "")
+                out.append((t2 + " backward mask == forward mask (mismatching elements)",
+                            float((((rd.grad != 0).cpu() != keep) & (xd.grad != 0).cpu()).sum().item()), 0.0))
+                out.append((t2 + " y", err(y, yr), tol))
+                out.append((t2 + " dx", err(xd.grad, xr.grad), tol))
+                out.append((t2 + " dr", err(rd.grad, rr.grad), tol))
+                out.append((t2 + " dgamma", err(gd.grad, gr.grad), tol * 2))
+            # output dropout (the encoder's first LayerNorm): mask from the forward, gradient through the same mask
+            xd = dev(x).requires_grad_(True)
+            yp, _ = F.LayerNormFn.apply(xd, None, dev(g), dev(b), 1e-5, 0, 0.0, 0, p, 999, 1.0)
+            keep_o = (yp != 0).cpu()
+            yp.backward(dev(dy))
+            xr = x.clone().double().requires_grad_(True)
+            yr = TF.layer_norm(xr, (D,), g.double(), b.double(), 1e-5) * keep_o.double() / (1 - p)
+            (yr * dy.double()).sum().backward()
+            out.append((tag + " output-dropout y", err(yp, yr), tol))
+            out.append((tag + " output-dropout dx with the forward's mask", err(xd.grad, xr.grad), tol))
+        # dropout-add of the unfused pre-LN block: y = x + dropout(r); backward dr = dropout(dy) with the same mask
+        from unispeech_amd.wavlm import ResidualAddFn
+        rows, D, p = 64, 1024, 0.1
+        xz = torch.zeros(rows, D, dtype=dtype, device=DEV)
+        r1 = torch.ones(rows, D, dtype=dtype, device=DEV, requires_grad=True)
+        ya = ResidualAddFn.apply(xz, r1, p, 31337)
+        ya.backward(torch.ones_like(ya))
+        out.append((f"dropout-exact dropout_add[{dtype}] backward mask == forward mask",
+                    float(((ya != 0) != (r1.grad != 0)).sum().item()), 0.0))
+        out.append((f"dropout-exact dropout_add[{dtype}] keep fraction", abs((ya != 0).float().mean().item() - (1 - p)), 0.02))
     return out
 
 
@@ -776,7 +938,7 @@ def check_adam():
 GROUPS = {
     "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
     "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv, "gemm_colsum": check_gemm_colsum,
-    "linear_ffn": check_linear_ffn, "loss": check_loss, "adam": check_adam,
+    "linear_ffn": check_linear_ffn, "loss": check_loss, "adam": check_adam, "dropout_exact": check_dropout_exact,
 }
 
 if __name__ == "__main__":

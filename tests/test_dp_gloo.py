@@ -137,3 +137,75 @@ def test_grad_reducer_gloo_world2():
         assert p.exitcode == 0
     for r in res:
         assert all(r[1:]), r
+
+
+def _seam_worker(rank, world, port, q):
+    """the Trainer's order of operations on the wrapper (CPU arenas: everything but the update kernel): wrap the model
+    FIRST (trainer.py:250-261), build the optimizer front-end from the bare parameter list afterwards (trainer.py:275-316),
+    backward under the wrapper, optimizer.all_reduce_grads(model) (trainer.py:781-785), multiply_grads(world / sample_size)
+    (trainer.py:796-801)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from types import SimpleNamespace
+        from unispeech_amd.dp import DataParallelWavLM
+        from unispeech_amd.optim import FairseqFusedAdam
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
+        ddp = DataParallelWavLM(net, None, bucket_bytes=1024)
+        assert ddp.reducer is None
+        cfg = SimpleNamespace(lr=[1e-3], adam_betas="(0.9, 0.98)", adam_eps=1e-6, weight_decay=0.0)
+        opt = FairseqFusedAdam(cfg, [p for p in ddp.parameters() if p.requires_grad])
+        bound = ddp.reducer is not None and len(ddp.reducer.buckets) >= 2
+        f = opt.fused
+        x = torch.randn(4, 16, generator=torch.Generator().manual_seed(100 + rank))
+        # local gradients of every rank, computed independently (same weights everywhere)
+        refs = []
+        for r in range(world):
+            torch.manual_seed(0)
+            n2 = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
+            n2(torch.randn(4, 16, generator=torch.Generator().manual_seed(100 + r))).pow(2).sum().backward()
+            refs.append([p.grad.clone() for p in n2.parameters()])
+        opt.zero_grad()
+        opt.backward(ddp(x).pow(2).sum())
+        opt.all_reduce_grads(ddp)
+        # the arena holds the SUM; the optimizer sees the AVERAGE (legacy_distributed_data_parallel.py:107-108)
+        ok_sum = all(torch.allclose(p.grad, refs[0][i] + refs[1][i], atol=1e-6) for i, p in enumerate(net.parameters()))
+        ok_avg = abs(f.pending_mult - 1.0 / world) < 1e-12
+        sample_size = 40.0
+        opt.multiply_grads(world / sample_size)
+        ok_mult = abs(f.pending_mult - 1.0 / sample_size) < 1e-12      # == (sum of gradients) / sample_size at the update
+        # accumulation (update_freq 2): first micro-batch under no_sync, all_reduce_grads once
+        opt.zero_grad()
+        ok_reset = f.pending_mult == 1.0
+        with ddp.no_sync():
+            opt.backward(ddp(x).pow(2).sum())
+        local_only = all(torch.allclose(p.grad, refs[rank][i], atol=1e-6) for i, p in enumerate(net.parameters()))
+        opt.backward(ddp(x).pow(2).sum())
+        opt.all_reduce_grads(ddp)
+        ok_acc = all(torch.allclose(p.grad, 2 * (refs[0][i] + refs[1][i]), atol=1e-5) for i, p in enumerate(net.parameters()))
+        ok_acc = ok_acc and abs(f.pending_mult - 1.0 / world) < 1e-12
+        keys = list(ddp.state_dict().keys()) == list(net.state_dict().keys())
+        q.put((rank, bound, ok_sum, ok_avg, ok_mult, ok_reset, local_only, ok_acc, keys, None))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_trainer_order_on_the_wrapper_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seam_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[-1] is None and all(r[1:-1]), r

@@ -1,0 +1,125 @@
+"""End-to-end parity of BASELINE.json configs[3] / configs[4] AT THEIR OWN WIDTH on the benchmarked path: WavLM-Large
+structure (d = 1024, 16 heads of 64, FFN 4096, LayerNorm-mode extractor, pre-LN blocks -> `forward_preln_fused`, 20 s
+utterances -> 999 frames) in bf16 with FusedAdam bound (packed q|k|v, gradient sinks, MFMA GEMMs with fused epilogues,
+fused attention at T = 999 / H = 16, direct pos_conv at Cg = 64, LayerNorm-mode conv0), against the fp32 CPU oracle on
+the same bf16-rounded parameters and waveform.  4 layers instead of 24 (the CPU oracle has to finish in a minute); every
+layer type, width and sequence length of the bench configuration is the real one.
+
+  * `large`: the masked-prediction step of configs[3] (reference lines: pre-LN block unispeech_sat.py:1088-1111, attention
+    multihead_attention.py:278-300, LayerNorm-mode extractor WavLM/WavLM.py:403-418).
+  * `sat_large`: the same + UniSpeech-SAT's utterance-contrastive head tapped after layer 2 through
+    `layer_norm_for_extract` (unispeech_sat.py:1195-1208, 701-737); the instance indices come from the torch CPU generator
+    on both sides (same seed -> same draws).
+
+Tolerances are those of tests/test_bf16_e2e_gpu.py (derivation in its docstring): loss 2e-3 relative; per gradient tensor
+relative L2 <= 4e-2, max-abs <= 6e-2 of the tensor's max-abs, cosine >= 0.999; analytically-zero gradients on an absolute
+floor.  Measured values are printed and carried in the assertion messages.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Cfg, TINY
+
+pytestmark = pytest.mark.gpu
+
+V = 504
+ADAM = dict(lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
+CLIP = 10.0
+LARGE = dict(TINY)
+LARGE.update(encoder_layers=4, encoder_embed_dim=1024, encoder_ffn_embed_dim=4096, encoder_attention_heads=16,
+             extractor_mode="layer_norm", layer_norm_first=True, normalize=True, feature_grad_mult=1.0,
+             conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2", conv_pos=128, conv_pos_groups=16,
+             num_buckets=320, max_distance=800, mask_length=10, mask_prob=0.8, final_dim=768)
+SAT = dict(LARGE)
+SAT.update(utterance_contrastive_loss=True, utterance_contrastive_layer=2, num_instances=0, cross_sample_instances=100)
+
+
+def compare_gradients(grads, og, l2_tol=4e-2, max_tol=6e-2, cos_tol=0.999):
+    """per-tensor comparison used by the bf16 end-to-end tests; returns (bad list, report string)"""
+    gmax = max(g.abs().max().item() for g in og.values())
+    rows, bad = [], []
+    for n, g in grads.items():
+        ref = og[n]
+        scale = ref.abs().max().item()
+        if scale < 1e-5 * gmax:   # analytically zero (k_proj.bias): absolute floor
+            if g.abs().max().item() > 1e-3 * gmax:
+                bad.append((n, "zero-gradient", g.abs().max().item(), gmax))
+            continue
+        d = g.double() - ref.double()
+        l2 = (d.norm() / ref.double().norm()).item()
+        mx = d.abs().max().item() / scale
+        cos = torch.nn.functional.cosine_similarity(g.double().flatten(), ref.double().flatten(), dim=0).item()
+        rows.append((l2, mx, cos, n))
+        if l2 > l2_tol or mx > max_tol or cos < cos_tol:
+            bad.append((n, l2, mx, cos))
+    rows.sort(reverse=True)
+    rep = "five worst tensors (rel-L2, max-abs, cos): " + "; ".join("%s %.2e %.2e %.5f" % (r[3], r[0], r[1], r[2]) for r in rows[:5])
+    rep += "\n  median rel-L2 over %d tensors: %.2e" % (len(rows), rows[len(rows) // 2][0])
+    return bad, rep
+
+
+@pytest.mark.parametrize("name", ["large", "sat_large"])
+def test_large_width_bf16_step_vs_fp32_oracle(name):
+    from oracle import wavlm_oracle as O
+    from unispeech_amd import wavlm as W
+    from unispeech_amd.masking import compute_mask_indices
+    from unispeech_amd.optim import FusedAdam
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    d = SAT if name == "sat_large" else LARGE
+    lw = [10.0, 10.0, 0.0] if name == "sat_large" else [10.0]
+    cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    torch.manual_seed(0)
+    model = WavLMPretrainModel(cfg, None, [range(V)])
+    sd = {k: (v.detach().to(torch.bfloat16).float() if v.is_floating_point() else v.detach().clone())
+          for k, v in model.state_dict().items()}
+    model = model.cuda().to(torch.bfloat16).train()
+    opt = FusedAdam(model.parameters(), clip_norm=CLIP, model=model, **ADAM)
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=lw)
+    assert W.PRELN_FUSED and model.encoder.layer_norm_first  # the path bench.py --config large / sat_large times
+
+    B, seconds = 2, 20.0
+    g = torch.Generator().manual_seed(4242)
+    T = int(16000 * seconds)
+    wav = torch.randn(B, T, generator=g).to(torch.bfloat16)
+    target = torch.randint(4, V, (B, int(50 * seconds)), generator=g)
+    pm = torch.zeros(B, T, dtype=torch.bool)
+    sample = {"id": torch.arange(B), "net_input": {"source": wav.cuda(), "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+              "target_list": [target.cuda()]}
+    opt.zero_grad()
+    np.random.seed(123)
+    torch.manual_seed(77)   # UniSpeech-SAT instance indices (torch CPU generator, as in the reference)
+    loss, ss, _ = crit(model, sample)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
+
+    Tp = T
+    for _, k, s in eval(cfg.conv_feature_layers):
+        Tp = (Tp - k) // s + 1
+    assert Tp == 999
+    Tp = min(Tp, target.shape[1])
+    np.random.seed(123)
+    m = compute_mask_indices((B, Tp), torch.zeros(B, Tp, dtype=torch.bool), cfg.mask_prob, cfg.mask_length, "static", 0,
+                             min_masks=2, no_overlap=False, min_space=1)
+    torch.manual_seed(77)
+    losses, sizes, _, _, og = O.train_steps(sd, Cfg(**d), [(wav.float(), target, pm, torch.from_numpy(m))], [V],
+                                            max_norm=CLIP, loss_weights=lw, return_grads=True, **ADAM)
+    assert ss == sizes[0]
+    rel_loss = abs(loss.item() - losses[0]) / abs(losses[0])
+    bad, rep = compare_gradients(grads, og)
+    msg = "%s (4L, d=1024, H=16, 2 x 20 s, T'=999) bf16 vs fp32 oracle: loss %.4f vs %.4f (rel %.2e)\n  %s" % (
+        name, loss.item(), losses[0], rel_loss, rep)
+    print(msg)
+    assert rel_loss < 2e-3, msg
+    assert not bad, msg + "\n" + "\n".join(map(str, bad[:20]))
+    if name == "sat_large":
+        assert any(n.startswith("spk_proj") for n in grads) and grads["encoder.layer_norm_for_extract.weight"].abs().max() > 0
+    # one optimizer update on top: finite master weights, parameters moved
+    before = opt.master.clone()
+    opt.step(grad_mult=1.0 / ss)
+    torch.cuda.synchronize()
+    assert torch.isfinite(opt.master).all() and (opt.master - before).abs().max().item() > 0

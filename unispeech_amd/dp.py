@@ -7,12 +7,18 @@ there is nothing to pack: the arena is cut into buckets in reverse parameter ord
 the gradients of a bucket as backward produces them, and a finished bucket is all-reduced immediately on a side
 HIP stream while the rest of backward keeps the compute stream busy.  xGMI is point-to-point (7 links x ~153 GB/s
 per GPU): a ring all-reduce is bound by one link, so buckets are kept large (default 32 MiB -> ~6 collectives for
-WavLM-Base) -- the goal is overlap, not message count.  The 1/world factor is not applied here: it is folded into
-the optimizer's gradient multiplier (one fewer pass over the arena).
+WavLM-Base) -- the goal is overlap, not message count.
 
 Semantics kept from the reference wrapper: `no_sync()` (gradient accumulation), `all_reduce_grads()` as the
-explicit completion point the fairseq Trainer calls (trainer.py:781-785), sum-then-divide == average.
+explicit completion point the fairseq Trainer calls (trainer.py:781-785), and the AVERAGE over ranks as its result
+(legacy_distributed_data_parallel.py:107-108 divides by the world size before the all-reduce; the Trainer then
+multiplies by world / sample_size, trainer.py:796-801).  The division costs no pass over the arena: the collectives SUM,
+and `DataParallelWavLM.all_reduce_grads()` folds 1/world into the optimizer's deferred gradient factor
+(`FusedAdam.pending_mult`, the counterpart of fp16_optimizer.py's `_multiply_factor`), which the update kernel and the
+gradient norm apply on the fly -- as the reference's own mixed-precision wrapper does with multiply_grads ("inspecting
+model.parameters() ... may still show the original, unscaled gradients", trainer.py:793-795).
 """
+import weakref
 from contextlib import contextmanager
 
 import torch
@@ -140,8 +146,9 @@ class GradReducer:
 
     def finish(self):
         """Complete the reduction of this step: launch buckets whose hooks never all fired (unused parameters,
-        accumulation steps), then make the compute stream wait for every collective.  Gradients hold the SUM over
-        ranks afterwards; multiply by `self.scale` (1/world) for the average."""
+        accumulation steps), then make the compute stream wait for every collective.  The arena holds the SUM over
+        ranks afterwards; `self.scale` (1/world) turns it into the average (DataParallelWavLM folds it into the
+        optimizer's deferred factor)."""
         if not self.enabled:
             return
         from . import functional
@@ -164,27 +171,98 @@ class GradReducer:
         return 1.0 / self.world
 
 
-class DataParallelWavLM(torch.nn.Module):
-    """LegacyDDP-shaped wrapper (forward / no_sync / all_reduce_grads / attribute pass-through) around a model
-    whose gradients live in a FusedAdam arena."""
+_LIVE_WRAPPERS = weakref.WeakSet()
 
-    def __init__(self, module, optimizer, process_group=None, bucket_bytes=32 << 20):
+
+def bind_live_wrappers(optimizer):
+    """called by an optimizer front-end built AFTER the model was wrapped (the fairseq Trainer wraps the model in its
+    `model` property, trainer.py:250-261, and builds the optimizer lazily from `self.model.parameters()` afterwards):
+    every unbound wrapper whose module owns the optimizer's parameters gets its reducer now"""
+    mine = {id(p) for p in optimizer.params}
+    for w in list(_LIVE_WRAPPERS):
+        if w.reducer is None and any(id(p) in mine for p in w.module.parameters()):
+            w.bind_optimizer(optimizer)
+
+
+class DataParallelWavLM(torch.nn.Module):
+    """LegacyDDP-shaped wrapper (forward / no_sync / all_reduce_grads / attribute pass-through, state_dict of the wrapped
+    module as fairseq's ModuleProxyWrapper gives it, distributed/module_proxy_wrapper.py:42-48) around a model whose
+    gradients live in a FusedAdam arena.  `optimizer` may be given later (`bind_optimizer`): the Trainer wraps the model
+    before it builds the optimizer."""
+
+    def __init__(self, module, optimizer=None, process_group=None, bucket_bytes=32 << 20):
         super().__init__()
         self.module = module
-        self.reducer = GradReducer(optimizer.params, optimizer.flat_grad, optimizer.offsets, process_group,
-                                   bucket_bytes)
+        self.reducer = None
+        self._optimizer = None
+        self._pg, self._bucket_bytes = process_group, bucket_bytes
+        self._accumulate = False
+        _LIVE_WRAPPERS.add(self)
+        if optimizer is not None:
+            self.bind_optimizer(optimizer)
+
+    def bind_optimizer(self, optimizer):
+        """optimizer: a FusedAdam (or a front-end exposing it as `.fused`)"""
+        optimizer = getattr(optimizer, "fused", optimizer)
+        if self.reducer is not None:
+            if self._optimizer is optimizer:
+                return
+            raise RuntimeError("DataParallelWavLM is already bound to another optimizer arena")
+        self._optimizer = optimizer
+        self.reducer = GradReducer(optimizer.params, optimizer.flat_grad, optimizer.offsets, self._pg, self._bucket_bytes)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
 
+    @contextmanager
     def no_sync(self):
-        return self.reducer.no_sync()
+        if self.reducer is None:  # nothing to hold back yet: the first all_reduce_grads() reduces the whole arena
+            yield
+            return
+        with self.reducer.no_sync():
+            yield
 
     def all_reduce_grads(self):
+        """gradients = AVERAGE over ranks afterwards, as seen by the optimizer (module docstring): the arena holds the
+        sum, 1/world rides in the optimizer's deferred factor"""
+        if self.reducer is None:
+            raise RuntimeError(
+                "DataParallelWavLM.all_reduce_grads(): no optimizer arena bound.  Gradients of this path live in a "
+                "FusedAdam arena; build the optimizer through unispeech_amd (optimizer `adam_mi355x`, or "
+                "fairseq_plugin.register(override=True) with --bf16) or call bind_optimizer(FusedAdam) first")
         self.reducer.finish()
+        if self.reducer.enabled:
+            self._optimizer.multiply_grads(self.reducer.scale)
+
+    def state_dict(self, *args, **kwargs):
+        return self.module.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        return self.module.load_state_dict(*args, **kwargs)
 
     def __getattr__(self, name):
         try:
             return super().__getattr__(name)
         except AttributeError:
             return getattr(super().__getattr__("module"), name)
+
+
+def distributed_model(args, model, process_group, device, fallback=None):
+    """Stand-in for `DistributedFairseqModel(args, model, process_group, device)` (models/distributed_fairseq_model.py:
+    32-137), installed by `fairseq_plugin.register(override=True)`: models of this package get `DataParallelWavLM` for the
+    ddp backends whose contract is "explicit or implicit all-reduce of averaged gradients" (legacy_ddp / no_c10d -- what the
+    WavLM / HuBERT recipes run -- and c10d / pytorch_ddp); everything else goes to the reference's own function."""
+    from .pretrain import WavLMPretrainModel
+    ours = isinstance(model, WavLMPretrainModel)
+    if not ours:
+        try:
+            from .wav2vec2 import Wav2Vec2Model
+            ours = isinstance(model, Wav2Vec2Model)
+        except ImportError:
+            pass
+    backend = getattr(args, "ddp_backend", "legacy_ddp")
+    if ours and backend in {"legacy_ddp", "no_c10d", "c10d", "pytorch_ddp"}:
+        return DataParallelWavLM(model.to(device), None, process_group)
+    if fallback is None:
+        raise ValueError("ddp_backend %r is not served by unispeech_amd.dp and no fallback was given" % backend)
+    return fallback(args, model, process_group, device)

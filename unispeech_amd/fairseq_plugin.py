@@ -9,7 +9,15 @@ built-ins in fairseq's registries instead, for drop-in use of unmodified recipes
 
 Registered:
   models     wavlm_mi355x  (WavLMPretrainModel  <- src/fairseq/models/wavlm/wavlm.py:255  @register_model("wavlm"))
-             hubert_mi355x, unispeech_sat_mi355x, ils_hubert_mi355x  (same class; structure / heads selected by config fields)
+             hubert_mi355x, unispeech_sat_mi355x, ils_hubert_mi355x  (same class; structure / heads selected by config
+             fields; each arch has its OWN dataclass with the field set and defaults of the reference's config for that
+             arch -- HubertConfig hubert.py:36-217, UniSpeechSATConfig unispeech_sat.py:44-287, ILSHubertConfig
+             ils_hubert.py:44-58 -- see ARCH_CONFIGS)
+  optimizer  adam_mi355x  (FairseqFusedAdam: the FairseqOptimizer API over the flat-arena fused Adam, optim.py).  With
+             register(override=True) it also stands in for `optim.FP16Optimizer` (what trainer.py:296-316 builds in bf16
+             mode), and `DistributedFairseqModel` (models/distributed_fairseq_model.py:32-137) hands models of this
+             package to dp.DataParallelWavLM (overlapped bucket all-reduce on a side stream) -- so the step the
+             benchmark times (gradient sinks, packed q|k|v, fused Adam, overlapped reducer) is the step train.py runs.
              wav2vec2_mi355x  (Wav2Vec2Model  <- src/fairseq/models/wav2vec/wav2vec2.py:274  @register_model("wav2vec2"))
   criterions wavlm_mi355x, hubert_mi355x  (WavLMCriterion  <- criterions/wavlm_criterion.py:38, hubert_criterion.py:39)
              wav2vec_mi355x  (Wav2vecCriterion  <- criterions/wav2vec_criterion.py:36)
@@ -26,6 +34,31 @@ from .pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
 
 _CLASSES = None          # (Model, Criterion, ModelCfg, CritCfg), built once
 _REGISTERED = set()      # {"names", "override"}
+_SAVED = {}              # what register(override=True) replaced, for unregister_override()
+
+_SAT_FIELDS = ["utterance_contrastive_loss", "utterance_contrastive_layer", "num_instances", "cross_sample_instances",
+               "quantize_targets", "latent_vars", "latent_groups", "latent_dim"]  # (latent_temp exists in all four configs)
+_ILS_FIELDS = ["predict_layers", "separate_label_embeds", "separate_layer_targets", "weighted_sum"]
+_RELPOS_FIELDS = ["relative_position_embedding", "num_buckets", "max_distance", "gru_rel_pos"]
+# arch -> (fields of WavLMPretrainConfig the reference's config of that arch does NOT have, defaults that differ).
+# tests/test_fairseq_plugin.py checks field sets and defaults against the reference dataclasses themselves.
+ARCH_CONFIGS = {
+    "wavlm": (_SAT_FIELDS + _ILS_FIELDS, {}),                                                     # wavlm.py:48-252
+    "hubert": (["boundary_mask", "expand_attention_head_size"] + _RELPOS_FIELDS + _SAT_FIELDS + _ILS_FIELDS, {}),  # hubert.py:36-217
+    "unispeech_sat": (_ILS_FIELDS, {}),                                                           # unispeech_sat.py:44-287
+    "ils_hubert": (["boundary_mask", "gru_rel_pos", "expand_attention_head_size"] + _SAT_FIELDS,  # ils_hubert.py:44-58
+                   {"max_distance": 800, "predict_layers": "[12]"}),
+}
+
+
+def complete_config(cfg):
+    """an arch-specific config (a subset of the fields) -> the full WavLMPretrainConfig the model reads; fields the arch
+    does not have take the value that switches the feature off (the WavLMPretrainConfig default)"""
+    full = WavLMPretrainConfig()
+    for name in WavLMPretrainConfig.__dataclass_fields__:
+        if hasattr(cfg, name):
+            setattr(full, name, getattr(cfg, name))
+    return full
 
 
 def _classes():
@@ -36,9 +69,14 @@ def _classes():
     from fairseq.dataclass import FairseqDataclass
     from fairseq.models import BaseFairseqModel
 
-    # dataclasses with fairseq's base so that argparse / hydra generation works (dataclass/utils.py)
-    cfg_fields = [(n, f.type, field(default=f.default)) for n, f in WavLMPretrainConfig.__dataclass_fields__.items()]
-    ModelCfg = make_dataclass("WavLMMI355XConfig", cfg_fields, bases=(FairseqDataclass,))
+    # dataclasses with fairseq's base so that argparse / hydra generation works (dataclass/utils.py); one per arch
+    def arch_cfg(arch):
+        drop, over = ARCH_CONFIGS[arch]
+        fields_ = [(n, f.type, field(default=over.get(n, f.default)))
+                   for n, f in WavLMPretrainConfig.__dataclass_fields__.items() if n not in drop]
+        return make_dataclass("".join(w.capitalize() for w in arch.split("_")) + "MI355XConfig", fields_, bases=(FairseqDataclass,))
+
+    ModelCfg = {arch: arch_cfg(arch) for arch in ARCH_CONFIGS}
 
     @dataclass
     class CritCfg(FairseqDataclass):
@@ -53,7 +91,7 @@ def _classes():
     class Model(WavLMPretrainModel, BaseFairseqModel):
         @classmethod
         def build_model(cls, cfg, task):
-            return cls(cfg, task.cfg, task.dictionaries)
+            return cls(complete_config(cfg), task.cfg, task.dictionaries)
 
     class Criterion(WavLMCriterion, FairseqCriterion):
         def __init__(self, task, pred_masked_weight, pred_nomask_weight, loss_weights=None, log_keys=None,
@@ -69,6 +107,44 @@ def _classes():
 
     _CLASSES = (Model, Criterion, ModelCfg, CritCfg)
     return _CLASSES
+
+
+_OPT_CLASSES = None
+
+
+def _optim_classes():
+    """FairseqFusedAdam mixed with the reference's FairseqOptimizer base (so that isinstance checks of the lr schedulers,
+    optim/lr_scheduler/fairseq_lr_scheduler.py:15-16, hold) + its config dataclass.  Two classes: `FusedAdamMI355X`
+    (registry name adam_mi355x) and a subclass NAMED `FP16Optimizer`, the stand-in for override mode -- the Trainer stores
+    and checks the optimizer's class name in checkpoints (trainer.py:391, 521), so checkpoints written by the reference's
+    bf16 runs resume here and vice versa."""
+    global _OPT_CLASSES
+    if _OPT_CLASSES is not None:
+        return _OPT_CLASSES
+    from typing import Any
+    from fairseq.dataclass import FairseqDataclass
+    from fairseq.optim import FairseqOptimizer
+    from .optim import FairseqFusedAdam
+
+    @dataclass
+    class AdamMI355XConfig(FairseqDataclass):   # the fields of FairseqAdamConfig (optim/adam.py:26-46) this path uses
+        adam_betas: Any = field(default=(0.9, 0.999), metadata={"help": "betas for Adam optimizer"})
+        adam_eps: float = field(default=1e-8, metadata={"help": "epsilon for Adam optimizer"})
+        weight_decay: float = field(default=0.0, metadata={"help": "weight decay"})
+        use_old_adam: bool = field(default=False, metadata={"help": "ignored (kept for recipe compatibility)"})
+        fp16_adam_stats: bool = field(default=False, metadata={"help": "ignored: the moments are fp32 arenas"})
+        tpu: bool = False
+        lr: Any = field(default_factory=lambda: [1e-3])
+
+    class FusedAdamMI355X(FairseqFusedAdam, FairseqOptimizer):
+        def __init__(self, cfg, params):
+            FairseqOptimizer.__init__(self, cfg)
+            FairseqFusedAdam.__init__(self, cfg, params)
+
+    FP16Standin = type("FP16Optimizer", (FusedAdamMI355X,), {
+        "__doc__": "FusedAdamMI355X under the class name the reference's bf16 checkpoints carry (override mode)"})
+    _OPT_CLASSES = (FusedAdamMI355X, FP16Standin, AdamMI355XConfig)
+    return _OPT_CLASSES
 
 
 def _w2v_classes():
@@ -117,32 +193,77 @@ def register(override: bool = False):
         from fairseq.criterions import CRITERION_DATACLASS_REGISTRY, CRITERION_REGISTRY
         from fairseq.models import (ARCH_CONFIG_REGISTRY, ARCH_MODEL_NAME_REGISTRY, ARCH_MODEL_REGISTRY,
                                     MODEL_DATACLASS_REGISTRY, MODEL_REGISTRY)
+        import fairseq.models as fmodels
+        import fairseq.models.distributed_fairseq_model as fdfm
+        import fairseq.optim as foptim
+        _SAVED.update(FP16Optimizer=foptim.FP16Optimizer, DistributedFairseqModel=fmodels.DistributedFairseqModel)
         for name in ("wavlm", "hubert", "unispeech_sat", "ils_hubert"):
             if name not in MODEL_REGISTRY:
                 continue  # not part of this fairseq fork's build
             MODEL_REGISTRY[name] = Model
             ARCH_MODEL_REGISTRY[name] = Model
             ARCH_MODEL_NAME_REGISTRY[name] = name
-            MODEL_DATACLASS_REGISTRY[name] = ModelCfg
+            MODEL_DATACLASS_REGISTRY[name] = ModelCfg[name]
             ARCH_CONFIG_REGISTRY.pop(name, None)  # the dataclass defaults are the architecture
         for name in ("wavlm", "hubert"):
             if name in CRITERION_REGISTRY:
                 CRITERION_REGISTRY[name] = Criterion
                 CRITERION_DATACLASS_REGISTRY[name] = CritCfg
+        # the optimizer the Trainer builds in bf16 mode (trainer.py:296-316 `optim.FP16Optimizer.build_optimizer(cfg, params)`)
+        # and the data-parallel wrapper it puts around the model (trainer.py:250-261 `models.DistributedFairseqModel(...)`)
+        _FusedAdam, FP16Standin, _ = _optim_classes()
+        orig_fp16, orig_dfm = _SAVED["FP16Optimizer"], _SAVED["DistributedFairseqModel"]
+
+        class _FP16Dispatch(orig_fp16):
+            """`optim.FP16Optimizer` in override mode: bf16 + an Adam-family optimizer -> the fused arena optimizer;
+            anything else (fp16 loss scaling, other optimizers) -> the reference's class, untouched"""
+
+            @classmethod
+            def build_optimizer(cls, cfg, params, **kwargs):
+                oname = getattr(cfg.optimizer, "_name", "adam")
+                if getattr(cfg.common, "bf16", False) and oname in ("adam", "adam_mi355x"):
+                    return FP16Standin.build_optimizer(cfg, params, **kwargs)
+                return orig_fp16.build_optimizer(cfg, params, **kwargs)
+
+        from . import dp
+
+        def _dfm(args, model, process_group, device):
+            return dp.distributed_model(args, model, process_group, device, fallback=orig_dfm)
+
+        foptim.FP16Optimizer = _FP16Dispatch
+        fmodels.DistributedFairseqModel = _dfm
+        fdfm.DistributedFairseqModel = _dfm
         _REGISTERED.add("override")
     if not override and "names" not in _REGISTERED:
-        register_model("wavlm_mi355x", dataclass=ModelCfg)(Model)
+        register_model("wavlm_mi355x", dataclass=ModelCfg["wavlm"])(Model)
         # the same class carries the plain HuBERT structure (no relative position bias; reference "hubert",
         # models/hubert/hubert.py:220), UniSpeech-SAT's utterance-contrastive head (utterance_contrastive_loss=True;
         # "unispeech_sat", models/unispeech_sat/unispeech_sat.py:283) and ILS-SSL (predict_layers="[4,12]"; "ils_hubert",
         # models/hubert/ils_hubert.py:60): registered under their own names for recipes that select by arch
-        register_model("hubert_mi355x", dataclass=ModelCfg)(type("HubertMI355X", (Model,), {}))
-        register_model("unispeech_sat_mi355x", dataclass=ModelCfg)(type("UniSpeechSATMI355X", (Model,), {}))
-        register_model("ils_hubert_mi355x", dataclass=ModelCfg)(type("ILSHubertMI355X", (Model,), {}))
+        register_model("hubert_mi355x", dataclass=ModelCfg["hubert"])(type("HubertMI355X", (Model,), {}))
+        register_model("unispeech_sat_mi355x", dataclass=ModelCfg["unispeech_sat"])(type("UniSpeechSATMI355X", (Model,), {}))
+        register_model("ils_hubert_mi355x", dataclass=ModelCfg["ils_hubert"])(type("ILSHubertMI355X", (Model,), {}))
         register_criterion("wavlm_mi355x", dataclass=CritCfg)(Criterion)
         register_criterion("hubert_mi355x", dataclass=CritCfg)(type("HubertCriterionMI355X", (Criterion,), {}))
         W2VModel, W2VCriterion, W2VCfg, W2VCritCfg = _w2v_classes()
         register_model("wav2vec2_mi355x", dataclass=W2VCfg)(W2VModel)
         register_criterion("wav2vec_mi355x", dataclass=W2VCritCfg)(W2VCriterion)
+        from fairseq.optim import register_optimizer
+        FusedAdamMI355X, _, AdamCfg = _optim_classes()
+        register_optimizer("adam_mi355x", dataclass=AdamCfg)(FusedAdamMI355X)
         _REGISTERED.add("names")
     return Model, Criterion
+
+
+def unregister_override():
+    """put `optim.FP16Optimizer` / `DistributedFairseqModel` back (tests); the model / criterion registry entries are
+    restored by the caller from its own snapshot"""
+    if "override" in _REGISTERED and _SAVED:
+        import fairseq.models as fmodels
+        import fairseq.models.distributed_fairseq_model as fdfm
+        import fairseq.optim as foptim
+        foptim.FP16Optimizer = _SAVED["FP16Optimizer"]
+        fmodels.DistributedFairseqModel = _SAVED["DistributedFairseqModel"]
+        fdfm.DistributedFairseqModel = _SAVED["DistributedFairseqModel"]
+        _SAVED.clear()
+    _REGISTERED.discard("override")

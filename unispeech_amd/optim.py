@@ -36,6 +36,16 @@ class FusedAdam:
             for m in model.modules():
                 if hasattr(m, "packed_param_groups"):
                     groups.extend(m.packed_param_groups())
+        else:
+            # built from a bare parameter list (the fairseq Trainer hands its optimizer `model.parameters()` only,
+            # trainer.py:275-316): the attention blocks tag their q|k|v parameters with their owner
+            owners = []
+            for p in self.params:
+                m = getattr(p, "_wl_pack_owner", None)
+                if m is not None and not any(m is o for o in owners):
+                    owners.append(m)
+            for m in owners:
+                groups.extend(m.packed_param_groups())
         member = {}
         for gi, (gp, _bind) in enumerate(groups):
             if all(any(q is p for p in self.params) for q in gp) and all(q.numel() % 8 == 0 for q in gp):
@@ -80,29 +90,58 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_count = 0
+        # deferred gradient factor (fp16_optimizer.py:182-184 `_multiply_factor`): multiply_grads() and the data-parallel
+        # wrapper's 1/world only update this number; the update kernel applies it (and the clip coefficient) on the fly, so
+        # the gradient arena is read exactly once per step.  Reset by zero_grad() and after every step.
+        self.pending_mult = 1.0
+        self._norm_fresh = False
 
     def zero_grad(self):
         from . import functional
         functional.reset_sink_uses()
         self.flat_grad.zero_()
+        self.pending_mult = 1.0
+        self._norm_fresh = False
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
 
-    def step(self, grad_mult=1.0, grad_mult_dev=None):
-        """grads are used as grad * grad_mult (* grad_mult_dev[0]); clipping uses the norm of the scaled gradient"""
+    def multiply_grads(self, c):
+        """deferred: folded into the next step's gradient multiplier (and into grad_norm())"""
+        self.pending_mult *= float(c)
+
+    def compute_grad_norm_sq(self):
+        """sum of squares of the (unscaled) gradient arena into self.gnorm_sq, on the device, no synchronisation"""
         from . import functional
         functional.flush_wgrad_groups()  # normally empty: groups fire during backward / at its end
-        self.step_count += 1
         ops.sumsq(self.flat_grad, 1.0, out=self.gnorm_sq)
+        self._norm_fresh = True
+        return self.gnorm_sq
+
+    def step(self, grad_mult=1.0, grad_mult_dev=None, max_norm=None):
+        """grads are used as grad * grad_mult * pending_mult (* grad_mult_dev[0]); clipping (max_norm, default: the
+        constructor's clip_norm) uses the norm of the scaled gradient"""
+        if not self._norm_fresh:
+            self.compute_grad_norm_sq()
+        self.step_count += 1
         ops.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.flat_grad,
                       self.flat_param if self.lowp else None, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                      eps=self.eps, weight_decay=self.weight_decay, step=self.step_count, grad_mult=grad_mult,
-                      grad_mult_dev=grad_mult_dev, gnorm_sq=self.gnorm_sq, max_norm=self.clip_norm)
+                      eps=self.eps, weight_decay=self.weight_decay, step=self.step_count,
+                      grad_mult=grad_mult * self.pending_mult, grad_mult_dev=grad_mult_dev, gnorm_sq=self.gnorm_sq,
+                      max_norm=self.clip_norm if max_norm is None else max_norm)
+        self.pending_mult = 1.0
+        self._norm_fresh = False
 
     def grad_norm(self, grad_mult=1.0):
-        """host value of the (scaled) global gradient norm -- synchronises; logging only"""
+        """host value of the (scaled) global gradient norm of the last step() / compute_grad_norm_sq() -- synchronises;
+        logging only.  (After step() the deferred factor is already consumed: pass the factor used as grad_mult.)"""
         return float(self.gnorm_sq.sqrt().item()) * abs(grad_mult)
+
+    def sync_master_from_params(self):
+        """after the model's parameters were overwritten in place (load_state_dict into the arena views): the fp32 master
+        copy follows, as FP16Optimizer rebuilds its fp32 parameters from the model's (fp16_optimizer.py:36-76)"""
+        if self.lowp:
+            self.master.copy_(self.flat_param)
 
     def _layout(self):
         """(offset, numel, shape) of every parameter in arena order of registration: what a checkpoint must agree on"""
@@ -175,3 +214,132 @@ class FusedAdam:
             self.step_count = int(st["step"])
         g = fsd["param_groups"][0]
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+
+
+class FairseqFusedAdam:
+    """The fairseq Trainer's optimizer seam over FusedAdam: every method `trainer.py` calls on `self.optimizer`
+    (optim/fairseq_optimizer.py:97-130 and the bf16 wrapper optim/fp16_optimizer.py:106-289 that trainer.py:296-316
+    instantiates) -- backward, all_reduce_grads, multiply_grads (deferred factor, fp16_optimizer.py:182-184),
+    clip_grad_norm (device-side norm, returned as a device scalar; the clip coefficient is applied inside the update
+    kernel), step, zero_grad, set_lr / get_lr, state_dict / load_state_dict in the layout fairseq's Adam checkpoints
+    (optim/adam.py:176-195).  Plain Python on purpose: `fairseq_plugin` mixes it with `FairseqOptimizer` and registers it
+    (`adam_mi355x`; `register(override=True)` also substitutes it for `optim.FP16Optimizer`) when fairseq is importable;
+    without fairseq the same class drives the same call sequence (tests/test_trainer_seam_gpu.py).
+
+    cfg: the optimizer config (`cfg.optimizer` of the reference: lr list, adam_betas, adam_eps, weight_decay)."""
+
+    def __init__(self, cfg, params):
+        self.cfg = cfg
+        betas = getattr(cfg, "adam_betas", (0.9, 0.999))
+        if isinstance(betas, str):
+            import ast
+            betas = ast.literal_eval(betas)
+        lr = getattr(cfg, "lr", [1e-3])
+        lr = float(lr[0]) if isinstance(lr, (list, tuple)) else float(lr)
+        self.fused = FusedAdam(list(params), lr=lr, betas=tuple(float(b) for b in betas),
+                               eps=float(getattr(cfg, "adam_eps", 1e-8)), weight_decay=float(getattr(cfg, "weight_decay", 0.0)),
+                               clip_norm=0.0)
+        self._mult_dev = None    # a factor that arrived as a device tensor (sample_size kept on the device)
+        self._max_norm = 0.0
+        self.scaler = None       # bf16: no loss scaling (fp16_optimizer.py:248-250); trainer.py:711,947 probe for it
+        from . import dp
+        dp.bind_live_wrappers(self.fused)
+
+    @classmethod
+    def build_optimizer(cls, cfg, params, **kwargs):
+        """the signature `optim.FP16Optimizer.build_optimizer(self.cfg, params)` is called with (trainer.py:312): the FULL
+        config; the registry path `optim.build_optimizer(cfg.optimizer, params)` constructs the class directly"""
+        if getattr(getattr(cfg, "common", None), "fp16", False) and not getattr(cfg.common, "bf16", False):
+            raise NotImplementedError("unispeech_amd: fp16 with dynamic loss scaling is not supported on the MI355X path; "
+                                      "run bf16 (cfg.common.bf16=True, INTEGRATION.md section 1)")
+        return cls(cfg.optimizer, params)
+
+    # -- what the Trainer reads ------------------------------------------------------------------------------------
+    @property
+    def optimizer(self):
+        return self.fused
+
+    @property
+    def optimizer_config(self):
+        return {"lr": self.fused.lr, "betas": self.fused.betas, "eps": self.fused.eps, "weight_decay": self.fused.weight_decay}
+
+    @property
+    def params(self):
+        return iter(self.fused.params)
+
+    @property
+    def param_groups(self):
+        f = self.fused
+        return [{"lr": f.lr, "betas": f.betas, "eps": f.eps, "weight_decay": f.weight_decay, "amsgrad": False,
+                 "params": f.params}]
+
+    supports_memory_efficient_fp16 = False
+    supports_step_with_scale = True
+    supports_groups = False
+    supports_flat_params = True
+
+    def get_lr(self):
+        return self.fused.lr
+
+    def set_lr(self, lr):
+        self.fused.lr = float(lr)
+
+    # -- the step sequence of trainer.py:697-860 -------------------------------------------------------------------
+    def backward(self, loss):
+        loss.backward()
+
+    def all_reduce_grads(self, module):
+        if hasattr(module, "bind_optimizer") and getattr(module, "reducer", True) is None:
+            module.bind_optimizer(self.fused)
+        if hasattr(module, "all_reduce_grads"):
+            module.all_reduce_grads()
+
+    def multiply_grads(self, c):
+        if torch.is_tensor(c):
+            c = c.detach().to(device=self.fused.flat_grad.device, dtype=torch.float32).reshape(1)
+            self._mult_dev = c if self._mult_dev is None else self._mult_dev * c
+        else:
+            self.fused.multiply_grads(c)
+
+    def clip_grad_norm(self, max_norm, aggregate_norm_fn=None):
+        """norm of the gradient as the update will see it (deferred factors included), as a 0-dim device tensor -- no host
+        synchronisation here; the Trainer's own isfinite check (trainer.py:817) is the first reader.  Clipping itself
+        happens inside the update kernel with the same coefficient formula (max_norm / (norm + 1e-6), clamped to 1)."""
+        if aggregate_norm_fn is not None:
+            raise NotImplementedError("aggregate_norm_fn (fully_sharded) is not part of this path")
+        n = self.fused.compute_grad_norm_sq().sqrt() * abs(self.fused.pending_mult)
+        if self._mult_dev is not None:
+            n = n * self._mult_dev.abs()
+        self._max_norm = float(max_norm) if max_norm else 0.0
+        return n.reshape(())
+
+    def step(self, closure=None, scale=1.0, groups=None):
+        if closure is not None or groups is not None:
+            raise NotImplementedError("closure / parameter groups are not supported by the fused update")
+        self.fused.step(grad_mult=1.0 / float(scale), grad_mult_dev=self._mult_dev, max_norm=self._max_norm)
+        self._mult_dev, self._max_norm = None, 0.0
+
+    def zero_grad(self):
+        self.fused.zero_grad()
+        self._mult_dev, self._max_norm = None, 0.0
+
+    # -- checkpoints (trainer.py:373-411, 511-543) ------------------------------------------------------------------
+    def state_dict(self):
+        return self.fused.fairseq_state_dict()
+
+    def load_state_dict(self, state_dict, optimizer_overrides=None):
+        self.fused.load_fairseq_state_dict(state_dict)
+        self.fused.sync_master_from_params()
+        if optimizer_overrides:
+            for k, v in optimizer_overrides.items():
+                if k == "lr":
+                    self.fused.lr = float(v)
+                elif k == "betas":
+                    self.fused.betas = tuple(v)
+                elif k == "eps":
+                    self.fused.eps = float(v)
+                elif k == "weight_decay":
+                    self.fused.weight_decay = float(v)
+
+    def broadcast_global_state_dict(self, state_dict):
+        return state_dict

@@ -180,6 +180,10 @@ class MultiheadAttention(nn.Module):
         if gru_rel_pos:
             self.grep_linear = nn.Linear(self.head_dim, 8)
             self.grep_a = nn.Parameter(torch.ones(1, num_heads, 1, 1))
+        # an optimizer built from a bare parameter list (the fairseq Trainer's) finds the packed q|k|v groups through this tag
+        for lin in (self.q_proj, self.k_proj, self.v_proj):
+            lin.weight._wl_pack_owner = self
+            lin.bias._wl_pack_owner = self
         self.reset_parameters()
 
     def reset_parameters(self):
