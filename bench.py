@@ -5,14 +5,17 @@ bf16, 32 x 15 s utterances per GPU, masked-prediction loss, forward + backward +
     python bench.py --gpus 1 --steps K --warmup W
     python bench.py --gpus N ...                        # no launcher: re-executes itself under torch.distributed.run
     python bench.py --config large ...                  # WavLM-Large, 20 s utterances (configs[3] per-GPU slice)
+    python bench.py --config extract ...                # eval `extract_features` per call, 32 x 15 s
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W          # one rank per GPU over RCCL, weak scaling
 
 Synthetic data of the real shape (randn waveform, random k-means labels), random-init weights of the real
 architecture; recipe dropouts on (dropout 0.1, attention_dropout 0.1, dropout_input 0.1), layerdrop 0 (no layer is
 ever skipped inside the timed region).  Rank 0 prints ONE JSON line.  Extra legs outside the timed region:
-`roofline` (HIP-event timing of every bf16 MFMA GEMM launch during two extra steps) and `cpu_baseline` (the CPU
-oracle timed on the host cores on a bounded 1 x 15 s sample, thread count chosen by a sweep; rank 0, N=1 only).
+`roofline` (HIP-event timing of every bf16 MFMA GEMM launch during two extra steps; `roofline.kernels` carries the same
+live measurement for the fused attention forward / backward (MFMA-bound), the conv0 stage and the LayerNorm row kernels
+(HBM-bound)) and `cpu_baseline` (the CPU oracle timed on the host cores on a bounded 1 x 15 s sample, thread count chosen
+by a sweep; rank 0, N=1 only).
 """
 import argparse
 import json
@@ -37,6 +40,7 @@ SR = 16000
 BATCH_PER_GPU = 32
 V = 504
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md line 42
+HBM_PEAK_GBS = 8000.0           # HBM3E spec, ibid. line 35 (the guide measures 6.29 TB/s on a copy)
 
 
 # name -> (layers, d, ffn, heads, extractor_mode, layer_norm_first, seconds, label); "base" is BASELINE.json configs[1]
@@ -52,6 +56,11 @@ CONFIGS = {
     "sat_large": dict(L=24, D=1024, F=4096, H=16, mode="layer_norm", pre_ln=True, seconds=20.0,
                       name="UniSpeech-SAT Large (24L, d=1024, utterance mixing + contrastive head)",
                       baseline="per-GPU slice of BASELINE.json configs[4]", fgm=1.0, sat=True),
+    # the metric "per call for extract_features" -- the standalone WavLM.extract_features API
+    # (WavLM/WavLM.py:323-375), eval mode, no mask, no padding mask, bf16, the batch of configs[1]
+    "extract": dict(L=12, D=768, F=3072, H=12, mode="default", pre_ln=False, seconds=15.0,
+                    name="WavLM-Base (12L, d=768)", baseline="the batch of BASELINE.json configs[1], forward API of configs[0]",
+                    fgm=0.1, extract=True),
 }
 
 
@@ -140,6 +149,74 @@ def cpu_baseline():
                       "sweep on a 3 s utterance: %s (host has %d)" % ({c: round(t, 2) for c, t in sweep.items()}, ncpu)}
 
 
+def cpu_baseline_extract():
+    """the oracle's `extract_features` (eval, no mask) on ONE 15 s utterance, fp32 on the host cores: BASELINE.json
+    configs[0]'s CPU-runnable case scaled to one utterance; threads by the same sweep as cpu_baseline()"""
+    from oracle import wavlm_oracle as O
+    from unispeech_amd.wavlm import WavLM, WavLMConfig
+    cfg = extract_cfg()
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in WavLM(cfg).state_dict().items()}
+
+    def run(seconds, seed):
+        wav = torch.randn(1, int(seconds * SR), generator=torch.Generator().manual_seed(seed))
+        t0 = time.time()
+        with torch.no_grad():
+            O.extract_features(sd, cfg, wav)
+        return time.time() - t0
+
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (4, 8, 16, 32) if c <= ncpu}) or [1]
+    old = torch.get_num_threads()
+    torch.set_num_threads(cands[0])
+    run(3.0, 1)
+    sweep = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        sweep[c] = run(3.0, 1)
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    run(SECONDS, 2)
+    times = sorted(run(SECONDS, 2) for _ in range(5))
+    torch.set_num_threads(old)
+    return {"value": round(SECONDS / times[2], 2), "unit": "audio-s/s", "cores": best, "kind": "port",
+            "sample": "oracle extract_features fp32 eval, 12 layers, B=1 x 15 s, median of 5 after 1 warm-up; threads chosen "
+                      "by a sweep on a 3 s utterance: %s (host has %d)" % ({c: round(t, 2) for c, t in sweep.items()}, ncpu)}
+
+
+def extract_cfg():
+    from unispeech_amd.wavlm import WavLMConfig
+    return WavLMConfig(dict(encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, encoder_attention_heads=12,
+                            relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True,
+                            feature_grad_mult=0.1, mask_prob=0.8))
+
+
+def kernel_rooflines(ops, nsteps):
+    """per-kernel-class roofline entries from the HIP events of the profiled steps (the same live measurement as the GEMM
+    entry): attention against the MFMA peak, conv0 / LayerNorm against the HBM peak"""
+    out = []
+    for name, bound, what in (
+            ("attn_fwd", "mfma", "fused gated-relative-position attention forward (attn_fwd_kernel): 4 B H T^2 hd FLOPs per call"),
+            ("attn_bwd", "mfma", "fused attention backward (attn_bwd_dq_kernel + attn_bwd_dkv_kernel + finishing launches): 10 B H T^2 hd FLOPs per call"),
+            ("conv0_fwd", "hbm", "conv0 + norm + GELU forward stage: waveform read once, output written once"),
+            ("conv0_bwd", "hbm", "conv0 stage backward: the incoming gradient read once (+ waveform)"),
+            ("ln_fwd", "hbm", "LayerNorm (+ residual / dropout / GELU) forward row kernel: every input / output tensor once"),
+            ("ln_bwd", "hbm", "LayerNorm backward row kernel + parameter-gradient finish: every input / output tensor once")):
+        n, ms, fl, by = ops.prof_collect_class(name)
+        if n == 0 or ms <= 0:
+            continue
+        if bound == "mfma":
+            ach = fl / (ms * 1e-3) / 1e12
+            e = {"achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4)}
+        else:
+            ach = by / (ms * 1e-3) / 1e9
+            e = {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+        e.update(name=name, bound=bound, kernel=what, calls_per_step=n // nsteps, ms_per_step=round(ms / nsteps, 3),
+                 avg_call_us=round(ms / n * 1e3, 2), algorithmic_bytes_per_call=round(by / n))
+        out.append(e)
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -157,7 +234,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="base",
                     help="base = BASELINE.json configs[1] (the headline); large = WavLM-Large, 20 s utterances; "
-                         "sat_large = UniSpeech-SAT Large with utterance mixing + contrastive head")
+                         "sat_large = UniSpeech-SAT Large with utterance mixing + contrastive head; extract = eval "
+                         "extract_features per call on the configs[1] batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -198,12 +276,18 @@ def main():
     from unispeech_amd.optim import FusedAdam
     from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainModel
 
-    cfg = base_cfg(True, args.config)
+    extract = bool(CONFIGS[args.config].get("extract"))
     torch.manual_seed(0)
-    model = WavLMPretrainModel(cfg, None, [range(V)]).to(dev).to(torch.bfloat16).train()
-    opt = FusedAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=10.0, model=model)
-    model.instance_sampling = "device"   # UniSpeech-SAT head: draw the instance indices on the GPU (no host work per step)
-    net = DataParallelWavLM(model, opt) if world > 1 else model
+    if extract:
+        from unispeech_amd.wavlm import WavLM
+        model = WavLM(extract_cfg()).to(dev).to(torch.bfloat16).eval()
+        opt = net = None
+    else:
+        cfg = base_cfg(True, args.config)
+        model = WavLMPretrainModel(cfg, None, [range(V)]).to(dev).to(torch.bfloat16).train()
+        opt = FusedAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=10.0, model=model)
+        model.instance_sampling = "device"   # UniSpeech-SAT head: draw the instance indices on the GPU (no host work per step)
+        net = DataParallelWavLM(model, opt) if world > 1 else model
     sat = bool(CONFIGS[args.config].get("sat"))
     crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0, 10.0, 0.0] if sat else [10.0], defer_logging=True)
 
@@ -225,6 +309,10 @@ def main():
         zero_rows = [False] * B
 
     def step():
+        if extract:   # one call of the public API: waveform [B, T] -> last-layer features [B, T', D] (no mask, eval)
+            with torch.no_grad():
+                feats, _ = model.extract_features(wav)
+            return feats
         opt.zero_grad()
         if mixer is not None:
             ops_np, begin_np, _ = mixer.draw_mixing_plan(B, T, zero_rows)
@@ -268,7 +356,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
-    final_loss = float(loss.item())
+    final_loss = float(loss.float().abs().mean().item()) if extract else float(loss.item())
 
     roof = None
     if not args.no_roofline:
@@ -277,6 +365,7 @@ def main():
             step()
         n_l, ms, fl = ops.prof_collect(1)
         alg_bytes = ops.prof_collect_bytes(1)
+        kern = kernel_rooflines(ops, 2)
         ops.prof_enable(False)
         if ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
@@ -305,7 +394,8 @@ def main():
                     "algorithmic_bytes_per_launch": round(alg_bytes / max(n_l, 1)),
                     "launches_per_step": n_l // 2, "gemm_ms_per_step": round(ms / 2, 3),
                     "gemm_algorithmic_tflop_per_step": round(fl / 2 / 1e12, 3),
-                    "avg_launch_us": round(ms / max(n_l, 1) * 1e3, 2)}
+                    "avg_launch_us": round(ms / max(n_l, 1) * 1e3, 2),
+                    "kernels": kern}
     fence()
 
     if rank == 0:
@@ -316,24 +406,33 @@ def main():
         for k_, s_ in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
             Tp = (Tp - k_) // s_ + 1
         out = {
-            "metric": "audio-seconds/sec pretraining, %s %ds@16kHz" % (c["name"].split(" (")[0], int(SECONDS)),
+            "metric": "audio-seconds/sec %s, %s %ds@16kHz" % ("extract_features" if extract else "pretraining",
+                                                            c["name"].split(" (")[0], int(SECONDS)),
             "value": round(value, 1),
             "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "%s pretrain fwd+bwd+grad-reduce+fused-Adam, bf16, "
-                                   "batch=%dx%ds per GPU, masked-pred loss (%s%s)"
+            "config": {"workload": ("%s extract_features (eval forward, no mask), bf16, batch=%dx%ds per GPU (%s%s)"
+                                    if extract else
+                                    "%s pretrain fwd+bwd+grad-reduce+fused-Adam, bf16, batch=%dx%ds per GPU, masked-pred loss (%s%s)")
                                    % (c["name"], B, int(SECONDS), c["baseline"], "" if world == 1 else ", dp%d" % world),
                        "global_batch": world * B, "seconds_per_utt": SECONDS, "frames_per_utt": Tp,
                        "parallelism": "dp%d" % world, "dropout": 0.1, "attention_dropout": 0.1, "layerdrop": 0.0,
                        "mask_prob": 0.8, "optimizer": "fused Adam, fp32 master, clip 10"},
             "final_loss": final_loss,
-            "model_tflops": round(algorithmic_flops_per_step(B, T, args.config) / (ms_per_step * 1e-3) / 1e12, 1),
+            "model_tflops": round(algorithmic_flops_per_step(B, T, args.config) / (1.0 if not extract else 3.0)
+                                  / (ms_per_step * 1e-3) / 1e12, 1),
         }
+        if extract:
+            out["config"].update(dropout=0.0, attention_dropout=0.0, optimizer=None, mask_prob=0.0)
+            out.pop("final_loss")
+            out["mean_abs_feature"] = final_loss
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline and args.config == "base":
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_cpu_baseline and extract:
+            out["cpu_baseline"] = cpu_baseline_extract()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 12
+#define WAVLM_HIP_ABI_VERSION 13
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -332,6 +332,19 @@ void wavlm_set_reserved_cus(int n);
 int wavlm_prof_collect(int dtype, double* total_ms, double* total_flops);
 /* algorithmic HBM bytes of the recorded launches: every operand, output and epilogue tensor counted once */
 double wavlm_prof_collect_bytes(int dtype);
+/* Kernel classes timed besides wavlm_gemm (class 0) while profiling is enabled: the fused attention forward / backward
+ * (backward = dQ + dK/dV kernels + their finishing launches), the conv0 stage forward / backward (either norm mode) and
+ * the LayerNorm row kernels.  Returns the number of recorded calls of class `cls`; totals: duration [ms], algorithmic
+ * FLOPs (attention: 4 B H T^2 hd forward, 10 B H T^2 hd backward) and algorithmic HBM bytes (every input / output tensor
+ * of the call once).  Blocks until the recorded launches have finished. */
+#define WL_PROF_GEMM 0
+#define WL_PROF_ATTN_FWD 1
+#define WL_PROF_ATTN_BWD 2
+#define WL_PROF_CONV0_FWD 3
+#define WL_PROF_CONV0_BWD 4
+#define WL_PROF_LN_FWD 5
+#define WL_PROF_LN_BWD 6
+int wavlm_prof_collect_class(int cls, double* total_ms, double* total_flops, double* total_bytes);
 
 #ifdef __cplusplus
 }

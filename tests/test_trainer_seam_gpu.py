@@ -116,6 +116,9 @@ def _worker(rank, world, port, q, dtype_name):
         out["p0"] = p0
         out["m"] = {n: f.exp_avg[o:o + p.numel()].view(p.shape).cpu().clone() for (n, p), o in zip(model.named_parameters(), f.offsets)}
         out["v"] = {n: f.exp_avg_sq[o:o + p.numel()].view(p.shape).cpu().clone() for (n, p), o in zip(model.named_parameters(), f.offsets)}
+        # numpy, pickled by value: torch tensors travel through the queue as shared-memory handles that die with this process
+        for key in ("p", "p0", "m", "v"):
+            out[key] = {n: t.numpy() for n, t in out[key].items()}
         q.put((rank, out if rank == 0 else {k: out[k] for k in ("gn", "ss")}, None))
     except Exception:
         import traceback
@@ -184,6 +187,8 @@ def test_trainer_step_sequence_world2_vs_oracle(dtype_name):
                                                              1, ADAM["lr"], ADAM["betas"][0], ADAM["betas"][1], ADAM["eps"],
                                                              ADAM["weight_decay"])
     r0 = res[0]
+    for key in ("p", "p0", "m", "v"):
+        r0[key] = {n: torch.from_numpy(a) for n, a in r0[key].items()}
     assert r0["ss_total"] == ss_total and r0["pending_after"] == 1.0
     assert abs(res[0]["gn"] - res[1]["gn"]) <= 1e-6 * gn, "ranks disagree on the gradient norm (trainer.py:1305-1341 would raise)"
     tol_gn, tol_m = (1e-3, 2e-3) if not bf16 else (2e-2, 4e-2)

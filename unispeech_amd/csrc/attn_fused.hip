@@ -548,6 +548,9 @@ int wavlm_attn_fused_fwd(const void* qkv, void* O, float* lse, const float* gate
   const size_t smem = 32768 + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float);
   p.nqb = (T + FA_BQ - 1) / FA_BQ;
   const dim3 grid((unsigned)(p.nqb * B * H));
+  // algorithmic: QK^T and PV (2 x 2 T^2 hd per head); qkv read once, O written once, lse
+  WlProfScope prof(WL_PROF_ATTN_FWD, WL_BF16, 4.0 * B * H * (double)T * T * FA_HD,
+                   (double)B * T * H * FA_HD * 2.0 * 4.0 + (double)B * H * T * 4.0, (hipStream_t)stream);
   if (p.th) {
     if (fa_set_smem(attn_fwd_kernel<true>, smem) != WL_OK) return WL_ELAUNCH;
     WL_LAUNCH(attn_fwd_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, p);
@@ -588,6 +591,10 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
   size_t smem1 = 32768 + (tab ? 4 * 6144 : 0) + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float) + 256;  // + gate fragments
   if (smem1 < FA_CS_FLOATS * sizeof(float)) smem1 = FA_CS_FLOATS * sizeof(float);
   p.nqb = nqt;
+  // algorithmic: S, dP, dQ, dK, dV (5 x 2 T^2 hd per head; the kernels recompute S and dP once more); qkv, O, dO read
+  // once, dqkv written once
+  WlProfScope prof(WL_PROF_ATTN_BWD, WL_BF16, 10.0 * B * H * (double)T * T * FA_HD,
+                   (double)B * T * H * FA_HD * 2.0 * 8.0 + (double)B * H * T * 8.0, st);
   if (p.th) {
 #define FA_DQ(DR, TB) do { if (fa_set_smem(attn_bwd_dq_kernel<DR, TB>, smem1) != WL_OK) return WL_ELAUNCH; \
     WL_LAUNCH((attn_bwd_dq_kernel<DR, TB>), dim3((unsigned)(nqt * B * H)), dim3(256), smem1, st, p); } while (0)

@@ -174,6 +174,15 @@ static thread_local int wl_launch_failed = 0;
       fprintf(stderr, "[wavlm_hip] kernel launch failed: %s (%s:%d)\n", hipGetErrorString(wl_e_), __FILE__, __LINE__); \
     }                                                             \
   } while (0)
+// per-launch timing of a kernel class while wavlm_prof_enable(1) (gemm_bf16.hip): HIP events on the launch stream
+int wl_prof_begin(int cls, int dtype, double flops, double bytes, hipStream_t st);
+void wl_prof_end(int i, hipStream_t st);
+struct WlProfScope {  // events around everything the enclosing entry point launches after this line
+  int i; hipStream_t st;
+  WlProfScope(int cls, int dtype, double flops, double bytes, hipStream_t s) : i(wl_prof_begin(cls, dtype, flops, bytes, s)), st(s) {}
+  ~WlProfScope() { wl_prof_end(i, st); }
+};
+
 static inline int wl_check_launch() {
   const int e = wl_launch_failed;
   wl_launch_failed = 0;

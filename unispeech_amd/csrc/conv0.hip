@@ -591,6 +591,9 @@ int wavlm_conv0_gn_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
   const size_t sm_apply = seg_floats(C0_TCH, stride) * sizeof(float) + (out_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
   float* partx = (float*)workspace;
   if (out_dtype == WL_BF16 && gelu_tab_ensure(st) != WL_OK) return WL_ELAUNCH;
+  // algorithmic: 2 * kw flops per output; the waveform read once, the output written once
+  WlProfScope prof(WL_PROF_CONV0_FWD, out_dtype, 2.0 * kw * B * (double)T0 * C,
+                   (double)B * T * (wav_dtype == WL_BF16 ? 2 : 4) + (double)B * T0 * C * (out_dtype == WL_BF16 ? 2 : 4), st);
   if (wav_dtype == WL_F32)
     WL_LAUNCH((conv0_gram_kernel<float>), grid, dim3(256), sm_gram, st, (const float*)wav, partx, (long)T, T0, (int)stride);
   else
@@ -639,6 +642,8 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   float* ab = dwb + (long)B * C * C0_KW;
   const size_t sm1 = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float) + (g_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
   if (g_dtype == WL_BF16 && gelu_tab_ensure(st) != WL_OK) return WL_ELAUNCH;
+  WlProfScope prof(WL_PROF_CONV0_BWD, g_dtype, 4.0 * C0_KW * B * (double)T0 * C,
+                   (double)B * T * (wav_dtype == WL_BF16 ? 2 : 4) + (double)B * T0 * C * (g_dtype == WL_BF16 ? 2 : 4), st);
 #define B1(TW, TP, TO) WL_LAUNCH((conv0_bwd_fused_kernel<TW, TP, TO>), grid, dim3(256), sm1, st, (const TW*)wav, \
     (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (const TO*)g, part, partx, (long)T, T0, (int)C, (int)stride, gscale)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
@@ -690,6 +695,8 @@ int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
   const dim3 grid((unsigned)((T0 + C0_TCH - 1) / C0_TCH), (unsigned)B);
   const size_t smem = seg_floats(C0_TCH, stride) * sizeof(float) + (out_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
   if (out_dtype == WL_BF16 && gelu_tab_ensure(st) != WL_OK) return WL_ELAUNCH;
+  WlProfScope prof(WL_PROF_CONV0_FWD, out_dtype, 2.0 * kw * B * (double)T0 * C,
+                   (double)B * T * (wav_dtype == WL_BF16 ? 2 : 4) + (double)B * T0 * C * (out_dtype == WL_BF16 ? 2 : 4), st);
 #define FW(TW, TP, TO) WL_LAUNCH((conv0_ln_fwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
     (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (TO*)out, (long)T, T0, (int)C, (int)stride, eps)
   const int key = wav_dtype * 100 + param_dtype * 10 + out_dtype;
@@ -717,6 +724,9 @@ int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   float* part = (float*)workspace;
   const size_t smem = (seg_floats(C0_TCH_BWD, stride) + 4 * 512) * sizeof(float) + (g_dtype == WL_BF16 ? GT_N * sizeof(float2) : 0);
   if (g_dtype == WL_BF16 && gelu_tab_ensure(st) != WL_OK) return WL_ELAUNCH;
+  // algorithmic: the incoming gradient read once + the waveform; conv recompute + weight gradient = 4 * kw flops per output
+  WlProfScope prof(WL_PROF_CONV0_BWD, g_dtype, 4.0 * kw * B * (double)T0 * C,
+                   (double)B * T * (wav_dtype == WL_BF16 ? 2 : 4) + (double)B * T0 * C * (g_dtype == WL_BF16 ? 2 : 4), st);
 #define BW(TW, TP, TO) WL_LAUNCH((conv0_ln_bwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
     (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (const TO*)g, part, (long)T, T0, (int)C, (int)stride, eps, gscale)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;

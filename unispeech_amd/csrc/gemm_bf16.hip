@@ -327,45 +327,51 @@ static struct {
   double flops[PROF_MAX];
   double bytes[PROF_MAX];  // algorithmic HBM bytes: each operand / output / epilogue tensor touched once
   int dtype[PROF_MAX];
+  int cls[PROF_MAX];       // WL_PROF_* kernel class (0 = wavlm_gemm)
   int created;
 } g_prof;
 
-static int prof_begin(const wavlm_gemm_desc* d, hipStream_t st) {
+// shared with the other translation units (common.hpp): a launcher brackets its kernels with wl_prof_begin / wl_prof_end
+int wl_prof_begin(int cls, int dtype, double flops, double bytes, hipStream_t st) {
   if (!g_prof.enabled || g_prof.n >= PROF_MAX) return -1;
   const int i = g_prof.n;
   if (i >= g_prof.created) {
     if (hipEventCreate(&g_prof.ev0[i]) != hipSuccess || hipEventCreate(&g_prof.ev1[i]) != hipSuccess) return -1;
     g_prof.created = i + 1;
   }
-  const double nb = (double)(d->batch_o < 1 ? 1 : d->batch_o) * (d->batch_i < 1 ? 1 : d->batch_i);
-  g_prof.flops[i] = 2.0 * d->M * d->N * (double)d->K * (d->KB < 1 ? 1 : d->KB) * nb;
-  {
-    const double es = d->dtype == WL_BF16 ? 2.0 : 4.0, cs = d->c_dtype == WL_BF16 ? 2.0 : 4.0;
-    const double kb = d->KB < 1 ? 1 : d->KB, mn = (double)d->M * d->N;
-    // overlapping-row operands (lda < K: strided conv) are counted once per stored element, not once per use
-    const double a_el = (!d->transA && d->lda < d->K) ? (double)d->M * d->lda : (double)d->M * d->K * kb;
-    const double b_el = (double)d->N * d->K * kb;
-    g_prof.bytes[i] = nb * (a_el * es + mn * cs * (d->accumulate ? 2.0 : 1.0) + (d->aux ? mn * 2.0 : 0.0) + (d->res ? mn * 2.0 : 0.0)) +
-                      ((d->sB_o || d->sB_i) ? nb : 1.0) * b_el * es;
-  }
-  g_prof.dtype[i] = d->dtype;
+  g_prof.flops[i] = flops; g_prof.bytes[i] = bytes; g_prof.dtype[i] = dtype; g_prof.cls[i] = cls;
   hipEventRecord(g_prof.ev0[i], st);
+  g_prof.n = i + 1;            // claimed now: a nested launcher (a GEMM inside a profiled composite) takes the next slot
   return i;
 }
-static void prof_end(int i, hipStream_t st) {
+void wl_prof_end(int i, hipStream_t st) {
   if (i < 0) return;
   hipEventRecord(g_prof.ev1[i], st);
-  g_prof.n = i + 1;
 }
 
+static int prof_begin(const wavlm_gemm_desc* d, hipStream_t st) {
+  if (!g_prof.enabled) return -1;
+  const double nb = (double)(d->batch_o < 1 ? 1 : d->batch_o) * (d->batch_i < 1 ? 1 : d->batch_i);
+  const double flops = 2.0 * d->M * d->N * (double)d->K * (d->KB < 1 ? 1 : d->KB) * nb;
+  const double es = d->dtype == WL_BF16 ? 2.0 : 4.0, cs = d->c_dtype == WL_BF16 ? 2.0 : 4.0;
+  const double kb = d->KB < 1 ? 1 : d->KB, mn = (double)d->M * d->N;
+  // overlapping-row operands (lda < K: strided conv) are counted once per stored element, not once per use
+  const double a_el = (!d->transA && d->lda < d->K) ? (double)d->M * d->lda : (double)d->M * d->K * kb;
+  const double b_el = (double)d->N * d->K * kb;
+  const double bytes = nb * (a_el * es + mn * cs * (d->accumulate ? 2.0 : 1.0) + (d->aux ? mn * 2.0 : 0.0) + (d->res ? mn * 2.0 : 0.0)) +
+                       ((d->sB_o || d->sB_i) ? nb : 1.0) * b_el * es;
+  return wl_prof_begin(WL_PROF_GEMM, d->dtype, flops, bytes, st);
+}
+static void prof_end(int i, hipStream_t st) { wl_prof_end(i, st); }
+
 extern "C" void wavlm_prof_enable(int on) { g_prof.enabled = on; if (on) g_prof.n = 0; }
-// Sums over the launches recorded since wavlm_prof_enable(1) with element type `dtype` (-1: all).
+// Sums over the wavlm_gemm launches recorded since wavlm_prof_enable(1) with element type `dtype` (-1: all).
 // Blocks until those launches have finished.  Returns the number of launches.
 extern "C" int wavlm_prof_collect(int dtype, double* total_ms, double* total_flops) {
   double ms = 0.0, fl = 0.0;
   int cnt = 0;
   for (int i = 0; i < g_prof.n; ++i) {
-    if (dtype >= 0 && g_prof.dtype[i] != dtype) continue;
+    if (g_prof.cls[i] != WL_PROF_GEMM || (dtype >= 0 && g_prof.dtype[i] != dtype)) continue;
     if (hipEventSynchronize(g_prof.ev1[i]) != hipSuccess) continue;
     float t = 0.f;
     if (hipEventElapsedTime(&t, g_prof.ev0[i], g_prof.ev1[i]) != hipSuccess) continue;
@@ -379,8 +385,24 @@ extern "C" int wavlm_prof_collect(int dtype, double* total_ms, double* total_flo
 extern "C" double wavlm_prof_collect_bytes(int dtype) {
   double by = 0.0;
   for (int i = 0; i < g_prof.n; ++i)
-    if (dtype < 0 || g_prof.dtype[i] == dtype) by += g_prof.bytes[i];
+    if (g_prof.cls[i] == WL_PROF_GEMM && (dtype < 0 || g_prof.dtype[i] == dtype)) by += g_prof.bytes[i];
   return by;
+}
+// the same per kernel class (WL_PROF_*): number of recorded calls; total duration, algorithmic flops and bytes
+extern "C" int wavlm_prof_collect_class(int cls, double* total_ms, double* total_flops, double* total_bytes) {
+  double ms = 0.0, fl = 0.0, by = 0.0;
+  int cnt = 0;
+  for (int i = 0; i < g_prof.n; ++i) {
+    if (g_prof.cls[i] != cls) continue;
+    if (hipEventSynchronize(g_prof.ev1[i]) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev0[i], g_prof.ev1[i]) != hipSuccess) continue;
+    ms += t; fl += g_prof.flops[i]; by += g_prof.bytes[i]; ++cnt;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (total_bytes) *total_bytes = by;
+  return cnt;
 }
 
 extern "C" uint64_t wavlm_gemm_workspace_bytes(const wavlm_gemm_desc* d) {

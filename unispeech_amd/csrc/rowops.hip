@@ -487,6 +487,7 @@ static inline unsigned grid_for(long work_items, int per_block, unsigned cap) {
 extern "C" {
 
 int wavlm_abi_version(void) { return WAVLM_HIP_ABI_VERSION; }
+static double g_ln_prof_bytes = 0.0;
 
 int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* mean, float* rstd, const void* gamma,
                         const void* beta, int64_t rows, int32_t D, float eps, int32_t dtype, int32_t param_dtype,
@@ -496,6 +497,11 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   hipStream_t st = (hipStream_t)stream;
   const unsigned ti = drop_thresh16(p_in), to = drop_thresh16(p_out);
   const float si = drop_scale16(ti), so = drop_scale16(to);
+  {
+    const double es = dtype == WL_BF16 ? 2.0 : 4.0;  // x (+ r) read, y (+ s) written
+    g_ln_prof_bytes = (double)rows * D * es * (2.0 + (r ? 1.0 : 0.0) + (s ? 1.0 : 0.0));
+  }
+  WlProfScope prof(WL_PROF_LN_FWD, dtype, 8.0 * rows * D, g_ln_prof_bytes, st);
   const unsigned grid = grid_for(rows, 4, (ti | to) ? LN_FWD_DROP_BLOCKS : 8192);  // with dropout: several rows per wave amortise the column words
   // chunk slots per lane are a template parameter: registers (and occupancy) follow the actual row width
 #define LN_FWD_N(T, TP, NCS) WL_LAUNCH((layernorm_fwd_kernel<T, TP, NCS>), dim3(grid), dim3(256), 0, st, (const T*)x, \
@@ -526,6 +532,9 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   hipStream_t st = (hipStream_t)stream;
   const unsigned ti = drop_thresh16(p_in), to = drop_thresh16(p_out);
   const float si = drop_scale16(ti), so = drop_scale16(to);
+  const double es_p = dtype == WL_BF16 ? 2.0 : 4.0;  // dy, s (+ dx_add) read, dx (+ dr) written
+  WlProfScope prof(WL_PROF_LN_BWD, dtype, 12.0 * rows * D,
+                   (double)rows * D * es_p * (3.0 + (dx_add ? 1.0 : 0.0) + ((dr && dr != dx) ? 1.0 : 0.0)), st);
   const unsigned grid = grid_for(rows, 4, LN_BWD_BLOCKS);
   float* part = (float*)workspace;
 #define LN_BWD_C(T, TP, NCS, CSF) WL_LAUNCH((layernorm_bwd_kernel<T, TP, NCS, CSF>), dim3(grid), dim3(256), 0, st, (const T*)dy, \

@@ -600,6 +600,17 @@ def prof_collect(dtype=-1):
     return n, ms.value, fl.value
 
 
+PROF_CLASSES = {"gemm": 0, "attn_fwd": 1, "attn_bwd": 2, "conv0_fwd": 3, "conv0_bwd": 4, "ln_fwd": 5, "ln_bwd": 6}
+
+
+def prof_collect_class(name):
+    """(calls, total_ms, algorithmic flops, algorithmic bytes) of one kernel class (PROF_CLASSES) recorded since
+    prof_enable(True); synchronises"""
+    ms, fl, by = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+    n = _lib.lib().wavlm_prof_collect_class(PROF_CLASSES[name], C.byref(ms), C.byref(fl), C.byref(by))
+    return n, ms.value, fl.value, by.value
+
+
 def prof_collect_bytes(dtype=-1):
     """algorithmic HBM bytes (each operand / output / epilogue tensor once) of the launches prof_collect reports"""
     return float(_lib.lib().wavlm_prof_collect_bytes(int(dtype)))
