@@ -329,6 +329,7 @@ void wavlm_gemm_set_variant(int v);
  * src/fairseq/distributed/legacy_distributed_data_parallel.py:132-165) find free CUs while backward is still running.
  * 0 (default) = use the whole chip.  Values are clamped to [0, 64]. */
 void wavlm_set_reserved_cus(int n);
+int wavlm_get_reserved_cus(void);
 int wavlm_prof_collect(int dtype, double* total_ms, double* total_flops);
 /* algorithmic HBM bytes of the recorded launches: every operand, output and epilogue tensor counted once */
 double wavlm_prof_collect_bytes(int dtype);

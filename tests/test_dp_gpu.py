@@ -73,10 +73,22 @@ def _worker(rank, world, port, q, grouped):
         want = sum(gathered)
 
         opt.zero_grad()
+        dp.reducer.record_trace = True
+        dp.reducer.trace.clear()
         backward()
+        end_bwd = torch.cuda.Event(enable_timing=True)
+        end_bwd.record()                   # compute stream: everything backward enqueued lies before this event
         early = sum(dp.reducer._launched)  # buckets already in flight when backward returned
         dp.all_reduce_grads()
         torch.cuda.synchronize()
+        # device-side evidence of the overlap: the point on the COMPUTE stream at which a bucket's all-reduce was handed to
+        # the side stream (it waits for exactly that point) precedes the end of backward by this many milliseconds
+        lead = [ev.elapsed_time(end_bwd) for _, ev in dp.reducer.trace[:early]]
+        from unispeech_amd import ops as _ops
+        assert _ops.get_reserved_cus() == 8, "persistent GEMM grids must leave CUs to the collectives (dp.GradReducer)"
+        assert dp.reducer.comm_stream is not None and [b for b, _ in dp.reducer.trace] == list(range(len(dp.reducer.trace)))
+        assert len(lead) == early and sum(1 for x in lead if x > 0.02) >= early // 2, lead
+        assert abs(opt.pending_mult - 1.0 / world) < 1e-12   # the wrapper's average rides in the deferred factor
         got = opt.flat_grad.detach().float().cpu()
         scale = want.abs().max().clamp_min(1e-6)
         err = ((got - want).abs().max() / scale).item()

@@ -156,10 +156,10 @@ def test_fused_adam_checkpoint_roundtrip_and_rehoming():
 
     same_params(m2)
     assert o2.step_count == opt.step_count == 4
-    # different layout: no packed q|k|v groups (model=None)
+    # different layout: no packed q|k|v groups
     m3, _ = _tiny()
     m3.load_state_dict(msd)
-    o3 = FusedAdam(m3.parameters(), lr=1e-3)
+    o3 = FusedAdam(m3.parameters(), lr=1e-3, pack=False)
     assert o3._layout() != opt._layout()
     with pytest.raises(ValueError):
         o3.load_state_dict(sd)
@@ -414,3 +414,24 @@ def test_sat_large_remove_pretraining_modules_then_features_only():
     with torch.no_grad():
         out = m(wav, padding_mask=torch.zeros(2, 4000, dtype=torch.bool, device="cuda"), mask=False, features_only=True)
     assert torch.isfinite(out["x"]).all()
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu_over_gloo():
+    """`bench.py --gpus 8` end to end with every rank on cuda:0 and gloo as the transport (WAVLM_SHARED_GPU=1,
+    WAVLM_DIST_BACKEND=gloo): the self-launch under torch.distributed.run, the rank-count check, eight reducers issuing
+    their buckets in the same order, the Trainer-order step (average, then world / sample_size) and the max-over-ranks
+    timing all run at the rank count of the 8-GPU node.  Tiny batch; the numbers mean nothing, the line must be sane."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WAVLM_SHARED_GPU="1", WAVLM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--batch", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline"], cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line from rank 0: " + r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["config"]["global_batch"] == 8
+    assert out["scaling"] == "weak" and out["value"] > 0 and np.isfinite(out["final_loss"])

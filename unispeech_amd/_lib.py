@@ -119,6 +119,7 @@ SIGNATURES = {
     "wavlm_prof_enable": (None, [c_i32]),
     "wavlm_gemm_set_variant": (None, [c_i32]),
     "wavlm_set_reserved_cus": (None, [c_i32]),
+    "wavlm_get_reserved_cus": (c_i32, []),
     "wavlm_prof_collect": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wavlm_prof_collect_bytes": (C.c_double, [c_i32]),
     "wavlm_prof_collect_class": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -593,6 +593,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
 int g_pp_mode = 1;  // 0: one block per tile, 1: persistent (256 blocks), 2: persistent with start skew
 int g_pp_reserved_cus = 0;  // data-parallel runs: persistent grids leave this many CUs to the RCCL kernels
 extern "C" void wavlm_set_reserved_cus(int n) { g_pp_reserved_cus = n < 0 ? 0 : (n > 64 ? 64 : n); }
+extern "C" int wavlm_get_reserved_cus(void) { return g_pp_reserved_cus; }
 
 template <bool TA, bool TB>
 static int pp_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {

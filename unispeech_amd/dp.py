@@ -71,6 +71,10 @@ class GradReducer:
         self._seen = [False] * len(self.params)
         self._next = 0  # buckets are launched strictly in index order on every rank (see _mark)
         self._works = []
+        # record_trace=True: every bucket launch leaves (bucket, timing event recorded on the COMPUTE stream at the point of
+        # the launch) in `trace` -- tests / tools/dp_overlap.py compare it with an event recorded when backward returns
+        self.record_trace = False
+        self.trace = []
         # arena element offsets (sorted) for sink notifications: backward kernels that accumulate straight into the
         # arena (functional._sink) report the slice they wrote; a packed q|k|v slice covers three parameters
         self._offsets = list(offsets)
@@ -127,8 +131,10 @@ class GradReducer:
         view = self.flat_grad[bk["lo"]:bk["hi"]]
         self._launched[b] = True
         if self.comm_stream is not None:
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.record_trace)
             ev.record(torch.cuda.current_stream())
+            if self.record_trace:
+                self.trace.append((b, ev))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))

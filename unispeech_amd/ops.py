@@ -5,6 +5,7 @@ below ends in exactly one (or a fixed short sequence of) libwavlm_hip.so entry p
 a CPU tensor raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -114,7 +115,7 @@ def gemm_wgrad_grouped(items, w_dtype):
     dev = _dev(items[0][0])
     n = items[0][0].shape[0]
     tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in items)
-    split = max(2, min(256 // max(tiles, 1), ((n + 63) // 64) // 8, 64))
+    split = grouped_split(tiles, (n + 63) // 64)
     L = _lib.lib()
     descs = (GemmDesc * len(items))()
     need = []
@@ -139,6 +140,26 @@ def gemm_wgrad_grouped(items, w_dtype):
         d.workspace, d.ws_bytes = ptr(ws, off), nb
         off += nb
     check(L.wavlm_gemm_grouped(descs, len(items), stream()), "wavlm_gemm_grouped[%d]" % len(items))
+
+
+def grouped_split(tiles, ktiles, grid=256):
+    """split-K factor of a grouped weight-gradient launch (persistent grid: `grid` workgroups walk tiles * split work
+    items): the makespan is rounds x K-steps per item, so the split is chosen to make tiles * split fill a whole number of
+    rounds -- e.g. the four dW of a Base layer are 108 tiles x 375 K-steps: split 2 leaves 40 CUs idle for 188 K-steps,
+    split 7 runs 2.95 rounds of 54 (162 against the ideal 158).  Each round costs about four K-steps of prologue + slab
+    store, each split a slab (256 KiB per tile) to write and reduce.  WAVLM_WGRAD_SPLIT overrides (A/B measurements)."""
+    forced = os.environ.get("WAVLM_WGRAD_SPLIT")
+    if forced:
+        return max(2, int(forced))
+    best, best_cost = 2, None
+    for s in range(2, 33):
+        if ktiles // s < 8:
+            break
+        rounds = (tiles * s + grid - 1) // grid
+        cost = rounds * ((ktiles + s - 1) // s + 4) + 0.5 * s
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = s, cost
+    return best
 
 
 def pick_split(M, N, ktiles, nbatch=1, target_blocks=768):
@@ -587,6 +608,10 @@ def gemm_set_variant(v):
 def set_reserved_cus(n):
     """leave n CUs out of every persistent GEMM grid (data-parallel runs: room for the RCCL kernels)"""
     _lib.lib().wavlm_set_reserved_cus(int(n))
+
+
+def get_reserved_cus():
+    return int(_lib.lib().wavlm_get_reserved_cus())
 
 
 def prof_enable(on):

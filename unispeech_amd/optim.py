@@ -22,7 +22,7 @@ class FusedAdam:
     written packed).  Every parameter is marked as a gradient sink (functional._sink): backward kernels accumulate
     into the arena directly."""
 
-    def __init__(self, params, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=0.0, model=None):
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=0.0, model=None, pack=True):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no parameters")
@@ -32,7 +32,9 @@ class FusedAdam:
                 raise ValueError("all parameters must share device and dtype")
         self.lr, self.betas, self.eps, self.weight_decay, self.clip_norm = lr, betas, eps, weight_decay, clip_norm
         groups = []
-        if model is not None:
+        if not pack:      # plain registration-order arena (tests: re-homing a checkpoint between layouts)
+            pass
+        elif model is not None:
             for m in model.modules():
                 if hasattr(m, "packed_param_groups"):
                     groups.extend(m.packed_param_groups())
