@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unispeech_amd import ops  # noqa: E402
 
-n, D = 23968, 768
+n, D = int(os.environ.get('LN_ROWS', 23968)), int(os.environ.get('LN_D', 768))
 dev = "cuda"
 x = torch.randn(n, D, device=dev).to(torch.bfloat16)
 r = torch.randn(n, D, device=dev).to(torch.bfloat16)
@@ -34,5 +34,5 @@ for p in (0.0, 0.1):
         torch.cuda.synchronize()
         tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
     mb = n * D * 2 / 1e6
-    print("lib %s p=%.1f: fwd %.1f us (%.2f TB/s on 4 passes), bwd+finish %.1f us"
-          % (os.path.basename(os.environ.get("WAVLM_HIP_LIB", "default")), p, tf / it * 1e3, 4 * mb / (tf / it * 1e3), tb / it * 1e3))
+    print("full=%s blocks=%s D=%d lib %s p=%.1f: fwd %.1f us (%.2f TB/s on 4 passes), bwd+finish %.1f us"
+          % (os.environ.get("WAVLM_LN_FULL", "1"), os.environ.get("WAVLM_LN_FWD_BLOCKS", "-"), D, os.path.basename(os.environ.get("WAVLM_HIP_LIB", "default")), p, tf / it * 1e3, 4 * mb / (tf / it * 1e3), tb / it * 1e3))

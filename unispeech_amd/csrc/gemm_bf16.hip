@@ -216,6 +216,42 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce8_kernel(GemmP p, int n
   }
 }
 
+// the slab reductions of a grouped weight-gradient launch as ONE launch: problem g owns the 8-element vectors
+// [base[g], base[g + 1]); plain epilogue only (alpha, optional accumulate into C), which is what wavlm_gemm_grouped accepts
+struct RedGrpP {
+  float* ws[4]; void* C[4]; long ldc[4]; int M[4], N[4], c_dtype[4], accumulate[4]; float alpha[4];
+  long base[5]; int n, S;
+};
+__global__ __launch_bounds__(256) void gemm_splitk_reduce8_grouped_kernel(RedGrpP p) {
+  const long total8 = p.base[p.n];
+  for (long i8 = (long)blockIdx.x * blockDim.x + threadIdx.x; i8 < total8; i8 += (long)gridDim.x * blockDim.x) {
+    const int g = (i8 >= p.base[1]) + (i8 >= p.base[2]) + (i8 >= p.base[3]);
+    const long i = (i8 - p.base[g]) << 3;
+    const int N = p.N[g];
+    const long mn = (long)p.M[g] * N;
+    const float* src = p.ws[g] + i;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int k = 0; k < p.S; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(src + (long)k * mn);
+      const float4 b = *reinterpret_cast<const float4*>(src + (long)k * mn + 4);
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    const long m = i / N, n = i - m * N;
+    const long off = m * p.ldc[g] + n;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.alpha[g];
+    if (p.accumulate[g]) {
+      float c[8];
+      ld8_dt(p.C[g], off, p.c_dtype[g], c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += c[e];
+    }
+    st8_dt(p.C[g], off, p.c_dtype[g], v);
+  }
+}
+
 template <bool TA, bool TB, int BM, int BN, int WM, int WN>
 static int launch_cfg(GemmP& p, int nbatch, bool vec, hipStream_t st) {
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -527,11 +563,18 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
     g_prof.bytes[pi] = by;
   }
   int rc = gemm_pp_launch_grouped(p, st);
-  for (int i = 0; rc == WL_OK && i < n; ++i) {
-    GemmP pr = make_gemm_params(d + i);
-    const long total = (long)pr.M * pr.N;
-    long blocks = ((total >> 3) + 255) / 256; if (blocks > 2048) blocks = 2048;
-    WL_LAUNCH(gemm_splitk_reduce8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pr, 1);
+  if (rc == WL_OK) {
+    RedGrpP r;
+    r.n = n; r.S = p.split_k; r.base[0] = 0;
+    for (int i = 0; i < 4; ++i) {
+      const wavlm_gemm_desc* e = d + (i < n ? i : n - 1);
+      r.ws[i] = (float*)e->workspace; r.C[i] = e->C; r.ldc[i] = e->ldc; r.M[i] = e->M; r.N[i] = e->N;
+      r.c_dtype[i] = e->c_dtype; r.accumulate[i] = e->accumulate; r.alpha[i] = e->alpha;
+      r.base[i + 1] = i < n ? r.base[i] + (((long)e->M * e->N) >> 3) : 0x7fffffffffffffffL;
+    }
+    const long total8 = r.base[n];  // (base[n + 1 ..] are "never reached": the kernel's problem search stops at n)
+    long blocks = (total8 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    WL_LAUNCH(gemm_splitk_reduce8_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r);
     rc = wl_check_launch();
   }
   prof_end(pi, st);

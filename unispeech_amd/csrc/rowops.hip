@@ -4,6 +4,7 @@
 // statistics through wave shuffles, column gradients accumulated in registers per lane and reduced
 // across waves/blocks deterministically (per-block partials + a finishing kernel, no atomics).
 #include "common.hpp"
+#include <stdlib.h>
 #include "../../include/wavlm_hip.h"
 
 // ---- 8-wide vector access ------------------------------------------------------------------------
@@ -253,6 +254,274 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Full-width LayerNorm kernels: D == VEC * 64 * NC exactly (512 = 8 x 64 x 1, 768 = 4 x 64 x 3, 1024 = 8 x 64 x 2 -- every
+// width of the path), so every lane owns NC full vectors and the row loop has NO branch around a memory instruction:
+// the compiler can then count its s_waitcnt vmcnt (gfx950 counts stores too; behind a maybe-skipped store every wait
+// degrades to vmcnt(0), i.e. "wait for the stores of the row before").  Rows are software-pipelined: the loads of the
+// wave's next row are issued right after the current row has been unpacked, before its reductions and stores.  gamma /
+// beta live in registers for the whole kernel.  The dropout masks are the same function of (seed, row, column) as in the
+// general kernels above: word(column >> 1) half (column & 1).
+template <typename T, int VEC> struct RawV;
+template <> struct RawV<bf16_t, 8> {
+  uint4 a;
+  __device__ __forceinline__ void ld(const bf16_t* p) { a = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void get(float (&v)[8]) const {
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+  }
+};
+template <> struct RawV<bf16_t, 4> {
+  uint2 a;
+  __device__ __forceinline__ void ld(const bf16_t* p) { a = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void get(float (&v)[4]) const {
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  }
+};
+template <> struct RawV<float, 8> {
+  float4 a, b;
+  __device__ __forceinline__ void ld(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void get(float (&v)[8]) const {
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+};
+template <> struct RawV<float, 4> {
+  float4 a;
+  __device__ __forceinline__ void ld(const float* p) { a = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void get(float (&v)[4]) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+};
+template <int VEC> __device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  if constexpr (VEC == 8) *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <int VEC> __device__ __forceinline__ void stv(bf16_t* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 8) {
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = o;
+  } else {
+    uint2 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = o;
+  }
+}
+template <typename TP, int VEC> __device__ __forceinline__ void ldp(const TP* p, float (&v)[VEC]) {
+  RawV<TP, VEC> q; q.ld(p); q.get(v);
+}
+// column words of the lane's vectors: word w covers columns 2 w, 2 w + 1 (same function as ln_drop_cols)
+template <int VEC, int NC>
+__device__ __forceinline__ void lnf_drop_cols(unsigned long long seed_in, unsigned long long seed_out, int lane,
+                                              unsigned (&cw)[NC][VEC / 2]) {
+  const unsigned k = (unsigned)seed_in * 0x2545F491u + (unsigned)seed_out + 0x7F4A7C15u;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int j = 0; j < VEC / 2; ++j) cw[c][j] = hash32(k ^ (unsigned)(((lane + 64 * c) * VEC >> 1) + j));
+}
+template <int VEC>
+__device__ __forceinline__ void lnf_drop_apply(float (&v)[VEC], unsigned rw, const unsigned (&cw)[VEC / 2], unsigned th, float sc) {
+#pragma unroll
+  for (int j = 0; j < VEC / 2; ++j) {
+    const unsigned w = drop_mix(rw + cw[j]);
+    v[2 * j] = (w & 0xffffu) >= th ? v[2 * j] * sc : 0.f;
+    v[2 * j + 1] = (w >> 16) >= th ? v[2 * j + 1] * sc : 0.f;
+  }
+}
+
+// HR: residual operand r present; HS: the pre-norm sum s is stored (training)
+template <typename T, typename TP, int VEC, int NC, bool HR, bool HS>
+__global__ __launch_bounds__(256) void layernorm_fwd_full_kernel(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ y,
+    T* __restrict__ s, float* __restrict__ mean_o, float* __restrict__ rstd_o, const TP* __restrict__ gamma,
+    const TP* __restrict__ beta, long rows, float eps, int act, unsigned th_in, float sc_in,
+    unsigned long long seed_in, unsigned th_out, float sc_out, unsigned long long seed_out) {
+  constexpr int D = VEC * 64 * NC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gm[NC][VEC], bt[NC][VEC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { ldp<TP, VEC>(gamma + (lane + 64 * c) * VEC, gm[c]); ldp<TP, VEC>(beta + (lane + 64 * c) * VEC, bt[c]); }
+  unsigned cw[NC][VEC / 2];
+  if (th_in | th_out) lnf_drop_cols<VEC, NC>(seed_in, seed_out, lane, cw);
+  RawV<T, VEC> px[NC], pr[NC];
+  const long rstep = (long)gridDim.x * 4;
+  long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  auto fetch = [&](long row_) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const long off = row_ * D + (lane + 64 * c) * VEC;
+      px[c].ld(x + off);
+      if constexpr (HR) pr[c].ld(r + off);
+    }
+  };
+  fetch(row);
+  for (; row < rows; row += rstep) {
+    float v[NC][VEC];
+    float sum = 0.f;
+    const unsigned rw_in = th_in ? ln_drop_row(seed_in, row) : 0u, rw_out = th_out ? ln_drop_row(seed_out, row) : 0u;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      px[c].get(v[c]);
+      if constexpr (HR) {
+        float rv[VEC];
+        pr[c].get(rv);
+        if (th_in) lnf_drop_apply<VEC>(rv, rw_in, cw[c], th_in, sc_in);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[c][e] += rv[e];
+        // statistics are taken on the sum as it is stored (bf16-rounded in bf16 mode): that is the tensor the
+        // reference normalises, and what backward re-reads from s
+        if (sizeof(T) == 2) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[c][e] = bf2f(f2bf(v[c][e]));
+        }
+      }
+    }
+    {  // next row of this wave (clamped: the last iteration re-reads its own row instead of branching around the loads)
+      const long nrow = row + rstep < rows ? row + rstep : row;
+      fetch(nrow);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if constexpr (HS) stv<VEC>(s + row * D + (lane + 64 * c) * VEC, v[c]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) sum += v[c][e];
+    }
+    const float mean = wave_sum(sum) * (1.f / (float)D);
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) * (1.f / (float)D) + eps);
+    if (HS && lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float z = (v[c][e] - mean) * rstd * gm[c][e] + bt[c][e];
+        if (act) z = gelu_f(z);
+        o[e] = z;
+      }
+      if (th_out) lnf_drop_apply<VEC>(o, rw_out, cw[c], th_out, sc_out);
+      stv<VEC>(y + row * D + (lane + 64 * c) * VEC, o);
+    }
+  }
+}
+
+// CS: column sums of the residual-branch gradient (third partial array); HA: dx_add present; HD: dr is written
+template <typename T, typename TP, int VEC, int NC, bool CS, bool HA, bool HD>
+__global__ __launch_bounds__(256) void layernorm_bwd_full_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+    const float* __restrict__ mean_i, const float* __restrict__ rstd_i, const TP* __restrict__ gamma,
+    const TP* __restrict__ beta, T* __restrict__ dx, T* __restrict__ dr, const T* __restrict__ dx_add,
+    float* __restrict__ part, long rows, int act, unsigned th_in, float sc_in, unsigned long long seed_in, unsigned th_out,
+    float sc_out, unsigned long long seed_out, float grad_scale, int dr_incl_add) {
+  constexpr int D = VEC * 64 * NC;
+  constexpr int NA = CS ? 3 : 2;
+  __shared__ float red[4][NA][64 * VEC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[NC][VEC], ab[NC][VEC], gm[NC][VEC], bt[NC][VEC], ac[CS ? NC : 1][VEC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; bt[c][e] = 0.f; if (CS) ac[c][e] = 0.f; }
+    ldp<TP, VEC>(gamma + (lane + 64 * c) * VEC, gm[c]);
+    if (act) ldp<TP, VEC>(beta + (lane + 64 * c) * VEC, bt[c]);
+  }
+  unsigned cw[NC][VEC / 2];
+  if (th_in | th_out) lnf_drop_cols<VEC, NC>(seed_in, seed_out, lane, cw);
+  RawV<T, VEC> pdy[NC], psv[NC], padd[NC];
+  const long rstep = (long)gridDim.x * 4;
+  long row = (long)blockIdx.x * 4 + wave;
+  float nmean = 0.f, nrstd = 0.f;
+  auto fetch = [&](long row_) __attribute__((always_inline)) {
+    nmean = mean_i[row_]; nrstd = rstd_i[row_];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const long off = row_ * D + (lane + 64 * c) * VEC;
+      pdy[c].ld(dy + off);
+      psv[c].ld(s + off);
+      if constexpr (HA) padd[c].ld(dx_add + off);
+    }
+  };
+  if (row < rows) fetch(row);
+  for (; row < rows; row += rstep) {
+    const float mean = nmean, rstd = nrstd;
+    const unsigned rw_in = th_in ? ln_drop_row(seed_in, row) : 0u, rw_out = th_out ? ln_drop_row(seed_out, row) : 0u;
+    float h[NC][VEC], xh[NC][VEC], addv[HA ? NC : 1][VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float g[VEC], sv[VEC];
+      pdy[c].get(g); psv[c].get(sv);
+      if constexpr (HA) padd[c].get(addv[c]);
+      if (th_out) lnf_drop_apply<VEC>(g, rw_out, cw[c], th_out, sc_out);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float xhat = (sv[e] - mean) * rstd;
+        float ge = g[e];
+        if (act) ge *= gelu_grad_f(xhat * gm[c][e] + bt[c][e]);
+        ag[c][e] += ge * xhat;
+        ab[c][e] += ge;
+        const float hh = ge * gm[c][e];
+        h[c][e] = hh; xh[c][e] = xhat;
+        s1 += hh; s2 += hh * xhat;
+      }
+    }
+    {
+      const long nrow = row + rstep < rows ? row + rstep : row;
+      fetch(nrow);
+    }
+    s1 = wave_sum(s1) * (1.f / (float)D);
+    s2 = wave_sum(s2) * (1.f / (float)D);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const long off = row * D + (lane + 64 * c) * VEC;
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = grad_scale * rstd * (h[c][e] - s1 - xh[c][e] * s2);  // grad_scale: input gradient only
+      if constexpr (HA) {  // gradient that reaches x past the LayerNorm (the residual stream of a pre-LN block)
+        float t[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) t[e] = o[e] + addv[c][e];
+        stv<VEC>(dx + off, t);
+        if (dr_incl_add) {  // the sum x + dropout(r) itself continues as the residual stream: r sees the total too
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = t[e];
+        }
+      } else stv<VEC>(dx + off, o);
+      if constexpr (HD || CS) {
+        if (th_in) lnf_drop_apply<VEC>(o, rw_in, cw[c], th_in, sc_in);
+        if constexpr (HD) stv<VEC>(dr + off, o);
+        if constexpr (CS) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) ac[c][e] += o[e];
+        }
+      }
+    }
+  }
+  // cross-wave reduction of the column accumulators, one slot (64 lanes x VEC columns) at a time
+  float* pg = part + (long)blockIdx.x * NA * D;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      red[wave][0][lane * VEC + e] = ag[c][e]; red[wave][1][lane * VEC + e] = ab[c][e];
+      if constexpr (CS) red[wave][2][lane * VEC + e] = ac[c][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * VEC; i += 256) {
+      const int col = c * 64 * VEC + i;
+      pg[col] = red[0][0][i] + red[1][0][i] + red[2][0][i] + red[3][0][i];
+      pg[D + col] = red[0][1][i] + red[1][1][i] + red[2][1][i] + red[3][1][i];
+      if constexpr (CS) pg[2 * D + col] = red[0][2][i] + red[1][2][i] + red[2][2][i] + red[3][2][i];
+    }
+  }
+}
+
 // out[c] (+)= sum_b part[b * stride + c].  Block = 16 columns x 64 row slices: the kernel is pure load latency (a few MB
 // read through short dependent chains), so the chains are kept short (nblk / 64 loads per thread) and the grid wide
 // (n / 16 blocks); slices are combined through LDS.
@@ -488,6 +757,8 @@ extern "C" {
 
 int wavlm_abi_version(void) { return WAVLM_HIP_ABI_VERSION; }
 static double g_ln_prof_bytes = 0.0;
+// WAVLM_LN_FULL=0: the general kernels for every width (same-build A/B, tools/ln_bench.py)
+static bool ln_full_enabled() { static const bool on = !(getenv("WAVLM_LN_FULL") && getenv("WAVLM_LN_FULL")[0] == '0'); return on; }
 
 int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* mean, float* rstd, const void* gamma,
                         const void* beta, int64_t rows, int32_t D, float eps, int32_t dtype, int32_t param_dtype,
@@ -503,6 +774,25 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   }
   WlProfScope prof(WL_PROF_LN_FWD, dtype, 8.0 * rows * D, g_ln_prof_bytes, st);
   const unsigned grid = grid_for(rows, 4, (ti | to) ? LN_FWD_DROP_BLOCKS : 8192);  // with dropout: several rows per wave amortise the column words
+  // the path's own widths run the branch-free, software-pipelined kernels (a few rows per wave: the pipeline needs them)
+  if (ln_full_enabled() && (D == 512 || D == 768 || D == 1024) && (s == nullptr) == (mean == nullptr) && (s == nullptr) == (rstd == nullptr)) {
+    static const int cap = getenv("WAVLM_LN_FWD_BLOCKS") ? atoi(getenv("WAVLM_LN_FWD_BLOCKS")) : 1024;
+    const unsigned gridf = grid_for(rows, 4, (unsigned)(cap > 0 ? cap : 1024));
+#define LNF_K(T, TP, VEC, NCS, HR, HS) WL_LAUNCH((layernorm_fwd_full_kernel<T, TP, VEC, NCS, HR, HS>), dim3(gridf), dim3(256), 0, st, \
+    (const T*)x, (const T*)r, (T*)y, (T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (long)rows, eps, (int)act, ti, si, \
+    (unsigned long long)seed_in, to, so, (unsigned long long)seed_out)
+#define LNF_W(T, TP, HR, HS) do { if (D == 512) LNF_K(T, TP, 8, 1, HR, HS); else if (D == 768) LNF_K(T, TP, 4, 3, HR, HS); else LNF_K(T, TP, 8, 2, HR, HS); } while (0)
+#define LNF(T, TP) do { if (r) { if (s) LNF_W(T, TP, true, true); else LNF_W(T, TP, true, false); } \
+                        else { if (s) LNF_W(T, TP, false, true); else LNF_W(T, TP, false, false); } } while (0)
+    if (dtype == WL_F32 && param_dtype == WL_F32) LNF(float, float);
+    else if (dtype == WL_BF16 && param_dtype == WL_BF16) LNF(bf16_t, bf16_t);
+    else if (dtype == WL_BF16 && param_dtype == WL_F32) LNF(bf16_t, float);
+    else return WL_EINVAL;
+#undef LNF
+#undef LNF_W
+#undef LNF_K
+    return wl_check_launch();
+  }
   // chunk slots per lane are a template parameter: registers (and occupancy) follow the actual row width
 #define LN_FWD_N(T, TP, NCS) WL_LAUNCH((layernorm_fwd_kernel<T, TP, NCS>), dim3(grid), dim3(256), 0, st, (const T*)x, \
     (const T*)r, (T*)y, (T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (long)rows, (int)D, eps, (int)act, ti, si, \
@@ -537,6 +827,25 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
                    (double)rows * D * es_p * (3.0 + (dx_add ? 1.0 : 0.0) + ((dr && dr != dx) ? 1.0 : 0.0)), st);
   const unsigned grid = grid_for(rows, 4, LN_BWD_BLOCKS);
   float* part = (float*)workspace;
+  if (ln_full_enabled() && (D == 512 || D == 768 || D == 1024)) {
+#define LNB_K(T, TP, VEC, NCS, CSF, HA, HD) WL_LAUNCH((layernorm_bwd_full_kernel<T, TP, VEC, NCS, CSF, HA, HD>), dim3(grid), dim3(256), 0, st, \
+    (const T*)dy, (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, (const T*)dx_add, part, (long)rows, (int)act, \
+    ti, si, (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale, (int)dr_incl_add)
+#define LNB_W(T, TP, CSF, HA, HD) do { if (D == 512) LNB_K(T, TP, 8, 1, CSF, HA, HD); else if (D == 768) LNB_K(T, TP, 4, 3, CSF, HA, HD); \
+                                       else LNB_K(T, TP, 8, 2, CSF, HA, HD); } while (0)
+#define LNB_D(T, TP, CSF, HA) do { if (dr) LNB_W(T, TP, CSF, HA, true); else LNB_W(T, TP, CSF, HA, false); } while (0)
+#define LNB_A(T, TP, CSF) do { if (dx_add) LNB_D(T, TP, CSF, true); else LNB_D(T, TP, CSF, false); } while (0)
+#define LNB(T, TP) do { if (dr_colsum) LNB_A(T, TP, true); else LNB_A(T, TP, false); } while (0)
+    if (dtype == WL_F32 && param_dtype == WL_F32) LNB(float, float);
+    else if (dtype == WL_BF16 && param_dtype == WL_BF16) LNB(bf16_t, bf16_t);
+    else if (dtype == WL_BF16 && param_dtype == WL_F32) LNB(bf16_t, float);
+    else return WL_EINVAL;
+#undef LNB
+#undef LNB_A
+#undef LNB_D
+#undef LNB_W
+#undef LNB_K
+  } else {
 #define LN_BWD_C(T, TP, NCS, CSF) WL_LAUNCH((layernorm_bwd_kernel<T, TP, NCS, CSF>), dim3(grid), dim3(256), 0, st, (const T*)dy, \
     (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, (const T*)dx_add, part, (long)rows, (int)D, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale, (int)dr_incl_add)
@@ -549,6 +858,7 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
 #undef LN_BWD
 #undef LN_BWD_N
 #undef LN_BWD_C
+  }
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   const unsigned g2 = (unsigned)((D + 15) / 16);

@@ -29,12 +29,14 @@ def _rup(x, m):
 # chained consumers (LinearFn / GateFn / FFNFn pass_x): removes the torch add kernels autograd would launch for tensors
 # with several consumers (3 per post-LN encoder layer).  WAVLM_CHAIN_CONSUMERS=0 restores one Function per consumer.
 CHAIN_CONSUMERS = os.environ.get("WAVLM_CHAIN_CONSUMERS", "1") == "1"
-SINK_LISTENERS = []
-# Grouped weight-gradient launches (WgradGroup) are OFF by default: measured on one box, same build, 12 grouped launches
-# of 425 us against 48 single ones of ~100 us each (401 us per layer) -- the K loop of the K-strided form runs at
-# ~2.1 us per step either way and 108 tiles x split 2 fill only 216 of 256 CUs; what the grouping saves in slab
-# reduction (0.78 -> 0.41 ms) it loses there.  Kept (and tested) for shapes where the single launches quantise badly.
-WGRAD_GROUPING = os.environ.get("WAVLM_WGRAD_GROUPING", "0") == "1"  # callables(tensor): told which arena slice a backward kernel has just accumulated into (dp.GradReducer)
+# Grouped weight-gradient launches (WgradGroup): the four dW of an encoder layer as ONE split-K launch when their tiles fit
+# one round of the persistent grid with a split >= 2 (ops.grouped_split: Base yes, Large no).  Measured on one box, same
+# build (profiles/r03/envab_wg.txt): per layer 335 us + 4 x 7 us of slab reduction against 349 us + 4 x 13 us for the single
+# launches, -0.47 ms per step at Base.  (Round 2 had it off: its measurement compared 425 us against 401 us on another
+# build.)  WAVLM_WGRAD_GROUPING=0 / 1 forces single / grouped launches.
+_WG = os.environ.get("WAVLM_WGRAD_GROUPING", "auto")
+WGRAD_GROUPING = _WG != "0"
+SINK_LISTENERS = []  # callables(tensor): told which arena slice a backward kernel has just accumulated into (dp.GradReducer)
 
 
 def h2d(a, dev):
@@ -158,9 +160,11 @@ class WgradGroup:
         self.fired = True
         if self in WgradGroup.pending:
             WgradGroup.pending.remove(self)
-        if len(self.items) == 1:
-            dy2d, x2d, out = self.items[0]
-            _linear_bwd_w(dy2d, x2d, out.dtype, out=out)
+        n = self.items[0][0].shape[0]
+        tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in self.items)
+        if len(self.items) == 1 or n == 0 or ops.grouped_split(tiles, (n + 63) // 64) < 2:
+            for dy2d, x2d, out in self.items:   # (too many tiles for one round: single launches, still in arrival order)
+                _linear_bwd_w(dy2d, x2d, out.dtype, out=out)
         else:
             ops.gemm_wgrad_grouped(self.items, self.items[0][2].dtype)
         for sk in self.sinks:

@@ -116,6 +116,8 @@ def gemm_wgrad_grouped(items, w_dtype):
     n = items[0][0].shape[0]
     tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in items)
     split = grouped_split(tiles, (n + 63) // 64)
+    if split < 2:
+        raise ValueError("grouped weight gradients: %d tiles do not fit one round; use single launches" % tiles)
     L = _lib.lib()
     descs = (GemmDesc * len(items))()
     need = []
@@ -143,23 +145,17 @@ def gemm_wgrad_grouped(items, w_dtype):
 
 
 def grouped_split(tiles, ktiles, grid=256):
-    """split-K factor of a grouped weight-gradient launch (persistent grid: `grid` workgroups walk tiles * split work
-    items): the makespan is rounds x K-steps per item, so the split is chosen to make tiles * split fill a whole number of
-    rounds -- e.g. the four dW of a Base layer are 108 tiles x 375 K-steps: split 2 leaves 40 CUs idle for 188 K-steps,
-    split 7 runs 2.95 rounds of 54 (162 against the ideal 158).  Each round costs about four K-steps of prologue + slab
-    store, each split a slab (256 KiB per tile) to write and reduce.  WAVLM_WGRAD_SPLIT overrides (A/B measurements)."""
+    """split-K factor of a grouped weight-gradient launch, or 0 when the members should run as single launches.
+    Measured (profiles/r03/envab_wg.txt, Base: 108 tiles x 375 K-steps per layer, same box): ONE round of tiles * split work
+    items is what pays -- split 2 (216 items) 335 us per layer against 349 us for the four single launches + 28 us less slab
+    reduction; split 7 (2.95 rounds) 371 us and split 14 423 us although they balance the K-steps better: every extra round
+    costs a slab store and a pipeline refill per CU.  So: the largest split that still fits one round, and no grouping when
+    even split 2 does not (Large: 192 tiles).  WAVLM_WGRAD_SPLIT overrides (A/B measurements)."""
     forced = os.environ.get("WAVLM_WGRAD_SPLIT")
     if forced:
         return max(2, int(forced))
-    best, best_cost = 2, None
-    for s in range(2, 33):
-        if ktiles // s < 8:
-            break
-        rounds = (tiles * s + grid - 1) // grid
-        cost = rounds * ((ktiles + s - 1) // s + 4) + 0.5 * s
-        if best_cost is None or cost < best_cost - 1e-9:
-            best, best_cost = s, cost
-    return best
+    s = min(grid // max(tiles, 1), ktiles // 8, 64)
+    return s if s >= 2 else 0
 
 
 def pick_split(M, N, ktiles, nbatch=1, target_blocks=768):
