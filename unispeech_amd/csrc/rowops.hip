@@ -807,7 +807,8 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   return wl_check_launch();
 }
 
-uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D) { return (uint64_t)LN_BWD_BLOCKS * 3 * D * sizeof(float); }
+static int ln_bwd_blocks() { static const int n = getenv("WAVLM_LN_BWD_BLOCKS") ? atoi(getenv("WAVLM_LN_BWD_BLOCKS")) : LN_BWD_BLOCKS; return n > 0 && n <= 4096 ? n : LN_BWD_BLOCKS; }
+uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D) { return (uint64_t)ln_bwd_blocks() * 3 * D * sizeof(float); }
 
 int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd, const void* gamma,
                         const void* beta, void* dx, void* dr, const void* dx_add, void* dgamma, void* dbeta,
@@ -825,7 +826,7 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   const double es_p = dtype == WL_BF16 ? 2.0 : 4.0;  // dy, s (+ dx_add) read, dx (+ dr) written
   WlProfScope prof(WL_PROF_LN_BWD, dtype, 12.0 * rows * D,
                    (double)rows * D * es_p * (3.0 + (dx_add ? 1.0 : 0.0) + ((dr && dr != dx) ? 1.0 : 0.0)), st);
-  const unsigned grid = grid_for(rows, 4, LN_BWD_BLOCKS);
+  const unsigned grid = grid_for(rows, 4, (unsigned)ln_bwd_blocks());
   float* part = (float*)workspace;
   if (ln_full_enabled() && (D == 512 || D == 768 || D == 1024)) {
 #define LNB_K(T, TP, VEC, NCS, CSF, HA, HD) WL_LAUNCH((layernorm_bwd_full_kernel<T, TP, VEC, NCS, CSF, HA, HD>), dim3(grid), dim3(256), 0, st, \

@@ -37,6 +37,14 @@ CHAIN_CONSUMERS = os.environ.get("WAVLM_CHAIN_CONSUMERS", "1") == "1"
 _WG = os.environ.get("WAVLM_WGRAD_GROUPING", "auto")
 WGRAD_GROUPING = _WG != "0"
 SINK_LISTENERS = []  # callables(tensor): told which arena slice a backward kernel has just accumulated into (dp.GradReducer)
+# WAVLM_WGRAD_STREAM=1: the grouped weight-gradient launches run on a side HIP stream.  They are off the critical path of
+# backward (nothing but the optimizer / the gradient reducer reads dW), a grouped launch leaves 40 of 256 CUs idle for its
+# whole duration and every kernel of the main chain has a tail: with a second queue the scheduler fills those with the
+# other stream's workgroups.  The side stream waits for the point at which the layer's last dy was produced; the optimizer
+# step / reducer finish wait for the side stream (flush_wgrad_groups); operands are kept alive across streams with
+# record_stream; the side stream has its own split-K workspace.
+WGRAD_STREAM = os.environ.get("WAVLM_WGRAD_STREAM", "0") == "1"
+_WG_SIDE = {}  # device index -> side stream
 
 
 def h2d(a, dev):
@@ -138,6 +146,7 @@ class WgradGroup:
     whatever is left, so a member that never receives a gradient cannot strand the others."""
     __slots__ = ("expected", "items", "sinks", "fired")
     pending = []
+    side_pending = False  # side-stream launches not yet joined by the main stream
     deferred = set()  # data_ptr of every sink slice whose accumulation is queued but not yet enqueued on the stream
 
     def __init__(self, expected):
@@ -160,16 +169,32 @@ class WgradGroup:
         self.fired = True
         if self in WgradGroup.pending:
             WgradGroup.pending.remove(self)
-        n = self.items[0][0].shape[0]
-        tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in self.items)
-        if len(self.items) == 1 or n == 0 or ops.grouped_split(tiles, (n + 63) // 64) < 2:
-            for dy2d, x2d, out in self.items:   # (too many tiles for one round: single launches, still in arrival order)
-                _linear_bwd_w(dy2d, x2d, out.dtype, out=out)
+        def launch():
+            n = self.items[0][0].shape[0]
+            tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in self.items)
+            if len(self.items) == 1 or n == 0 or ops.grouped_split(tiles, (n + 63) // 64) < 2:
+                for dy2d, x2d, out in self.items:   # (too many tiles for one round: single launches, still in arrival order)
+                    _linear_bwd_w(dy2d, x2d, out.dtype, out=out)
+            else:
+                ops.gemm_wgrad_grouped(self.items, self.items[0][2].dtype)
+            for sk in self.sinks:  # (on the side stream: a reducer orders its all-reduce behind THIS stream's work)
+                WgradGroup.deferred.discard(sk.data_ptr())
+                _sink_written(sk)
+
+        dev = self.items[0][0].device
+        if WGRAD_STREAM and dev.type == "cuda":
+            side = _WG_SIDE.get(dev.index)
+            if side is None:
+                side = _WG_SIDE[dev.index] = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                launch()
+            for dy2d, x2d, _ in self.items:  # the allocator must not hand these blocks out again before the side stream is done
+                dy2d.record_stream(side)
+                x2d.record_stream(side)
+            WgradGroup.side_pending = True
         else:
-            ops.gemm_wgrad_grouped(self.items, self.items[0][2].dtype)
-        for sk in self.sinks:
-            WgradGroup.deferred.discard(sk.data_ptr())
-            _sink_written(sk)
+            launch()
         self.items, self.sinks = [], []
 
 
@@ -181,8 +206,14 @@ def grad_write_deferred(grad_view):
 
 
 def flush_wgrad_groups():
+    """fire what is still queued and, with side-stream weight gradients, make the current stream wait for them: called by
+    every reader of the gradient arena (optimizer step / norm, reducer finish)"""
     for g in list(WgradGroup.pending):
         g.fire()
+    if WgradGroup.side_pending:
+        WgradGroup.side_pending = False
+        for idx, side in _WG_SIDE.items():
+            torch.cuda.current_stream(idx).wait_stream(side)
 
 
 class BiasGradToken:

@@ -48,8 +48,8 @@ def ptr(t, offset=0):
 
 
 def workspace(device, nbytes, tag="main"):
-    """grow-only scratch buffer; reuse is safe because all launches are ordered on one stream"""
-    key = (device.index, tag)
+    """grow-only scratch buffer per (device, tag, stream): reuse is safe because the launches of one stream are ordered"""
+    key = (device.index, tag, _RAW_STREAM(device.index) if _RAW_STREAM is not None else torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -115,9 +115,7 @@ def gemm_wgrad_grouped(items, w_dtype):
     dev = _dev(items[0][0])
     n = items[0][0].shape[0]
     tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in items)
-    split = grouped_split(tiles, (n + 63) // 64)
-    if split < 2:
-        raise ValueError("grouped weight gradients: %d tiles do not fit one round; use single launches" % tiles)
+    split = max(2, grouped_split(tiles, (n + 63) // 64))  # (callers that only group when one round fits: WgradGroup.fire)
     L = _lib.lib()
     descs = (GemmDesc * len(items))()
     need = []
