@@ -323,7 +323,8 @@ def check_layernorm():
         dx1, dr1, _, _, cs1 = ops.layernorm_bwd(dyb, sv, mean, rstd, g.detach(), b.detach(), p_in=p, seed_in=999,
                                                 need_dr=True, dr_colsum=True, dx_add=extra)
         out.append((f"layernorm[{dtype}] dx_add", err(dx1, dx0.double() + extra.double()), tol))
-        out.append((f"layernorm[{dtype}] dx_add leaves dr", err(dr1, dr0), 0.0))
+        # (same values; the two template instantiations may contract the fp32 expression differently: last-bit slack)
+        out.append((f"layernorm[{dtype}] dx_add leaves dr", err(dr1, dr0), 1e-6 if dtype == torch.float32 else 0.0))
         out.append((f"layernorm[{dtype}] dx_add leaves colsum", err(cs1, cs0), tol))
         # the same through autograd: y = LN(x) + x with x handed through as an alias
         xa = gen(rows, D, seed=31).to(dtype).to(DEV).requires_grad_(True)

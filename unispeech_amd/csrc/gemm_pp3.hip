@@ -18,6 +18,7 @@
 // K-strided operands: A units are [64 k][64 rows] (128-B k rows, 32-B granule ^ 2*((k>>1)&1)), B is
 // [64 k][384 rows] (768-B k rows, granule ^ 2*(k&3) inside aligned groups of 8), both read with ds_read_b64_tr_b16.
 #include "gemm_common.hpp"
+#include <stdlib.h>
 
 #include "tile_loaders.hpp"
 
@@ -36,14 +37,19 @@ template <bool TA, bool TB, int EP>
 __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 * P3_STAGE
 
+  // Persistent launch (as gemm_pp.hip): gridDim.x workgroups (at most one per CU) walk the virtual ids vid = block,
+  // block + grid, ...; vid -> (tile, batch z, split).  A launch of several rounds (N = 2304 / 3072 at 24 k rows: 2.9 / 3.9)
+  // no longer pays a workgroup launch per tile, and a tile's epilogue stores drain under the next tile's first DMA.
+  for (int vid = blockIdx.x; vid < p.vtotal; vid += gridDim.x) {
   int tile;
+  const int ntile_ = p.tiles_m * p.tiles_n;
   {
-    const int nt = p.tiles_m * p.tiles_n, bid = blockIdx.x;
+    const int nt = ntile_, bid = vid % ntile_;
     const int q = nt >> 3, rem = nt & 7, xcd = bid & 7, idx = bid >> 3;
     tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
   const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-  const int z = blockIdx.y, split = blockIdx.z;
+  const int z = (vid / ntile_) % p.nbatch, split = vid / (ntile_ * p.nbatch);
   const int zo = z / p.batch_i, zi = z % p.batch_i;
   const int m0 = tm * 192, n0 = tn * 384;
   const int lane = threadIdx.x & 63;
@@ -461,13 +467,21 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
       if (csum) gemm_colsum_finish<96>(p, reinterpret_cast<float*>(smem + 106496), wave, wm, lane, tm, nw, cs);
     }
   }
+  __syncthreads();  // every wave has read its staging slice (and the table) before the next tile's DMA lands there
+  }
 }
+
+extern int g_pp_reserved_cus;  // gemm_pp.hip: CUs left to the RCCL kernels in data-parallel runs
 
 template <bool TA, bool TB>
 static int pp3_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
   p.tiles_m = (p.M + 191) / 192;
   p.tiles_n = (p.N + 383) / 384;
-  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)nbatch, (unsigned)p.split_k);
+  p.nbatch = nbatch;
+  p.vtotal = p.tiles_m * p.tiles_n * nbatch * p.split_k;
+  const int pgrid = 256 - g_pp_reserved_cus;
+  static const bool persistent = !(getenv("WAVLM_PP3_PERSISTENT") && getenv("WAVLM_PP3_PERSISTENT")[0] == '0');  // A/B switch
+  dim3 grid((unsigned)(!persistent || p.vtotal < pgrid ? p.vtotal : pgrid), 1, 1);
   constexpr int smem = 2 * P3_STAGE;
   static bool done[5] = {false, false, false, false, false};
 #define PP_CASE(E) case E: { \
