@@ -217,6 +217,53 @@ def kernel_rooflines(ops, nsteps):
     return out
 
 
+def live_gemm_traffic(args):
+    """(HBM bytes per GEMM launch, source string) from two rocprofv3 PMC passes of this command run as subprocesses, or
+    (None, None) when rocprofv3 is missing / a pass fails / times out.  Same reduction as tools/pmc_traffic.py."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, None
+    tmp = tempfile.mkdtemp(prefix="wavlm_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    tot = {}
+    launches = 0
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "run", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+                   "--config", args.config, "--batch", str(args.batch)]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, None
+            per = collections.defaultdict(lambda: [0, 0.0])
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != ctr:
+                    continue
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                if name.startswith(("gemm_pp", "gemm_bf16", "gemm_splitk")):
+                    per[name][0] += 1
+                    per[name][1] += float(row["Counter_Value"])
+            scale = 2.0 * 1024.0 if ctr == "FETCH_SIZE" else 1024.0   # gfx950: FETCH_SIZE counts 128-B requests as 64 B
+            tot[ctr] = sum(v[1] for v in per.values()) * scale
+            launches = sum(v[0] for k, v in per.items() if not k.startswith("gemm_splitk"))
+        if launches == 0:
+            return None, None
+        return round((tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / launches), \
+            "live: two rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE) of this command, 2 steps each, %d GEMM launches" % launches
+    except Exception:
+        return None, None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -238,6 +285,8 @@ def main():
                          "extract_features per call on the configs[1] batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--live-traffic", action="store_true",
+                    help="collect roofline.traffic live (two rocprofv3 PMC passes of this command as subprocesses, ~1 min)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -369,17 +418,21 @@ def main():
         ops.prof_enable(False)
         if ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
-            # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x 2 on
-            # gfx950 + WRITE_SIZE, tools/pmc_traffic.py); counters cannot be read from inside the run
+            # HBM bytes per GEMM launch: counters cannot be read from inside the run.  --live-traffic collects them NOW with
+            # two rocprofv3 PMC passes of this same command in subprocesses (FETCH_SIZE x 2 on gfx950, WRITE_SIZE, each with
+            # --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes); the default reads the passes
+            # committed with this round's build (tools/gpu_pmc.sh -> profiles/r03/gemm_hbm_traffic.json) and says so
             traffic, traffic_src = None, None
-            if args.config == "base":
-                for rnd in ("r02", "r01"):
+            if args.live_traffic and world == 1:
+                traffic, traffic_src = live_gemm_traffic(args)
+            if traffic is None and args.config == "base":
+                for rnd in ("r03", "r02", "r01"):
                     tj = os.path.join(ROOT, "profiles", rnd, "gemm_hbm_traffic.json")
                     if os.path.exists(tj):
                         try:
                             traffic = round(json.load(open(tj))["gemm_hbm_bytes_per_launch"])
                             traffic_src = "profiles/%s/gemm_hbm_traffic.json (committed rocprofv3 PMC passes of this " \
-                                          "command, not this run)" % rnd
+                                          "command, not this run; `bench.py --live-traffic` collects them live)" % rnd
                             break
                         except Exception:
                             traffic = None
