@@ -453,6 +453,27 @@ __global__ __launch_bounds__(256) void conv0_ln_fwd_kernel(const TW* __restrict_
   }
 }
 
+// 8 gradient elements as loaded (not yet converted): the LayerNorm-mode backward below issues the load of its NEXT frame
+// before the four dependent wave reductions of the current one
+template <typename T> struct C0Raw8;
+template <> struct C0Raw8<bf16_t> {
+  uint4 a;
+  __device__ __forceinline__ void ld(const bf16_t* p) { a = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void get(float (&v)[8]) const {
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+  }
+};
+template <> struct C0Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void ld(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void get(float (&v)[8]) const {
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+};
+
 // part[(b * nchunk + chunk)][12][C]: dbeta, dgamma, dW[.][0..9]
 template <typename TW, typename TP, typename TO>
 __global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
@@ -487,13 +508,18 @@ __global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict_
     for (int k = 0; k < C0_KW; ++k) pw[e][k] = 0.f;
   }
   const float invC = 1.f / (float)C;
+  // A wave owns a frame: per frame four DEPENDENT wave reductions sit between the gradient load and the accumulation, and
+  // at ~220 VGPRs only two waves per SIMD hide them -- the kernel was bound by the load latency of every frame (4.3 ms at
+  // Large, 0.06 of the HBM roofline).  The gradient of the wave's next frame is now in flight during the current frame.
+  C0Raw8<TO> gnext;
+  const TO* gbase = g + ((long)b * T0 + t0) * C + (act ? lane * 8 : 0);
+  if (wave < nt) gnext.ld(gbase + (long)wave * C);
   for (int tt = wave; tt < nt; tt += 4) {
     float xw[C0_KW], y[8], gv[8];
 #pragma unroll
     for (int k = 0; k < C0_KW; ++k) xw[k] = seg[tt * stride + k];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) gv[e] = 0.f;
-    if (act) V8<TO>::ld(g + ((long)b * T0 + t0 + tt) * C + lane * 8, gv);
+    gnext.get(gv);   // (inactive lanes hold channel 0..7's values: every use below is masked by `act`)
+    gnext.ld(gbase + (long)(tt + 4 < nt ? tt + 4 : tt) * C);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
