@@ -51,16 +51,35 @@ template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
-// ---- 64-lane wave reductions (butterfly over DPP/ds_swizzle via __shfl_xor) ----
+// ---- 64-lane wave reductions ----
+// Within a 16-lane row: four DPP adds (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- the compiler folds each into
+// one v_add_f32_dpp); across the four rows: v_readlane of one lane per row and three adds on uniform values.  ~12
+// instructions and ~60 cycles of latency.  The former butterfly over __shfl_xor compiled to six DEPENDENT ds_bpermute_b32
+// (LDS round trips, ~900 cycles per reduction): with four reductions per frame and one wave per SIMD that was the whole
+// run time of the LayerNorm-mode conv0 backward (4.2 us per frame).  All 64 lanes must be active (every caller reduces
+// with the full wave); the result is wave-uniform.
+template <int CTRL> __device__ __forceinline__ float wl_dpp_f32(float v) {  // lanes whose source is invalid read 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ float wl_dpp_keep_f32(float v) {  // ... keep their own value
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wl_lane_f32(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += wl_dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += wl_dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += wl_dpp_f32<0x141>(v);   // row_half_mirror: lane i <-> 7 - i, the other quad of its 8
+  v += wl_dpp_f32<0x140>(v);   // row_mirror: lane i <-> 15 - i, the other half of its row
+  return (wl_lane_f32(v, 0) + wl_lane_f32(v, 16)) + (wl_lane_f32(v, 32) + wl_lane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, wl_dpp_keep_f32<0xB1>(v));
+  v = fmaxf(v, wl_dpp_keep_f32<0x4E>(v));
+  v = fmaxf(v, wl_dpp_keep_f32<0x141>(v));
+  v = fmaxf(v, wl_dpp_keep_f32<0x140>(v));
+  return fmaxf(fmaxf(wl_lane_f32(v, 0), wl_lane_f32(v, 16)), fmaxf(wl_lane_f32(v, 32), wl_lane_f32(v, 48)));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

@@ -453,30 +453,11 @@ __global__ __launch_bounds__(256) void conv0_ln_fwd_kernel(const TW* __restrict_
   }
 }
 
-// 8 gradient elements as loaded (not yet converted): the LayerNorm-mode backward below issues the load of its NEXT frame
-// before the four dependent wave reductions of the current one
-template <typename T> struct C0Raw8;
-template <> struct C0Raw8<bf16_t> {
-  uint4 a;
-  __device__ __forceinline__ void ld(const bf16_t* p) { a = *reinterpret_cast<const uint4*>(p); }
-  __device__ __forceinline__ void get(float (&v)[8]) const {
-    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
-    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
-    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
-    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
-  }
-};
-template <> struct C0Raw8<float> {
-  float4 a, b;
-  __device__ __forceinline__ void ld(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
-  __device__ __forceinline__ void get(float (&v)[8]) const {
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  }
-};
-
 // part[(b * nchunk + chunk)][12][C]: dbeta, dgamma, dW[.][0..9]
-template <typename TW, typename TP, typename TO>
-__global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
+// OCC: workgroups per CU the register allocation aims at (2: 256 VGPRs with a dozen spilled words reloaded per frame;
+// 1: 258-260 VGPRs, no spill, one wave per SIMD) -- WAVLM_CONV0_LN_OCC selects, default from the A/B in profiles/r03
+template <typename TW, typename TP, typename TO, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv0_ln_bwd_kernel(const TW* __restrict__ wav, const TP* __restrict__ W,
     const TP* __restrict__ cbias, const TP* __restrict__ gamma, const TP* __restrict__ beta, const TO* __restrict__ g,
     float* __restrict__ part, long T, int T0, int C, int stride, float eps, float gscale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -508,18 +489,17 @@ __global__ __launch_bounds__(256) void conv0_ln_bwd_kernel(const TW* __restrict_
     for (int k = 0; k < C0_KW; ++k) pw[e][k] = 0.f;
   }
   const float invC = 1.f / (float)C;
-  // A wave owns a frame: per frame four DEPENDENT wave reductions sit between the gradient load and the accumulation, and
-  // at ~220 VGPRs only two waves per SIMD hide them -- the kernel was bound by the load latency of every frame (4.3 ms at
-  // Large, 0.06 of the HBM roofline).  The gradient of the wave's next frame is now in flight during the current frame.
-  C0Raw8<TO> gnext;
-  const TO* gbase = g + ((long)b * T0 + t0) * C + (act ? lane * 8 : 0);
-  if (wave < nt) gnext.ld(gbase + (long)wave * C);
+  // A wave owns a frame: per frame four DEPENDENT wave reductions sit between the gradient load and the accumulation.  With
+  // the reductions as LDS butterflies (six ds_bpermute each) and the kernel's ~260 VGPRs (one wave per SIMD) the frame took
+  // 4.2 us: 4.3 ms at Large, 0.06 of the HBM roofline; common.hpp's DPP reductions are what this kernel needed.  (Issuing the
+  // next frame's gradient load early was measured and changes nothing: 4.34 -> 4.24 ms; it is not the load that is waited for.)
   for (int tt = wave; tt < nt; tt += 4) {
     float xw[C0_KW], y[8], gv[8];
 #pragma unroll
     for (int k = 0; k < C0_KW; ++k) xw[k] = seg[tt * stride + k];
-    gnext.get(gv);   // (inactive lanes hold channel 0..7's values: every use below is masked by `act`)
-    gnext.ld(gbase + (long)(tt + 4 < nt ? tt + 4 : tt) * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gv[e] = 0.f;
+    if (act) V8<TO>::ld(g + ((long)b * T0 + t0 + tt) * C + lane * 8, gv);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -753,8 +733,10 @@ int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   // algorithmic: the incoming gradient read once + the waveform; conv recompute + weight gradient = 4 * kw flops per output
   WlProfScope prof(WL_PROF_CONV0_BWD, g_dtype, 4.0 * kw * B * (double)T0 * C,
                    (double)B * T * (wav_dtype == WL_BF16 ? 2 : 4) + (double)B * T0 * C * (g_dtype == WL_BF16 ? 2 : 4), st);
-#define BW(TW, TP, TO) WL_LAUNCH((conv0_ln_bwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
+  static const int occ = (getenv("WAVLM_CONV0_LN_OCC") && getenv("WAVLM_CONV0_LN_OCC")[0] == '1') ? 1 : 2;
+#define BW_O(TW, TP, TO, O) WL_LAUNCH((conv0_ln_bwd_kernel<TW, TP, TO, O>), grid, dim3(256), smem, st, (const TW*)wav, \
     (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (const TO*)g, part, (long)T, T0, (int)C, (int)stride, eps, gscale)
+#define BW(TW, TP, TO) do { if (occ == 1) BW_O(TW, TP, TO, 1); else BW_O(TW, TP, TO, 2); } while (0)
   const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
   if (key == 0) BW(float, float, float);
   else if (key == 111) BW(bf16_t, bf16_t, bf16_t);
@@ -762,6 +744,7 @@ int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   else if (key == 1) BW(float, float, bf16_t);
   else return WL_EINVAL;
 #undef BW
+#undef BW_O
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   const int n = C0_LN_NQ * C;
