@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
           tmax = fmaxf(tmax, x);
         }
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = wl_max_xor32(tmax);
     const float m_new = fmaxf(m, tmax);
     const bool dead = (m_new == -INFINITY);
     const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
         }
         pf[f][r >> 3].u[(r & 7) >> 1] = pk;
       }
-    rs += __shfl_xor(rs, 32, 64);
+    rs = wl_sum_xor32(rs);
     l = l * alpha + rs;
     m = m_new;
     if (__any(alpha != 1.f)) {  // the running maximum settles after the first tiles: skip the rescale then
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
       dl += __uint_as_float(dof[kk].u[e] & 0xffff0000u) * __uint_as_float(ov.u[e] & 0xffff0000u);
     }
   }
-  dl += __shfl_xor(dl, 32, 64);
+  dl = wl_sum_xor32(dl);
   const float dls = dl * p.inv_sc;
   for (int d = threadIdx.x; d < p.Ltab; d += 256) tabs[d] = (p.tab && d < L) ? p.tab[(long)h * L + d] : 0.f;
   for (int j = threadIdx.x; j < p.Tkb; j += 256)
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     const int d = dlo0 + 64 * nkv + lane;
     if (d >= 0 && d < L) prow[d] = v;
   }
-  dg += __shfl_xor(dg, 32, 64);
+  dg = wl_sum_xor32(dg);
   if (p.dbias_part)  // rows past T carry dS = 0, i.e. dq = 0
     fa_wave_colsum(dq, p.scale, reinterpret_cast<float*>(smem),
                    p.dbias_part + (((long)b * p.nqb + qblk) * 4 + wave_u) * D3 + h * FA_HD, lane, wave_u);

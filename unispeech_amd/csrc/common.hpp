@@ -81,6 +81,16 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, wl_dpp_keep_f32<0x140>(v));
   return fmaxf(fmaxf(wl_lane_f32(v, 0), wl_lane_f32(v, 16)), fmaxf(wl_lane_f32(v, 32), wl_lane_f32(v, 48)));
 }
+// exchange between the two 32-lane halves of a wave with gfx950's v_permlane32_swap_b32 (VALU, a few cycles) instead of
+// ds_bpermute_b32 (an LDS round trip): lo / hi = the value of lane (l & 31) / (l & 31) + 32 in every lane.  Inline asm with
+// its own wait states (through the builtin the compiler folded the two results of a swap of two copies of one value).
+__device__ __forceinline__ void wl_halves(float x, float& lo, float& hi) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  lo = a; hi = b;
+}
+__device__ __forceinline__ float wl_sum_xor32(float x) { float lo, hi; wl_halves(x, lo, hi); return lo + hi; }
+__device__ __forceinline__ float wl_max_xor32(float x) { float lo, hi; wl_halves(x, lo, hi); return fmaxf(lo, hi); }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
