@@ -328,9 +328,7 @@ __global__ __launch_bounds__(256) void gate_fwd64_kernel(const T* __restrict__ x
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sa = fmaf(xv[i][e], wa[e], sa); sb = fmaf(xv[i][e], wb[e], sb); }
       }
-      sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
-      sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
-      sa += __shfl_xor(sa, 4, 64); sb += __shfl_xor(sb, 4, 64);
+      sa = wl_sum8(sa); sb = wl_sum8(sb);  // the 8 lanes of a head (DPP; was three ds_bpermute round trips each)
       if (ok[i] && sub == 0) {
         const int q = lane + 64 * i;
         const long row = 2 * rp + q / CPR;

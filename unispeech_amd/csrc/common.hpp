@@ -74,6 +74,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += wl_dpp_f32<0x140>(v);   // row_mirror: lane i <-> 15 - i, the other half of its row
   return (wl_lane_f32(v, 0) + wl_lane_f32(v, 16)) + (wl_lane_f32(v, 32) + wl_lane_f32(v, 48));
 }
+// sum over each aligned group of 8 lanes, in every lane of the group (three DPP adds)
+__device__ __forceinline__ float wl_sum8(float v) {
+  v += wl_dpp_f32<0xB1>(v);
+  v += wl_dpp_f32<0x4E>(v);
+  v += wl_dpp_f32<0x141>(v);
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, wl_dpp_keep_f32<0xB1>(v));
   v = fmaxf(v, wl_dpp_keep_f32<0x4E>(v));

@@ -40,6 +40,11 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
   // Persistent launch (as gemm_pp.hip): gridDim.x workgroups (at most one per CU) walk the virtual ids vid = block,
   // block + grid, ...; vid -> (tile, batch z, split).  A launch of several rounds (N = 2304 / 3072 at 24 k rows: 2.9 / 3.9)
   // no longer pays a workgroup launch per tile, and a tile's epilogue stores drain under the next tile's first DMA.
+  if (p.skew) {
+    // de-phase the CUs of a multi-round launch: in lockstep every CU reaches its HBM-bound epilogue (and the next tile's
+    // cold prologue) at the same time and the memory system alternates between idle and saturated
+    for (int i = (int)((blockIdx.x >> 3) & 3) * p.skew; i > 0; --i) __builtin_amdgcn_s_sleep(127);
+  }
   for (int vid = blockIdx.x; vid < p.vtotal; vid += gridDim.x) {
   int tile;
   const int ntile_ = p.tiles_m * p.tiles_n;
@@ -482,6 +487,9 @@ static int pp3_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
   const int pgrid = 256 - g_pp_reserved_cus;
   static const bool persistent = !(getenv("WAVLM_PP3_PERSISTENT") && getenv("WAVLM_PP3_PERSISTENT")[0] == '0');  // A/B switch
   dim3 grid((unsigned)(!persistent || p.vtotal < pgrid ? p.vtotal : pgrid), 1, 1);
+  // WAVLM_PP3_SKEW=n: start phases 0..3 x n x ~3.9 us (s_sleep 127) for launches of >= 2 rounds (experiment switch)
+  static const int skew = getenv("WAVLM_PP3_SKEW") ? atoi(getenv("WAVLM_PP3_SKEW")) : 0;
+  p.skew = (persistent && skew > 0 && p.vtotal >= 2 * pgrid) ? skew : 0;
   constexpr int smem = 2 * P3_STAGE;
   static bool done[5] = {false, false, false, false, false};
 #define PP_CASE(E) case E: { \
