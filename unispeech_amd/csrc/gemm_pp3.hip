@@ -22,6 +22,11 @@
 
 #include "tile_loaders.hpp"
 
+#ifndef P3_PROBE
+// 0 in the product build.  Timing probes (tools/probe/build_probe.py pp3:<tag>:-DP3_PROBE=<bits>; results are wrong by
+// construction): bit 0 skips the K loop and the prologue DMA (tile set-up + epilogue only)
+#define P3_PROBE 0
+#endif
 #define P3_AU 8192
 #define P3_BB 49152
 #define P3_STAGE (3 * P3_AU + P3_BB)  // 73728
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                  :: "s"(lds_dst), "v"(voff32), "s"(sbase) : "memory", "m0");
   };
-  const int nt = t1 - t0;
+  const int nt = (P3_PROBE & 1) ? 0 : t1 - t0;
 
   // ---- DMA side -------------------------------------------------------------------------------------------------
   // A unit i, piece = wave: K-contiguous -> buffer rows 8 w .. +8 (lane: row + (l >> 3), physical chunk l & 7);
