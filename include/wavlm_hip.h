@@ -120,6 +120,21 @@ int wavlm_select_rows(const void* x, void* y, const uint8_t* sel, const void* em
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0.  x[masked_indices] (wavlm.py:541,557) and its scatter-back. */
 int wavlm_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_out, int32_t D, int32_t dtype,
                       void* stream);
+/* Operand images of the feature extractor's Conv1d weights (WavLM/WavLM.py:378-504: conv_layers.{i}.0.weight
+ * [Cout, Cin, k]) for every layer of the stack in ONE launch: Wf[l] = [Cout][k * Cin] (forward GEMM over overlapping
+ * rows) and, if Wb[l] != NULL, the s[l] stride-phase images of the data-gradient GEMMs back to back, phase r as
+ * [Cin][J_r * Cout] with J_r = ceil((k - r) / s) taps newest first.  wavlm_conv_wgrad_scatter is the way back for the
+ * weight gradients: W[l][co][ci][kk] (+)= Wf[l][co][kk * Cin + ci] (here W = the gradient tensors, Wf = the GEMM outputs). */
+#define WL_CONV_RELAYOUT_MAX 8
+typedef struct {
+  const void* W[WL_CONV_RELAYOUT_MAX];
+  void* Wf[WL_CONV_RELAYOUT_MAX];
+  void* Wb[WL_CONV_RELAYOUT_MAX];
+  int32_t Cout[WL_CONV_RELAYOUT_MAX], Cin[WL_CONV_RELAYOUT_MAX], k[WL_CONV_RELAYOUT_MAX], s[WL_CONV_RELAYOUT_MAX];
+  int32_t n_layers, dtype;
+} wavlm_conv_relayout_desc;
+int wavlm_conv_weights_relayout(const wavlm_conv_relayout_desc* d, void* stream);
+int wavlm_conv_wgrad_scatter(const wavlm_conv_relayout_desc* d, int32_t accumulate, void* stream);
 /* y = a*x + b*y */
 int wavlm_axpby(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, float a, float b, void* stream);
 /* y *= scalar[0] * extra, scalar on the device (upstream loss gradient without a host sync) */

@@ -18,6 +18,13 @@ F32, BF16 = 0, 1
 c_i32, c_i64, c_u64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 
 
+class ConvRelayoutDesc(C.Structure):
+    """wavlm_conv_relayout_desc (include/wavlm_hip.h)"""
+    _fields_ = [("W", c_vp * 8), ("Wf", c_vp * 8), ("Wb", c_vp * 8),
+                ("Cout", c_i32 * 8), ("Cin", c_i32 * 8), ("k", c_i32 * 8), ("s", c_i32 * 8),
+                ("n_layers", c_i32), ("dtype", c_i32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("dtype", c_i32), ("c_dtype", c_i32),
@@ -53,6 +60,8 @@ SIGNATURES = {
     "wavlm_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_u64, c_vp]),
     "wavlm_select_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "wavlm_gather_rows": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "wavlm_conv_weights_relayout": (c_i32, [C.POINTER(ConvRelayoutDesc), c_vp]),
+    "wavlm_conv_wgrad_scatter": (c_i32, [C.POINTER(ConvRelayoutDesc), c_i32, c_vp]),
     "wavlm_axpby": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_vp]),
     "wavlm_scale_dev": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_f32, c_vp]),
     "wavlm_dropout": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_u64, c_i32, c_vp]),

@@ -753,6 +753,44 @@ static inline unsigned grid_for(long work_items, int per_block, unsigned cap) {
 #endif
 #define CS_BLOCKS 512
 
+// Operand images of the extractor's convolution weights W[Cout][Cin][k] for ALL layers of the stack in one launch
+// (blockIdx.y = layer): the forward GEMM's Wf[co][kk * Cin + ci] and, per stride phase r, the data-gradient GEMM's
+// Wb_r[ci][j * Cout + co] with the phase's taps newest first (tap kk = r + s * (J_r - 1 - j)), the s images back to back.
+// Replaces six permute copies and twelve flip + copy pairs of torch per step (41 launches of ~5 us).
+__global__ __launch_bounds__(256) void conv_weights_relayout_kernel(wavlm_conv_relayout_desc d) {
+  const int l = blockIdx.y;
+  const int Cout = d.Cout[l], Cin = d.Cin[l], k = d.k[l], st = d.s[l];
+  const long n = (long)Cout * Cin * k;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int kk = (int)(e % k);
+    const long t = e / k;
+    const int ci = (int)(t % Cin), co = (int)(t / Cin);
+    const float v = ld_elem(d.W[l], e, d.dtype);
+    st_elem(d.Wf[l], (long)co * (k * Cin) + (long)kk * Cin + ci, d.dtype, v);
+    if (d.Wb[l]) {
+      const int r = kk % st, jj = kk / st;
+      const int Jr = (k - r + st - 1) / st;
+      long base = 0;  // images of the phases before r: Cin * J_r' * Cout each
+      for (int q = 0; q < r; ++q) base += (long)Cin * ((k - q + st - 1) / st) * Cout;
+      st_elem(d.Wb[l], base + (long)ci * (Jr * Cout) + (long)(Jr - 1 - jj) * Cout + co, d.dtype, v);
+    }
+  }
+}
+// the inverse for the weight gradients: G[co][ci][kk] (+)= dWf[co][kk * Cin + ci] (d.W = G, d.Wf = dWf), all layers at once
+__global__ __launch_bounds__(256) void conv_wgrad_scatter_kernel(wavlm_conv_relayout_desc d, int accumulate) {
+  const int l = blockIdx.y;
+  const int Cout = d.Cout[l], Cin = d.Cin[l], k = d.k[l];
+  const long n = (long)Cout * Cin * k;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int kk = (int)(e % k);
+    const long t = e / k;
+    const int ci = (int)(t % Cin), co = (int)(t / Cin);
+    float v = ld_elem(d.Wf[l], (long)co * (k * Cin) + (long)kk * Cin + ci, d.dtype);
+    if (accumulate) v += ld_elem(d.W[l], e, d.dtype);
+    st_elem(const_cast<void*>(d.W[l]), e, d.dtype, v);
+  }
+}
+
 extern "C" {
 
 int wavlm_abi_version(void) { return WAVLM_HIP_ABI_VERSION; }
@@ -932,6 +970,32 @@ int wavlm_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_
     WL_LAUNCH((gather_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, idx, (bf16_t*)dst,
                        (long)n_out, (int)D);
   else return WL_EINVAL;
+  return wl_check_launch();
+}
+
+int wavlm_conv_weights_relayout(const wavlm_conv_relayout_desc* d, void* stream) {
+  if (!d || d->n_layers < 1 || d->n_layers > WL_CONV_RELAYOUT_MAX || (d->dtype != WL_F32 && d->dtype != WL_BF16)) return WL_EINVAL;
+  long mx = 0;
+  for (int l = 0; l < d->n_layers; ++l) {
+    if (!d->W[l] || !d->Wf[l] || d->Cout[l] <= 0 || d->Cin[l] <= 0 || d->k[l] <= 0 || d->s[l] <= 0 || d->s[l] > d->k[l]) return WL_EINVAL;
+    const long n = (long)d->Cout[l] * d->Cin[l] * d->k[l];
+    if (n > mx) mx = n;
+  }
+  const unsigned gx = grid_for(mx, 256, 8192);
+  WL_LAUNCH(conv_weights_relayout_kernel, dim3(gx, (unsigned)d->n_layers), dim3(256), 0, (hipStream_t)stream, *d);
+  return wl_check_launch();
+}
+
+int wavlm_conv_wgrad_scatter(const wavlm_conv_relayout_desc* d, int32_t accumulate, void* stream) {
+  if (!d || d->n_layers < 1 || d->n_layers > WL_CONV_RELAYOUT_MAX || (d->dtype != WL_F32 && d->dtype != WL_BF16)) return WL_EINVAL;
+  long mx = 0;
+  for (int l = 0; l < d->n_layers; ++l) {
+    if (!d->W[l] || !d->Wf[l] || d->Cout[l] <= 0 || d->Cin[l] <= 0 || d->k[l] <= 0) return WL_EINVAL;
+    const long n = (long)d->Cout[l] * d->Cin[l] * d->k[l];
+    if (n > mx) mx = n;
+  }
+  const unsigned gx = grid_for(mx, 256, 8192);
+  WL_LAUNCH(conv_wgrad_scatter_kernel, dim3(gx, (unsigned)d->n_layers), dim3(256), 0, (hipStream_t)stream, *d, (int)accumulate);
   return wl_check_launch();
 }
 

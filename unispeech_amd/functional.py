@@ -170,13 +170,27 @@ class WgradGroup:
         if self in WgradGroup.pending:
             WgradGroup.pending.remove(self)
         def launch():
+            # Members are packed, in arrival order, into sub-groups whose tiles still fit ONE round of the persistent grid
+            # with a split >= 2 (ops.grouped_split): Base: all four dW of a layer (108 tiles); Large: fc2 | fc1 | out_proj +
+            # q|k|v (64 tiles each) -- out_proj alone needs a split of 16 (16 fp32 slabs for a 1024 x 1024 output).
             n = self.items[0][0].shape[0]
-            tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in self.items)
-            if len(self.items) == 1 or n == 0 or ops.grouped_split(tiles, (n + 63) // 64) < 2:
-                for dy2d, x2d, out in self.items:   # (too many tiles for one round: single launches, still in arrival order)
-                    _linear_bwd_w(dy2d, x2d, out.dtype, out=out)
-            else:
-                ops.gemm_wgrad_grouped(self.items, self.items[0][2].dtype)
+            kt = (n + 63) // 64
+            tl = [((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in self.items]
+            groups, cur, cur_t = [], [], 0
+            for it, t in zip(self.items, tl):
+                if cur and (n == 0 or ops.grouped_split(cur_t + t, kt) < 2 or len(cur) == 4):
+                    groups.append(cur)
+                    cur, cur_t = [], 0
+                cur.append(it)
+                cur_t += t
+            if cur:
+                groups.append(cur)
+            for grp in groups:
+                if len(grp) == 1 or n == 0:
+                    for dy2d, x2d, out in grp:
+                        _linear_bwd_w(dy2d, x2d, out.dtype, out=out)
+                else:
+                    ops.gemm_wgrad_grouped(grp, grp[0][2].dtype)
             for sk in self.sinks:  # (on the side stream: a reducer orders its all-reduce behind THIS stream's work)
                 WgradGroup.deferred.discard(sk.data_ptr())
                 _sink_written(sk)
@@ -508,23 +522,30 @@ class ConvStackFn(torch.autograd.Function):
         weights = params[:nl]
         biases = params[nl:] if len(params) > nl else (None,) * nl
         ctx.has_bias = len(params) > nl
-        xs, us, wfs = [], [], []
+        xs, us = [], []
         cur = x.contiguous()
-        for (k, s), W, bias in zip(specs, weights, biases):
+        # GEMM operand images of all layers' weights in ONE launch (forward layout and, when a backward will follow, the
+        # stride-phase layouts of the data-gradient GEMMs): six permute copies + twelve flip / copy pairs of torch before
+        need_bwd = any(ctx.needs_input_grad)
+        wfs, wbs = ops.conv_weights_relayout([W.contiguous() for W in weights], specs, need_bwd)
+        for (k, s), W, bias, Wf in zip(specs, weights, biases, wfs):
             Cout, Cin, _ = W.shape
             T_in = cur.shape[1]
             T_out = (T_in - k) // s + 1
-            Wf = W.permute(0, 2, 1).reshape(Cout, k * Cin).contiguous()
             y = torch.empty((B, T_out, Cout), dtype=cur.dtype, device=cur.device)
             u = torch.empty_like(y) if act else y.new_empty(0)
             ops.gemm(cur, Wf, y, T_out, Cout, k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout, batch=(B, 1),
                      sA=(T_in * Cin, 0), sC=(T_out * Cout, 0), epi=3 if act else 0, aux=u if act else None, ld_aux=Cout,
                      sAux=(T_out * Cout, 0), bias=bias)
-            xs.append(cur); us.append(u); wfs.append(Wf)
+            xs.append(cur); us.append(u)
             cur = y
         ctx.specs = specs
         ctx.act = act
         ctx.nl = len(specs)
+        ctx.wbs = wbs
+        for i, W in enumerate(weights):
+            if ctx.needs_input_grad[3 + i]:
+                _sink_use(W)
         ctx.save_for_backward(*xs, *us, *weights)
         return cur
 
@@ -557,7 +578,7 @@ class ConvStackFn(torch.autograd.Function):
                 split = ops.pick_split(Cout, k * Cin, B * ((T_out + 63) // 64))
                 ops.gemm(P, x, dWf, Cout, k * Cin, T_out, lda=Cout, ldb=s * Cin, ldc=k * Cin, transA=True, transB=True,
                          a_off=fp * Cout, KB=B, sA_kb=Tp * Cout, sB_kb=T_in * Cin, split_k=split)
-                grads[i] = dWf.view(Cout, k, Cin).permute(0, 2, 1)
+                grads[i] = dWf   # [Cout][k * Cin]: scattered into the parameter layout for all layers at once below
             if ctx.has_bias and ctx.needs_input_grad[3 + nl + i]:
                 # bias gradient = column sums of du_i; the zero pad rows of the staged buffer add nothing
                 bgrads[i] = ops.colsum(P.reshape(-1, Cout), W.dtype)
@@ -587,7 +608,7 @@ class ConvStackFn(torch.autograd.Function):
                 # with a Python list builds the index tensor on the host and copies it with a blocking H2D transfer, i.e.
                 # a stream synchronisation in the middle of backward (measured: the launch thread stalled 23 ms here
                 # every step and lost all its run-ahead for the rest of the step)
-                Wb = W[:, :, r::s].flip(2).permute(1, 2, 0).reshape(Cin, Jr * Cout).contiguous()
+                Wb = ctx.wbs[i][r]   # [Cin, Jr * Cout], taps of the phase newest first (ops.conv_weights_relayout)
                 Mr = (T_in - r + s - 1) // s
                 ops.gemm(P, Wb, nxt, Mr, Cin, Jr * Cout, lda=Cout, ldb=Jr * Cout, ldc=s * Cin, batch=(B, 1),
                          a_off=(fp - Jr + 1) * Cout, sA=(Tp * Cout, 0), c_off=(fpp + r) * Cin, sC=(Tpp * Cin, 0),
@@ -595,6 +616,26 @@ class ConvStackFn(torch.autograd.Function):
                          sAux=(T_in * Cin, 0))
             P = nxt
         dx = P if ctx.needs_input_grad[0] else None
+        # weight gradients [Cout][k * Cin] -> [Cout][Cin][k] for all layers in one launch: accumulated straight into the
+        # gradient arena where the parameters have sinks (no per-layer permuted views for autograd to add), fresh
+        # tensors otherwise
+        have = [i for i in range(nl) if grads[i] is not None]
+        if have:
+            sinks = [_sink(weights[i]) for i in have]
+            if all(t is not None for t in sinks):
+                ops.conv_wgrad_scatter([t.view(weights[i].shape) for t, i in zip(sinks, have)], [grads[i] for i in have],
+                                       [specs[i] for i in have], accumulate=True)
+                for t, i in zip(sinks, have):
+                    grads[i] = None
+                    _sink_written(t)
+            else:
+                outs = [torch.empty_like(weights[i], memory_format=torch.contiguous_format) for i in have]
+                ops.conv_wgrad_scatter(outs, [grads[i] for i in have], [specs[i] for i in have], accumulate=False)
+                for o, i in zip(outs, have):
+                    grads[i] = o
+                    t = _sink(weights[i])   # (mixed case: a sink that autograd fills through the returned tensor)
+                    if t is not None:
+                        _SINK_USES.pop(t.data_ptr(), None)
         return (dx, None, None) + tuple(grads) + (tuple(bgrads) if ctx.has_bias else ())
 
 

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, GemmDesc, check
+from ._lib import BF16, F32, ConvRelayoutDesc, GemmDesc, check
 
 _WS = {}
 
@@ -261,6 +261,57 @@ def gather_rows(src2d, idx, n_out):
     check(_lib.lib().wavlm_gather_rows(ptr(src2d), ptr(idx), ptr(dst), n_out, D, dt(src2d), stream()),
           "wavlm_gather_rows")
     return dst
+
+
+def _conv_desc(weights, specs):
+    d = ConvRelayoutDesc()
+    if len(weights) > 8:
+        raise ValueError("at most 8 convolution layers per call")
+    d.n_layers, d.dtype = len(weights), dt(weights[0])
+    for l, (W, (k, s_)) in enumerate(zip(weights, specs)):
+        _dev(W); _contig(W)
+        Cout, Cin, kk = W.shape
+        if kk != k:
+            raise ValueError("kernel width of layer %d does not match its spec" % l)
+        d.Cout[l], d.Cin[l], d.k[l], d.s[l] = Cout, Cin, k, s_
+        d.W[l] = W.data_ptr()
+    return d
+
+
+def conv_weights_relayout(weights, specs, want_bwd):
+    """GEMM operand images of the extractor's Conv1d weights, all layers in one launch.  weights: [Cout, Cin, k] tensors,
+    specs: [(k, stride)].  Returns (Wf list [Cout, k * Cin], Wb list of per-phase lists [Cin, J_r * Cout] or None)."""
+    d = _conv_desc(weights, specs)
+    Wf, Wb, keep = [], [], []
+    for l, (W, (k, s_)) in enumerate(zip(weights, specs)):
+        Cout, Cin, _ = W.shape
+        f = torch.empty((Cout, k * Cin), dtype=W.dtype, device=W.device)
+        d.Wf[l] = f.data_ptr()
+        Wf.append(f)
+        if want_bwd:
+            J = [len(range(r, k, s_)) for r in range(s_)]
+            flat = torch.empty(Cin * Cout * k, dtype=W.dtype, device=W.device)
+            d.Wb[l] = flat.data_ptr()
+            views, off = [], 0
+            for Jr in J:
+                views.append(flat[off:off + Cin * Jr * Cout].view(Cin, Jr * Cout))
+                off += Cin * Jr * Cout
+            Wb.append(views)
+            keep.append(flat)
+        else:
+            d.Wb[l] = None
+    check(_lib.lib().wavlm_conv_weights_relayout(C.byref(d), stream()), "wavlm_conv_weights_relayout")
+    return Wf, (Wb if want_bwd else None)
+
+
+def conv_wgrad_scatter(grads, dWf, specs, accumulate):
+    """grads[l][co][ci][kk] (+)= dWf[l][co][kk * Cin + ci] for all layers in one launch"""
+    d = _conv_desc(grads, specs)
+    for l, f in enumerate(dWf):
+        _contig(f)
+        d.Wf[l] = f.data_ptr()
+        d.Wb[l] = None
+    check(_lib.lib().wavlm_conv_wgrad_scatter(C.byref(d), int(bool(accumulate)), stream()), "wavlm_conv_wgrad_scatter")
 
 
 def axpby_(y, x, a, b):
