@@ -237,7 +237,7 @@ def live_gemm_traffic(args):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "run", "--", sys.executable,
-                   os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+                   os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-settle", "--no-cpu-baseline", "--no-roofline",
                    "--config", args.config, "--batch", str(args.batch)]
             r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -252,11 +252,11 @@ def live_gemm_traffic(args):
                     per[name][0] += 1
                     per[name][1] += float(row["Counter_Value"])
             scale = 2.0 * 1024.0 if ctr == "FETCH_SIZE" else 1024.0   # gfx950: FETCH_SIZE counts 128-B requests as 64 B
-            tot[ctr] = sum(v[1] for v in per.values()) * scale
             launches = sum(v[0] for k, v in per.items() if not k.startswith("gemm_splitk"))
-        if launches == 0:
-            return None, None
-        return round((tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / launches), \
+            if launches == 0:
+                return None, None
+            tot[ctr] = sum(v[1] for v in per.values()) * scale / launches   # per launch of THIS pass
+        return round(tot["FETCH_SIZE"] + tot["WRITE_SIZE"]), \
             "live: two rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE) of this command, 2 steps each, %d GEMM launches" % launches
     except Exception:
         return None, None

@@ -287,6 +287,10 @@ int wavlm_rows_wsum(const void* Y, int32_t dtype, const int32_t* src, const floa
 uint64_t wavlm_bce_workspace_bytes(void);
 int wavlm_bce_logits(const float* logits, const uint8_t* targets, float* dlogits, float* out, int64_t n, float gscale,
                      void* workspace, uint64_t ws_bytes, void* stream);
+/* nn.GLU over the last dimension (target_glu, src/fairseq/models/wavlm/wavlm.py:322-327, 529-531: Linear(F, 2F) + GLU on
+ * the label embeddings): y[rows, F] = x[:, :F] * sigmoid(x[:, F:]) and its backward dx[rows, 2F]. */
+int wavlm_glu_fwd(const void* x, void* y, int64_t rows, int32_t F, int32_t dtype, void* stream);
+int wavlm_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int32_t F, int32_t dtype, void* stream);
 uint64_t wavlm_sum_workspace_bytes(void);
 int wavlm_sum_f32(const float* x, int64_t n, float* out, void* workspace, uint64_t ws_bytes, void* stream);
 

@@ -194,7 +194,7 @@ def gen_tiny_pretrain(overrides=None, fname="tiny_pretrain.npz"):
     cfg.skip_masked = False
     cfg.skip_nomask = False
     cfg.untie_final_proj = False
-    cfg.target_glu = False
+    cfg.target_glu = bool((overrides or {}).get("target_glu", False))
     cfg.boundary_mask = False
     cfg.expand_attention_head_size = -1
     V = 23
@@ -241,6 +241,11 @@ def gen_tiny_pretrain(overrides=None, fname="tiny_pretrain.npz"):
     for n, p in model.named_parameters():
         out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
     np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def gen_tiny_targetglu():
+    """tiny_pretrain with target_glu=True (Linear(F, 2F) + GLU on the label embeddings, wavlm.py:322-327, 529-531)"""
+    gen_tiny_pretrain({"target_glu": True}, "tiny_targetglu.npz")
 
 
 def gen_tiny_convbias():
@@ -637,6 +642,7 @@ if __name__ == "__main__":
     gen_tiny_pretrain()
     gen_tiny_chanmask()
     gen_tiny_convbias()
+    gen_tiny_targetglu()
     gen_tiny_large()
     gen_tiny_large_convbias()
     gen_tiny_sat()

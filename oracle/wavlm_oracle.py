@@ -289,6 +289,8 @@ def pretrain_forward(sd, cfg, source, target_list, padding_mask, mask_indices, n
             else:
                 pairs = list(zip(embs.split(num_classes, 0), target_list))
             for emb, t in pairs:
+                if getattr(cfg, "target_glu", False):  # wavlm.py:322-327, 529-531: Linear(F, 2F) + GLU, row by row
+                    emb = F.glu(F.linear(emb, sd["target_glu.0.weight"], sd["target_glu.0.bias"]), dim=-1)
                 pos = torch.index_select(emb, 0, t[sel].long())
                 negs = emb.unsqueeze(1).expand(-1, proj.size(0), -1)
                 out.append(compute_nce(proj, pos, negs, cfg.logit_temp))

@@ -77,9 +77,11 @@ def _tiny_pretrain(dtype=torch.float32, golden="tiny_pretrain.npz", **overrides)
 
 @pytest.mark.parametrize("golden,overrides", [("tiny_pretrain.npz", {}),
                                               ("tiny_chanmask.npz", {"mask_channel_prob": 0.25, "mask_channel_length": 4}),
-                                              ("tiny_convbias.npz", {"conv_bias": True})])
+                                              ("tiny_convbias.npz", {"conv_bias": True}),
+                                              ("tiny_targetglu.npz", {"target_glu": True})])
 def test_pretrain_loss_and_grads_vs_reference_golden(golden, overrides):
-    """tiny_chanmask: time mask + channel mask drawn from the same numpy stream as the reference's apply_mask"""
+    """tiny_chanmask: time mask + channel mask drawn from the same numpy stream as the reference's apply_mask;
+    tiny_targetglu: target_glu=True (Linear(F, 2F) + GLU on the label embeddings, wavlm.py:322-327, 529-531)"""
     model, crit, z = _tiny_pretrain(golden=golden, **overrides)
     sample = {"id": torch.arange(2),
               "net_input": {"source": torch.from_numpy(z["in/source"]).cuda(),

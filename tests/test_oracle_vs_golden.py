@@ -69,10 +69,14 @@ def test_seeded_init_matches_reference_constructor():
         assert torch.equal(sd[k], ref_sd[k]), k
 
 
-def test_seeded_init_pretrain_model():
-    z = load_golden("tiny_pretrain.npz")
+@pytest.mark.parametrize("golden,overrides", [("tiny_pretrain.npz", {}), ("tiny_targetglu.npz", {"target_glu": True})])
+def test_seeded_init_pretrain_model(golden, overrides):
+    """(tiny_targetglu: the target_glu Linear is created between the encoder and final_proj, as in wavlm.py:322-333)"""
+    z = load_golden(golden)
     ref_sd = golden_state_dict(z)
-    cfg = WavLMPretrainConfig(**{k: v for k, v in TINY.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+    d = dict(TINY)
+    d.update(overrides)
+    cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
     torch.manual_seed(0)
     model = WavLMPretrainModel(cfg, None, [range(23)])
     sd = model.state_dict()
@@ -110,10 +114,12 @@ def test_oracle_extract_features(tiny_cfg):
         assert rel_err(rm["x"], z["out/x_masked"]) < RTOL
 
 
-@pytest.mark.parametrize("golden", ["tiny_pretrain.npz", "tiny_chanmask.npz", "tiny_convbias.npz"])
+@pytest.mark.parametrize("golden", ["tiny_pretrain.npz", "tiny_chanmask.npz", "tiny_convbias.npz", "tiny_targetglu.npz"])
 def test_oracle_pretrain_loss_and_grads(tiny_cfg, golden):
     """tiny_chanmask: the same run with mask_channel_prob 0.25 (apply_mask's channel half, wavlm.py:405-422);
-    tiny_convbias: conv_bias=True (Conv1d biases in the extractor)"""
+    tiny_convbias: conv_bias=True (Conv1d biases in the extractor); tiny_targetglu: target_glu=True (Linear + GLU on the
+    label embeddings, wavlm.py:322-327, 529-531)"""
+    tiny_cfg.target_glu = golden == "tiny_targetglu.npz"
     z = load_golden(golden)
     sd = golden_state_dict(z, as_param=True)
     wav = torch.from_numpy(z["in/source"])

@@ -115,6 +115,8 @@ SIGNATURES = {
     "wavlm_rows_wsum": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "wavlm_bce_workspace_bytes": (c_u64, []),
     "wavlm_bce_logits": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_u64, c_vp]),
+    "wavlm_glu_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "wavlm_glu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "wavlm_sum_workspace_bytes": (c_u64, []),
     "wavlm_sum_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_u64, c_vp]),
     "wavlm_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,

@@ -202,6 +202,29 @@ __global__ void bce_finish_kernel(const double* part, int nblk, float* out, doub
   }
 }
 
+// nn.GLU over the last dimension: y[r][c] = a * sigmoid(b) with (a, b) = x[r][c], x[r][F + c]; backward
+// da = dy * sigmoid(b), db = dy * a * sigmoid(b) * (1 - sigmoid(b)).  (target_glu: wavlm.py:322-327, applied to the
+// [V, F] label-embedding table -- a few hundred rows.)
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, long rows, int F, int dt) {
+  const long n = rows * F;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / F; const int c = (int)(i - r * F);
+    const float a = ld_elem(x, r * 2 * F + c, dt), b = ld_elem(x, r * 2 * F + F + c, dt);
+    st_elem(y, i, dt, a / (1.f + __expf(-b)));
+  }
+}
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, void* __restrict__ dx,
+                                                      long rows, int F, int dt) {
+  const long n = rows * F;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / F; const int c = (int)(i - r * F);
+    const float a = ld_elem(x, r * 2 * F + c, dt), b = ld_elem(x, r * 2 * F + F + c, dt), g = ld_elem(dy, i, dt);
+    const float sg = 1.f / (1.f + __expf(-b));
+    st_elem(dx, r * 2 * F + c, dt, g * sg);
+    st_elem(dx, r * 2 * F + F + c, dt, g * a * sg * (1.f - sg));
+  }
+}
+
 extern "C" {
 
 int wavlm_l2norm_fwd(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, float* inv_norm, int64_t rows,
@@ -305,6 +328,22 @@ int wavlm_bce_logits(const float* logits, const uint8_t* targets, float* dlogits
   long grid = (n + 256 * 8 - 1) / (256 * 8); if (grid > 1024) grid = 1024;
   WL_LAUNCH(bce_logits_kernel, dim3((unsigned)grid), dim3(256), 0, st, logits, targets, dlogits, (double*)workspace, (long)n, gscale);
   WL_LAUNCH(bce_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)grid, out, 1.0 / (double)n);
+  return wl_check_launch();
+}
+
+int wavlm_glu_fwd(const void* x, void* y, int64_t rows, int32_t F, int32_t dtype, void* stream) {
+  if (!x || !y || rows < 0 || F <= 0 || (dtype != WL_F32 && dtype != WL_BF16)) return WL_EINVAL;
+  if (rows == 0) return WL_OK;
+  long grid = (rows * F + 255) / 256; if (grid > 2048) grid = 2048;
+  WL_LAUNCH(glu_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, (int)F, (int)dtype);
+  return wl_check_launch();
+}
+
+int wavlm_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int32_t F, int32_t dtype, void* stream) {
+  if (!x || !dy || !dx || rows < 0 || F <= 0 || (dtype != WL_F32 && dtype != WL_BF16)) return WL_EINVAL;
+  if (rows == 0) return WL_OK;
+  long grid = (rows * F + 255) / 256; if (grid > 2048) grid = 2048;
+  WL_LAUNCH(glu_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)rows, (int)F, (int)dtype);
   return wl_check_launch();
 }
 

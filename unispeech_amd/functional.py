@@ -954,6 +954,22 @@ class MaskedPredLossFn(torch.autograd.Function):
         return dproj, demb, None, None, None
 
 
+class GLUFn(torch.autograd.Function):
+    """nn.GLU over the last dimension (target_glu's second half, src/fairseq/models/wavlm/wavlm.py:322-327)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x2d = x.reshape(-1, x.shape[-1]).contiguous()
+        ctx.save_for_backward(x2d)
+        ctx.xshape = x.shape
+        return ops.glu_fwd(x2d).view(*x.shape[:-1], x.shape[-1] // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2d,) = ctx.saved_tensors
+        return ops.glu_bwd(x2d, dy.reshape(-1, dy.shape[-1]).contiguous()).view(ctx.xshape)
+
+
 class FeaturesPenFn(torch.autograd.Function):
     """features.float().pow(2).mean()  (src/fairseq/models/wavlm/wavlm.py:486)"""
 

@@ -687,6 +687,23 @@ def prof_collect_bytes(dtype=-1):
 
 
 # ------------------------------------------------------------------------- sampled-instance cosine head
+def glu_fwd(x2d):
+    """nn.GLU(dim=-1): [rows, 2F] -> [rows, F]"""
+    _dev(x2d); _contig(x2d)
+    rows, F2 = x2d.shape
+    y = torch.empty((rows, F2 // 2), dtype=x2d.dtype, device=x2d.device)
+    check(_lib.lib().wavlm_glu_fwd(ptr(x2d), ptr(y), rows, F2 // 2, dt(x2d), stream()), "wavlm_glu_fwd")
+    return y
+
+
+def glu_bwd(x2d, dy):
+    _dev(x2d); _contig(x2d); _contig(dy)
+    rows, F2 = x2d.shape
+    dx = torch.empty_like(x2d)
+    check(_lib.lib().wavlm_glu_bwd(ptr(x2d), ptr(dy), ptr(dx), rows, F2 // 2, dt(x2d), stream()), "wavlm_glu_bwd")
+    return dx
+
+
 def gather_dot(X, Y, idx, scale, mask_equal=False):
     """out[s, n] = scale * <X[s], Y[idx[s, n]]>  (rows [., D], idx: int32 [S, N]); mask_equal: columns n >= 1 whose
     gathered row equals the row of column 0 become -inf"""

@@ -99,8 +99,6 @@ class WavLMPretrainModel(WavLM):
     def __init__(self, cfg, task_cfg=None, dictionaries=None) -> None:
         # parameter creation order follows the reference constructor (wavlm.py:257-345)
         super().__init__(cfg)
-        if getattr(cfg, "target_glu", False):
-            raise NotImplementedError("target_glu is not supported by the HIP path")
         if getattr(cfg, "expand_attention_head_size", -1) > 0:
             raise NotImplementedError("expand_attention_head_size disables the reference fast path; unsupported")
         task_cfg = task_cfg or TaskConfig()
@@ -112,6 +110,11 @@ class WavLMPretrainModel(WavLM):
         self.skip_masked = cfg.skip_masked
         self.skip_nomask = cfg.skip_nomask
         final_dim = cfg.final_dim if cfg.final_dim > 0 else cfg.encoder_embed_dim
+        # target_glu (wavlm.py:322-327): Linear(F, 2F) + GLU on the label embeddings; created between the encoder and
+        # final_proj like the reference, so that seeded initialisation lines up
+        self.target_glu = None
+        if getattr(cfg, "target_glu", False):
+            self.target_glu = nn.Sequential(nn.Linear(final_dim, final_dim * 2), nn.GLU())
         self.untie_final_proj = cfg.untie_final_proj
         dictionaries = dictionaries or []
         if self.untie_final_proj:
@@ -349,6 +352,11 @@ class WavLMPretrainModel(WavLM):
             out = []
             idx64 = idx.long()
             for pj, (emb, t) in zip(projs, pairs):
+                if self.target_glu is not None:
+                    # wavlm.py:529-531 applies target_glu to the positives and to every negative, i.e. row by row to the
+                    # label embeddings: transforming the [V, F] table once is the same computation
+                    tg = self.target_glu[0]
+                    emb = F.GLUFn.apply(F.LinearFn.apply(emb.contiguous(), tg.weight, tg.bias))
                 tt = t[:, tinds_dev(t.device)].reshape(-1).index_select(0, idx64).to(torch.int32)
                 loss, ncorrect = F.MaskedPredLossFn.apply(pj.contiguous(), emb, tt, self.logit_temp, need_grad)
                 out.append({"loss": loss, "correct": ncorrect, "count": S, "proj": pj, "target": tt, "label_embs": emb})
@@ -495,6 +503,7 @@ class WavLMPretrainModel(WavLM):
         return extra_losses, names
 
     def remove_pretraining_modules(self):
+        self.target_glu = None
         self.final_proj = None
         self.label_embs_concat = None
         if self.utterance_contrastive_loss:
