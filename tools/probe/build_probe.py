@@ -12,14 +12,16 @@ from unispeech_amd import build as B  # noqa: E402
 
 B.build_library(verbose=False)
 # arguments: <bits> (PP_PROBE value) or <tag>:-DNAME=V[,-DNAME2=V2] (free-form defines, library suffix <tag>);
-# a leading "pp3:" probes gemm_pp3.hip instead (pp3:<tag>:-DP3_PROBE=1)
+# a leading "pp3:" probes gemm_pp3.hip instead (pp3:<tag>:-DP3_PROBE=1), "attn:" attn_fused.hip
 for a in sys.argv[1:] or ["1", "2", "3", "4"]:
     src = "gemm_pp.hip"
     if a.startswith("pp3:"):
         src, a = "gemm_pp3.hip", a[4:]
+    elif a.startswith("attn:"):  # attn:<tag>:-DFA_FWD_LAZY=1,... builds attn_fused.hip (forward + dQ kernels) with the defines
+        src, a = "attn_fused.hip", a[5:]
     tag, defs = (a, ["-DPP_PROBE=%d" % int(a)]) if a.isdigit() else (a.split(":")[0], a.split(":")[1].split(","))
     obj = os.path.join(B.OBJ_DIR, "%s_probe%s.o" % (src[:-4], tag))
-    subprocess.check_call([B._hipcc()] + B.FLAGS + defs + ["-c", os.path.join(B.CSRC, src), "-o", obj])
+    subprocess.check_call([B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + defs + ["-c", os.path.join(B.CSRC, src), "-o", obj])
     objs = [os.path.join(B.OBJ_DIR, s.replace(".hip", ".o")) for s in B.SOURCES if s != src] + [obj]
     out = os.path.join(B.LIB_DIR, "libwavlm_hip_probe%s.so" % tag)
     subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", out] + objs)

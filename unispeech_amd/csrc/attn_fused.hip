@@ -2,6 +2,19 @@
 // attn_fused.hpp; dK/dV kernel: attn_fused_dkv.hip).
 #include "attn_fused.hpp"
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// FA_FWD_LAZY: lazy running maximum + packed row sums in the forward (see the tile loop)
+#ifndef FA_FWD_LAZY
+#define FA_FWD_LAZY 1
+#endif
+#ifndef FA_FWD_THETA
+#define FA_FWD_THETA 8.f
+#endif
+// FA_DQ_PK: packed-fp32 bias fmas and gate-gradient accumulation in the dQ kernel's element pass
+#ifndef FA_DQ_PK
+#define FA_DQ_PK 1
+#endif
+
 // ------------------------------------------------------------------------------------------------- forward
 template <bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
@@ -43,6 +56,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
   float m = -INFINITY, l = 0.f;
+#if FA_FWD_LAZY
+  float mref = 0.f;
+  bool seen = false;
+#endif
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
   const unsigned vtr = fa_tr_base(lane);
 
@@ -69,6 +86,68 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
       for (int kk = 0; kk < 4; ++kk)
         s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s[f], 0, 0, 0);
     }
+#if FA_FWD_LAZY
+    // Lazy running maximum: the scores come out of the bias fma already relative to the row's reference `mref` (the
+    // subtraction rides in the fma's addend), and the reference moves only when a tile's maximum exceeds it by more than
+    // FA_FWD_THETA (log2 units) -- then this tile's 32 values are shifted and o / l rescaled; otherwise 2^x is taken
+    // directly (values up to 2^THETA, harmless in fp32 sums and scale-free in bf16).  Removes the per-element subtract.
+    float tmax = -INFINITY;
+    const bool edge = (p.kpm != nullptr) || (j0 + FA_BKV > T);
+    const float nm = -mref;
+    if (!edge) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float x = fmaf(s[f][r], p.sc2, fmaf(g2, trow[j], nm));
+          s[f][r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float x = fmaf(s[f][r], p.sc2, fmaf(g2, trow[j], nm)) + kb[j];
+          s[f][r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+    }
+    tmax = wl_max_xor32(tmax);
+    const bool fin = tmax > -INFINITY;
+    // a row without a finite score so far takes the first finite maximum as its reference (either sign, o = l = 0)
+    const float delta = !seen ? (fin ? tmax : 0.f) : (tmax > FA_FWD_THETA ? tmax : 0.f);
+    if (__any(delta != 0.f)) {
+      const float alpha = seen ? __builtin_amdgcn_exp2f(-delta) : 1.f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[f][r] -= delta;
+      l *= alpha;
+#pragma unroll
+      for (int f2 = 0; f2 < 2; ++f2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[f2][r] *= alpha;
+      mref += delta;
+    }
+    seen = seen || fin;
+    f32x2_t rs2 = f32x2_t{0.f, 0.f};
+    U4 pf[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(s[f][r]);
+        const float p1 = __builtin_amdgcn_exp2f(s[f][r + 1]);
+        rs2 += f32x2_t{p0, p1};
+        unsigned pk = pack_bf16(p0, p1);
+        if constexpr (DROP) pk &= fa_keepmask2(fa_mix(roww + cwp[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]), p.k2);
+        pf[f][r >> 3].u[(r & 7) >> 1] = pk;
+      }
+    l += wl_sum_xor32(rs2[0] + rs2[1]);
+#else
     // scores -> log2 domain with the Toeplitz bias; key padding / keys past T only on edge tiles
     float tmax = -INFINITY;
     const bool edge = (p.kpm != nullptr) || (j0 + FA_BKV > T);
@@ -123,6 +202,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[f2][r] *= alpha;
     }
+#endif
     // O^T += V^T P^T
 #pragma unroll
     for (int f2 = 0; f2 < 2; ++f2)
@@ -146,6 +226,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
         w.y = pack_bf16(o[f2][4 * q4 + 2] * inv, o[f2][4 * q4 + 3] * inv);
         *reinterpret_cast<uint2*>(dst + 32 * f2 + 8 * q4 + 4 * hi) = w;
       }
+#if FA_FWD_LAZY
+    m = mref;
+#endif
     if (hi == 0) p.lse[(long)bh * T + i] = (m + __log2f(l)) * FA_LN2;
   }
 }
@@ -281,6 +364,9 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     gfrag.v = *reinterpret_cast<const uint4*>(gb + (lane >> 4) * 8);
   }
   float dg = 0.f;
+#if FA_DQ_PK
+  f32x2_t dg2 = f32x2_t{0.f, 0.f};
+#endif
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
 
   glds_tile64(base + D, D3, 0, T, kbuf(0), wave_u);
@@ -376,6 +462,25 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
           if constexpr (PF) w = fa_mix(roww + cww[f][r >> 1]);
           else w = fa_mix(roww + (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]);
         }
+#if FA_DQ_PK
+        {
+          const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;  // r even: j, j + 1 are this pair's keys
+          f32x2_t tv2;
+          if constexpr (PF) tv2 = f32x2_t{tvv[f][r], tvv[f][r + 1]}; else tv2 = f32x2_t{trow[j], trow[j + 1]};
+          f32x2_t x2 = __builtin_elementwise_fma(f32x2_t{s[f][r], s[f][r + 1]}, f32x2_t{p.sc2, p.sc2},
+                                                 __builtin_elementwise_fma(f32x2_t{g2, g2}, tv2, f32x2_t{nlse2, nlse2}));
+          if constexpr (EDGE) x2 += f32x2_t{kb[j], kb[j + 1]};
+          const f32x2_t pe2 = f32x2_t{__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
+          f32x2_t dp2 = f32x2_t{dp[f][r], dp[f][r + 1]};
+          if constexpr (DROP) {
+            dp2[0] = fa_keep_lo(w, p.ths) ? dp2[0] : 0.f;
+            dp2[1] = fa_keep_hi(w, p.ths) ? dp2[1] : 0.f;
+          }
+          const f32x2_t ds2 = pe2 * (dp2 - f32x2_t{dls, dls});
+          dv[0] = ds2[0]; dv[1] = ds2[1];
+          dg2 = __builtin_elementwise_fma(ds2, tv2, dg2);
+        }
+#else
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int rr = r + e;
@@ -391,6 +496,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
           dv[e] = ds;
           dg = fmaf(ds, tv, dg);
         }
+#endif
         const unsigned u2 = pack_bf16(dv[0], dv[1]);
         if constexpr (f == 0) dsf0[r >> 3].u[(r & 7) >> 1] = u2; else dsf1[r >> 3].u[(r & 7) >> 1] = u2;
         if constexpr (TAB) {  // the skew buffer takes dS itself; the gate multiplies inside the diagonal-sum MFMA
@@ -438,6 +544,9 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     const int d = dlo0 + 64 * nkv + lane;
     if (d >= 0 && d < L) prow[d] = v;
   }
+#if FA_DQ_PK
+  dg = dg2[0] + dg2[1];
+#endif
   dg = wl_sum_xor32(dg);
   if (p.dbias_part)  // rows past T carry dS = 0, i.e. dq = 0
     fa_wave_colsum(dq, p.scale, reinterpret_cast<float*>(smem),
