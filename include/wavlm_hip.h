@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 13
+#define WAVLM_HIP_ABI_VERSION 14
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -287,10 +287,17 @@ int wavlm_rows_wsum(const void* Y, int32_t dtype, const int32_t* src, const floa
 uint64_t wavlm_bce_workspace_bytes(void);
 int wavlm_bce_logits(const float* logits, const uint8_t* targets, float* dlogits, float* out, int64_t n, float gscale,
                      void* workspace, uint64_t ws_bytes, void* stream);
-/* nn.GLU over the last dimension (target_glu, src/fairseq/models/wavlm/wavlm.py:322-327, 529-531: Linear(F, 2F) + GLU on
- * the label embeddings): y[rows, F] = x[:, :F] * sigmoid(x[:, F:]) and its backward dx[rows, 2F]. */
-int wavlm_glu_fwd(const void* x, void* y, int64_t rows, int32_t F, int32_t dtype, void* stream);
-int wavlm_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int32_t F, int32_t dtype, void* stream);
+/* Gated linear unit over the last dimension: y[rows, F] = x[:, :F] * g(x[:, F:]) and its backward dx[rows, 2F].
+ * gate: 0 sigmoid = nn.GLU (target_glu, src/fairseq/models/wavlm/wavlm.py:322-327, 529-531: Linear(F, 2F) + GLU on the label
+ * embeddings) | 1 swish (GLU_Linear(.., "swish"): the feed-forward fc1 under activation_fn = "glu", WavLM/modules.py:99-129,
+ * WavLM/WavLM.py:668-669, 707-708) | 2 relu | 3 gelu | 4 bilinear. */
+int wavlm_glu_fwd(const void* x, void* y, int64_t rows, int32_t F, int32_t dtype, int32_t gate, void* stream);
+int wavlm_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int32_t F, int32_t dtype, int32_t gate, void* stream);
+/* Elementwise feed-forward activations other than the erf GELU of the GEMM epilogues (utils.get_activation_fn,
+ * src/fairseq/utils.py:533-555; WavLM/modules.py:144-160): kind 1 relu | 2 gelu_accurate (tanh form,
+ * src/fairseq/modules/gelu.py:14-19) | 3 tanh | 4 erf gelu.  The backward takes the pre-activation x: dx = dy * act'(x). */
+int wavlm_act_fwd(const void* x, void* y, int64_t n, int32_t dtype, int32_t kind, void* stream);
+int wavlm_act_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, int32_t kind, void* stream);
 uint64_t wavlm_sum_workspace_bytes(void);
 int wavlm_sum_f32(const float* x, int64_t n, float* out, void* workspace, uint64_t ws_bytes, void* stream);
 

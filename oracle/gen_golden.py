@@ -248,6 +248,14 @@ def gen_tiny_targetglu():
     gen_tiny_pretrain({"target_glu": True}, "tiny_targetglu.npz")
 
 
+def gen_tiny_activations():
+    """tiny_pretrain with the feed-forward activation_fn options no released model uses (utils.get_activation_fn,
+    src/fairseq/utils.py:533-555; "glu": fc1 = GLU_Linear(D, F, "swish"), src/fairseq/models/unispeech_sat/unispeech_sat.py:
+    977-1007, 1065-1066)"""
+    for act in ("relu", "glu", "gelu_accurate", "tanh"):
+        gen_tiny_pretrain({"activation_fn": act}, "tiny_act_%s.npz" % act)
+
+
 def gen_tiny_convbias():
     """tiny_pretrain with conv_bias=True ('default' extractor: block 0's bias cancels in its GroupNorm, blocks 1-6 add it
     before the GELU)"""
@@ -487,7 +495,16 @@ def gen_tiny_ils_variants():
                  "tiny_ils_sep_targets.npz", vocabs=(23, 17))
 
 
-def gen_tiny_w2v2():
+def gen_tiny_w2v2_variants():
+    """negatives_from_everywhere (+ codebook_negatives) with the quantiser, and negatives_from_everywhere without it
+    (wav2vec2.py:653-692)"""
+    gen_tiny_w2v2({"negatives_from_everywhere": True, "codebook_negatives": 2}, "tiny_w2v2_everywhere_cb.npz")
+    gen_tiny_w2v2({"negatives_from_everywhere": True, "quantize_targets": False}, "tiny_w2v2_everywhere.npz")
+    # quantised encoder input through its own quantiser + project_inp, and Linear + GLU on targets and negatives
+    gen_tiny_w2v2({"quantize_input": True, "target_glu": True}, "tiny_w2v2_qinput_glu.npz")
+
+
+def gen_tiny_w2v2(overrides=None, fname="tiny_w2v2.npz"):
     """wav2vec 2.0 at tiny size: the reference's Wav2Vec2Model (quantize_targets with a 2 x 20 Gumbel codebook, 7 in-utterance +
     3 cross-utterance negatives) + Wav2vecCriterion(infonce, loss_weights [0.1, 10]) in train mode: loss, logits, perplexities
     and every parameter gradient.  The Gumbel noise (F.gumbel_softmax) and the negative indices (torch.randint) come from the
@@ -506,11 +523,15 @@ def gen_tiny_w2v2():
     cfg.num_negatives, cfg.cross_sample_negatives = 7, 3
     cfg.logit_temp = 0.1
     cfg.pretrained_path = None
+    for k, v in (overrides or {}).items():
+        setattr(cfg, k, v)
     torch.manual_seed(0)
     model = w2.Wav2Vec2Model(cfg)
     model.train()
-    crit = Wav2vecCriterion(SimpleNamespace(), infonce=True, loss_weights=[0.1, 10.0])
+    lw = [0.1, 10.0] if cfg.quantize_targets else [10.0]  # one weight per extra loss (diversity, features_pen)
+    crit = Wav2vecCriterion(SimpleNamespace(), infonce=True, loss_weights=list(lw))
     out = sd_to_np(model.state_dict())
+    out["in/loss_weights"] = np.array(lw, dtype=np.float64)
     g = torch.Generator().manual_seed(808)
     wav = torch.randn(3, 16000, generator=g)
     pm = torch.zeros(3, 16000, dtype=torch.bool)
@@ -529,8 +550,9 @@ def gen_tiny_w2v2():
     for k, v in log.items():
         out["log/" + k] = np.float64(v)
     out["out/logits"] = model.get_logits(net).float().numpy()
-    out["out/prob_perplexity"] = np.float64(net["prob_perplexity"].item())
-    out["out/code_perplexity"] = np.float64(net["code_perplexity"].item())
+    if "prob_perplexity" in net:
+        out["out/prob_perplexity"] = np.float64(net["prob_perplexity"].item())
+        out["out/code_perplexity"] = np.float64(net["code_perplexity"].item())
     out["out/features_pen"] = np.float64(net["features_pen"].item())
     np.random.seed(77)
     from fairseq.data.data_utils import compute_mask_indices
@@ -539,7 +561,7 @@ def gen_tiny_w2v2():
                                                   cfg.mask_selection, cfg.mask_other, min_masks=2, no_overlap=False, min_space=1)
     for n, p in model.named_parameters():
         out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
-    np.savez_compressed(os.path.join(OUT, "tiny_w2v2.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def gen_mixing():
@@ -643,6 +665,7 @@ if __name__ == "__main__":
     gen_tiny_chanmask()
     gen_tiny_convbias()
     gen_tiny_targetglu()
+    gen_tiny_activations()
     gen_tiny_large()
     gen_tiny_large_convbias()
     gen_tiny_sat()
@@ -653,6 +676,7 @@ if __name__ == "__main__":
     gen_tiny_ils_variants()
     gen_sampled_negatives()
     gen_tiny_w2v2()
+    gen_tiny_w2v2_variants()
     gen_mixing()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -123,8 +123,26 @@ def encoder_layer(sd, pre, x, key_padding_mask, position_bias, cfg, first_layer_
         return F.layer_norm(t, (D,), sd[pre + name + ".weight"], sd[pre + name + ".bias"], 1e-5)
 
     def ffn(t):
-        h = F.linear(t, sd[pre + "fc1.weight"], sd[pre + "fc1.bias"])
-        h = F.gelu(h.float()).type_as(h)
+        # activation_fn (WavLM/modules.py:144-160 get_activation_fn; "glu": fc1 = GLU_Linear(D, F, "swish"),
+        # WavLM/modules.py:99-129, WavLM/WavLM.py:668-669, 707-708, followed by the identity)
+        act = getattr(cfg, "activation_fn", "gelu")
+        if act == "glu":
+            h = F.linear(t, sd[pre + "fc1.linear.weight"], sd[pre + "fc1.linear.bias"])
+            Fd = h.shape[-1] // 2
+            g = h[..., Fd:]
+            h = h[..., :Fd] * (g * torch.sigmoid(g))
+        else:
+            h = F.linear(t, sd[pre + "fc1.weight"], sd[pre + "fc1.bias"])
+            if act == "gelu":
+                h = F.gelu(h.float()).type_as(h)
+            elif act == "relu":
+                h = F.relu(h)
+            elif act in ("gelu_accurate", "gelu_fast"):  # src/fairseq/modules/gelu.py:14-19
+                h = 0.5 * h * (1 + torch.tanh(math.sqrt(2 / math.pi) * (h + 0.044715 * torch.pow(h, 3))))
+            elif act == "tanh":
+                h = torch.tanh(h)
+            elif act != "linear":
+                raise RuntimeError("--activation-fn {} not supported".format(act))
         return F.linear(h, sd[pre + "fc2.weight"], sd[pre + "fc2.bias"])
 
     residual = x
@@ -525,8 +543,7 @@ def gumbel_vq(sd, prefix, x, groups, num_vars, tau, training):
 
 def wav2vec2_forward(sd, cfg, source, padding_mask, mask_indices, training=True):
     """Wav2Vec2Model.forward (src/fairseq/models/wav2vec/wav2vec2.py:556-718) with dropouts 0, the time mask given
-    explicitly, default options (quantize_input / negatives_from_everywhere / codebook_negatives / target_glu / transpose
-    off).  Returns the reference's result dict with `x` = logits [N+1, B, T_m]."""
+    explicitly; quantize_input, negatives_from_everywhere, codebook_negatives and target_glu as configured (transpose off).  Returns the reference's result dict with `x` = logits [N+1, B, T_m]."""
     feats = conv_feature_extractor(sd, cfg, source)
     features_pen = feats.float().pow(2).mean()
     features = feats.transpose(1, 2)
@@ -538,23 +555,60 @@ def wav2vec2_forward(sd, cfg, source, padding_mask, mask_indices, training=True)
         padding_mask = forward_padding_mask(T, padding_mask)
     if "post_extract_proj.weight" in sd:
         features = F.linear(features, sd["post_extract_proj.weight"], sd["post_extract_proj.bias"])
+    res = {"features_pen": features_pen, "padding_mask": padding_mask}
+    if getattr(cfg, "quantize_input", False):  # wav2vec2.py:346-363, 602-609
+        pre = "quantizer." if (getattr(cfg, "same_quantizer", False) and cfg.quantize_targets) else "input_quantizer."
+        qi = gumbel_vq(sd, pre, features, cfg.latent_groups, cfg.latent_vars, cfg.latent_temp[0], training)
+        features = F.linear(qi["x"], sd["project_inp.weight"], sd["project_inp.bias"])
+        res.update(prob_perplexity=qi["prob_perplexity"], code_perplexity=qi["code_perplexity"], num_vars=qi["num_vars"])
     x = torch.where(mask_indices.unsqueeze(-1), sd["mask_emb"].view(1, 1, -1), features)
     B = x.shape[0]
     y = unmasked[mask_indices].view(B, -1, C)
     x, _, _ = transformer_encoder(sd, cfg, x, padding_mask, None)
-    res = {"features_pen": features_pen, "padding_mask": padding_mask}
+    from unispeech_amd.functional import sample_negatives_indices  # host index draws: pinned bit-exact by sampled_negatives.npz
+    N = cfg.num_negatives + cfg.cross_sample_negatives
+    nfe = bool(getattr(cfg, "negatives_from_everywhere", False))
+    cbn = int(getattr(cfg, "codebook_negatives", 0))
+    Tm = y.shape[1]
+
+    def gather(cand, tsz):  # sample_negatives' gather (wav2vec2.py:521-531): cand [B, tsz, F] -> [N, B, Tm, F]
+        idx = sample_negatives_indices(B, tsz, Tm, cfg.num_negatives, cfg.cross_sample_negatives)
+        return cand.reshape(-1, cand.size(-1))[idx.view(-1)].view(B, Tm, N, -1).permute(2, 0, 1, 3)
+
+    def project_q(t):
+        return F.linear(t, sd["project_q.weight"], sd["project_q.bias"])
+
     if cfg.quantize_targets:
         q = gumbel_vq(sd, "quantizer.", y, cfg.latent_groups, cfg.latent_vars, cfg.latent_temp[0], training)
-        y = F.linear(q["x"], sd["project_q.weight"], sd["project_q.bias"])
-        gumbel_vq(sd, "quantizer.", unmasked, cfg.latent_groups, cfg.latent_vars, cfg.latent_temp[0], training)  # results['q'] (wav2vec2.py:655)
+        y = project_q(q["x"])
+        q2 = gumbel_vq(sd, "quantizer.", unmasked, cfg.latent_groups, cfg.latent_vars, cfg.latent_temp[0], training)  # results['q'] (wav2vec2.py:655)
         res.update(prob_perplexity=q["prob_perplexity"], code_perplexity=q["code_perplexity"], num_vars=q["num_vars"])
+        negs = gather(project_q(q2["x"]), T) if nfe else gather(y, Tm)   # wav2vec2.py:657-668
+        if cbn > 0:  # wav2vec2.py:669-677 + GumbelVectorQuantizer.sample_from_codebook (gumbel_vector_quantizer.py:90-128)
+            from itertools import product
+            G, V = cfg.latent_groups, cfg.latent_vars
+            inds = torch.tensor(list(product(*[range(V)] * G)), dtype=torch.long).view(V ** G, -1)
+            for g in range(1, G):
+                inds[:, g] += V * g
+            assert cbn < inds.size(0)
+            sample_idx = torch.randint(low=0, high=inds.size(0), size=(B * Tm * cbn,))
+            z = sd["quantizer.vars"].squeeze(0).index_select(0, inds[sample_idx].flatten()).view(B * Tm, cbn, -1)
+            negs = torch.cat([negs, project_q(z.view(cbn, B, Tm, -1))], dim=0)
     else:
-        y = F.linear(y, sd["project_q.weight"], sd["project_q.bias"])
-    Tm = y.shape[1]
-    from unispeech_amd.functional import sample_negatives_indices  # host index draws: pinned bit-exact by sampled_negatives.npz
-    neg = sample_negatives_indices(B, Tm, Tm, cfg.num_negatives, cfg.cross_sample_negatives)
+        y = project_q(y)
+        negs = project_q(gather(unmasked, T)) if nfe else gather(y, Tm)      # wav2vec2.py:679-692
+    if getattr(cfg, "target_glu", False):  # wav2vec2.py:371-375, 697-699
+        def tglu(t):
+            return F.glu(F.linear(t, sd["target_glu.0.weight"], sd["target_glu.0.bias"]), dim=-1)
+        y, negs = tglu(y), tglu(negs)
     xm = F.linear(x[mask_indices].view(B, -1, x.size(-1)), sd["final_proj.weight"], sd["final_proj.bias"])
-    res["x"] = sampled_negatives_logits(xm, y, neg, cfg.num_negatives + cfg.cross_sample_negatives, cfg.logit_temp)
+    # compute_preds (wav2vec2.py:533-553)
+    neg_is_pos = (y == negs).all(-1)
+    targets = torch.cat([y.unsqueeze(0), negs], dim=0)
+    logits = torch.cosine_similarity(xm.float(), targets.float(), dim=-1).type_as(xm) / cfg.logit_temp
+    if neg_is_pos.any():
+        logits[1:] = logits[1:].masked_fill(neg_is_pos, float("-inf"))
+    res["x"] = logits
     return res
 
 

@@ -936,10 +936,68 @@ def check_adam():
     return out
 
 
+def check_activations():
+    """elementwise feed-forward activations and gated linear units (wavlm_act_* / wavlm_glu_*) against torch in fp64, forward
+    and backward, both dtypes; and FFNFn with every activation_fn against the same composition in torch"""
+    import torch.nn.functional as tF
+    from unispeech_amd import functional as Fn
+    out = []
+    refs = {"relu": torch.relu, "tanh": torch.tanh, "gelu": lambda x: tF.gelu(x),
+            "gelu_accurate": lambda x: 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))}
+    gates = {"sigmoid": torch.sigmoid, "swish": lambda b: b * torch.sigmoid(b), "relu": torch.relu, "gelu": lambda b: tF.gelu(b),
+             "bilinear": lambda b: b}
+    for dtype in (torch.float32, torch.bfloat16):
+        tol = tol_for(dtype)
+        x = q(2.0 * gen(301, 96, seed=5), dtype)
+        dy = q(gen(301, 96, seed=6), dtype)
+        for kind, f in refs.items():
+            xr = x.double().requires_grad_(True)
+            yr = f(xr)
+            (dxr,) = torch.autograd.grad(yr, xr, dy.double())
+            y = ops.act_fwd(x.to('cuda', dtype), kind)
+            dx = ops.act_bwd(x.to('cuda', dtype), dy.to('cuda', dtype), kind)
+            out.append((f"act[{dtype}] {kind} fwd", err(y.float().cpu(), yr.detach().float()), tol))
+            out.append((f"act[{dtype}] {kind} bwd", err(dx.float().cpu(), dxr.float()), tol))
+        dyh = q(gen(301, 48, seed=7), dtype)
+        for gate, g in gates.items():
+            xr = x.double().requires_grad_(True)
+            yr = xr[:, :48] * g(xr[:, 48:])
+            (dxr,) = torch.autograd.grad(yr, xr, dyh.double())
+            y = ops.glu_fwd(x.to('cuda', dtype), gate)
+            dx = ops.glu_bwd(x.to('cuda', dtype), dyh.to('cuda', dtype), gate)
+            out.append((f"glu[{dtype}] {gate} fwd", err(y.float().cpu(), yr.detach().float()), tol))
+            out.append((f"glu[{dtype}] {gate} bwd", err(dx.float().cpu(), dxr.float()), tol))
+        # the feed-forward block end to end, every activation_fn (no dropout)
+        n, D, Fd = 200, 64, 128
+        for act in ("gelu", "relu", "gelu_accurate", "tanh", "linear", "glu"):
+            xin = q(gen(n, D, seed=11), dtype)
+            W1 = q(0.2 * gen(Fd * (2 if act == "glu" else 1), D, seed=12), dtype)
+            b1 = q(0.1 * gen(W1.shape[0], seed=13), dtype)
+            W2, b2 = q(0.2 * gen(D, Fd, seed=14), dtype), q(0.1 * gen(D, seed=15), dtype)
+            dyo = q(gen(n, D, seed=16), dtype)
+            ts = [t.double().requires_grad_(True) for t in (xin, W1, b1, W2, b2)]
+            u = tF.linear(ts[0], ts[1], ts[2])
+            if act == "glu":
+                h = u[:, :Fd] * (u[:, Fd:] * torch.sigmoid(u[:, Fd:]))
+            elif act == "linear":
+                h = u
+            else:
+                h = refs[act](u)
+            yr = tF.linear(h, ts[3], ts[4])
+            gr = torch.autograd.grad(yr, ts, dyo.double())
+            td = [t.to('cuda', dtype).requires_grad_(True) for t in (xin, W1, b1, W2, b2)]
+            y = Fn.FFNFn.apply(td[0], td[1], td[2], td[3], td[4], 0.0, 0, None, None, False, act)
+            gd = torch.autograd.grad(y, td, dyo.to('cuda', dtype))
+            out.append((f"ffn[{dtype}] {act} y", err(y.detach().float().cpu(), yr.detach().float()), tol))
+            for nm, a, b in zip(("dx", "dW1", "db1", "dW2", "db2"), gd, gr):
+                out.append((f"ffn[{dtype}] {act} {nm}", err(a.float().cpu(), b.float()), tol))
+    return out
+
+
 GROUPS = {
     "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
     "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv, "gemm_colsum": check_gemm_colsum,
-    "linear_ffn": check_linear_ffn, "loss": check_loss, "adam": check_adam, "dropout_exact": check_dropout_exact,
+    "linear_ffn": check_linear_ffn, "activations": check_activations, "loss": check_loss, "adam": check_adam, "dropout_exact": check_dropout_exact,
 }
 
 if __name__ == "__main__":

@@ -78,10 +78,16 @@ def _tiny_pretrain(dtype=torch.float32, golden="tiny_pretrain.npz", **overrides)
 @pytest.mark.parametrize("golden,overrides", [("tiny_pretrain.npz", {}),
                                               ("tiny_chanmask.npz", {"mask_channel_prob": 0.25, "mask_channel_length": 4}),
                                               ("tiny_convbias.npz", {"conv_bias": True}),
-                                              ("tiny_targetglu.npz", {"target_glu": True})])
+                                              ("tiny_targetglu.npz", {"target_glu": True}),
+                                              ("tiny_act_relu.npz", {"activation_fn": "relu"}),
+                                              ("tiny_act_glu.npz", {"activation_fn": "glu"}),
+                                              ("tiny_act_gelu_accurate.npz", {"activation_fn": "gelu_accurate"}),
+                                              ("tiny_act_tanh.npz", {"activation_fn": "tanh"})])
 def test_pretrain_loss_and_grads_vs_reference_golden(golden, overrides):
     """tiny_chanmask: time mask + channel mask drawn from the same numpy stream as the reference's apply_mask;
-    tiny_targetglu: target_glu=True (Linear(F, 2F) + GLU on the label embeddings, wavlm.py:322-327, 529-531)"""
+    tiny_targetglu: target_glu=True (Linear(F, 2F) + GLU on the label embeddings, wavlm.py:322-327, 529-531);
+    tiny_act_*: the feed-forward activation_fn options (relu / gelu_accurate / tanh as an elementwise pass, glu = fc1 as
+    GLU_Linear(D, F, "swish"): src/fairseq/utils.py:533-555, unispeech_sat.py:977-1007)"""
     model, crit, z = _tiny_pretrain(golden=golden, **overrides)
     sample = {"id": torch.arange(2),
               "net_input": {"source": torch.from_numpy(z["in/source"]).cuda(),
@@ -472,20 +478,31 @@ def test_fused_adam_vs_reference_optimizer_golden():
                 assert rel_err(opt.exp_avg_sq[:n], z["out/v%d" % step]) < 1e-5
 
 
-def test_wav2vec2_model_vs_reference_golden():
+@pytest.mark.parametrize("golden,overrides", [("tiny_w2v2.npz", {}),
+                                              ("tiny_w2v2_everywhere_cb.npz", {"negatives_from_everywhere": True, "codebook_negatives": 2}),
+                                              ("tiny_w2v2_everywhere.npz", {"negatives_from_everywhere": True, "quantize_targets": False}),
+                                              ("tiny_w2v2_qinput_glu.npz", {"quantize_input": True, "target_glu": True})])
+def test_wav2vec2_model_vs_reference_golden(golden, overrides):
     """wav2vec 2.0 (north_star's `src/fairseq/models/wav2vec` encoder) on the HIP path against the golden
     generated from the reference's Wav2Vec2Model + Wav2vecCriterion(infonce): Gumbel quantiser in train mode (noise drawn on
     the host from the torch CPU generator, the reference's own draws), sampled negatives, fused InfoNCE, diversity and
     features penalties: loss, reference-shaped logits, perplexities and every parameter gradient."""
     from test_oracle_vs_golden import W2V2
     from unispeech_amd.wav2vec2 import Wav2Vec2Config, Wav2Vec2Model, Wav2vecCriterion
-    z = load_golden("tiny_w2v2.npz")
-    cfg = Wav2Vec2Config(**{k: v for k, v in W2V2.items() if k in Wav2Vec2Config.__dataclass_fields__})
+    z = load_golden(golden)
+    d = dict(W2V2)
+    d.update(overrides)  # tiny_w2v2_everywhere*: negatives from every frame / from the codebook (wav2vec2.py:653-692)
+    cfg = Wav2Vec2Config(**{k: v for k, v in d.items() if k in Wav2Vec2Config.__dataclass_fields__})
     m = Wav2Vec2Model(cfg)
     m.load_state_dict(golden_state_dict(z), strict=True)
     m = m.cuda().train()
-    m.quantizer.gumbel_noise = "host"
-    crit = Wav2vecCriterion(None, infonce=True, loss_weights=[0.1, 10.0])
+    quant = m.quantizer is not None
+    if quant:
+        m.quantizer.gumbel_noise = "host"
+    if m.input_quantizer is not None:
+        m.input_quantizer.gumbel_noise = "host"
+    lw = [float(v) for v in z["in/loss_weights"]] if "in/loss_weights" in z.files else [0.1, 10.0]
+    crit = Wav2vecCriterion(None, infonce=True, loss_weights=lw)
     pm = torch.zeros(3, 16000, dtype=torch.bool)
     sample = {"id": torch.arange(3), "net_input": {"source": torch.from_numpy(z["in/source"]).cuda(), "padding_mask": pm.cuda(),
                                                    "padding_mask_cpu": pm}}
@@ -495,7 +512,7 @@ def test_wav2vec2_model_vs_reference_golden():
     assert ss == int(z["out/sample_size"])
     assert abs(loss.item() - float(z["out/loss"])) < RTOL * abs(float(z["out/loss"])), (loss.item(), float(z["out/loss"]))
     assert int(log["correct"]) == int(z["log/correct"])
-    for k in ("loss_0", "loss_1", "loss_2"):
+    for k in ("loss_0", "loss_1", "loss_2")[:1 + len(lw)]:
         assert abs(log[k] - float(z["log/" + k])) < RTOL * abs(float(z["log/" + k])) + 1e-6, k
     loss.backward()
     gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
@@ -512,6 +529,8 @@ def test_wav2vec2_model_vs_reference_golden():
     ref = torch.from_numpy(z["out/logits"])
     fin = torch.isfinite(ref)
     assert torch.equal(torch.isfinite(lg), fin) and rel_err(lg[fin], ref[fin]) < RTOL
+    if not quant:
+        return
     assert abs(float(net["prob_perplexity"]) - float(z["out/prob_perplexity"])) < RTOL * float(z["out/prob_perplexity"])
     assert abs(float(net["code_perplexity"]) - float(z["out/code_perplexity"])) < RTOL * float(z["out/code_perplexity"])
     # device-drawn Gumbel noise (the production mode): same law, different stream -> finite, plausible perplexities

@@ -69,9 +69,11 @@ def test_seeded_init_matches_reference_constructor():
         assert torch.equal(sd[k], ref_sd[k]), k
 
 
-@pytest.mark.parametrize("golden,overrides", [("tiny_pretrain.npz", {}), ("tiny_targetglu.npz", {"target_glu": True})])
+@pytest.mark.parametrize("golden,overrides", [("tiny_pretrain.npz", {}), ("tiny_targetglu.npz", {"target_glu": True}),
+                                              ("tiny_act_glu.npz", {"activation_fn": "glu"})])
 def test_seeded_init_pretrain_model(golden, overrides):
-    """(tiny_targetglu: the target_glu Linear is created between the encoder and final_proj, as in wavlm.py:322-333)"""
+    """(tiny_targetglu: the target_glu Linear is created between the encoder and final_proj, as in wavlm.py:322-333;
+    tiny_act_glu: fc1 is a GLU_Linear whose parameters are fc1.linear.*, unispeech_sat.py:977-1007, 1065-1066)"""
     z = load_golden(golden)
     ref_sd = golden_state_dict(z)
     d = dict(TINY)
@@ -114,12 +116,17 @@ def test_oracle_extract_features(tiny_cfg):
         assert rel_err(rm["x"], z["out/x_masked"]) < RTOL
 
 
-@pytest.mark.parametrize("golden", ["tiny_pretrain.npz", "tiny_chanmask.npz", "tiny_convbias.npz", "tiny_targetglu.npz"])
+ACT_GOLDENS = ["tiny_act_relu.npz", "tiny_act_glu.npz", "tiny_act_gelu_accurate.npz", "tiny_act_tanh.npz"]
+
+
+@pytest.mark.parametrize("golden", ["tiny_pretrain.npz", "tiny_chanmask.npz", "tiny_convbias.npz", "tiny_targetglu.npz"] + ACT_GOLDENS)
 def test_oracle_pretrain_loss_and_grads(tiny_cfg, golden):
     """tiny_chanmask: the same run with mask_channel_prob 0.25 (apply_mask's channel half, wavlm.py:405-422);
     tiny_convbias: conv_bias=True (Conv1d biases in the extractor); tiny_targetglu: target_glu=True (Linear + GLU on the
     label embeddings, wavlm.py:322-327, 529-531)"""
     tiny_cfg.target_glu = golden == "tiny_targetglu.npz"
+    if golden in ACT_GOLDENS:  # tiny_act_*: activation_fn of the feed-forward block (utils.get_activation_fn; glu = GLU_Linear)
+        tiny_cfg.activation_fn = golden[len("tiny_act_"):-len(".npz")]
     z = load_golden(golden)
     sd = golden_state_dict(z, as_param=True)
     wav = torch.from_numpy(z["in/source"])
@@ -405,19 +412,29 @@ W2V2.update(final_dim=32, quantize_targets=True, latent_vars=20, latent_groups=2
             relative_position_embedding=False, gru_rel_pos=False)
 
 
-def _w2v2_cfg():
+# golden -> config overrides: negatives_from_everywhere with the quantiser (+ codebook negatives) and without it
+W2V2_GOLDENS = [("tiny_w2v2.npz", {}),
+                ("tiny_w2v2_everywhere_cb.npz", {"negatives_from_everywhere": True, "codebook_negatives": 2}),
+                ("tiny_w2v2_everywhere.npz", {"negatives_from_everywhere": True, "quantize_targets": False}),
+                ("tiny_w2v2_qinput_glu.npz", {"quantize_input": True, "target_glu": True})]
+
+
+def _w2v2_cfg(overrides=None):
     from unispeech_amd.wav2vec2 import Wav2Vec2Config
-    return Wav2Vec2Config(**{k: v for k, v in W2V2.items() if k in Wav2Vec2Config.__dataclass_fields__})
+    d = dict(W2V2)
+    d.update(overrides or {})
+    return Wav2Vec2Config(**{k: v for k, v in d.items() if k in Wav2Vec2Config.__dataclass_fields__})
 
 
-def test_seeded_init_wav2vec2_model():
+@pytest.mark.parametrize("golden,overrides", W2V2_GOLDENS)
+def test_seeded_init_wav2vec2_model(golden, overrides):
     """parameter set and creation order of Wav2Vec2Model incl. the Gumbel quantiser (wav2vec2.py:276-395,
     gumbel_vector_quantizer.py:41-74): same seed -> bit-identical initial weights, strict state-dict load"""
     from unispeech_amd.wav2vec2 import Wav2Vec2Model
-    z = load_golden("tiny_w2v2.npz")
+    z = load_golden(golden)
     ref_sd = golden_state_dict(z)
     torch.manual_seed(0)
-    model = Wav2Vec2Model(_w2v2_cfg())
+    model = Wav2Vec2Model(_w2v2_cfg(overrides))
     sd = model.state_dict()
     assert set(sd.keys()) == set(ref_sd.keys()), set(sd.keys()) ^ set(ref_sd.keys())
     for k in ref_sd:
@@ -425,21 +442,26 @@ def test_seeded_init_wav2vec2_model():
     model.load_state_dict(ref_sd)
 
 
-def test_oracle_wav2vec2_model_and_criterion():
+@pytest.mark.parametrize("golden,overrides", W2V2_GOLDENS)
+def test_oracle_wav2vec2_model_and_criterion(golden, overrides):
     """wav2vec 2.0 end to end: extractor, Gumbel quantiser in TRAIN mode (noise from the torch CPU
     generator, as the reference draws it), sampled negatives, InfoNCE, diversity + features penalties, against the golden
     generated from the reference's Wav2Vec2Model + Wav2vecCriterion: logits, perplexities, loss, every gradient."""
     from conftest import Cfg
-    z = load_golden("tiny_w2v2.npz")
-    cfg = Cfg(**W2V2)
+    z = load_golden(golden)
+    d = dict(W2V2)
+    d.update(overrides)   # (tiny_w2v2_everywhere*: negatives_from_everywhere / codebook_negatives, wav2vec2.py:653-692)
+    cfg = Cfg(**d)
     sd = golden_state_dict(z, as_param=True)
     wav = torch.from_numpy(z["in/source"])
     m = torch.from_numpy(z["out/mask_seed77"])
     torch.manual_seed(31)
     res = O.wav2vec2_forward(sd, cfg, wav, torch.zeros(3, 16000, dtype=torch.bool), m, training=True)
-    assert abs(res["prob_perplexity"].item() - float(z["out/prob_perplexity"])) < RTOL * float(z["out/prob_perplexity"])
-    assert abs(res["code_perplexity"].item() - float(z["out/code_perplexity"])) < RTOL * float(z["out/code_perplexity"])
-    loss, ss, log = O.wav2vec_criterion(res, [0.1, 10.0])
+    if cfg.quantize_targets:
+        assert abs(res["prob_perplexity"].item() - float(z["out/prob_perplexity"])) < RTOL * float(z["out/prob_perplexity"])
+        assert abs(res["code_perplexity"].item() - float(z["out/code_perplexity"])) < RTOL * float(z["out/code_perplexity"])
+    lw = [float(v) for v in z["in/loss_weights"]] if "in/loss_weights" in z.files else [0.1, 10.0]
+    loss, ss, log = O.wav2vec_criterion(res, lw)
     l2 = res["x"].detach().transpose(0, 2).reshape(-1, res["x"].size(0))
     ref = torch.from_numpy(z["out/logits"])
     fin = torch.isfinite(ref)

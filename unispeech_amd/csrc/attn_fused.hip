@@ -3,9 +3,13 @@
 #include "attn_fused.hpp"
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-// FA_FWD_LAZY: lazy running maximum + packed row sums in the forward (see the tile loop)
+// FA_FWD_LAZY: lazy running maximum + packed row sums in the forward (see the tile loop).  Measured -4 % on the forward
+// kernel (profiles/r03/ab_attn_lazy_pk.txt) and OFF: with the exact running maximum the dominant key of a row has
+// P = 2^0 = 1, which bf16 holds exactly; relative to a stale reference it is 2^frac and rounds like every other term.  The
+// 12-layer gradient comparison with the fp32 oracle (tests/test_bf16_e2e_gpu.py) keeps its median (1.52e-2 against
+// 1.59e-2 relative L2) but its worst tensor moves from 3.2e-2 to 4.4e-2 of a 4e-2 bound -- not worth 5 us per layer.
 #ifndef FA_FWD_LAZY
-#define FA_FWD_LAZY 1
+#define FA_FWD_LAZY 0
 #endif
 #ifndef FA_FWD_THETA
 #define FA_FWD_THETA 8.f

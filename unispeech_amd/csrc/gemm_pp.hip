@@ -48,6 +48,11 @@
 // bit 4 reports clocks into C, bit 5 drops the steady-state DMA waits, bit 6 stamps the phases of one K step.
 #define PP_PROBE 0
 #endif
+// PP_DMA_RD: steady-state DMA issue in the idle read intervals (1: P2 and P4 read intervals, 2: A-bot stays in P2's MFMA
+// section) instead of inside the MFMA sections (0)
+#ifndef PP_DMA_RD
+#define PP_DMA_RD 1
+#endif
 #define PP_HB 16384     // bytes per half-tile buffer
 #define PP_STAGE 65536  // bytes per stage: [A-top][A-bot][B-left][B-right]
 
@@ -376,6 +381,54 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     constexpr bool FIRST = decltype(first_c)::value;
     const bool more1 = SD || t + 1 < nt, more2 = SD || t + 2 < nt;
     auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) { issue_gen(which_c, stage); };
+#if PP_DMA_RD
+    if constexpr (SD) {
+      // Steady state, DMA in the IDLE read intervals: the four phases read 12 / 4 / 8 / 0 fragments, so the waves have
+      // nothing to do in the P4 read interval and little in P2's, while a DMA instruction costs its issuer 40-60 cycles
+      // wherever it sits -- inside an MFMA section that is 40 cycles of an idle matrix pipe per instruction (K step 2160
+      // cycles without DMA, ~2500 with).  Same issue ORDER as the in-section form (B-right, A-bot of t+1; A-top, B-left
+      // of t+2), so steady and general steps mix freely; only the waits move.
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bl[s] = rd_b(SB + 2 * PP_HB, s);
+#pragma unroll
+      for (int f = (EARLY && !FIRST) ? 1 : 0; f < 2; ++f)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) at[f][s] = rd_a(SB, f, s);
+      PP_VMWAIT(6);  // B-right(t) landed; younger: A-bot(t), A-top / B-left(t+1)
+      PP_MFMA_SECTION(at, 0, bl, 0)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) br[s] = rd_b(SB + 3 * PP_HB, s);
+      issue_one(I3{}, ST ^ 1, 0); issue_one(I3{}, ST ^ 1, 1);
+#if PP_DMA_RD == 1
+      issue_one(I1{}, ST ^ 1, 0); issue_one(I1{}, ST ^ 1, 1);
+      PP_VMWAIT(8);  // A-bot(t) landed; younger: A-top / B-left(t+1), B-right / A-bot(t+1)
+      PP_MFMA_SECTION(at, 0, br, 1)
+#else
+      PP_VMWAIT(6);
+      PP_MFMA_SECTION_H(at, 0, br, 1, issue_one(I1{}, ST ^ 1, 0), issue_one(I1{}, ST ^ 1, 1))
+#endif
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ab[f][s] = rd_a(SB + PP_HB, f, s);
+      if constexpr (EARLY) {
+        PP_VMWAIT(6);  // A-top(t+1) landed (its first fragment is read inside P4's section); younger: B-left, B-right, A-bot(t+1)
+        PP_MFMA_SECTION(ab, 2, br, 1)
+        issue_one(I0{}, ST, 0); issue_one(I0{}, ST, 1); issue_one(I2{}, ST, 0); issue_one(I2{}, ST, 1);
+        PP_VMWAIT(8);  // B-left(t+1) landed
+        constexpr int NB = (ST ^ 1) * PP_STAGE;
+#define PP_RD_AT(S_) { at[0][S_] = rd_a(NB, 0, S_); }
+        PP_MFMA_SECTION_H4(ab, 2, bl, 0, PP_RD_AT(0), PP_RD_AT(1), PP_RD_AT(2), PP_RD_AT(3), (void)0)
+#undef PP_RD_AT
+      } else {
+        PP_MFMA_SECTION(ab, 2, br, 1)
+        issue_one(I0{}, ST, 0); issue_one(I0{}, ST, 1); issue_one(I2{}, ST, 0); issue_one(I2{}, ST, 1);
+        PP_VMWAIT(8);  // A-top / B-left(t+1) landed; younger: B-right / A-bot(t+1), A-top / B-left(t+2)
+        PP_MFMA_SECTION(ab, 2, bl, 0)
+      }
+      return;
+    }
+#else
     if constexpr (SD) {
       // same phases; the half-tile of a phase is issued by each wave inside its own MFMA section (after MFMA pairs 1 and
       // 3), so the read interval is ds_reads only and a full vector-memory queue stalls behind running MFMAs.  The
@@ -411,6 +464,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
       }
       return;
     }
+#endif
     // ---- P1: A-top, B-left -> quadrant (0,0)
 #pragma unroll
     for (int s = 0; s < 4; ++s) bl[s] = rd_b(SB + 2 * PP_HB, s);
@@ -514,7 +568,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     constexpr int EP_LD = 64 + 4;
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
     // GELU epilogue: the chord table sits behind the staging slices (8 x 8704 B = 68 KiB) at 96 KiB; the K loop is over
-    // (barrier above), the next tile's DMA only starts after the barrier that ends this epilogue
+    // (barrier above), the next tile's DMA only starts after the barrier that ends this epilogue.  (Keeping the table
+    // RESIDENT behind the two stages -- staged once per workgroup instead of once per tile -- was built and measured in
+    // round 3: no change, fc1 + GELU 1.50 x the plain launch against 1.48 x, conv1 1.33 x against 1.30 x.)
     const float4* tab = nullptr;
     if constexpr (EP == 3) {
       if (P.gtab) {

@@ -202,26 +202,67 @@ __global__ void bce_finish_kernel(const double* part, int nblk, float* out, doub
   }
 }
 
-// nn.GLU over the last dimension: y[r][c] = a * sigmoid(b) with (a, b) = x[r][c], x[r][F + c]; backward
-// da = dy * sigmoid(b), db = dy * a * sigmoid(b) * (1 - sigmoid(b)).  (target_glu: wavlm.py:322-327, applied to the
-// [V, F] label-embedding table -- a few hundred rows.)
-__global__ __launch_bounds__(256) void glu_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, long rows, int F, int dt) {
+// Gated linear unit over the last dimension: y[r][c] = a * g(b) with (a, b) = x[r][c], x[r][F + c]; backward
+// da = dy * g(b), db = dy * a * g'(b).  gate: 0 sigmoid (nn.GLU = target_glu, wavlm.py:322-327, applied to the [V, F]
+// label-embedding table), 1 swish b * sigmoid(b) (GLU_Linear(.., "swish"), the feed-forward block's fc1 under
+// activation_fn = "glu": WavLM/modules.py:99-129, WavLM/WavLM.py:668-669), 2 relu, 3 gelu (erf), 4 bilinear (g = b).
+__device__ __forceinline__ void glu_gate(int gate, float b, float& g, float& dg) {
+  if (gate == 0) { const float sg = 1.f / (1.f + __expf(-b)); g = sg; dg = sg * (1.f - sg); }
+  else if (gate == 1) { const float sg = 1.f / (1.f + __expf(-b)); g = b * sg; dg = sg * (1.f + b * (1.f - sg)); }
+  else if (gate == 2) { g = b > 0.f ? b : 0.f; dg = b > 0.f ? 1.f : 0.f; }
+  else if (gate == 3) { const float cdf = 0.5f * (1.f + erff(b * 0.70710678118654752f)); g = b * cdf; dg = cdf + b * 0.3989422804014327f * __expf(-0.5f * b * b); }
+  else { g = b; dg = 1.f; }
+}
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, long rows, int F, int dt, int gate) {
   const long n = rows * F;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const long r = i / F; const int c = (int)(i - r * F);
     const float a = ld_elem(x, r * 2 * F + c, dt), b = ld_elem(x, r * 2 * F + F + c, dt);
-    st_elem(y, i, dt, a / (1.f + __expf(-b)));
+    float g, dg;
+    glu_gate(gate, b, g, dg);
+    st_elem(y, i, dt, a * g);
   }
 }
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, void* __restrict__ dx,
-                                                      long rows, int F, int dt) {
+                                                      long rows, int F, int dt, int gate) {
   const long n = rows * F;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const long r = i / F; const int c = (int)(i - r * F);
-    const float a = ld_elem(x, r * 2 * F + c, dt), b = ld_elem(x, r * 2 * F + F + c, dt), g = ld_elem(dy, i, dt);
-    const float sg = 1.f / (1.f + __expf(-b));
-    st_elem(dx, r * 2 * F + c, dt, g * sg);
-    st_elem(dx, r * 2 * F + F + c, dt, g * a * sg * (1.f - sg));
+    const float a = ld_elem(x, r * 2 * F + c, dt), b = ld_elem(x, r * 2 * F + F + c, dt), gy = ld_elem(dy, i, dt);
+    float g, dg;
+    glu_gate(gate, b, g, dg);
+    st_elem(dx, r * 2 * F + c, dt, gy * g);
+    st_elem(dx, r * 2 * F + F + c, dt, gy * a * dg);
+  }
+}
+
+// Elementwise activations of the feed-forward block other than the erf GELU (which lives in the GEMM epilogues):
+// utils.get_activation_fn (src/fairseq/utils.py:533-555; WavLM/modules.py:144-160).  kind: 1 relu, 2 gelu_accurate
+// 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) (src/fairseq/modules/gelu.py:14-19), 3 tanh, 4 erf gelu.
+// Backward takes the PRE-activation.
+__device__ __forceinline__ void act_eval(int kind, float x, float& y, float& dy) {
+  if (kind == 1) { y = x > 0.f ? x : 0.f; dy = x > 0.f ? 1.f : 0.f; }
+  else if (kind == 2) {
+    const float c0 = 0.7978845608028654f, c1 = 0.044715f;
+    const float u = c0 * (x + c1 * x * x * x), t = tanhf(u);
+    y = 0.5f * x * (1.f + t);
+    dy = 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * c0 * (1.f + 3.f * c1 * x * x);
+  } else if (kind == 3) { const float t = tanhf(x); y = t; dy = 1.f - t * t; }
+  else { const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f)); y = x * cdf; dy = cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x); }
+}
+__global__ __launch_bounds__(256) void act_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, long n, int dt, int kind) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v, d;
+    act_eval(kind, ld_elem(x, i, dt), v, d);
+    st_elem(y, i, dt, v);
+  }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, void* __restrict__ dx,
+                                                      long n, int dt, int kind) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v, d;
+    act_eval(kind, ld_elem(x, i, dt), v, d);
+    st_elem(dx, i, dt, ld_elem(dy, i, dt) * d);
   }
 }
 
@@ -331,19 +372,35 @@ int wavlm_bce_logits(const float* logits, const uint8_t* targets, float* dlogits
   return wl_check_launch();
 }
 
-int wavlm_glu_fwd(const void* x, void* y, int64_t rows, int32_t F, int32_t dtype, void* stream) {
-  if (!x || !y || rows < 0 || F <= 0 || (dtype != WL_F32 && dtype != WL_BF16)) return WL_EINVAL;
+int wavlm_glu_fwd(const void* x, void* y, int64_t rows, int32_t F, int32_t dtype, int32_t gate, void* stream) {
+  if (!x || !y || rows < 0 || F <= 0 || gate < 0 || gate > 4 || (dtype != WL_F32 && dtype != WL_BF16)) return WL_EINVAL;
   if (rows == 0) return WL_OK;
-  long grid = (rows * F + 255) / 256; if (grid > 2048) grid = 2048;
-  WL_LAUNCH(glu_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, (int)F, (int)dtype);
+  long grid = (rows * F + 255) / 256; if (grid > 8192) grid = 8192;
+  WL_LAUNCH(glu_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, (int)F, (int)dtype, (int)gate);
   return wl_check_launch();
 }
 
-int wavlm_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int32_t F, int32_t dtype, void* stream) {
-  if (!x || !dy || !dx || rows < 0 || F <= 0 || (dtype != WL_F32 && dtype != WL_BF16)) return WL_EINVAL;
+int wavlm_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int32_t F, int32_t dtype, int32_t gate, void* stream) {
+  if (!x || !dy || !dx || rows < 0 || F <= 0 || gate < 0 || gate > 4 || (dtype != WL_F32 && dtype != WL_BF16)) return WL_EINVAL;
   if (rows == 0) return WL_OK;
-  long grid = (rows * F + 255) / 256; if (grid > 2048) grid = 2048;
-  WL_LAUNCH(glu_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)rows, (int)F, (int)dtype);
+  long grid = (rows * F + 255) / 256; if (grid > 8192) grid = 8192;
+  WL_LAUNCH(glu_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)rows, (int)F, (int)dtype, (int)gate);
+  return wl_check_launch();
+}
+
+int wavlm_act_fwd(const void* x, void* y, int64_t n, int32_t dtype, int32_t kind, void* stream) {
+  if (!x || !y || n < 0 || kind < 1 || kind > 4 || (dtype != WL_F32 && dtype != WL_BF16)) return WL_EINVAL;
+  if (n == 0) return WL_OK;
+  long grid = (n + 255) / 256; if (grid > 8192) grid = 8192;
+  WL_LAUNCH(act_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, (int)dtype, (int)kind);
+  return wl_check_launch();
+}
+
+int wavlm_act_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t dtype, int32_t kind, void* stream) {
+  if (!x || !dy || !dx || n < 0 || kind < 1 || kind > 4 || (dtype != WL_F32 && dtype != WL_BF16)) return WL_EINVAL;
+  if (n == 0) return WL_OK;
+  long grid = (n + 255) / 256; if (grid > 8192) grid = 8192;
+  WL_LAUNCH(act_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)n, (int)dtype, (int)kind);
   return wl_check_launch();
 }
 

@@ -320,16 +320,32 @@ class FFNFn(torch.autograd.Function):
     input-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, p_act, seed, b2_tok=None, wgroup=None, pass_x=False):
+    def forward(ctx, x, W1, b1, W2, b2, p_act, seed, b2_tok=None, wgroup=None, pass_x=False, act="gelu"):
+        """act: the reference's activation_fn (utils.get_activation_fn, WavLM/modules.py:144-160).  "gelu" (every released
+        model) is the fused path; "relu" / "gelu_accurate" (= "gelu_fast") / "tanh" / "linear" run fc1 as a plain GEMM and
+        the activation as one elementwise pass each way; "glu" makes fc1 a GLU_Linear(D, F, "swish") (W1 [2F, D]:
+        WavLM/modules.py:99-129, WavLM/WavLM.py:668-669, 707-708)."""
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
         n = x2d.shape[0]
         F = W1.shape[0]
-        u = torch.empty((n, F), dtype=x2d.dtype, device=x2d.device)
-        # without activation dropout the auxiliary tensor holds gelu'(pre-activation) (epi 3): backward multiplies
-        # by it (epi 4) instead of re-evaluating erf / exp; with dropout it holds the pre-activation itself
-        h = _linear_fwd(x2d, W1, b1, epi=3 if p_act <= 0 else 1, aux=u)
+        ctx.act = act
+        if act == "gelu":
+            u = torch.empty((n, F), dtype=x2d.dtype, device=x2d.device)
+            # without activation dropout the auxiliary tensor holds gelu'(pre-activation) (epi 3): backward multiplies
+            # by it (epi 4) instead of re-evaluating erf / exp; with dropout it holds the pre-activation itself
+            h = _linear_fwd(x2d, W1, b1, epi=3 if p_act <= 0 else 1, aux=u)
+        else:
+            u = _linear_fwd(x2d, W1, b1)  # the pre-activation ([n, 2F] for "glu")
+            if act == "glu":
+                h = ops.glu_fwd(u, "swish")
+            elif act == "linear":
+                h = u
+            elif act in ops.ACT_KINDS:
+                h = ops.act_fwd(u, act)
+            else:
+                raise RuntimeError("--activation-fn %s not supported" % act)  # the reference's message (utils.py:555)
         hd = ops.dropout(h, p_act, seed) if p_act > 0 else h
         y = _linear_fwd(hd, W2, b2)
         ctx.save_for_backward(x2d, W1, W2, u, hd, b1, b2)
@@ -347,13 +363,23 @@ class FFNFn(torch.autograd.Function):
     def backward(ctx, dy, dx_pass=None):
         x2d, W1, W2, u, hd, b1, b2 = ctx.saved_tensors
         if dy is None:
-            return (dx_pass,) + (None,) * 9
+            return (dx_pass,) + (None,) * 10
         dy2d = dy.reshape(-1, dy.shape[-1])
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
         dW2, db2 = _param_grads(dy2d, hd, W2, b2, b2 is not None, True, True, bias_tok=ctx.b2_tok, wgroup=ctx.wgroup)
         fused_b1 = False
-        if ctx.p_act > 0:
+        if ctx.act != "gelu":
+            dh = _linear_bwd_x(dy2d, W2)
+            if ctx.p_act > 0:
+                dh = ops.dropout(dh, ctx.p_act, ctx.seed)
+            if ctx.act == "glu":
+                du = ops.glu_bwd(u, dh, "swish")
+            elif ctx.act == "linear":
+                du = dh
+            else:
+                du = ops.act_bwd(u, dh, ctx.act)
+        elif ctx.p_act > 0:
             dh = _linear_bwd_x(dy2d, W2)
             dh = ops.dropout(dh, ctx.p_act, ctx.seed)
             n, F = dh.shape
@@ -375,7 +401,7 @@ class FFNFn(torch.autograd.Function):
                 if not res.is_contiguous():
                     res = res.contiguous()
             dx = _linear_bwd_x(du, W1, res=res).view(ctx.xshape)
-        return dx, dW1, db1, dW2, db2, None, None, None, None, None
+        return dx, dW1, db1, dW2, db2, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------- LayerNorm

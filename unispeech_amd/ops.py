@@ -687,20 +687,40 @@ def prof_collect_bytes(dtype=-1):
 
 
 # ------------------------------------------------------------------------- sampled-instance cosine head
-def glu_fwd(x2d):
-    """nn.GLU(dim=-1): [rows, 2F] -> [rows, F]"""
+GLU_GATES = {"sigmoid": 0, "swish": 1, "relu": 2, "gelu": 3, "bilinear": 4}
+ACT_KINDS = {"relu": 1, "gelu_accurate": 2, "gelu_fast": 2, "tanh": 3, "gelu": 4}
+
+
+def glu_fwd(x2d, gate="sigmoid"):
+    """[rows, 2F] -> [rows, F]: x[:, :F] * g(x[:, F:]); gate "sigmoid" = nn.GLU(dim=-1), "swish" = GLU_Linear's"""
     _dev(x2d); _contig(x2d)
     rows, F2 = x2d.shape
     y = torch.empty((rows, F2 // 2), dtype=x2d.dtype, device=x2d.device)
-    check(_lib.lib().wavlm_glu_fwd(ptr(x2d), ptr(y), rows, F2 // 2, dt(x2d), stream()), "wavlm_glu_fwd")
+    check(_lib.lib().wavlm_glu_fwd(ptr(x2d), ptr(y), rows, F2 // 2, dt(x2d), GLU_GATES[gate], stream()), "wavlm_glu_fwd")
     return y
 
 
-def glu_bwd(x2d, dy):
+def glu_bwd(x2d, dy, gate="sigmoid"):
     _dev(x2d); _contig(x2d); _contig(dy)
     rows, F2 = x2d.shape
     dx = torch.empty_like(x2d)
-    check(_lib.lib().wavlm_glu_bwd(ptr(x2d), ptr(dy), ptr(dx), rows, F2 // 2, dt(x2d), stream()), "wavlm_glu_bwd")
+    check(_lib.lib().wavlm_glu_bwd(ptr(x2d), ptr(dy), ptr(dx), rows, F2 // 2, dt(x2d), GLU_GATES[gate], stream()), "wavlm_glu_bwd")
+    return dx
+
+
+def act_fwd(x, kind):
+    """elementwise activation (ACT_KINDS) of a contiguous tensor"""
+    _dev(x); _contig(x)
+    y = torch.empty_like(x)
+    check(_lib.lib().wavlm_act_fwd(ptr(x), ptr(y), x.numel(), dt(x), ACT_KINDS[kind], stream()), "wavlm_act_fwd")
+    return y
+
+
+def act_bwd(x, dy, kind):
+    """dx = dy * act'(x), x the pre-activation"""
+    _dev(x); _contig(x); _contig(dy)
+    dx = torch.empty_like(x)
+    check(_lib.lib().wavlm_act_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), dt(x), ACT_KINDS[kind], stream()), "wavlm_act_bwd")
     return dx
 
 

@@ -11,8 +11,10 @@ What differs from the reference is how the numbers are produced: the [N+1, B, T_
 built (gathered cosine logits + fused cross entropy, functional.SampledNegativesLossFn), the quantiser's [n, G, V]
 one-hot x codebook product is a gather, and index lists come from the host-generated mask (no device nonzero()).
 
-Options of the reference that no shipped recipe uses raise NotImplementedError: quantize_input, negatives_from_everywhere,
-codebook_negatives, target_glu, transpose, quantizer_depth > 1, and the non-infonce (BCE) criterion.
+negatives_from_everywhere and codebook_negatives (wav2vec2.py:653-686) are built on the same gathered-row head (the candidate
+table grows by one projected row per frame / per sampled code).  Options of the reference that no shipped recipe uses and
+that raise NotImplementedError: transpose, quantizer_depth > 1, and the non-infonce (BCE)
+criterion (it pairs with wav2vec 1.0's get_targets / get_target_weights, models/wav2vec/wav2vec.py, outside SURVEY.md 8).
 """
 import ast
 import math
@@ -130,6 +132,18 @@ class GumbelVectorQuantizer(nn.Module):
             raise NotImplementedError("produce_targets (code indices) is only used by offline quantisation")
         return res
 
+    def sample_from_codebook(self, b, n):
+        """b x n random full codes (one index per group, groups concatenated) -> [b, n, vq_dim]
+        (gumbel_vector_quantizer.py:90-128: the same torch.randint draw on the CPU generator; differentiable in `vars`)"""
+        G, V = self.groups, self.num_vars
+        cb_size = V ** G
+        assert n < cb_size, f"sample size {n} is greater than size of codebook {cb_size}"
+        sample_idx = torch.randint(low=0, high=cb_size, size=(b * n,))
+        # row r of the reference's index table = digits of r in base V (itertools.product order) + V * group
+        digits = torch.stack([(sample_idx // (V ** (G - 1 - g))) % V + V * g for g in range(G)], dim=1)
+        flat = F.h2d(digits.reshape(-1).to(torch.int64), self.vars.device)
+        return self.vars.squeeze(0).index_select(0, flat).view(b, n, -1)
+
     def burn_host_noise(self, n_rows):
         """advance the CPU generator as one more forward on n_rows rows would (the reference quantises the unmasked
         features a second time, wav2vec2.py:655-656, a result only its `transpose` option reads)"""
@@ -140,11 +154,14 @@ class GumbelVectorQuantizer(nn.Module):
 class Wav2Vec2Model(nn.Module):
     def __init__(self, cfg: Wav2Vec2Config):
         super().__init__()
-        for opt in ("quantize_input", "negatives_from_everywhere", "target_glu", "transpose"):
-            if getattr(cfg, opt, False):
-                raise NotImplementedError("wav2vec 2.0 option %s is not supported by the HIP path" % opt)
-        if getattr(cfg, "codebook_negatives", 0) > 0 or getattr(cfg, "quantizer_depth", 1) != 1:
-            raise NotImplementedError("codebook_negatives / quantizer_depth > 1 are not supported by the HIP path")
+        if getattr(cfg, "transpose", False):
+            raise NotImplementedError("wav2vec 2.0 option transpose is not supported by the HIP path")
+        if getattr(cfg, "quantizer_depth", 1) != 1:
+            raise NotImplementedError("quantizer_depth > 1 is not supported by the HIP path")
+        self.negatives_from_everywhere = bool(getattr(cfg, "negatives_from_everywhere", False))
+        self.codebook_negatives = int(getattr(cfg, "codebook_negatives", 0))
+        if self.codebook_negatives > 0 and not cfg.quantize_targets:
+            raise ValueError("codebook_negatives needs quantize_targets (the reference dereferences self.quantizer)")
         self.cfg = cfg
         # parameter creation order of the reference constructor (wav2vec2.py:276-395): seeded-init parity
         layers = eval(cfg.conv_feature_layers)
@@ -152,7 +169,7 @@ class Wav2Vec2Model(nn.Module):
         self.feature_extractor = ConvFeatureExtractionModel(conv_layers=layers, dropout=0.0, mode=cfg.extractor_mode,
                                                             conv_bias=cfg.conv_bias)
         self.post_extract_proj = (nn.Linear(self.embed, cfg.encoder_embed_dim)
-                                  if self.embed != cfg.encoder_embed_dim else None)
+                                  if self.embed != cfg.encoder_embed_dim and not cfg.quantize_input else None)
         self.mask_prob, self.mask_selection, self.mask_other = cfg.mask_prob, cfg.mask_selection, cfg.mask_other
         self.mask_length, self.no_mask_overlap, self.mask_min_space = cfg.mask_length, cfg.no_mask_overlap, cfg.mask_min_space
         self.mask_channel_prob = cfg.mask_channel_prob
@@ -176,9 +193,23 @@ class Wav2Vec2Model(nn.Module):
             self.project_q = nn.Linear(vq_dim, final_dim)
         else:
             self.project_q = nn.Linear(self.embed, final_dim)
+        self.input_quantizer = None
+        if cfg.quantize_input:  # wav2vec2.py:346-363: the encoder input is a (projected) codebook entry
+            if cfg.same_quantizer and self.quantizer is not None:
+                vq_dim = final_dim
+                self.input_quantizer = self.quantizer
+            else:
+                vq_dim = cfg.latent_dim if cfg.latent_dim > 0 else cfg.encoder_embed_dim
+                self.input_quantizer = GumbelVectorQuantizer(dim=self.embed, num_vars=cfg.latent_vars, temp=cfg.latent_temp,
+                                                             groups=cfg.latent_groups, combine_groups=False, vq_dim=vq_dim,
+                                                             time_first=True)
+            self.project_inp = nn.Linear(vq_dim, cfg.encoder_embed_dim)
         self.mask_emb = nn.Parameter(torch.FloatTensor(cfg.encoder_embed_dim).uniform_())
         self.encoder = TransformerEncoder(cfg)
         self.layer_norm = nn.LayerNorm(self.embed)
+        self.target_glu = None
+        if cfg.target_glu:  # wav2vec2.py:371-375
+            self.target_glu = nn.Sequential(nn.Linear(final_dim, final_dim * 2), nn.GLU())
         self.final_proj = nn.Linear(cfg.encoder_embed_dim, final_dim)
 
     @classmethod
@@ -192,6 +223,8 @@ class Wav2Vec2Model(nn.Module):
         self.num_updates = num_updates
         if self.quantizer is not None:
             self.quantizer.set_num_updates(num_updates)
+        if self.input_quantizer is not None and self.input_quantizer is not self.quantizer:
+            self.input_quantizer.set_num_updates(num_updates)
 
     def max_positions(self):
         return None
@@ -242,6 +275,10 @@ class Wav2Vec2Model(nn.Module):
             x = F.LinearFn.apply(x, self.post_extract_proj.weight, self.post_extract_proj.bias)
         x = F.dropout(x, self.dropout_input.p, self.training)
         unmasked = F.dropout(normed, self.dropout_features.p, self.training)
+        inq = None
+        if self.input_quantizer is not None:  # wav2vec2.py:602-609
+            inq = self.input_quantizer(x)
+            x = F.LinearFn.apply(inq["x"].reshape(B * T, -1), self.project_inp.weight, self.project_inp.bias).view(B, T, -1)
         # -- masking (apply_mask, wav2vec2.py:405-472): same numpy draws in the same order
         mask_np = None
         if mask:
@@ -277,20 +314,50 @@ class Wav2Vec2Model(nn.Module):
         idx, inv = F.h2d(idx_np, dev), F.h2d(inv_np, dev)
         y = F.GatherRowsFn.apply(unmasked.reshape(B * T, -1), idx, inv)                # [S, C], row = b * Tm + t
         result = {"features": x, "feature_padding_mask": padding_mask}
+        if inq is not None:  # overwritten by the target quantiser's values below, as in the reference
+            result.update(prob_perplexity=inq["prob_perplexity"], code_perplexity=inq["code_perplexity"],
+                          num_vars=inq["num_vars"], temp=inq["temp"])
+        nfe, cbn = self.negatives_from_everywhere, self.codebook_negatives
+        cand = None  # candidates of negatives_from_everywhere: one projected row per frame [B * T, F]
         if self.quantizer is not None:
             q = self.quantizer(y.view(B, Tm, -1))
             y = q["x"].reshape(S, -1)
             result.update(prob_perplexity=q["prob_perplexity"], code_perplexity=q["code_perplexity"],
                           num_vars=q["num_vars"], temp=q["temp"])
-            self.quantizer.burn_host_noise(B * T)
-        y = F.LinearFn.apply(y, self.project_q.weight, self.project_q.bias)          # [S, F]
-        neg = F.sample_negatives_indices(B, Tm, Tm, self.n_negatives, self.cross_sample_negatives, padding_count)
+            if nfe:  # the reference's second quantiser pass over ALL frames supplies the candidates (wav2vec2.py:653-661)
+                q_all = self.quantizer(unmasked.reshape(B, T, -1))["x"].reshape(B * T, -1)
+                cand = F.LinearFn.apply(q_all, self.project_q.weight, self.project_q.bias)
+            else:
+                self.quantizer.burn_host_noise(B * T)
+            y = F.LinearFn.apply(y, self.project_q.weight, self.project_q.bias)          # [S, F]
+            own = torch.arange(S)
+            table = y if cand is None else torch.cat([y, cand], dim=0)
+            neg_base = 0 if cand is None else S
+        elif nfe:
+            # negatives from every frame of the un-quantised features (wav2vec2.py:679-686): project_q is applied per row, so
+            # the positives are rows of the same projected table
+            table = F.LinearFn.apply(unmasked.reshape(B * T, -1), self.project_q.weight, self.project_q.bias)
+            own, neg_base = torch.from_numpy(idx_np.astype(np.int64)), 0
+        else:
+            y = F.LinearFn.apply(y, self.project_q.weight, self.project_q.bias)          # [S, F]
+            own, table, neg_base = torch.arange(S), y, 0
+        neg = F.sample_negatives_indices(B, T if nfe else Tm, Tm, self.n_negatives, self.cross_sample_negatives, padding_count)
         N = self.n_negatives + self.cross_sample_negatives
+        cols = [own.view(S, 1), neg.view(B, Tm, N).reshape(S, N) + neg_base]
+        if cbn > 0:
+            # codebook negatives (wav2vec2.py:669-677): S * cbn random full codes through project_q; the reference views the
+            # [S, cbn, .] samples as [cbn, B, Tm, .] ("order doesnt matter"): negative k of position s is flat sample k * S + s
+            codes = self.quantizer.sample_from_codebook(S, cbn).reshape(S * cbn, -1)
+            cb = F.LinearFn.apply(codes.to(table.dtype), self.project_q.weight, self.project_q.bias)
+            cols.append(table.shape[0] + torch.arange(cbn).view(1, cbn) * S + torch.arange(S).view(S, 1))
+            table = torch.cat([table, cb], dim=0)
         xs = F.GatherRowsFn.apply(x.reshape(B * T, -1), idx, inv)
         xs = F.LinearFn.apply(xs, self.final_proj.weight, self.final_proj.bias)      # [S, F]
-        own = torch.arange(S).view(S, 1)
-        idx_full = torch.cat([own, neg.view(B, Tm, N).reshape(S, N)], dim=1).to(torch.int32)
-        idx_full = F.h2d(idx_full, dev)
+        idx_full = F.h2d(torch.cat(cols, dim=1).to(torch.int32), dev)
+        if self.target_glu is not None:  # y and the negatives alike (wav2vec2.py:697-699): per row of the candidate table
+            tg = self.target_glu[0]
+            table = F.GLUFn.apply(F.LinearFn.apply(table.contiguous(), tg.weight, tg.bias))
+        y = table
         loss, ncorrect = F.SampledNegativesLossFn.apply(xs, y, idx_full, self.logit_temp)
         result["head"] = {"loss": loss, "correct": ncorrect, "count": S, "x": xs, "y": y, "idx": idx_full, "B": B, "Tm": Tm}
         result["x"] = None   # reference-shaped logits [N+1, B, Tm] are materialised on demand by get_logits()
@@ -329,6 +396,7 @@ class Wav2Vec2Model(nn.Module):
     def remove_pretraining_modules(self):
         self.quantizer = None
         self.project_q = None
+        self.target_glu = None
         self.final_proj = None
 
 

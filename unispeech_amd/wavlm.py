@@ -292,6 +292,19 @@ class ResidualAddFn(torch.autograd.Function):
         return dy, dr, None, None
 
 
+ACTIVATION_FNS = ("relu", "gelu", "gelu_accurate", "tanh", "linear", "glu")  # utils.get_available_activation_fns
+
+
+class GLULinear(nn.Module):
+    """Parameter holder of GLU_Linear(input_dim, output_dim, "swish") (WavLM/modules.py:99-129): `linear` maps to 2 x
+    output_dim, the output is x[..., :F] * swish(x[..., F:]).  The arithmetic lives in functional.FFNFn (act="glu")."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.output_dim = output_dim
+        self.linear = nn.Linear(input_dim, output_dim * 2)
+
+
 class TransformerSentenceEncoderLayer(nn.Module):
     """post-LN (Base) / pre-LN (Large) encoder block (WavLM/WavLM.py:615-742)"""
 
@@ -299,8 +312,11 @@ class TransformerSentenceEncoderLayer(nn.Module):
                  attention_dropout=0.1, activation_dropout=0.1, activation_fn="relu", layer_norm_first=False,
                  has_relative_attention_bias=False, num_buckets=0, max_distance=0, gru_rel_pos=False):
         super().__init__()
-        if activation_fn != "gelu":
-            raise NotImplementedError("only activation_fn='gelu' (every released WavLM/UniSpeech model) is supported")
+        if activation_fn == "gelu_fast":  # deprecated name of gelu_accurate (src/fairseq/utils.py:541-545)
+            activation_fn = "gelu_accurate"
+        if activation_fn not in ACTIVATION_FNS:
+            raise RuntimeError("--activation-fn {} not supported".format(activation_fn))  # utils.get_activation_fn
+        self.activation_name = activation_fn
         self.embedding_dim = embedding_dim
         self.dropout = dropout
         self.activation_dropout = activation_dropout
@@ -312,14 +328,18 @@ class TransformerSentenceEncoderLayer(nn.Module):
         self.dropout3 = nn.Dropout(dropout)
         self.layer_norm_first = layer_norm_first
         self.self_attn_layer_norm = nn.LayerNorm(embedding_dim)
-        self.fc1 = nn.Linear(embedding_dim, ffn_embedding_dim)
+        if activation_fn == "glu":  # WavLM/WavLM.py:668-669: fc1 = GLU_Linear(D, F, "swish"), parameters fc1.linear.*
+            self.fc1 = GLULinear(embedding_dim, ffn_embedding_dim)
+        else:
+            self.fc1 = nn.Linear(embedding_dim, ffn_embedding_dim)
         self.fc2 = nn.Linear(ffn_embedding_dim, embedding_dim)
         self.final_layer_norm = nn.LayerNorm(embedding_dim)
 
     def _ffn(self, x, b2_tok=None, wgroup=None, chain=False):
         p = self.activation_dropout if self.training else 0.0
-        return F.FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, p,
-                             F.next_seed() if p > 0 else 0, b2_tok, wgroup, chain)
+        fc1 = self.fc1.linear if self.activation_name == "glu" else self.fc1
+        return F.FFNFn.apply(x, fc1.weight, fc1.bias, self.fc2.weight, self.fc2.bias, p,
+                             F.next_seed() if p > 0 else 0, b2_tok, wgroup, chain, self.activation_name)
 
     def forward_preln_fused(self, x, pending, key_padding_u8=None, position_table=None):
         """Pre-LN block with both residual adds fused into the LayerNorm that follows them (training path of the encoder,
