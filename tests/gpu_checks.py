@@ -544,7 +544,7 @@ def check_attention():
     # (3, 64): 16-byte fast path with idle lanes, even row count; (12, 64) x 67 rows: Base geometry, odd row count (half
     # step at the end); (2, 32): generic kernel
     for dtype, (B, T, H, hd) in [(dt_, g_) for dt_ in (torch.float32, torch.bfloat16)
-                                 for g_ in ((2, 33, 3, 64), (1, 67, 12, 64), (2, 19, 2, 32))]:
+                                 for g_ in ((2, 33, 3, 64), (1, 67, 12, 64), (2, 19, 2, 32), (3, 41, 16, 64), (2, 3001, 12, 64))]:
         tol = tol_for(dtype)
         x = q(gen(B, T, H * hd, seed=1), dtype)
         W, b = q(0.2 * gen(8, hd, seed=2), dtype), q(0.1 * gen(8, seed=3), dtype)
@@ -564,6 +564,13 @@ def check_attention():
         out.append((tag + " dW", err(Wd.grad, Wr.grad), tol * 2))
         out.append((tag + " dbias", err(bd.grad, br.grad), tol * 2))
         out.append((tag + " dgrep_a", err(ad.grad, ar.grad), tol * 2))
+        if hd == 64:  # accumulate form: the gate's gradient of x is added into a buffer that already holds another consumer's
+            base = q(gen(B, T, H * hd, seed=6), dtype)
+            acc = base.to(dtype).to(DEV).clone()
+            _, ga_d, gb_d = ops.gate_fwd(xd.detach(), Wd.detach(), bd.detach(), ad.detach().view(-1), H)
+            dx2, _, _, _ = ops.gate_bwd(dg.to(DEV), xd.detach(), Wd.detach(), bd.detach(), ad.detach().view(-1), ga_d, gb_d, H,
+                                        dx_accumulate=acc)
+            out.append((tag + " dx (accumulate)", err(dx2, xr.grad + base), tol * 2))
     # relpos table
     emb = gen(32, 4, seed=1).requires_grad_(True)
     bucket = torch.randint(0, 32, (97,), generator=torch.Generator().manual_seed(0)).to(torch.int32)

@@ -10,6 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python bench
 TR=$(find $OUT/raw -name "*kernel_trace.csv" | head -1)
 ST=$(find $OUT/raw -name "*kernel_stats.csv" | head -1)
 python tools/prof_laststep.py $TR 70 > $OUT/summary.txt 2>&1 || true
+python tools/prof_gaps.py $TR 25 > $OUT/gaps.txt 2>&1 || true
 [ -n "$ST" ] && cp $ST $OUT/kernel_stats.csv
 tail -1 $OUT/bench.log >> $OUT/summary.txt
 rm -rf $OUT/raw

@@ -11,6 +11,7 @@
 // same pass: dgate[b,h,i] = sum_j dS*rel  (wave shuffle) and drel[h,d] = sum_{b,i} gate*dS[i,i+d]
 // (LDS diagonal accumulators per block, then a deterministic cross-block sum).
 #include "common.hpp"
+#include <stdlib.h>
 #include "../../include/wavlm_hip.h"
 
 #define SM_NCH 4  // chunks of 256 keys: row length up to 1024 (T' = 749 @15 s, 999 @20 s)
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ x, 
   }
 }
 
-#define GATE_BLOCKS 512
+#define GATE_BLOCKS 1024  // upper bound of the backward grid (sizes the partial-sum workspace); the launch uses 512
 // ---- head_dim 64 fast path: 16-byte accesses -------------------------------------------------------------------
 // A row of x is H heads x 8 chunks of 8 channels.  A wave takes TWO rows per step = 16 H chunks; lane l owns chunks
 // l, l + 64, ... : chunk q -> row q / (8H), head (q % 8H) >> 3, sub-chunk q & 7.  Because 64 is a multiple of 8 a
@@ -430,6 +431,226 @@ __global__ __launch_bounds__(256) void gate_bwd64_kernel(const float* __restrict
       const int q = lane + 64 * i;
       if (q < NCH) atomicAdd(&sm[130 + ((q % CPR) >> 3)], da[i]);
     }
+  }
+  __syncthreads();
+  float* out = part + (long)blockIdx.x * PW;
+  for (int i = threadIdx.x; i < PW; i += 256) out[i] = sm[i];
+}
+
+// ---- head_dim 64, H = 4 NI (12 or 16 heads): the row pair of a step is exactly NI chunks per lane -----------------
+// Round 3: the kernels above ran at 2.2 (forward) / 3.1 TB/s (backward).  Both issued a step's loads, waited, and (backward,
+// accumulate form) then issued a second dependent round of loads for dx.  Here every load of step n + 1 (x, dx, dgate / ga /
+// gb) is in flight while step n computes: backward 35.0 -> 24.2 us per layer, forward 17.0 -> 14.6 us (profiles/r03/
+// envab_gate_piped.txt).  What did NOT matter (same file family): the grid (256 ... 4096 blocks), 16-byte weight loads in the
+// prologue, contiguous row ranges per block (whole output lines per XCD), and removing the 64-bit row / Tn per chunk and
+// step -- a 37 MB pass of ~15 us is launch ramp + first-fetch latency + tail for half of its duration; the remaining lever is
+// to compute the gate inside the LayerNorm kernel that already streams this tensor.
+template <typename T> struct GateRaw;  // one 16-byte (bf16) / 32-byte (fp32) chunk of 8 channels as loaded
+template <> struct GateRaw<bf16_t> {
+  uint4 a;
+  __device__ __forceinline__ void ld(const bf16_t* p) { a = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void get(float (&v)[8]) const {
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+  }
+};
+template <> struct GateRaw<float> {
+  float4 a, b;
+  __device__ __forceinline__ void ld(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void get(float (&v)[8]) const {
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+};
+// summed weights of this lane's 8 channels: wa = rows 0-3, wb = rows 4-7 of grep_linear.weight [8, 64]
+template <typename TP>
+__device__ __forceinline__ void gate_weights(const TP* W, int sub, float (&wa)[8], float (&wb)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { wa[e] = 0.f; wb[e] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float ra[8], rb[8];
+    gate_ld8(W + k * 64 + sub * 8, ra);
+    gate_ld8(W + (4 + k) * 64 + sub * 8, rb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { wa[e] += ra[e]; wb[e] += rb[e]; }
+  }
+}
+
+template <typename T, typename TP, int NI>
+__global__ __launch_bounds__(256) void gate_fwd64p_kernel(const T* __restrict__ x, const TP* __restrict__ W,
+    const TP* __restrict__ bias, const TP* __restrict__ grep_a, float* __restrict__ gate, float* __restrict__ ga_o,
+    float* __restrict__ gb_o, int B, int Tn) {
+  constexpr int H = 4 * NI, D = H * 64, CPR = 8 * H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long nbt = (long)B * Tn, npair = (nbt + 1) >> 1;
+  const int sub = lane & 7;
+  float ba = 0.f, bb = 0.f;
+  for (int k = 0; k < 4; ++k) { ba += Elem<TP>::ld(bias + k); bb += Elem<TP>::ld(bias + 4 + k); }
+  float wa[8], wb[8];
+  gate_weights(W, sub, wa, wb);
+  int rsel[NI], hsel[NI];
+  float av[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int q = lane + 64 * i;
+    rsel[i] = q / CPR; hsel[i] = (q % CPR) >> 3;
+    av[i] = Elem<TP>::ld(grep_a + hsel[i]);
+  }
+  // a block walks a contiguous range of row pairs (the [B, H, T] outputs are 4-byte writes along t: whole lines per block)
+  const long per = (npair + gridDim.x - 1) / gridDim.x;
+  const long pend = min(npair, (long)(blockIdx.x + 1) * per);
+  constexpr long pstep = 4;
+  long rp = (long)blockIdx.x * per + wave;
+  if (rp >= pend) return;
+  GateRaw<T> px[NI];
+  auto fetch = [&](long rp_) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      long row = 2 * rp_ + rsel[i]; if (row > nbt - 1) row = nbt - 1;
+      px[i].ld(x + row * D + ((lane + 64 * i) % CPR) * 8);
+    }
+  };
+  fetch(rp);
+  // output offset (b * H + h) * Tn + t of this lane's row, advanced by 8 rows per step (no 64-bit division in the loop)
+  long oo[NI];
+  int tt[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const long row = 2 * rp + rsel[i];
+    const long b = row / Tn;
+    tt[i] = (int)(row - b * Tn);
+    oo[i] = (b * H + hsel[i]) * Tn + tt[i];
+  }
+  for (; rp < pend; rp += pstep) {
+    float xv[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) px[i].get(xv[i]);
+    fetch(rp + pstep < pend ? rp + pstep : rp);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sa = fmaf(xv[i][e], wa[e], sa); sb = fmaf(xv[i][e], wb[e], sb); }
+      sa = wl_sum8(sa); sb = wl_sum8(sb);
+      const long row = 2 * rp + rsel[i];
+      if (sub == 0 && row < nbt) {
+        const float ga = 1.f / (1.f + __expf(-(sa + ba))), gb = 1.f / (1.f + __expf(-(sb + bb)));
+        const long o = oo[i];
+        gate[o] = ga * (gb * av[i] - 1.f) + 2.f;
+        ga_o[o] = ga; gb_o[o] = gb;
+      }
+      tt[i] += 2 * (int)pstep; oo[i] += 2 * pstep;
+      while (tt[i] >= Tn) { tt[i] -= Tn; oo[i] += (long)(H - 1) * Tn; }
+    }
+  }
+}
+
+// partial layout per block as gate_bwd64_kernel: [2*64 (dWa, dWb)] [2 (dba, dbb)] [H (da)]
+template <typename T, typename TP, int NI, bool ACC>
+__global__ __launch_bounds__(256) void gate_bwd64p_kernel(const float* __restrict__ dgate, const T* __restrict__ x,
+    const TP* __restrict__ W, const TP* __restrict__ grep_a, const float* __restrict__ ga_i,
+    const float* __restrict__ gb_i, T* __restrict__ dx, float* __restrict__ part, int B, int Tn) {
+  constexpr int H = 4 * NI, D = H * 64, CPR = 8 * H, PW = 128 + 2 + H;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long nbt = (long)B * Tn, npair = (nbt + 1) >> 1;
+  const int sub = lane & 7;
+  for (int i = threadIdx.x; i < PW; i += 256) sm[i] = 0.f;
+  float wa[8], wb[8], dwa[8], dwb[8];
+  gate_weights(W, sub, wa, wb);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { dwa[e] = 0.f; dwb[e] = 0.f; }
+  int rsel[NI], hsel[NI];
+  float av[NI], da[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int q = lane + 64 * i;
+    rsel[i] = q / CPR; hsel[i] = (q % CPR) >> 3;
+    av[i] = Elem<TP>::ld(grep_a + hsel[i]);
+    da[i] = 0.f;
+  }
+  float dba = 0.f, dbb = 0.f;
+  __syncthreads();
+  // contiguous range of row pairs per block (see the forward)
+  const long per = (npair + gridDim.x - 1) / gridDim.x;
+  const long pend = min(npair, (long)(blockIdx.x + 1) * per);
+  constexpr long pstep = 4;
+  long rp = (long)blockIdx.x * per + wave;
+  GateRaw<T> px[NI], pd[ACC ? NI : 1];
+  float pg[NI], pa[NI], pb[NI];
+  // [B, H, T] offset of the row being FETCHED, advanced by 8 rows per step (no 64-bit division per chunk and step)
+  const long ototal = (long)B * H * Tn;
+  long on[NI];
+  int tn[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const long row = 2 * rp + rsel[i];
+    const long b = row / Tn;
+    tn[i] = (int)(row - b * Tn);
+    on[i] = (b * H + hsel[i]) * Tn + tn[i];
+  }
+  auto advance = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      tn[i] += 2 * (int)pstep; on[i] += 2 * pstep;
+      while (tn[i] >= Tn) { tn[i] -= Tn; on[i] += (long)(H - 1) * Tn; }
+    }
+  };
+  auto fetch = [&](long rp_) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      long row = 2 * rp_ + rsel[i]; if (row > nbt - 1) row = nbt - 1;
+      const long off = row * D + ((lane + 64 * i) % CPR) * 8;
+      px[i].ld(x + off);
+      if constexpr (ACC) pd[i].ld(dx + off);
+      const long o = on[i] < ototal ? on[i] : ototal - 1;  // (the row past an odd row count: any valid address, unused)
+      pg[i] = dgate[o]; pa[i] = ga_i[o]; pb[i] = gb_i[o];
+    }
+  };
+  if (rp < pend) fetch(rp);
+  for (; rp < pend; rp += pstep) {
+    float xv[NI][8], p8[ACC ? NI : 1][8], dsa[NI], dsb[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      px[i].get(xv[i]);
+      if constexpr (ACC) pd[i].get(p8[i]);
+      const bool ok = 2 * rp + rsel[i] < nbt;
+      const float dg = ok ? pg[i] : 0.f, ga = pa[i], gb = pb[i];
+      dsa[i] = dg * (gb * av[i] - 1.f) * ga * (1.f - ga);
+      dsb[i] = dg * ga * av[i] * gb * (1.f - gb);
+      if (sub == 0) { da[i] = fmaf(dg * ga, gb, da[i]); dba += dsa[i]; dbb += dsb[i]; }
+    }
+    if (rp + pstep < pend) { advance(); fetch(rp + pstep); }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const long row = 2 * rp + rsel[i];
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o8[e] = dsa[i] * wa[e] + dsb[i] * wb[e];
+        if constexpr (ACC) o8[e] += p8[i][e];
+        dwa[e] = fmaf(dsa[i], xv[i][e], dwa[e]);
+        dwb[e] = fmaf(dsb[i], xv[i][e], dwb[e]);
+      }
+      if (row < nbt) gate_st8(dx + row * D + ((lane + 64 * i) % CPR) * 8, o8);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) { dwa[e] += __shfl_xor(dwa[e], o, 64); dwb[e] += __shfl_xor(dwb[e], o, 64); }
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&sm[sub * 8 + e], dwa[e]); atomicAdd(&sm[64 + sub * 8 + e], dwb[e]); }
+  }
+  dba = wave_sum(dba); dbb = wave_sum(dbb);
+  if (lane == 0) { atomicAdd(&sm[128], dba); atomicAdd(&sm[129], dbb); }
+  if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) atomicAdd(&sm[130 + hsel[i]], da[i]);
   }
   __syncthreads();
   float* out = part + (long)blockIdx.x * PW;
@@ -606,6 +827,21 @@ int wavlm_gate_fwd(const void* x, const void* W, const void* bias, const void* g
   long grid = ((long)B * T + 3) / 4; if (grid > 8192) grid = 8192;
   const bool fast = hd == 64 && H <= 16 && (((uintptr_t)x) & 15) == 0;
   if (fast) { grid = ((long)B * T + 7) / 8; if (grid > 2048) grid = 2048; }
+  static const bool piped = !(getenv("WAVLM_GATE_PIPED") && getenv("WAVLM_GATE_PIPED")[0] == '0');  // A/B switch
+  if (fast && piped && (H == 12 || H == 16) && (((uintptr_t)W) & 15) == 0) {
+    static const int fwd_blocks = getenv("WAVLM_GATE_FWD_BLOCKS") ? atoi(getenv("WAVLM_GATE_FWD_BLOCKS")) : 512;  // measurement switch
+    if (grid > fwd_blocks) grid = fwd_blocks;
+#define GFP(TT, TP) do { if (H == 12) WL_LAUNCH((gate_fwd64p_kernel<TT, TP, 3>), dim3((unsigned)grid), dim3(256), 0, st, (const TT*)x, \
+      (const TP*)W, (const TP*)bias, (const TP*)grep_a, gate, ga, gb, (int)B, (int)T); \
+    else WL_LAUNCH((gate_fwd64p_kernel<TT, TP, 4>), dim3((unsigned)grid), dim3(256), 0, st, (const TT*)x, \
+      (const TP*)W, (const TP*)bias, (const TP*)grep_a, gate, ga, gb, (int)B, (int)T); } while (0)
+    if (dtype == WL_F32 && param_dtype == WL_F32) GFP(float, float);
+    else if (dtype == WL_BF16 && param_dtype == WL_BF16) GFP(bf16_t, bf16_t);
+    else if (dtype == WL_BF16 && param_dtype == WL_F32) GFP(bf16_t, float);
+    else return WL_EINVAL;
+#undef GFP
+    return wl_check_launch();
+  }
 #define GF(TT, TP) do { if (fast) WL_LAUNCH((gate_fwd64_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), 0, st, (const TT*)x, \
     (const TP*)W, (const TP*)bias, (const TP*)grep_a, gate, ga, gb, (int)B, (int)T, (int)H); \
   else WL_LAUNCH((gate_fwd_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), 0, st, (const TT*)x, \
@@ -632,6 +868,21 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
   long grid = ((long)B * T + 3) / 4; if (grid > GATE_BLOCKS) grid = GATE_BLOCKS;
   const size_t smem = 4 * (2 * (size_t)hd + 2 + H) * sizeof(float);
   const bool fast = hd == 64 && H <= 16 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)dx) & 15) == 0;
+  static const bool piped = !(getenv("WAVLM_GATE_PIPED") && getenv("WAVLM_GATE_PIPED")[0] == '0');  // A/B switch
+  const bool fastp = fast && piped && (H == 12 || H == 16) && (((uintptr_t)W) & 15) == 0;
+  static const int bwd_blocks = getenv("WAVLM_GATE_BWD_BLOCKS") ? atoi(getenv("WAVLM_GATE_BWD_BLOCKS")) : 512;  // measurement switch
+  if (fastp && bwd_blocks > 0 && bwd_blocks < GATE_BLOCKS && grid > bwd_blocks) grid = bwd_blocks;
+  if (!fastp && grid > 512) grid = 512;
+#define GBP4(TT, TP, NI_, ACC_) WL_LAUNCH((gate_bwd64p_kernel<TT, TP, NI_, ACC_>), dim3((unsigned)grid), dim3(256), smem, st, dgate, \
+    (const TT*)x, (const TP*)W, (const TP*)grep_a, ga, gb, (TT*)dx, (float*)workspace, (int)B, (int)T)
+#define GBP(TT, TP) do { if (H == 12) { if (accumulate_params & 2) GBP4(TT, TP, 3, true); else GBP4(TT, TP, 3, false); } \
+    else { if (accumulate_params & 2) GBP4(TT, TP, 4, true); else GBP4(TT, TP, 4, false); } } while (0)
+  if (fastp) {
+    if (dtype == WL_F32 && param_dtype == WL_F32) GBP(float, float);
+    else if (dtype == WL_BF16 && param_dtype == WL_BF16) GBP(bf16_t, bf16_t);
+    else if (dtype == WL_BF16 && param_dtype == WL_F32) GBP(bf16_t, float);
+    else return WL_EINVAL;
+  } else {
 #define GB(TT, TP) do { if (fast) WL_LAUNCH((gate_bwd64_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), smem, st, dgate, \
     (const TT*)x, (const TP*)W, (const TP*)grep_a, ga, gb, (TT*)dx, (float*)workspace, (int)B, (int)T, (int)H, (int)(accumulate_params & 2)); \
   else WL_LAUNCH((gate_bwd_kernel<TT, TP>), dim3((unsigned)grid), dim3(256), smem, st, dgate, \
@@ -641,6 +892,9 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
   else if (dtype == WL_BF16 && param_dtype == WL_F32) GB(bf16_t, float);
   else return WL_EINVAL;
 #undef GB
+  }
+#undef GBP
+#undef GBP4
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
   WL_LAUNCH(gate_bwd_finish_kernel, dim3((unsigned)((2 * hd + 2 + H + 15) / 16)), dim3(1024), 0, st, (const float*)workspace,

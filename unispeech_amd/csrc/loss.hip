@@ -214,26 +214,25 @@ __device__ __forceinline__ void glu_gate(int gate, float b, float& g, float& dg)
   else { g = b; dg = 1.f; }
 }
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, long rows, int F, int dt, int gate) {
-  const long n = rows * F;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const long r = i / F; const int c = (int)(i - r * F);
-    const float a = ld_elem(x, r * 2 * F + c, dt), b = ld_elem(x, r * 2 * F + F + c, dt);
-    float g, dg;
-    glu_gate(gate, b, g, dg);
-    st_elem(y, i, dt, a * g);
-  }
+  // rows over blocks, columns over threads: no per-element 64-bit division (the feed-forward form runs on [24 k, 2 x 3072])
+  for (long r = blockIdx.x; r < rows; r += gridDim.x)
+    for (int c = threadIdx.x; c < F; c += 256) {
+      const float a = ld_elem(x, r * 2 * F + c, dt), b = ld_elem(x, r * 2 * F + F + c, dt);
+      float g, dg;
+      glu_gate(gate, b, g, dg);
+      st_elem(y, r * F + c, dt, a * g);
+    }
 }
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, void* __restrict__ dx,
                                                       long rows, int F, int dt, int gate) {
-  const long n = rows * F;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const long r = i / F; const int c = (int)(i - r * F);
-    const float a = ld_elem(x, r * 2 * F + c, dt), b = ld_elem(x, r * 2 * F + F + c, dt), gy = ld_elem(dy, i, dt);
-    float g, dg;
-    glu_gate(gate, b, g, dg);
-    st_elem(dx, r * 2 * F + c, dt, gy * g);
-    st_elem(dx, r * 2 * F + F + c, dt, gy * a * dg);
-  }
+  for (long r = blockIdx.x; r < rows; r += gridDim.x)
+    for (int c = threadIdx.x; c < F; c += 256) {
+      const float a = ld_elem(x, r * 2 * F + c, dt), b = ld_elem(x, r * 2 * F + F + c, dt), gy = ld_elem(dy, r * F + c, dt);
+      float g, dg;
+      glu_gate(gate, b, g, dg);
+      st_elem(dx, r * 2 * F + c, dt, gy * g);
+      st_elem(dx, r * 2 * F + F + c, dt, gy * a * dg);
+    }
 }
 
 // Elementwise activations of the feed-forward block other than the erf GELU (which lives in the GEMM epilogues):
@@ -375,7 +374,7 @@ int wavlm_bce_logits(const float* logits, const uint8_t* targets, float* dlogits
 int wavlm_glu_fwd(const void* x, void* y, int64_t rows, int32_t F, int32_t dtype, int32_t gate, void* stream) {
   if (!x || !y || rows < 0 || F <= 0 || gate < 0 || gate > 4 || (dtype != WL_F32 && dtype != WL_BF16)) return WL_EINVAL;
   if (rows == 0) return WL_OK;
-  long grid = (rows * F + 255) / 256; if (grid > 8192) grid = 8192;
+  long grid = rows; if (grid > 8192) grid = 8192;
   WL_LAUNCH(glu_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, (int)F, (int)dtype, (int)gate);
   return wl_check_launch();
 }
@@ -383,7 +382,7 @@ int wavlm_glu_fwd(const void* x, void* y, int64_t rows, int32_t F, int32_t dtype
 int wavlm_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int32_t F, int32_t dtype, int32_t gate, void* stream) {
   if (!x || !dy || !dx || rows < 0 || F <= 0 || gate < 0 || gate > 4 || (dtype != WL_F32 && dtype != WL_BF16)) return WL_EINVAL;
   if (rows == 0) return WL_OK;
-  long grid = (rows * F + 255) / 256; if (grid > 8192) grid = 8192;
+  long grid = rows; if (grid > 8192) grid = 8192;
   WL_LAUNCH(glu_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)rows, (int)F, (int)dtype, (int)gate);
   return wl_check_launch();
 }
