@@ -443,8 +443,9 @@ __global__ __launch_bounds__(256) void gate_bwd64_kernel(const float* __restrict
 // gb) is in flight while step n computes: backward 35.0 -> 24.2 us per layer, forward 17.0 -> 14.6 us (profiles/r03/
 // envab_gate_piped.txt).  What did NOT matter (same file family): the grid (256 ... 4096 blocks), 16-byte weight loads in the
 // prologue, contiguous row ranges per block (whole output lines per XCD), and removing the 64-bit row / Tn per chunk and
-// step -- a 37 MB pass of ~15 us is launch ramp + first-fetch latency + tail for half of its duration; the remaining lever is
-// to compute the gate inside the LayerNorm kernel that already streams this tensor.
+// step -- a 37 MB pass of ~13 us is launch ramp + first-fetch latency + tail for half of its duration.  Computing the gate
+// inside the LayerNorm kernels that stream this tensor anyway was built and measured too: the extra
+// registers cost those kernels an occupancy step and most of what the two gate kernels take.
 template <typename T> struct GateRaw;  // one 16-byte (bf16) / 32-byte (fp32) chunk of 8 channels as loaded
 template <> struct GateRaw<bf16_t> {
   uint4 a;
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(256) void gate_fwd64p_kernel(const T* __restrict__ 
     const TP* __restrict__ bias, const TP* __restrict__ grep_a, float* __restrict__ gate, float* __restrict__ ga_o,
     float* __restrict__ gb_o, int B, int Tn) {
   constexpr int H = 4 * NI, D = H * 64, CPR = 8 * H;
+  extern __shared__ __attribute__((aligned(16))) float stg[];  // [3][H][R]: the block's outputs, written out at the end
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long nbt = (long)B * Tn, npair = (nbt + 1) >> 1;
   const int sub = lane & 7;
@@ -498,12 +500,15 @@ __global__ __launch_bounds__(256) void gate_fwd64p_kernel(const T* __restrict__ 
     rsel[i] = q / CPR; hsel[i] = (q % CPR) >> 3;
     av[i] = Elem<TP>::ld(grep_a + hsel[i]);
   }
-  // a block walks a contiguous range of row pairs (the [B, H, T] outputs are 4-byte writes along t: whole lines per block)
+  // A block walks a contiguous range of row pairs and keeps its [B, H, T] outputs in LDS until the end: written from the loop
+  // they are 36 scattered 4-byte stores per row, and every wait for the next step's prefetched rows (s_waitcnt vmcnt) also
+  // waits for those stores' acknowledgements -- one store round trip per step was the kernel's time (14.6 us for 37 MB,
+  // whatever the grid or the instruction count).
   const long per = (npair + gridDim.x - 1) / gridDim.x;
-  const long pend = min(npair, (long)(blockIdx.x + 1) * per);
+  const long p0 = (long)blockIdx.x * per, pend = min(npair, p0 + per);
+  const int R = (int)(2 * per);
   constexpr long pstep = 4;
-  long rp = (long)blockIdx.x * per + wave;
-  if (rp >= pend) return;
+  long rp = p0 + wave;
   GateRaw<T> px[NI];
   auto fetch = [&](long rp_) __attribute__((always_inline)) {
 #pragma unroll
@@ -512,17 +517,7 @@ __global__ __launch_bounds__(256) void gate_fwd64p_kernel(const T* __restrict__ 
       px[i].ld(x + row * D + ((lane + 64 * i) % CPR) * 8);
     }
   };
-  fetch(rp);
-  // output offset (b * H + h) * Tn + t of this lane's row, advanced by 8 rows per step (no 64-bit division in the loop)
-  long oo[NI];
-  int tt[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const long row = 2 * rp + rsel[i];
-    const long b = row / Tn;
-    tt[i] = (int)(row - b * Tn);
-    oo[i] = (b * H + hsel[i]) * Tn + tt[i];
-  }
+  if (rp < pend) fetch(rp);
   for (; rp < pend; rp += pstep) {
     float xv[NI][8];
 #pragma unroll
@@ -534,15 +529,25 @@ __global__ __launch_bounds__(256) void gate_fwd64p_kernel(const T* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 8; ++e) { sa = fmaf(xv[i][e], wa[e], sa); sb = fmaf(xv[i][e], wb[e], sb); }
       sa = wl_sum8(sa); sb = wl_sum8(sb);
-      const long row = 2 * rp + rsel[i];
-      if (sub == 0 && row < nbt) {
-        const float ga = 1.f / (1.f + __expf(-(sa + ba))), gb = 1.f / (1.f + __expf(-(sb + bb)));
-        const long o = oo[i];
-        gate[o] = ga * (gb * av[i] - 1.f) + 2.f;
-        ga_o[o] = ga; gb_o[o] = gb;
+      if (sub == 0) {
+        const float ga = __builtin_amdgcn_rcpf(1.f + __expf(-(sa + ba))), gb = __builtin_amdgcn_rcpf(1.f + __expf(-(sb + bb)));
+        const int rr = (int)(2 * (rp - p0)) + rsel[i];
+        stg[hsel[i] * R + rr] = ga * (gb * av[i] - 1.f) + 2.f;
+        stg[(H + hsel[i]) * R + rr] = ga;
+        stg[(2 * H + hsel[i]) * R + rr] = gb;
       }
-      tt[i] += 2 * (int)pstep; oo[i] += 2 * pstep;
-      while (tt[i] >= Tn) { tt[i] -= Tn; oo[i] += (long)(H - 1) * Tn; }
+    }
+  }
+  __syncthreads();
+  const long row0 = 2 * p0;
+  const int nrow = (int)min((long)R, nbt - row0);
+  for (int idx = threadIdx.x; idx < 3 * H * R; idx += 256) {
+    const int rr = idx % R, ah = idx / R, h = ah % H, arr = ah / H;
+    if (rr < nrow) {
+      const long row = row0 + rr;
+      const long b = row / Tn; const int t = (int)(row - b * Tn);
+      float* dst = arr == 0 ? gate : arr == 1 ? ga_o : gb_o;
+      dst[(b * H + h) * Tn + t] = stg[idx];
     }
   }
 }
@@ -831,9 +836,13 @@ int wavlm_gate_fwd(const void* x, const void* W, const void* bias, const void* g
   if (fast && piped && (H == 12 || H == 16) && (((uintptr_t)W) & 15) == 0) {
     static const int fwd_blocks = getenv("WAVLM_GATE_FWD_BLOCKS") ? atoi(getenv("WAVLM_GATE_FWD_BLOCKS")) : 512;  // measurement switch
     if (grid > fwd_blocks) grid = fwd_blocks;
-#define GFP(TT, TP) do { if (H == 12) WL_LAUNCH((gate_fwd64p_kernel<TT, TP, 3>), dim3((unsigned)grid), dim3(256), 0, st, (const TT*)x, \
+    const long npair_ = ((long)B * T + 1) / 2;
+    if (grid < (npair_ + 63) / 64) grid = (npair_ + 63) / 64;  // at most 64 row pairs per block: the staging slice stays < 25 KiB
+    const long per_ = (npair_ + grid - 1) / grid;
+    const size_t smemf = (size_t)3 * H * 2 * per_ * sizeof(float);
+#define GFP(TT, TP) do { if (H == 12) WL_LAUNCH((gate_fwd64p_kernel<TT, TP, 3>), dim3((unsigned)grid), dim3(256), smemf, st, (const TT*)x, \
       (const TP*)W, (const TP*)bias, (const TP*)grep_a, gate, ga, gb, (int)B, (int)T); \
-    else WL_LAUNCH((gate_fwd64p_kernel<TT, TP, 4>), dim3((unsigned)grid), dim3(256), 0, st, (const TT*)x, \
+    else WL_LAUNCH((gate_fwd64p_kernel<TT, TP, 4>), dim3((unsigned)grid), dim3(256), smemf, st, (const TT*)x, \
       (const TP*)W, (const TP*)bias, (const TP*)grep_a, gate, ga, gb, (int)B, (int)T); } while (0)
     if (dtype == WL_F32 && param_dtype == WL_F32) GFP(float, float);
     else if (dtype == WL_BF16 && param_dtype == WL_BF16) GFP(bf16_t, bf16_t);
