@@ -381,8 +381,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     constexpr bool FIRST = decltype(first_c)::value;
     const bool more1 = SD || t + 1 < nt, more2 = SD || t + 2 < nt;
     auto issue = [&](auto which_c, int stage) __attribute__((always_inline)) { issue_gen(which_c, stage); };
-#if PP_DMA_RD
-    if constexpr (SD) {
+    // (the grouped weight-gradient launch keeps the in-section issue: read-interval issue measured +6 % there, 340 -> 361 us
+    // per layer, against -1 ... -2 % on the conv stack's launches: profiles/r03/ab_pp_dma_rd_step.txt)
+    if constexpr (SD && PP_DMA_RD != 0 && !GRP) {
       // Steady state, DMA in the IDLE read intervals: the four phases read 12 / 4 / 8 / 0 fragments, so the waves have
       // nothing to do in the P4 read interval and little in P2's, while a DMA instruction costs its issuer 40-60 cycles
       // wherever it sits -- inside an MFMA section that is 40 cycles of an idle matrix pipe per instruction (K step 2160
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
       }
       return;
     }
-#else
+
     if constexpr (SD) {
       // same phases; the half-tile of a phase is issued by each wave inside its own MFMA section (after MFMA pairs 1 and
       // 3), so the read interval is ds_reads only and a full vector-memory queue stalls behind running MFMAs.  The
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
       }
       return;
     }
-#endif
+
     // ---- P1: A-top, B-left -> quadrant (0,0)
 #pragma unroll
     for (int s = 0; s < 4; ++s) bl[s] = rd_b(SB + 2 * PP_HB, s);
