@@ -17,6 +17,8 @@ for a in sys.argv[1:] or ["1", "2", "3", "4"]:
     src = "gemm_pp.hip"
     if a.startswith("pp3:"):
         src, a = "gemm_pp3.hip", a[4:]
+    elif a.startswith("row:"):  # row:<tag>:-DLN_PF2=1 builds rowops.hip with the defines
+        src, a = "rowops.hip", a[4:]
     elif a.startswith("attn:"):  # attn:<tag>:-DFA_FWD_LAZY=1,... builds attn_fused.hip (forward + dQ kernels) with the defines
         src, a = "attn_fused.hip", a[5:]
     tag, defs = (a, ["-DPP_PROBE=%d" % int(a)]) if a.isdigit() else (a.split(":")[0], a.split(":")[1].split(","))
