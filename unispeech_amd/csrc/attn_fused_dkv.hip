@@ -111,16 +111,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
           const int rr = 4 * q4 + e;
           // x - lse as two fmas (the -lse rides in the bias term)
           const float pe = __builtin_amdgcn_exp2f(fmaf(s[rr], p.sc2, fmaf(gatv[e], tq[-e], lsev[e])));  // rows past T: -inf -> 0
-          float dpe = dp[rr];
           float pd = pe;
           if constexpr (DROP) {
             const unsigned w = fa_mix(roww[e] + cw);
             const bool kp = (int)(short)((w >> csh) & 0xffffu) >= p.ths;
             pd = kp ? pe : 0.f;
-            dpe = kp ? dpe : 0.f;
           }
           pv[e] = pd;
-          dsv[e] = pe * (dpe - delv[e]);
+          // dS = P (keep dP - delta) = (keep P) dP - P delta: the kept probability is needed anyway (dV), so one select
+          // instead of two
+          dsv[e] = fmaf(pd, dp[rr], -(pe * delv[e]));
         }
         pf[q4 >> 1].u[2 * (q4 & 1)] = pack_bf16(pv[0], pv[1]);
         pf[q4 >> 1].u[2 * (q4 & 1) + 1] = pack_bf16(pv[2], pv[3]);
