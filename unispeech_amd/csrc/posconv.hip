@@ -120,13 +120,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void pc_group_major_kernel(const T* __restrict__ x, const T* __restrict__ aux,
     T* __restrict__ out, T* __restrict__ nat, int B, int Tn, int D, int G, int left_pad, int Tp, int aux_is_grad) {
   const int Cg = D / G, c8n = Cg >> 3;
-  const long total = (long)B * G * Tp * c8n;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c8 = (int)(i % c8n);
-    long r = i / c8n;
-    const int tp = (int)(r % Tp); r /= Tp;
-    const int g = (int)(r % G);
-    const int b = (int)(r / G);
+  const long total = (long)B * G * Tp * c8n;  // (< 2^31, checked by the launcher: the index arithmetic below is 32-bit --
+  // three 64-bit divisions per 16-byte chunk were most of this copy kernel's instruction stream)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % (unsigned)c8n);
+    unsigned r = i / (unsigned)c8n;
+    const int tp = (int)(r % (unsigned)Tp); r /= (unsigned)Tp;
+    const int g = (int)(r % (unsigned)G);
+    const int b = (int)(r / (unsigned)G);
     const int t = tp - left_pad;
     unsigned short o[8];
 #pragma unroll
@@ -233,6 +234,7 @@ int wavlm_posconv_group_major(const void* x, const void* aux, void* out, void* n
     return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)B * G * Tp * ((D / G) >> 3);
+  if (total >= (1L << 31) - 8192L * 256) return WL_EINVAL;  // 32-bit chunk indices in the kernel (16 bytes per chunk: 32 GiB)
   long grid = (total + 255) / 256; if (grid > 8192) grid = 8192;
   if (dtype == WL_F32)
     WL_LAUNCH((pc_group_major_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)x,
