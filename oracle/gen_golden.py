@@ -502,6 +502,8 @@ def gen_tiny_w2v2_variants():
     gen_tiny_w2v2({"negatives_from_everywhere": True, "quantize_targets": False}, "tiny_w2v2_everywhere.npz")
     # quantised encoder input through its own quantiser + project_inp, and Linear + GLU on targets and negatives
     gen_tiny_w2v2({"quantize_input": True, "target_glu": True}, "tiny_w2v2_qinput_glu.npz")
+    # two-layer projection in front of the quantiser's logits (quantizer_depth 2, inner width 2 x)
+    gen_tiny_w2v2({"quantizer_depth": 2, "quantizer_factor": 2}, "tiny_w2v2_qdepth.npz")
 
 
 def gen_tiny_w2v2(overrides=None, fname="tiny_w2v2.npz"):

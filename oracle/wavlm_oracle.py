@@ -524,7 +524,13 @@ def gumbel_vq(sd, prefix, x, groups, num_vars, tau, training):
     time_first=True.  x [B, T, C].  Training draws the Gumbel noise with F.gumbel_softmax from the global torch generator,
     exactly as the reference does."""
     bsz, tsz, fsz = x.shape
-    lg = F.linear(x.reshape(-1, fsz), sd[prefix + "weight_proj.weight"], sd[prefix + "weight_proj.bias"])
+    h = x.reshape(-1, fsz)
+    i = 0
+    while prefix + "weight_proj.%d.0.weight" % i in sd:  # weight_proj_depth > 1: Linear + GELU blocks (lines 54-66)
+        h = F.gelu(F.linear(h, sd[prefix + "weight_proj.%d.0.weight" % i], sd[prefix + "weight_proj.%d.0.bias" % i]))
+        i += 1
+    wk = prefix + ("weight_proj.%d." % i if i else "weight_proj.")
+    lg = F.linear(h, sd[wk + "weight"], sd[wk + "bias"])
     lg = lg.view(bsz * tsz * groups, -1)
     _, k = lg.max(-1)
     hard_x = lg.new_zeros(*lg.shape).scatter_(-1, k.view(-1, 1), 1.0).view(bsz * tsz, groups, -1)

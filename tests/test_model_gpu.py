@@ -481,7 +481,8 @@ def test_fused_adam_vs_reference_optimizer_golden():
 @pytest.mark.parametrize("golden,overrides", [("tiny_w2v2.npz", {}),
                                               ("tiny_w2v2_everywhere_cb.npz", {"negatives_from_everywhere": True, "codebook_negatives": 2}),
                                               ("tiny_w2v2_everywhere.npz", {"negatives_from_everywhere": True, "quantize_targets": False}),
-                                              ("tiny_w2v2_qinput_glu.npz", {"quantize_input": True, "target_glu": True})])
+                                              ("tiny_w2v2_qinput_glu.npz", {"quantize_input": True, "target_glu": True}),
+                                              ("tiny_w2v2_qdepth.npz", {"quantizer_depth": 2, "quantizer_factor": 2})])
 def test_wav2vec2_model_vs_reference_golden(golden, overrides):
     """wav2vec 2.0 (north_star's `src/fairseq/models/wav2vec` encoder) on the HIP path against the golden
     generated from the reference's Wav2Vec2Model + Wav2vecCriterion(infonce): Gumbel quantiser in train mode (noise drawn on

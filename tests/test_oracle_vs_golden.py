@@ -416,7 +416,8 @@ W2V2.update(final_dim=32, quantize_targets=True, latent_vars=20, latent_groups=2
 W2V2_GOLDENS = [("tiny_w2v2.npz", {}),
                 ("tiny_w2v2_everywhere_cb.npz", {"negatives_from_everywhere": True, "codebook_negatives": 2}),
                 ("tiny_w2v2_everywhere.npz", {"negatives_from_everywhere": True, "quantize_targets": False}),
-                ("tiny_w2v2_qinput_glu.npz", {"quantize_input": True, "target_glu": True})]
+                ("tiny_w2v2_qinput_glu.npz", {"quantize_input": True, "target_glu": True}),
+                ("tiny_w2v2_qdepth.npz", {"quantizer_depth": 2, "quantizer_factor": 2})]
 
 
 def _w2v2_cfg(overrides=None):

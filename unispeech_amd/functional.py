@@ -980,6 +980,23 @@ class MaskedPredLossFn(torch.autograd.Function):
         return dproj, demb, None, None, None
 
 
+class ActFn(torch.autograd.Function):
+    """elementwise activation of ops.ACT_KINDS (erf gelu, relu, gelu_accurate, tanh) on its own -- the projection MLP of a deeper
+    GumbelVectorQuantizer (modules/gumbel_vector_quantizer.py:54-66)"""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc)
+        ctx.kind = kind
+        return ops.act_fwd(xc, kind)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        return ops.act_bwd(xc, dy.contiguous(), ctx.kind), None
+
+
 class GLUFn(torch.autograd.Function):
     """nn.GLU over the last dimension (target_glu's second half, src/fairseq/models/wavlm/wavlm.py:322-327)"""
 

@@ -13,7 +13,7 @@ one-hot x codebook product is a gather, and index lists come from the host-gener
 
 negatives_from_everywhere and codebook_negatives (wav2vec2.py:653-686) are built on the same gathered-row head (the candidate
 table grows by one projected row per frame / per sampled code).  Options of the reference that no shipped recipe uses and
-that raise NotImplementedError: transpose, quantizer_depth > 1, and the non-infonce (BCE)
+that raise NotImplementedError: transpose and the non-infonce (BCE)
 criterion (it pairs with wav2vec 1.0's get_targets / get_target_weights, models/wav2vec/wav2vec.py, outside SURVEY.md 8).
 """
 import ast
@@ -96,16 +96,23 @@ class GumbelVectorQuantizer(nn.Module):
     def __init__(self, dim, num_vars, temp, groups, combine_groups, vq_dim, time_first, weight_proj_depth=1,
                  weight_proj_factor=1):
         super().__init__()
-        if combine_groups or not time_first or weight_proj_depth != 1:
-            raise NotImplementedError("GumbelVectorQuantizer: only combine_groups=False, time_first=True, depth 1")
+        if combine_groups or not time_first:
+            raise NotImplementedError("GumbelVectorQuantizer: only combine_groups=False, time_first=True")
         self.groups, self.combine_groups, self.input_dim, self.num_vars, self.time_first = groups, False, dim, num_vars, True
         assert vq_dim % groups == 0, f"dim {vq_dim} must be divisible by groups {groups} for concatenation"
         var_dim = vq_dim // groups
         self.vars = nn.Parameter(torch.FloatTensor(1, groups * num_vars, var_dim))
         nn.init.uniform_(self.vars)
-        self.weight_proj = nn.Linear(self.input_dim, groups * num_vars)
-        nn.init.normal_(self.weight_proj.weight, mean=0, std=1)
-        nn.init.zeros_(self.weight_proj.bias)
+        if weight_proj_depth > 1:  # Linear + GELU blocks in front of the logits projection (default nn.Linear init, as the reference)
+            inner_dim = self.input_dim * weight_proj_factor
+            self.weight_proj = nn.Sequential(
+                *[nn.Sequential(nn.Linear(self.input_dim if i == 0 else inner_dim, inner_dim), nn.GELU())
+                  for i in range(weight_proj_depth - 1)],
+                nn.Linear(inner_dim, groups * num_vars))
+        else:
+            self.weight_proj = nn.Linear(self.input_dim, groups * num_vars)
+            nn.init.normal_(self.weight_proj.weight, mean=0, std=1)
+            nn.init.zeros_(self.weight_proj.bias)
         if isinstance(temp, str):
             temp = ast.literal_eval(temp)
         assert len(temp) == 3, f"{temp}, {len(temp)}"
@@ -120,7 +127,13 @@ class GumbelVectorQuantizer(nn.Module):
         """x [B, T, C] -> {"x": [B, T, vq_dim], "prob_perplexity", "code_perplexity", "num_vars", "temp", ("targets")}"""
         B, T, C = x.shape
         G, V = self.groups, self.num_vars
-        logits = F.LinearFn.apply(x.reshape(B * T, C), self.weight_proj.weight, self.weight_proj.bias)
+        if isinstance(self.weight_proj, nn.Sequential):
+            h = x.reshape(B * T, C)
+            for blk in list(self.weight_proj)[:-1]:
+                h = F.ActFn.apply(F.LinearFn.apply(h, blk[0].weight, blk[0].bias), "gelu")
+            logits = F.LinearFn.apply(h, self.weight_proj[-1].weight, self.weight_proj[-1].bias)
+        else:
+            logits = F.LinearFn.apply(x.reshape(B * T, C), self.weight_proj.weight, self.weight_proj.bias)
         noise = None
         if self.training and self.gumbel_noise == "host":
             noise = F.h2d(F.host_gumbel_noise(B * T * G, V), x.device)
@@ -156,8 +169,6 @@ class Wav2Vec2Model(nn.Module):
         super().__init__()
         if getattr(cfg, "transpose", False):
             raise NotImplementedError("wav2vec 2.0 option transpose is not supported by the HIP path")
-        if getattr(cfg, "quantizer_depth", 1) != 1:
-            raise NotImplementedError("quantizer_depth > 1 is not supported by the HIP path")
         self.negatives_from_everywhere = bool(getattr(cfg, "negatives_from_everywhere", False))
         self.codebook_negatives = int(getattr(cfg, "codebook_negatives", 0))
         if self.codebook_negatives > 0 and not cfg.quantize_targets:
@@ -189,7 +200,8 @@ class Wav2Vec2Model(nn.Module):
             vq_dim = cfg.latent_dim if cfg.latent_dim > 0 else final_dim
             self.quantizer = GumbelVectorQuantizer(dim=self.embed, num_vars=cfg.latent_vars, temp=cfg.latent_temp,
                                                    groups=cfg.latent_groups, combine_groups=False, vq_dim=vq_dim,
-                                                   time_first=True)
+                                                   time_first=True, weight_proj_depth=cfg.quantizer_depth,
+                                                   weight_proj_factor=cfg.quantizer_factor)
             self.project_q = nn.Linear(vq_dim, final_dim)
         else:
             self.project_q = nn.Linear(self.embed, final_dim)
@@ -202,7 +214,8 @@ class Wav2Vec2Model(nn.Module):
                 vq_dim = cfg.latent_dim if cfg.latent_dim > 0 else cfg.encoder_embed_dim
                 self.input_quantizer = GumbelVectorQuantizer(dim=self.embed, num_vars=cfg.latent_vars, temp=cfg.latent_temp,
                                                              groups=cfg.latent_groups, combine_groups=False, vq_dim=vq_dim,
-                                                             time_first=True)
+                                                             time_first=True, weight_proj_depth=cfg.quantizer_depth,
+                                                             weight_proj_factor=cfg.quantizer_factor)
             self.project_inp = nn.Linear(vq_dim, cfg.encoder_embed_dim)
         self.mask_emb = nn.Parameter(torch.FloatTensor(cfg.encoder_embed_dim).uniform_())
         self.encoder = TransformerEncoder(cfg)
