@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_full_kernel(const T* __rest
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      if constexpr (HS) stv<VEC>(s + row * D + (lane + 64 * c) * VEC, v[c]);
+      if constexpr (HS) { if (s) stv<VEC>(s + row * D + (lane + 64 * c) * VEC, v[c]); }  // (no residual: s IS x, not stored again)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) sum += v[c][e];
     }
@@ -813,15 +813,17 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   WlProfScope prof(WL_PROF_LN_FWD, dtype, 8.0 * rows * D, g_ln_prof_bytes, st);
   const unsigned grid = grid_for(rows, 4, (ti | to) ? LN_FWD_DROP_BLOCKS : 8192);  // with dropout: several rows per wave amortise the column words
   // the path's own widths run the branch-free, software-pipelined kernels (a few rows per wave: the pipeline needs them)
-  if (ln_full_enabled() && (D == 512 || D == 768 || D == 1024) && (s == nullptr) == (mean == nullptr) && (s == nullptr) == (rstd == nullptr)) {
+  // (HS = the row statistics are kept; without a residual the pre-norm sum is x itself and s stays NULL -- until round 3 that
+  // case fell through to the general kernels: the extractor's LayerNorms of layer_norm-mode models, the encoder's first one)
+  if (ln_full_enabled() && (D == 512 || D == 768 || D == 1024) && (mean == nullptr) == (rstd == nullptr) && (!s || mean)) {
     static const int cap = getenv("WAVLM_LN_FWD_BLOCKS") ? atoi(getenv("WAVLM_LN_FWD_BLOCKS")) : 1024;
     const unsigned gridf = grid_for(rows, 4, (unsigned)(cap > 0 ? cap : 1024));
 #define LNF_K(T, TP, VEC, NCS, HR, HS) WL_LAUNCH((layernorm_fwd_full_kernel<T, TP, VEC, NCS, HR, HS>), dim3(gridf), dim3(256), 0, st, \
     (const T*)x, (const T*)r, (T*)y, (T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (long)rows, eps, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out)
 #define LNF_W(T, TP, HR, HS) do { if (D == 512) LNF_K(T, TP, 8, 1, HR, HS); else if (D == 768) LNF_K(T, TP, 4, 3, HR, HS); else LNF_K(T, TP, 8, 2, HR, HS); } while (0)
-#define LNF(T, TP) do { if (r) { if (s) LNF_W(T, TP, true, true); else LNF_W(T, TP, true, false); } \
-                        else { if (s) LNF_W(T, TP, false, true); else LNF_W(T, TP, false, false); } } while (0)
+#define LNF(T, TP) do { if (r) { if (mean) LNF_W(T, TP, true, true); else LNF_W(T, TP, true, false); } \
+                        else { if (mean) LNF_W(T, TP, false, true); else LNF_W(T, TP, false, false); } } while (0)
     if (dtype == WL_F32 && param_dtype == WL_F32) LNF(float, float);
     else if (dtype == WL_BF16 && param_dtype == WL_BF16) LNF(bf16_t, bf16_t);
     else if (dtype == WL_BF16 && param_dtype == WL_F32) LNF(bf16_t, float);
