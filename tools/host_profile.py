@@ -1,6 +1,6 @@
 """cProfile of the launch thread: where does the host time of a pre-training step go?  Batch 1 (the same launches with almost
 no GPU work), GC frozen, 6 profiled steps; prints the 40 most expensive functions by internal time.
-usage (GPU box): python tools/host_profile.py [steps]"""
+usage (GPU box): python tools/host_profile.py [steps] [batch]"""
 import cProfile
 import gc
 import io
@@ -24,7 +24,7 @@ torch.manual_seed(0)
 model = WavLMPretrainModel(cfg, None, [range(bench.V)]).to(dev).to(torch.bfloat16).train()
 opt = FusedAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=10.0, model=model)
 crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0], defer_logging=True)
-B, T = 1, int(bench.SECONDS * bench.SR)
+B, T = (int(sys.argv[2]) if len(sys.argv) > 2 else 1), int(bench.SECONDS * bench.SR)
 g = torch.Generator().manual_seed(1234)
 wav = torch.randn(B, T, generator=g).to(dev).to(torch.bfloat16)
 pm_cpu = torch.zeros(B, T, dtype=torch.bool)
@@ -53,6 +53,6 @@ pr.disable()
 torch.cuda.synchronize()
 out = io.StringIO()
 st = pstats.Stats(pr, stream=out).sort_stats("tottime")
-st.print_stats(40)
+st.print_stats(28)
 txt = out.getvalue()
 print("\n".join(l[:170] for l in txt.split("\n")))

@@ -68,8 +68,10 @@ def reset_sink_uses():
 
 def _sink_use(p, explicit=None):
     """forward side: this parameter (or explicit sink view) will receive one more accumulation in backward"""
+    if not SINK_LISTENERS:  # (single process: nobody listens -- skip the p.grad look-up, ~170 calls per step)
+        return
     t = explicit if explicit is not None else _sink(p)
-    if t is not None and SINK_LISTENERS:
+    if t is not None:
         k = t.data_ptr()
         _SINK_USES[k] = _SINK_USES.get(k, 0) + 1
 
