@@ -431,13 +431,19 @@ def main():
 
     roof = None
     if not args.no_roofline:
-        ops.prof_enable(True)
-        for _ in range(2):
+        # Three single-step passes, the one with the smallest GEMM time is reported.  The events bracket each launch ON THE
+        # STREAM; with the events' own host cost the launch thread runs level with the GPU, so one of the HIP runtime's
+        # periodic launch stalls (tens of ms every ~2000 launches on these boxes) lands between an event and its kernel
+        # and is booked as kernel time (observed once: 40 ms of "GEMM time" in a 36 ms step).  A stall can only inflate.
+        best = None
+        for _ in range(3):
+            ops.prof_enable(True)
             step()
-        n_l, ms, fl = ops.prof_collect(1)
-        alg_bytes = ops.prof_collect_bytes(1)
-        kern = kernel_rooflines(ops, 2)
-        ops.prof_enable(False)
+            got = (ops.prof_collect(1), ops.prof_collect_bytes(1), kernel_rooflines(ops, 1))
+            ops.prof_enable(False)
+            if got[0][1] > 0 and (best is None or got[0][1] < best[0][1]):
+                best = got
+        (n_l, ms, fl), alg_bytes, kern = best if best is not None else ((0, 0.0, 0.0), 0.0, [])
         if ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
             # HBM bytes per GEMM launch: counters cannot be read from inside the run.  --live-traffic collects them NOW with
@@ -467,8 +473,8 @@ def main():
                     "traffic_unit": "HBM bytes per launch (avg over the step's GEMM launches, PMC)",
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(alg_bytes / max(n_l, 1)),
-                    "launches_per_step": n_l // 2, "gemm_ms_per_step": round(ms / 2, 3),
-                    "gemm_algorithmic_tflop_per_step": round(fl / 2 / 1e12, 3),
+                    "launches_per_step": n_l, "gemm_ms_per_step": round(ms, 3),
+                    "gemm_algorithmic_tflop_per_step": round(fl / 1e12, 3),
                     "avg_launch_us": round(ms / max(n_l, 1) * 1e3, 2),
                     "kernels": kern}
     fence()
