@@ -90,7 +90,10 @@ def compute_mask_indices(shape: Tuple[int, int], padding_mask: Optional[torch.Te
                 idc = (starts[:, None] + np.arange(int(mask_length))[None, :]).reshape(-1)
             else:
                 idc = np.asarray([starts[j] + o for j in range(len(starts)) for o in range(lengths[j])])
-        per_row.append(np.unique(idc[idc < sz]))
+        flags = np.zeros(sz, dtype=bool)          # np.unique(idc[idc < sz]) without the sort: the distinct indices, ascending
+        idc = np.asarray(idc, dtype=np.int64)
+        flags[idc[idc < sz]] = True
+        per_row.append(np.flatnonzero(flags))
 
     keep = min(len(r) for r in per_row)
     for b, idc in enumerate(per_row):
