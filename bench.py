@@ -264,6 +264,60 @@ def live_gemm_traffic(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def pin_rank_cores(local_rank, local_world):
+    """one disjoint, contiguous block of host cores per rank (launch thread, autograd thread, HIP / RCCL helper threads of a
+    rank stay off the other ranks' cores).  N = 1: nothing to separate, unless WAVLM_PIN_CORES=lo-hi asks for a block."""
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    spec = os.environ.get("WAVLM_PIN_CORES")
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        if spec:
+            lo, hi = (int(v) for v in spec.split("-"))
+            cores = [c for c in avail if lo <= c <= hi]
+        elif local_world > 1:
+            per = max(1, len(avail) // local_world)
+            cores = avail[local_rank * per:(local_rank + 1) * per]
+        else:
+            return None
+        if cores:
+            os.sched_setaffinity(0, cores)
+            return "%d-%d" % (cores[0], cores[-1])
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def busy_and_enqueue(step, reps=5):
+    """(gpu_busy_ms, host_enqueue_ms) of one step, medians over `reps`: the GPU is first parked on a spin kernel
+    (torch.cuda._sleep) and one un-measured step (which also brings the clocks back up after the spin), the measured step is
+    enqueued behind them -- the launch thread is never waiting for the GPU and the GPU never for the launch thread -- and
+    two events around it give the time the GPU needs when nothing starves it; the host clock around the same call gives
+    what the launch thread needs to enqueue it.  ms_per_step of the timed region within a few % of gpu_busy = the step is
+    GPU-bound on this box; ms_per_step ~ host_enqueue = launch-bound."""
+    # calibrate the spin kernel: cycles per ms on this part
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(); torch.cuda._sleep(20_000_000); e1.record()
+    torch.cuda.synchronize()
+    per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
+    busy, host = [], []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(per_ms * 80))   # ~80 ms + one step: longer than any host needs to enqueue two steps
+        step()
+        e0.record()
+        t0 = time.perf_counter()
+        step()
+        t1 = time.perf_counter()
+        e1.record()
+        torch.cuda.synchronize()
+        busy.append(e0.elapsed_time(e1))
+        host.append((t1 - t0) * 1e3)
+    busy.sort(); host.sort()
+    return busy[len(busy) // 2], host[len(host) // 2]
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -313,6 +367,7 @@ def main():
     backend = os.environ.get("WAVLM_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    pinned = pin_rank_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -428,6 +483,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     final_loss = float(loss.float().abs().mean().item()) if extract else float(loss.item())
+    # second clock on the same build, outside the timed region: what the GPU needs for a step when the launch thread is not
+    # in its way, and what the launch thread needs to enqueue one (see busy_and_enqueue)
+    gpu_busy_ms, host_enq_ms = busy_and_enqueue(step) if world == 1 else (None, None)
 
     roof = None
     if not args.no_roofline:
@@ -491,7 +549,10 @@ def main():
                                                             c["name"].split(" (")[0], int(SECONDS)),
             "value": round(value, 1),
             "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "settle_steps": settle, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 2),
+            "gpu_busy_ms_per_step": None if gpu_busy_ms is None else round(gpu_busy_ms, 2),
+            "host_enqueue_ms_per_step": None if host_enq_ms is None else round(host_enq_ms, 2),
+            "host_cores_pinned": pinned, "settle_steps": settle, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("%s extract_features (eval forward, no mask), bf16, batch=%dx%ds per GPU (%s%s)"
                                     if extract else

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 14
+#define WAVLM_HIP_ABI_VERSION 15
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -343,6 +343,58 @@ int wavlm_gumbel_vq_fwd(const void* logits, int32_t dtype, const float* noise, u
 int wavlm_vq_perplexity(const float* sums, int64_t n, int32_t G, int32_t V, float* out, float* dA, void* stream);
 int wavlm_gumbel_vq_bwd(const void* logits, int32_t dtype, const float* ysoft, const float* dret, const float* dA,
                         const float* dppl, float tau, int64_t n, int32_t G, int32_t V, void* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One transformer encoder block per call (WavLM/WavLM.py:615-742 TransformerSentenceEncoderLayer.forward + the
+ * MultiheadAttention it owns, WavLM/modules.py:417-563; fairseq twin models/unispeech_sat/unispeech_sat.py:1040-1139).
+ * The kernel sequence of a block is fixed, so the host issues it from C: one call (and one autograd node) per block and
+ * direction instead of ~35 -- the reference's training loop calls the model once per micro-batch (trainer.py:697-760)
+ * and the launch thread must stay ahead of a 35 ms step.
+ *   forward, post-LN (pre_ln = 0):  a = out_proj(attn(x)); x1 = LN1(x + drop(a)); f = fc2(gelu(fc1 x1)); y = LN2(x1 + drop(f))
+ *   forward, pre-LN (pre_ln = 1), residual adds fused into the LayerNorms: s1 = x + drop(r_in) (r_in = the previous
+ *     block's feed-forward output, NULL for the first block: s1 = x); h1 = LN1(s1); a = out_proj(attn(h1));
+ *     y = s1 + drop(a); h2 = LN2(y); r_out = fc2(gelu(fc1 h2))  -- the caller adds r_out in the next block / final LN.
+ * attn = gate (gru_rel_pos, optional) -> packed q|k|v projection -> wavlm_attn_fused_fwd.  bf16, head_dim 64 only.
+ * `saved` holds what backward needs (wavlm_layer_saved_bytes; forward with saved == NULL = inference: nothing kept, the
+ * workspace must then hold wavlm_layer_fwd_workspace_bytes, which includes that region).  Backward accumulates EVERY
+ * parameter gradient into the given gradient pointers ((+)=, the flat gradient arena of the optimizer), returns the input
+ * gradient(s) and (+)= or = the gradient of the relative-position table.
+ * All parameters share param_dtype; activations are bf16.  Dropout seeds: one per mask, regenerated in backward.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct wavlm_layer_desc {
+  int32_t B, T, D, H, F;           /* batch, frames, model width, heads (D / H == 64), feed-forward width */
+  int32_t pre_ln;                  /* 0 post-LN (Base), 1 pre-LN with fused residual adds (Large) */
+  int32_t param_dtype;             /* 0 f32 | 1 bf16 */
+  int32_t dtab_accumulate;         /* backward: dtab (+)= instead of = */
+  float eps1, eps2, scale;         /* LayerNorm epsilons, q scaling (head_dim^-0.5) */
+  float p_drop, p_attn;            /* residual dropout, attention dropout (0 in eval) */
+  uint64_t seed_r1, seed_r2, seed_attn;
+  /* parameters (and, backward only, their gradient accumulators) */
+  const void *Wqkv, *bqkv, *Wo, *bo, *W1, *b1, *W2, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  const void *Wgate, *bgate, *grep_a;           /* grep_linear [8, 64], [8]; grep_a [H]; all NULL: gate == 1 */
+  void *dWqkv, *dbqkv, *dWo, *dbo, *dW1, *db1, *dW2, *db2, *dln1_g, *dln1_b, *dln2_g, *dln2_b, *dWgate, *dbgate, *dgrep_a;
+  void* db2_prev;                  /* pre-LN backward: gradient of the bias of the linear that produced r_in (or NULL) */
+  const float* tab;                /* [H, 2T-1] Toeplitz generator of the position bias, or NULL */
+  const uint8_t* kpm;              /* [B, T] key padding (1 = padded) or NULL */
+  /* activations */
+  const void* x;                   /* [B, T, D] block input (pre-LN: the residual stream) */
+  const void* r_in;                /* pre-LN: [B, T, D] pending feed-forward output of the previous block, or NULL */
+  void* y;                         /* [B, T, D] block output (pre-LN: the residual stream after the attention branch) */
+  void* r_out;                     /* pre-LN: [B, T, D] this block's feed-forward output */
+  void* saved; uint64_t saved_bytes;
+  void* workspace; uint64_t ws_bytes;
+  /* backward */
+  const void* dy;                  /* gradient of y */
+  const void* dr_out;              /* pre-LN: gradient of r_out */
+  void* dx;                        /* gradient of x */
+  void* dr_in;                     /* pre-LN: gradient of r_in (if r_in != NULL) */
+  float* dtab;                     /* [H, 2T-1] (if tab != NULL) */
+} wavlm_layer_desc;
+uint64_t wavlm_layer_saved_bytes(const wavlm_layer_desc* d);
+uint64_t wavlm_layer_fwd_workspace_bytes(const wavlm_layer_desc* d);   /* for saved == NULL add wavlm_layer_saved_bytes */
+uint64_t wavlm_layer_bwd_workspace_bytes(const wavlm_layer_desc* d);
+int wavlm_encoder_layer_fwd(const wavlm_layer_desc* d, void* stream);
+int wavlm_encoder_layer_bwd(const wavlm_layer_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): HIP events around every wavlm_gemm launch while enabled.

@@ -1,0 +1,149 @@
+"""The one-call-per-block path (unispeech_amd/layerfn.py -> wavlm_encoder_layer_fwd / _bwd, csrc/layer.hip) against the
+composed path (one autograd node per kernel, unispeech_amd/functional.py): both issue the same kernels with the same
+arguments, so loss and EVERY parameter gradient must agree BIT FOR BIT -- with the recipe dropouts on (the seeds are drawn
+in the same order), with key padding, with layerdrop (a dropped first block = no relative position table for anyone), post-LN
+(Base) and pre-LN with fused residual adds (Large), and with the UniSpeech-SAT speaker tap that pulls the pending
+feed-forward branch out of the chain.  Parity of the composed path with the oracle is what the other GPU tests establish
+(test_bf16_e2e_gpu.py and test_large_e2e_gpu.py run THROUGH the fused path since it exists)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TINY
+
+pytestmark = pytest.mark.gpu
+
+V = 60
+
+
+def _cfg(**over):
+    from unispeech_amd.pretrain import WavLMPretrainConfig
+    c = dict(TINY)
+    c.update(encoder_layers=3, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_attention_heads=2,
+             conv_feature_layers="[(64,10,5)] + [(64,3,2)] * 4 + [(64,2,2)] * 2", conv_pos=16, conv_pos_groups=4,
+             dropout=0.1, attention_dropout=0.1, dropout_input=0.1, final_dim=32)
+    c.update(over)
+    return WavLMPretrainConfig(**{k: v for k, v in c.items() if k in WavLMPretrainConfig.__dataclass_fields__})
+
+
+def _run(cfg, fused, padded=False, sat=False, steps=2, B=3, T=16000):
+    from unispeech_amd import functional as F
+    from unispeech_amd import layerfn
+    from unispeech_amd.optim import FusedAdam
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainModel
+    layerfn.LAYER_FUSED = fused
+    try:
+        torch.manual_seed(0)
+        model = WavLMPretrainModel(cfg, None, [range(V)]).cuda().to(torch.bfloat16).train()
+        model.instance_sampling = "host"
+        opt = FusedAdam(model.parameters(), lr=1e-3, clip_norm=10.0, model=model)
+        crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0, 10.0, 0.0] if sat else [10.0])
+        g = torch.Generator().manual_seed(7)
+        wav = torch.randn(B, T, generator=g).to(torch.bfloat16).cuda()
+        pm = torch.zeros(B, T, dtype=torch.bool)
+        if padded:
+            pm[1, 12000:] = True
+            pm[2, 9000:] = True
+        target = torch.randint(4, V, (B, T // 320), generator=g).cuda()
+        sample = {"id": torch.arange(B), "net_input": {"source": wav, "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+                  "target_list": [target]}
+        np.random.seed(11)
+        torch.manual_seed(5)
+        F._SEED_CTR[0] = 0
+        out = []
+        for _ in range(steps):
+            opt.zero_grad()
+            loss, ss, _ = crit(model, sample)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append((loss.detach().float().cpu().clone(), opt.flat_grad.detach().float().cpu().clone()))
+            opt.step(grad_mult=1.0 / max(ss, 1))
+        names = [n for n, _ in model.named_parameters()]
+        return out, names, model
+    finally:
+        layerfn.LAYER_FUSED = True
+
+
+def _count_nodes(model_out_loss):
+    seen, stack, names = set(), [model_out_loss.grad_fn], []
+    while stack:
+        f = stack.pop()
+        if f is None or f in seen:
+            continue
+        seen.add(f)
+        names.append(type(f).__name__)
+        stack.extend(n for n, _ in f.next_functions)
+    return names
+
+
+@pytest.mark.parametrize("case", ["post_ln", "post_ln_padded", "post_ln_layerdrop", "pre_ln", "pre_ln_padded",
+                                  "pre_ln_sat_tap", "no_relpos"])
+def test_fused_block_equals_composed_path_bit_for_bit(case):
+    over = {}
+    padded = case.endswith("padded")
+    if case.startswith("pre_ln"):
+        over.update(layer_norm_first=True, extractor_mode="layer_norm")
+    if case == "post_ln_layerdrop":
+        over.update(encoder_layerdrop=0.5, encoder_layers=6)
+    if case == "pre_ln_sat_tap":
+        over.update(utterance_contrastive_loss=True, utterance_contrastive_layer=2, num_instances=0, cross_sample_instances=10)
+    if case == "no_relpos":
+        over.update(relative_position_embedding=False, gru_rel_pos=False)
+    cfg = _cfg(**over)
+    a, names, _ = _run(cfg, True, padded, sat=case == "pre_ln_sat_tap")
+    b, _, _ = _run(cfg, False, padded, sat=case == "pre_ln_sat_tap")
+    for step, ((la, ga), (lb, gb)) in enumerate(zip(a, b)):
+        assert torch.equal(la, lb), "step %d: loss %r (one call per block) != %r (composed)" % (step, la.item(), lb.item())
+        assert torch.isfinite(ga).all()
+        assert ga.abs().max() > 0
+        if not torch.equal(ga, gb):
+            d = (ga - gb).abs()
+            raise AssertionError("step %d: gradient arenas differ in %d of %d elements, max |diff| %.3e (max |g| %.3e)"
+                                 % (step, int((d > 0).sum()), d.numel(), d.max().item(), gb.abs().max().item()))
+
+
+@pytest.mark.parametrize("pre_ln", [False, True])
+def test_fused_block_equals_composed_path_at_model_width(pre_ln):
+    """Base / Large width with enough rows (8 x 2.5 s = 992 frames) for the grouped weight-gradient launches and the
+    192 x 384 tiles: the C side regroups the four dW of a block exactly as functional.WgradGroup does"""
+    over = dict(encoder_layers=2, conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2", conv_pos=128,
+                conv_pos_groups=16, num_buckets=320, max_distance=800, final_dim=256)
+    if pre_ln:
+        over.update(encoder_embed_dim=1024, encoder_ffn_embed_dim=4096, encoder_attention_heads=16, layer_norm_first=True,
+                    extractor_mode="layer_norm")
+    else:
+        over.update(encoder_embed_dim=768, encoder_ffn_embed_dim=3072, encoder_attention_heads=12)
+    cfg = _cfg(**over)
+    a, _, _ = _run(cfg, True, steps=1, B=8, T=40000)
+    b, _, _ = _run(cfg, False, steps=1, B=8, T=40000)
+    assert torch.equal(a[0][0], b[0][0]), (a[0][0].item(), b[0][0].item())
+    d = (a[0][1] - b[0][1]).abs()
+    assert torch.equal(a[0][1], b[0][1]), "gradient arenas differ in %d of %d elements, max |diff| %.3e" % (
+        int((d > 0).sum()), d.numel(), d.max().item())
+
+
+def test_fused_path_is_the_one_that_runs_and_is_one_node_per_block():
+    """the benchmarked configuration takes the one-call path: one EncoderLayerFn node per executed block in the graph and
+    none of the per-kernel nodes of an encoder block"""
+    from unispeech_amd import layerfn
+    from unispeech_amd.optim import FusedAdam
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainModel
+    cfg = _cfg()
+    torch.manual_seed(0)
+    model = WavLMPretrainModel(cfg, None, [range(V)]).cuda().to(torch.bfloat16).train()
+    opt = FusedAdam(model.parameters(), lr=1e-3, model=model)
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0])
+    B, T = 2, 16000
+    wav = torch.randn(B, T).to(torch.bfloat16).cuda()
+    pm = torch.zeros(B, T, dtype=torch.bool)
+    sample = {"id": torch.arange(B), "net_input": {"source": wav, "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+              "target_list": [torch.randint(4, V, (B, 50)).cuda()]}
+    opt.zero_grad()
+    loss, _, _ = crit(model, sample)
+    nodes = _count_nodes(loss)
+    assert sum(n.startswith("EncoderLayerFn") for n in nodes) == cfg.encoder_layers
+    assert not any(n.startswith(("AttnCoreFn", "FFNFn", "GateFn")) for n in nodes)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(opt.flat_grad.float()).all()
+    assert layerfn.LAYER_FUSED

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVLM_HIP_LIB") or os.path.join(_HERE, "lib", "libwavlm_hip.so")
 
 _lib = None
-ABI_VERSION = 14  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 15  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
 
 F32, BF16 = 0, 1
 
@@ -42,6 +42,27 @@ class GemmDesc(C.Structure):
         ("accumulate", c_i32), ("split_k", c_i32),
         ("workspace", c_vp), ("ws_bytes", c_u64),
         ("colsum", c_vp), ("colsum_dtype", c_i32), ("colsum_accumulate", c_i32),
+    ]
+
+
+class LayerDesc(C.Structure):
+    """wavlm_layer_desc (include/wavlm_hip.h): one transformer encoder block per call"""
+    _fields_ = [
+        ("B", c_i32), ("T", c_i32), ("D", c_i32), ("H", c_i32), ("F", c_i32),
+        ("pre_ln", c_i32), ("param_dtype", c_i32), ("dtab_accumulate", c_i32),
+        ("eps1", c_f32), ("eps2", c_f32), ("scale", c_f32), ("p_drop", c_f32), ("p_attn", c_f32),
+        ("seed_r1", c_u64), ("seed_r2", c_u64), ("seed_attn", c_u64),
+        ("Wqkv", c_vp), ("bqkv", c_vp), ("Wo", c_vp), ("bo", c_vp), ("W1", c_vp), ("b1", c_vp), ("W2", c_vp), ("b2", c_vp),
+        ("ln1_g", c_vp), ("ln1_b", c_vp), ("ln2_g", c_vp), ("ln2_b", c_vp),
+        ("Wgate", c_vp), ("bgate", c_vp), ("grep_a", c_vp),
+        ("dWqkv", c_vp), ("dbqkv", c_vp), ("dWo", c_vp), ("dbo", c_vp), ("dW1", c_vp), ("db1", c_vp), ("dW2", c_vp),
+        ("db2", c_vp), ("dln1_g", c_vp), ("dln1_b", c_vp), ("dln2_g", c_vp), ("dln2_b", c_vp),
+        ("dWgate", c_vp), ("dbgate", c_vp), ("dgrep_a", c_vp),
+        ("db2_prev", c_vp),
+        ("tab", c_vp), ("kpm", c_vp),
+        ("x", c_vp), ("r_in", c_vp), ("y", c_vp), ("r_out", c_vp),
+        ("saved", c_vp), ("saved_bytes", c_u64), ("workspace", c_vp), ("ws_bytes", c_u64),
+        ("dy", c_vp), ("dr_out", c_vp), ("dx", c_vp), ("dr_in", c_vp), ("dtab", c_vp),
     ]
 
 
@@ -129,6 +150,11 @@ SIGNATURES = {
     "wavlm_gumbel_vq_fwd": (c_i32, [c_vp, c_i32, c_vp, c_u64, c_f32, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "wavlm_vq_perplexity": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "wavlm_gumbel_vq_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "wavlm_layer_saved_bytes": (c_u64, [C.POINTER(LayerDesc)]),
+    "wavlm_layer_fwd_workspace_bytes": (c_u64, [C.POINTER(LayerDesc)]),
+    "wavlm_layer_bwd_workspace_bytes": (c_u64, [C.POINTER(LayerDesc)]),
+    "wavlm_encoder_layer_fwd": (c_i32, [C.POINTER(LayerDesc), c_vp]),
+    "wavlm_encoder_layer_bwd": (c_i32, [C.POINTER(LayerDesc), c_vp]),
     "wavlm_prof_enable": (None, [c_i32]),
     "wavlm_gemm_set_variant": (None, [c_i32]),
     "wavlm_set_reserved_cus": (None, [c_i32]),

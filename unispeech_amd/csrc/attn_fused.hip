@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
 // lo = T - 1 - (128 qblk + 32 w) - 31 (attn_bwd_dq_kernel); the rest of it was never written (garbage: select, never
 // multiply).  The kernel is pure load latency: four independent 16-byte loads in flight per thread.
 __global__ __launch_bounds__(1024) void fa_dtab_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              int B, int H, int nqt, int L, int Lp, int T, int nkv) {
+                                                              int B, int H, int nqt, int L, int Lp, int T, int nkv, int accumulate) {
   __shared__ float4 red[64][17];
   const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
   const int d = (blockIdx.x * 16 + col) * 4;
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(1024) void fa_dtab_reduce_kernel(const float* __res
                         (a0.w + a1.w) + (a2.w + a3.w)};
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (d + k < L) out[(long)h * L + d + k] = o[k];
+      if (d + k < L) out[(long)h * L + d + k] = accumulate ? out[(long)h * L + d + k] + o[k] : o[k];
   }
 }
 
@@ -686,6 +686,18 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
                          const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, void* dbias,
                          int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T, int32_t head_dim,
                          float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes, void* stream) {
+  return wl_attn_fused_bwd_ex(qkv, O, dO, lse, gate, tab, kpm, dqkv, dgate, dtab, 0, dbias, dbias_dtype, dbias_accumulate, B, H, T,
+                              head_dim, scale, p_drop, seed, workspace, ws_bytes, stream);
+}
+
+}  // extern "C"
+
+// the same with dtab (+)= (layer.hip: the table is shared by every block of the encoder, their gradients meet in one buffer)
+int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
+                         const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, int dtab_accumulate,
+                         void* dbias, int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T,
+                         int32_t head_dim, float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes,
+                         void* stream) {
   if (!qkv || !O || !dO || !lse || !dqkv || !workspace || B <= 0 || H <= 0 || T <= 0 || head_dim != FA_HD)
     return WL_EINVAL;
   if ((gate == nullptr) != (tab == nullptr)) return WL_EINVAL;
@@ -730,8 +742,6 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
   }
   if (tab)
     WL_LAUNCH(fa_dtab_reduce_kernel, dim3((unsigned)((Lp / 4 + 15) / 16), (unsigned)H), dim3(1024), 0, st,
-              (const float*)p.dtab_part, dtab, (int)B, (int)H, nqt, L, Lp, (int)T, (T + FA_BKV - 1) / FA_BKV);
+              (const float*)p.dtab_part, dtab, (int)B, (int)H, nqt, L, Lp, (int)T, (T + FA_BKV - 1) / FA_BKV, (int)dtab_accumulate);
   return wl_check_launch();
 }
-
-}  // extern "C"

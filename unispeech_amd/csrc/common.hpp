@@ -225,5 +225,11 @@ static inline int wl_check_launch() {
   return e ? WL_ELAUNCH : WL_OK;
 }
 
+// attn_fused.hip: wavlm_attn_fused_bwd with dtab (+)= when dtab_accumulate != 0
+int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
+                         const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, int dtab_accumulate,
+                         void* dbias, int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T,
+                         int32_t head_dim, float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes,
+                         void* stream);
 // rowops.hip: out[c] (+)= sum over nblk rows of part[nblk][n]
 int wl_colsum_finish(const float* part, int nblk, int n, void* out, int out_dtype, int accumulate, hipStream_t st);

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as F
+from . import layerfn
 from .masking import compute_mask_indices, relative_position_buckets
 
 
@@ -350,6 +351,12 @@ class TransformerSentenceEncoderLayer(nn.Module):
         gone.  Returns (x, pending', position_table) with this block's own feed-forward output pending."""
         ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
         p = self.dropout if self.training else 0.0
+        if layerfn.eligible(self, x, position_table):   # the whole block as one node / one C call each way
+            tf = F.BiasGradToken(self.fc2.bias)
+            x, f, position_table = layerfn.run_block(self, x, key_padding_u8, position_table,
+                                                     r_in=None if pending is None else pending[0],
+                                                     prev_tok=None if pending is None else pending[1], out_tok=tf)
+            return x, (f, tf), position_table
         wg = self._wgrad_group()
         if pending is None:
             h, _, x = F.layer_norm(x, ln1.weight, ln1.bias, ln1.eps, pass_x=True)
@@ -400,6 +407,8 @@ class TransformerSentenceEncoderLayer(nn.Module):
                 h, _ = F.layer_norm(x, ln2.weight, ln2.bias, ln2.eps)
             f = self._ffn(h, wgroup=wg)
             x = ResidualAddFn.apply(x, f, p, F.next_seed() if p > 0 else 0)
+        elif layerfn.eligible(self, x, position_table):   # the whole block as one node / one C call each way
+            x, _, position_table = layerfn.run_block(self, x, key_padding_u8, position_table)
         else:
             # post-LN: the LayerNorm that follows a sub-layer also delivers the bias gradient of its last linear
             grad = torch.is_grad_enabled()
