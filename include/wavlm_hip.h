@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 15
+#define WAVLM_HIP_ABI_VERSION 16
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -395,6 +395,21 @@ uint64_t wavlm_layer_fwd_workspace_bytes(const wavlm_layer_desc* d);   /* for sa
 uint64_t wavlm_layer_bwd_workspace_bytes(const wavlm_layer_desc* d);
 int wavlm_encoder_layer_fwd(const wavlm_layer_desc* d, void* stream);
 int wavlm_encoder_layer_bwd(const wavlm_layer_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel seam below Python.  The reference reduces gradients AFTER the whole backward, from one flat buffer
+ * (src/fairseq/distributed/legacy_distributed_data_parallel.py:76-165); here backward kernels accumulate straight into
+ * the caller's flat gradient arena, and a reducer that wants to start a bucket's all-reduce while backward is still running
+ * has to learn which slice has just been written.  Every entry point that ACCUMULATES into a caller-designated parameter
+ * gradient -- wavlm_gemm / wavlm_gemm_grouped with `accumulate` or an accumulating `colsum`, wavlm_layernorm_bwd with
+ * accumulate_params (dgamma, dbeta, dr_colsum), wavlm_colsum with accumulate, wavlm_gate_bwd (bit 0), wavlm_attn_fused_bwd
+ * (dbias), wavlm_conv_wgrad_scatter with accumulate, and through them wavlm_encoder_layer_bwd -- calls the listener with
+ * (base, bytes, stream, user) right after it has ENQUEUED the kernels: the slice is complete in `stream` order (record an
+ * event on `stream`, make the communication stream wait for it).  One call per accumulation: a parameter used twice in
+ * one forward is reported twice.  The callback runs on the launch thread and must not block.  cb == NULL: none.
+ * ------------------------------------------------------------------------------------------ */
+typedef void (*wavlm_grad_listener)(const void* base, uint64_t bytes, void* stream, void* user);
+void wavlm_dp_set_listener(wavlm_grad_listener cb, void* user);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): HIP events around every wavlm_gemm launch while enabled.

@@ -209,3 +209,135 @@ def test_trainer_order_on_the_wrapper_gloo_world2():
         p.join(timeout=60)
     for r in res:
         assert r[-1] is None and all(r[1:-1]), r
+
+
+def _rebuild_worker(rank, world, port, q):
+    """the Trainer builds its optimizer a SECOND time over the same wrapped model (trainer.py load_checkpoint: 'rebuild
+    optimizer after loading model'; reinitialize): the wrapper must follow to the new arena -- the old reducer's hooks and sink
+    listener go, the new arena is what gets reduced, and 1/world lands on the NEW optimizer's deferred factor"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from types import SimpleNamespace
+        from unispeech_amd import functional as Fn
+        from unispeech_amd.dp import DataParallelWavLM
+        from unispeech_amd.optim import FairseqFusedAdam
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
+        ddp = DataParallelWavLM(net, None, bucket_bytes=1024)
+        cfg = SimpleNamespace(lr=[1e-3], adam_betas="(0.9, 0.98)", adam_eps=1e-6, weight_decay=0.0)
+        params = [p for p in ddp.parameters() if p.requires_grad]
+        opt1 = FairseqFusedAdam(cfg, params)
+        red1 = ddp.reducer
+        n_listeners_1 = len(Fn.SINK_LISTENERS)
+        opt2 = FairseqFusedAdam(cfg, params)                       # rebuilt: a new arena, p.grad re-pointed
+        red2 = ddp.reducer
+        rebound = red2 is not red1 and ddp._optimizer is opt2.fused and red2.flat_grad is opt2.fused.flat_grad
+        old_detached = (not red1.enabled) and not red1._hooks and len(Fn.SINK_LISTENERS) == n_listeners_1
+        x = torch.randn(4, 16, generator=torch.Generator().manual_seed(100 + rank))
+        refs = []
+        for r in range(world):
+            torch.manual_seed(0)
+            n2 = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
+            n2(torch.randn(4, 16, generator=torch.Generator().manual_seed(100 + r))).pow(2).sum().backward()
+            refs.append([p.grad.clone() for p in n2.parameters()])
+        opt2.zero_grad()
+        opt2.backward(ddp(x).pow(2).sum())
+        opt2.all_reduce_grads(ddp)
+        in_new_arena = all(p.grad.data_ptr() >= opt2.fused.flat_grad.data_ptr() for p in net.parameters())
+        ok_sum = all(torch.allclose(p.grad, refs[0][i] + refs[1][i], atol=1e-6) for i, p in enumerate(net.parameters()))
+        ok_factor = abs(opt2.fused.pending_mult - 1.0 / world) < 1e-12 and opt1.fused.pending_mult == 1.0
+        # a wrapper that was handed the stale optimizer explicitly and meets the new one only in all_reduce_grads()
+        ddp.reducer.close()   # (one live wrapper per model: two reducers on one arena would reduce it twice)
+        ddp3 = DataParallelWavLM(net, opt1.fused, bucket_bytes=1024)
+        opt2.zero_grad()
+        opt2.backward(ddp3(x).pow(2).sum())
+        opt2.all_reduce_grads(ddp3)
+        ok_late = ddp3._optimizer is opt2.fused and all(
+            torch.allclose(p.grad, refs[0][i] + refs[1][i], atol=1e-6) for i, p in enumerate(net.parameters()))
+        q.put((rank, rebound, old_detached, in_new_arena, ok_sum, ok_factor, ok_late, None))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_optimizer_rebuilt_over_one_wrapper_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rebuild_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[-1] is None and all(r[1:-1]), r
+
+
+def _inorder8_worker(rank, world, port, q):
+    """eight ranks, every rank 'drops' a different pair of parameters (encoder_layerdrop draws diverge per rank): the
+    all-reduces must still be ISSUED in bucket order 0, 1, 2, ... on every rank and the sums must be right"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from unispeech_amd.dp import GradReducer
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(24 + 8 * (i % 3))) for i in range(24)]
+        offsets, off = [], 0
+        for p in params:
+            offsets.append(off)
+            off += (p.numel() + 7) // 8 * 8
+        flat = torch.zeros(off)
+        for p, o in zip(params, offsets):
+            p.grad = flat[o:o + p.numel()].view_as(p)
+        red = GradReducer(params, flat, offsets, bucket_bytes=256)
+        issued = []
+        orig = red._launch
+        red._launch = lambda b: (issued.append(b), orig(b))[1]
+        order = sorted(range(len(params)), key=lambda i: -offsets[i])
+        drop = {order[(3 * rank + 1) % len(order)], order[(5 * rank + 7) % len(order)]}
+        for i in order:
+            if i not in drop:
+                params[i].grad.add_(float(rank + 1))
+                red._mark(i)
+        mid = list(issued)
+        red.finish()
+        ok_order = issued == list(range(len(red.buckets))) and mid == list(range(len(mid)))
+        want = torch.zeros_like(flat)
+        for r_ in range(world):
+            d_ = {order[(3 * r_ + 1) % len(order)], order[(5 * r_ + 7) % len(order)]}
+            for i in range(len(params)):
+                if i not in d_:
+                    want[offsets[i]:offsets[i] + params[i].numel()] += float(r_ + 1)
+        live = torch.zeros_like(flat, dtype=torch.bool)
+        for p_, o_ in zip(params, offsets):
+            live[o_:o_ + p_.numel()] = True
+        q.put((rank, ok_order, bool(torch.allclose(flat[live], want[live])), len(red.buckets) >= 6, None))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_in_order_issue_with_divergent_layerdrop_gloo_world8():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_inorder8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[-1] is None and all(r[1:-1]), r

@@ -147,3 +147,69 @@ def test_fused_path_is_the_one_that_runs_and_is_one_node_per_block():
     torch.cuda.synchronize()
     assert torch.isfinite(opt.flat_grad.float()).all()
     assert layerfn.LAYER_FUSED
+
+
+def test_c_level_gradient_listener_reports_every_sink_of_a_step():
+    """wavlm_dp_set_listener (include/wavlm_hip.h): a caller BELOW Python learns which slice of its gradient arena a backward
+    kernel has just accumulated into.  One training step with a ctypes callback registered: every parameter's arena slice
+    is covered by the reported (base, bytes) ranges, every report lies inside the arena, and the blocks report in backward
+    order (last block first) -- what a reducer needs to start bucket 0 while backward is still running."""
+    import ctypes
+    from unispeech_amd import _lib
+    from unispeech_amd.optim import FusedAdam
+    from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainModel
+    cfg = _cfg()
+    torch.manual_seed(0)
+    model = WavLMPretrainModel(cfg, None, [range(V)]).cuda().to(torch.bfloat16).train()
+    opt = FusedAdam(model.parameters(), lr=1e-3, model=model)
+    crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0])
+    B, T = 2, 16000
+    wav = torch.randn(B, T).to(torch.bfloat16).cuda()
+    pm = torch.zeros(B, T, dtype=torch.bool)
+    sample = {"id": torch.arange(B), "net_input": {"source": wav, "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+              "target_list": [torch.randint(4, V, (B, 50)).cuda()]}
+    got = []
+    cb = _lib.GRAD_LISTENER(lambda base, nbytes, stream, user: got.append((int(base or 0), int(nbytes))))
+    L = _lib.lib()
+    opt.zero_grad()
+    loss, _, _ = crit(model, sample)
+    L.wavlm_dp_set_listener(ctypes.cast(cb, ctypes.c_void_p), None)
+    try:
+        loss.backward()
+    finally:
+        L.wavlm_dp_set_listener(None, None)
+    torch.cuda.synchronize()
+    lo, es = opt.flat_grad.data_ptr(), opt.flat_grad.element_size()
+    hi = lo + opt.flat_grad.numel() * es
+    inside = [(b, n) for b, n in got if lo <= b < hi]
+    assert inside and all(b + n <= hi for b, n in inside)
+    covered = torch.zeros(opt.flat_grad.numel(), dtype=torch.bool)
+    for b, n in inside:
+        covered[(b - lo) // es:(b - lo + n) // es] = True
+    names = dict((id(p), n) for n, p in model.named_parameters())
+    # what the C side sees: every gradient that a kernel ACCUMULATES into the arena.  Gradients that autograd adds itself
+    # (tensors returned by a Function: conv0 / GroupNorm, pos_conv, mask_emb, label embeddings, the position embedding) are
+    # the Python hooks' business (dp.GradReducer uses both).
+    enc = [p for n, p in model.named_parameters() if n.startswith("encoder.layers.")
+           and "relative_attention_bias" not in n]
+    assert len(enc) >= 3 * 16
+    for p, o in zip(opt.params, opt.offsets):
+        if any(p is q for q in enc):
+            assert bool(covered[o:o + p.numel()].all()), "no C-level notification covers " + names[id(p)]
+    # order: the first encoder-block report belongs to the LAST block, the last one to block 0
+    def block_of(addr):
+        for p, o in zip(opt.params, opt.offsets):
+            if lo + o * es <= addr < lo + (o + p.numel()) * es:
+                n = names[id(p)]
+                return int(n.split(".")[2]) if n.startswith("encoder.layers.") else None
+        return None
+    blocks = [b for b in (block_of(a) for a, _ in inside) if b is not None]
+    assert blocks[0] == cfg.encoder_layers - 1 and blocks[-1] == 0
+    assert blocks == sorted(blocks, reverse=True)
+    # with the listener cleared nothing is reported
+    got.clear()
+    opt.zero_grad()
+    loss, _, _ = crit(model, sample)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert not got

@@ -49,6 +49,45 @@ def test_gemm_desc_layout_matches_header():
     assert fields == [f[0] for f in GemmDesc._fields_]
 
 
+def _struct_fields(name):
+    src = open(os.path.join(ROOT, "include", "wavlm_hip.h")).read()
+    body = src[src.index("typedef struct %s {" % name):src.index("} %s;" % name)]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for stmt in body.split("{", 1)[1].split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        decl = stmt.split(None, 1)[1] if not stmt.startswith("const") else stmt.split(None, 2)[2]
+        for nm in decl.split(","):
+            fields.append(nm.replace("*", "").strip())
+    return fields
+
+
+def test_layer_desc_layout_matches_header():
+    """wavlm_layer_desc (one encoder block per call): ctypes field order == C field order, and the C side agrees on the
+    size (a wrong field type would shift every pointer after it)"""
+    from unispeech_amd._lib import LayerDesc
+    assert _struct_fields("wavlm_layer_desc") == [f[0] for f in LayerDesc._fields_]
+    import ctypes
+    d = LayerDesc()
+    # sizes only: no GPU needed.  An invalid descriptor reports 0; a valid one the byte counts of its carve-up
+    from unispeech_amd import _lib
+    L = _lib.lib()
+    assert L.wavlm_layer_saved_bytes(ctypes.byref(d)) == 0
+    d.B, d.T, d.D, d.H, d.F, d.param_dtype = 2, 100, 128, 2, 256, 1
+    for f in ("Wqkv", "bqkv", "Wo", "bo", "W1", "b1", "W2", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b"):
+        setattr(d, f, 4096)
+    n = 2 * 100
+    got = L.wavlm_layer_saved_bytes(ctypes.byref(d))
+    # lse + 4 row statistics (fp32), qkv, O, s1, x1, s2 (bf16 [n, D] resp. [n, 3D]), u, hact ([n, F]); 256-byte granules
+    r = lambda b: (b + 255) // 256 * 256
+    want = r(2 * 2 * 100 * 4) + 4 * r(n * 4) + r(n * 3 * 128 * 2) + 4 * r(n * 128 * 2) + 2 * r(n * 256 * 2)
+    assert got == want, (got, want)
+    assert L.wavlm_layer_fwd_workspace_bytes(ctypes.byref(d)) == r(n * 128 * 2) + want   # saved == NULL: inference
+    assert L.wavlm_layer_bwd_workspace_bytes(ctypes.byref(d)) > 10 * n * 128 * 2
+
+
 def test_no_cpu_fallback():
     from unispeech_amd import _lib, ops
     x = torch.randn(4, 64)

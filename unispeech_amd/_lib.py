@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVLM_HIP_LIB") or os.path.join(_HERE, "lib", "libwavlm_hip.so")
 
 _lib = None
-ABI_VERSION = 15  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 16  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
 
 F32, BF16 = 0, 1
 
@@ -64,6 +64,10 @@ class LayerDesc(C.Structure):
         ("saved", c_vp), ("saved_bytes", c_u64), ("workspace", c_vp), ("ws_bytes", c_u64),
         ("dy", c_vp), ("dr_out", c_vp), ("dx", c_vp), ("dr_in", c_vp), ("dtab", c_vp),
     ]
+
+
+# wavlm_grad_listener: void (*)(const void* base, uint64_t bytes, void* stream, void* user)
+GRAD_LISTENER = C.CFUNCTYPE(None, c_vp, c_u64, c_vp, c_vp)
 
 
 # name -> (restype, argtypes); mirrors include/wavlm_hip.h one to one
@@ -155,6 +159,7 @@ SIGNATURES = {
     "wavlm_layer_bwd_workspace_bytes": (c_u64, [C.POINTER(LayerDesc)]),
     "wavlm_encoder_layer_fwd": (c_i32, [C.POINTER(LayerDesc), c_vp]),
     "wavlm_encoder_layer_bwd": (c_i32, [C.POINTER(LayerDesc), c_vp]),
+    "wavlm_dp_set_listener": (None, [c_vp, c_vp]),
     "wavlm_prof_enable": (None, [c_i32]),
     "wavlm_gemm_set_variant": (None, [c_i32]),
     "wavlm_set_reserved_cus": (None, [c_i32]),

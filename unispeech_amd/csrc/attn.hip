@@ -908,7 +908,12 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
   if (rc != WL_OK) return rc;
   WL_LAUNCH(gate_bwd_finish_kernel, dim3((unsigned)((2 * hd + 2 + H + 15) / 16)), dim3(1024), 0, st, (const float*)workspace,
                      (int)grid, (int)H, (int)hd, dW, dbias, dgrep_a, (int)param_dtype, (int)(accumulate_params & 1));
-  return wl_check_launch();
+  rc = wl_check_launch();
+  if (rc == WL_OK && (accumulate_params & 1)) {   // grep_linear.weight [8, hd], grep_linear.bias [8], grep_a [H]
+    const uint64_t es = wl_esize(param_dtype);
+    wl_notify_grad(dW, 8ull * hd * es, stream); wl_notify_grad(dbias, 8ull * es, stream); wl_notify_grad(dgrep_a, (uint64_t)H * es, stream);
+  }
+  return rc;
 }
 
 }  // extern "C"

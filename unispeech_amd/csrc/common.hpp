@@ -225,6 +225,10 @@ static inline int wl_check_launch() {
   return e ? WL_ELAUNCH : WL_OK;
 }
 
+// layer.hip: tell the registered gradient listener (wavlm_dp_set_listener) that an accumulation into the caller's gradient
+// buffer [base, base + bytes) has been enqueued on `stream`; a no-op without a listener
+void wl_notify_grad(const void* base, uint64_t bytes, void* stream);
+static inline uint64_t wl_esize(int dt) { return dt == WL_BF16 ? 2 : 4; }
 // attn_fused.hip: wavlm_attn_fused_bwd with dtab (+)= when dtab_accumulate != 0
 int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
                          const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, int dtab_accumulate,

@@ -456,6 +456,14 @@ extern "C" uint64_t wavlm_gemm_workspace_bytes(const wavlm_gemm_desc* d) {
   return need;
 }
 
+// gradient listener (wavlm_dp_set_listener): an accumulating GEMM is a weight gradient landing in the caller's arena
+static void gemm_notify(const wavlm_gemm_desc* d, bool colsum_fused, void* stream) {
+  if (d->accumulate && d->batch_o <= 1 && d->batch_i <= 1)
+    wl_notify_grad(d->C, ((uint64_t)(d->M - 1) * d->ldc + d->N) * wl_esize(d->c_dtype), stream);
+  if (d->colsum && d->colsum_accumulate && colsum_fused)   // (the stand-alone pass reports through wavlm_colsum)
+    wl_notify_grad(d->colsum, (uint64_t)d->N * wl_esize(d->colsum_dtype), stream);
+}
+
 extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return WL_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return WL_EINVAL;
@@ -471,6 +479,7 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
     if (r == WL_OK && d->colsum)
       r = wavlm_colsum(d->C, d->M, d->N, d->ldc, d->c_dtype, nullptr, nullptr, d->colsum, d->colsum_dtype,
                        d->colsum_accumulate, d->workspace, d->ws_bytes, stream);
+    if (r == WL_OK) gemm_notify(d, false, stream);
     return r;
   }
   if (d->dtype != WL_BF16) return WL_EINVAL;
@@ -516,6 +525,7 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
                            d->colsum_accumulate, d->workspace, d->ws_bytes, stream);
   }
   prof_end(pi, st);
+  if (rc == WL_OK) gemm_notify(d, csum_rows > 0, stream);
   return rc;
 }
 
@@ -578,5 +588,7 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
     rc = wl_check_launch();
   }
   prof_end(pi, st);
+  if (rc == WL_OK)
+    for (int i = 0; i < n; ++i) gemm_notify(d + i, false, stream);
   return rc;
 }

@@ -12,8 +12,23 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "common.hpp"
 #include "wavlm_hip.h"
+
+// ---- gradient listener: which slice of the caller's gradient arena has just received an accumulation (in stream order) ----
+static std::atomic<wavlm_grad_listener> g_listener{nullptr};
+static std::atomic<void*> g_listener_user{nullptr};
+void wl_notify_grad(const void* base, uint64_t bytes, void* stream) {
+  const wavlm_grad_listener cb = g_listener.load(std::memory_order_acquire);
+  if (cb && base && bytes) cb(base, bytes, stream, g_listener_user.load(std::memory_order_acquire));
+}
+extern "C" void wavlm_dp_set_listener(wavlm_grad_listener cb, void* user) {
+  g_listener.store(nullptr, std::memory_order_release);
+  g_listener_user.store(user, std::memory_order_release);
+  g_listener.store(cb, std::memory_order_release);
+}
 
 namespace {
 

@@ -906,7 +906,13 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   const int na = dr_colsum ? 3 : 2;
   WL_LAUNCH(colsum_finish_kernel, dim3(g2, na), dim3(1024), 0, st, part, (int)grid, (long)(na * D), (int)D, dgamma,
                      (int)param_dtype, (int)accumulate_params, (long)D, dbeta, dr_colsum);
-  return wl_check_launch();
+  rc = wl_check_launch();
+  if (rc == WL_OK && accumulate_params) {
+    const uint64_t nb = (uint64_t)D * wl_esize(param_dtype);
+    wl_notify_grad(dgamma, nb, stream); wl_notify_grad(dbeta, nb, stream);
+    if (dr_colsum) wl_notify_grad(dr_colsum, nb, stream);
+  }
+  return rc;
 }
 
 }  // extern "C"
@@ -940,7 +946,9 @@ int wavlm_colsum(const void* x, int64_t rows, int32_t N, int64_t ld, int32_t dty
   if (rc != WL_OK) return rc;
   WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((N + 15) / 16)), dim3(1024), 0, st, part, (int)grid, (long)N,
                      (int)N, out, (int)out_dtype, (int)accumulate, 0L, (void*)nullptr, (void*)nullptr);
-  return wl_check_launch();
+  rc = wl_check_launch();
+  if (rc == WL_OK && accumulate) wl_notify_grad(out, (uint64_t)N * wl_esize(out_dtype), stream);
+  return rc;
 }
 
 int wavlm_select_rows(const void* x, void* y, const uint8_t* sel, const void* emb, const uint8_t* zero, int64_t rows,
@@ -998,7 +1006,11 @@ int wavlm_conv_wgrad_scatter(const wavlm_conv_relayout_desc* d, int32_t accumula
   }
   const unsigned gx = grid_for(mx, 256, 8192);
   WL_LAUNCH(conv_wgrad_scatter_kernel, dim3(gx, (unsigned)d->n_layers), dim3(256), 0, (hipStream_t)stream, *d, (int)accumulate);
-  return wl_check_launch();
+  const int rc = wl_check_launch();
+  if (rc == WL_OK && accumulate)
+    for (int l = 0; l < d->n_layers; ++l)
+      wl_notify_grad(d->W[l], (uint64_t)d->Cout[l] * d->Cin[l] * d->k[l] * wl_esize(d->dtype), stream);
+  return rc;
 }
 
 int wavlm_axpby(const void* x, int32_t x_dtype, void* y, int32_t y_dtype, int64_t n, float a, float b, void* stream) {

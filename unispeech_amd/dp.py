@@ -80,11 +80,30 @@ class GradReducer:
         self._offsets = list(offsets)
         self._order = sorted(range(len(self.params)), key=lambda i: self._offsets[i])
         self._sorted_off = [self._offsets[i] for i in self._order]
+        self._hooks = []
+        self._listener = None
         if self.enabled:
             for idx, p in enumerate(self.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(idx))
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
             from . import functional
-            functional.SINK_LISTENERS.append(self._sink_written)
+            self._listener = self._sink_written   # (one bound-method object: `remove` below must find this very one)
+            functional.SINK_LISTENERS.append(self._listener)
+
+    def close(self):
+        """detach from the parameters and from the kernels' sink notifications: called when the wrapper is re-bound to
+        another optimizer arena (the Trainer rebuilds its optimizer in load_checkpoint / reinitialize) -- a reducer left
+        behind would keep launching collectives on a dead arena"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self._listener is not None:
+            from . import functional
+            try:
+                functional.SINK_LISTENERS.remove(self._listener)
+            except ValueError:
+                pass
+            self._listener = None
+        self.enabled = False
 
     def _mark(self, idx):
         """parameter idx has its gradient of this backward in the arena (autograd hook or sink notification; idempotent)"""
@@ -186,7 +205,10 @@ def bind_live_wrappers(optimizer):
     every unbound wrapper whose module owns the optimizer's parameters gets its reducer now"""
     mine = {id(p) for p in optimizer.params}
     for w in list(_LIVE_WRAPPERS):
-        if w.reducer is None and any(id(p) in mine for p in w.module.parameters()):
+        # also a wrapper bound to an OLDER arena of the same parameters: the Trainer builds its optimizer again after
+        # load_checkpoint / reinitialize, p.grad then points into the new arena and the old reducer would go on reducing
+        # the old one (ranks diverge silently)
+        if w._optimizer is not optimizer and any(id(p) in mine for p in w.module.parameters()):
             w.bind_optimizer(optimizer)
 
 
@@ -213,7 +235,9 @@ class DataParallelWavLM(torch.nn.Module):
         if self.reducer is not None:
             if self._optimizer is optimizer:
                 return
-            raise RuntimeError("DataParallelWavLM is already bound to another optimizer arena")
+            # a new arena for the same model (optimizer rebuilt): the old reducer's hooks and listener go, a new one is cut
+            self.reducer.close()
+            self.reducer = None
         self._optimizer = optimizer
         self.reducer = GradReducer(optimizer.params, optimizer.flat_grad, optimizer.offsets, self._pg, self._bucket_bytes)
 

@@ -291,7 +291,9 @@ class FairseqFusedAdam:
         loss.backward()
 
     def all_reduce_grads(self, module):
-        if hasattr(module, "bind_optimizer") and getattr(module, "reducer", True) is None:
+        # bound late (the Trainer wraps the model before it builds the optimizer) or bound to an arena this optimizer has
+        # replaced (the Trainer rebuilt its optimizer: trainer.py load_checkpoint / reinitialize)
+        if hasattr(module, "bind_optimizer") and getattr(module, "_optimizer", self.fused) is not self.fused:
             module.bind_optimizer(self.fused)
         if hasattr(module, "all_reduce_grads"):
             module.all_reduce_grads()
