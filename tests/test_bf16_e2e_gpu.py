@@ -173,6 +173,51 @@ def test_bf16_ten_update_trajectory_vs_fp32_oracle():
     assert max(rl) < 1e-2 and max(rg) < 3e-2, msg
 
 
+def test_bf16_loss_at_bench_batch_vs_fp32_oracle():
+    """The headline configuration itself -- BASELINE.json configs[1]: 12 layers, 32 x 15 s, bf16, FusedAdam bound, i.e. the
+    one-call-per-block path bench.py times -- against the fp32 CPU oracle's forward + criterion (no_grad) on the same
+    bf16-rounded weights, waveform and masks: loss 2e-3 relative (the tolerance derived in the module docstring), sample
+    size and the logged counters equal, accuracy counter within 1 %."""
+    from oracle import wavlm_oracle as O
+    from unispeech_amd.masking import compute_mask_indices
+    _oracle_threads()
+    model, opt, crit, sd, cfg = _build(torch.bfloat16)
+    B, seconds = 32, 15.0
+    wav, target, pm = _batch(B, seconds, seed=7)
+    sample = {"id": torch.arange(B), "net_input": {"source": wav.cuda(), "padding_mask": pm.cuda(), "padding_mask_cpu": pm},
+              "target_list": [target.cuda()]}
+    opt.zero_grad()
+    np.random.seed(4321)
+    loss, ss, log = crit(model, sample)      # grad enabled, optimizer bound: the benchmarked path (no backward needed here)
+    from unispeech_amd import layerfn
+    f, n_blocks = loss.grad_fn, 0
+    seen, stack = set(), [loss.grad_fn]
+    while stack:
+        f = stack.pop()
+        if f is None or f in seen:
+            continue
+        seen.add(f)
+        n_blocks += type(f).__name__.startswith("EncoderLayerFn")
+        stack.extend(n for n, _ in f.next_functions)
+    assert n_blocks == 12 and layerfn.LAYER_FUSED
+    l16, c16 = loss.item(), float(log["correct_m_0"])
+    del loss
+    Tp = min(_frames(wav.shape[1], cfg), target.shape[1])
+    np.random.seed(4321)
+    m = compute_mask_indices((B, Tp), torch.zeros(B, Tp, dtype=torch.bool), cfg.mask_prob, cfg.mask_length, "static", 0,
+                             min_masks=2, no_overlap=False, min_space=1)
+    with torch.no_grad():
+        net = O.pretrain_forward(sd, cfg, wav.float(), [target], pm, torch.from_numpy(m), [V])
+        oloss, oss, olog = O.criterion(net, 1.0, 0.0, [10.0])
+    rel = abs(l16 - oloss.item()) / abs(oloss.item())
+    msg = "B=32x15s, 12L: loss bf16 HIP %.3f vs fp32 oracle %.3f (rel %.2e), sample_size %d / %d, correct %d / %d of %d" % (
+        l16, oloss.item(), rel, ss, oss, c16, olog["correct_m_0"], olog["count_m_0"])
+    print(msg)
+    assert ss == oss and int(log["count_m_0"]) == olog["count_m_0"], msg
+    assert rel < 2e-3, msg
+    assert abs(c16 - olog["correct_m_0"]) <= 0.01 * olog["count_m_0"] + 2, msg
+
+
 def test_bf16_loss_at_bench_batch_vs_fp32_hip_mode():
     """configs[1] batch (32 x 15 s), dropouts 0: the loss of the bf16 path against the fp32 mode of the same HIP path
     (exact-FMA GEMMs, unfused attention) with identical masks and bf16-rounded parameters; 2e-3 relative as above."""

@@ -2,8 +2,8 @@
 structure (d = 1024, 16 heads of 64, FFN 4096, LayerNorm-mode extractor, pre-LN blocks -> `forward_preln_fused`, 20 s
 utterances -> 999 frames) in bf16 with FusedAdam bound (packed q|k|v, gradient sinks, MFMA GEMMs with fused epilogues,
 fused attention at T = 999 / H = 16, direct pos_conv at Cg = 64, LayerNorm-mode conv0), against the fp32 CPU oracle on
-the same bf16-rounded parameters and waveform.  4 layers instead of 24 (the CPU oracle has to finish in a minute); every
-layer type, width and sequence length of the bench configuration is the real one.
+the same bf16-rounded parameters and waveform.  Run at 4 layers (fast: every layer type, width and sequence length of the
+bench configuration is the real one) AND at the full 24 layers.
 
   * `large`: the masked-prediction step of configs[3] (reference lines: pre-LN block unispeech_sat.py:1088-1111, attention
     multihead_attention.py:278-300, LayerNorm-mode extractor WavLM/WavLM.py:403-418).
@@ -61,15 +61,22 @@ def compare_gradients(grads, og, l2_tol=4e-2, max_tol=6e-2, cos_tol=0.999):
     return bad, rep
 
 
-@pytest.mark.parametrize("name", ["large", "sat_large"])
-def test_large_width_bf16_step_vs_fp32_oracle(name):
+@pytest.mark.parametrize("name,layers", [("large", 4), ("sat_large", 4), ("large", 24), ("sat_large", 24)])
+def test_large_width_bf16_step_vs_fp32_oracle(name, layers):
+    """layers = 24: configs[3] / configs[4] at their FULL depth (the speaker tap then sits after layer 6 as in the released
+    UniSpeech-SAT Large config, unispeech_sat.py:248-262); the same gradient bound as at 4 / 12 layers (4e-2; sqrt(24 layers
+    x 6 roundings) u = 2.3e-2 expected, measured worst tensor 2.9e-2, median 1.3e-2)"""
     from oracle import wavlm_oracle as O
     from unispeech_amd import wavlm as W
     from unispeech_amd.masking import compute_mask_indices
     from unispeech_amd.optim import FusedAdam
     from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
-    d = SAT if name == "sat_large" else LARGE
+    d = dict(SAT if name == "sat_large" else LARGE)
+    d["encoder_layers"] = layers
+    if layers == 24 and name == "sat_large":
+        d["utterance_contrastive_layer"] = 6
+    l2_tol, max_tol = 4e-2, 6e-2
     lw = [10.0, 10.0, 0.0] if name == "sat_large" else [10.0]
     cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
     torch.manual_seed(0)
@@ -110,9 +117,9 @@ def test_large_width_bf16_step_vs_fp32_oracle(name):
                                             max_norm=CLIP, loss_weights=lw, return_grads=True, **ADAM)
     assert ss == sizes[0]
     rel_loss = abs(loss.item() - losses[0]) / abs(losses[0])
-    bad, rep = compare_gradients(grads, og)
-    msg = "%s (4L, d=1024, H=16, 2 x 20 s, T'=999) bf16 vs fp32 oracle: loss %.4f vs %.4f (rel %.2e)\n  %s" % (
-        name, loss.item(), losses[0], rel_loss, rep)
+    bad, rep = compare_gradients(grads, og, l2_tol=l2_tol, max_tol=max_tol)
+    msg = "%s (%dL, d=1024, H=16, 2 x 20 s, T'=999) bf16 vs fp32 oracle: loss %.4f vs %.4f (rel %.2e)\n  %s" % (
+        name, layers, loss.item(), losses[0], rel_loss, rep)
     print(msg)
     assert rel_loss < 2e-3, msg
     assert not bad, msg + "\n" + "\n".join(map(str, bad[:20]))
