@@ -1,5 +1,5 @@
 """Timing probes of the ping-pong GEMM: rebuild libwavlm_hip with gemm_pp.hip compiled under -DPP_PROBE=<bits> into
-unispeech_amd/lib/libwavlm_hip_probe<bits>.so (bit 0: no LDS fragment reads, bit 1: no operand DMA, bit 2: one MFMA
+tools/probe/lib/libwavlm_hip_probe<bits>.so (built with -DWAVLM_EXPERIMENTAL: the product library carries no probe branch) (bit 0: no LDS fragment reads, bit 1: no operand DMA, bit 2: one MFMA
 pair per section instead of four).  Results of probe builds are WRONG by construction; they only answer "what does
 the K loop cost without X".  Use: WAVLM_HIP_LIB=.../libwavlm_hip_probe3.so python tools/gemm_ksweep.py 3 2048"""
 import os
@@ -23,8 +23,10 @@ for a in sys.argv[1:] or ["1", "2", "3", "4"]:
         src, a = "attn_fused.hip", a[5:]
     tag, defs = (a, ["-DPP_PROBE=%d" % int(a)]) if a.isdigit() else (a.split(":")[0], a.split(":")[1].split(","))
     obj = os.path.join(B.OBJ_DIR, "%s_probe%s.o" % (src[:-4], tag))
-    subprocess.check_call([B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + defs + ["-c", os.path.join(B.CSRC, src), "-o", obj])
+    subprocess.check_call([B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + ["-DWAVLM_EXPERIMENTAL"] + defs + ["-c", os.path.join(B.CSRC, src), "-o", obj])
     objs = [os.path.join(B.OBJ_DIR, s.replace(".hip", ".o")) for s in B.SOURCES if s != src] + [obj]
-    out = os.path.join(B.LIB_DIR, "libwavlm_hip_probe%s.so" % tag)
+    # probe libraries live outside the package (unispeech_amd/lib/ ships ONLY libwavlm_hip.so): select one with WAVLM_HIP_LIB
+    os.makedirs(os.path.join(ROOT, "tools", "probe", "lib"), exist_ok=True)
+    out = os.path.join(ROOT, "tools", "probe", "lib", "libwavlm_hip_probe%s.so" % tag)
     subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", out] + objs)
     print("built", out)

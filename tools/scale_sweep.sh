@@ -1,0 +1,29 @@
+#!/bin/bash
+# usage (a node with N >= 2 MI355X): bash tools/scale_sweep.sh [N=8] [steps=20]
+#   -> gpurun_out/scale_sweep/<tag>.json, one bench line per setting; read `data_parallel.comm_wait_ms_per_rank` (0 = the
+#      gradient all-reduce is fully hidden behind backward) next to `value`.
+# Sweeps what the build environment (one GPU per call) could not measure: the CU reservation of the persistent GEMM grids
+# (WAVLM_DP_RESERVED_CUS: CUs left to the RCCL kernels while backward runs) and the bucket size (WAVLM_DP_BUCKET_MIB; xGMI is
+# point-to-point, a ring all-reduce is bound by one ~153 GB/s link: few large buckets).  Reference seam:
+# src/fairseq/distributed/legacy_distributed_data_parallel.py:132-165 (one blocking all-reduce after backward).
+N=${1:-8}; STEPS=${2:-20}
+cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}; mkdir -p gpurun_out/scale_sweep
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+run() { # tag, env...
+  tag=$1; shift
+  env "$@" timeout 900 python bench.py --gpus $N --steps $STEPS --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/scale_sweep/$tag.log 2>&1
+  tail -1 gpurun_out/scale_sweep/$tag.log > gpurun_out/scale_sweep/$tag.json
+  python - "$tag" <<'PY'
+import json, sys
+tag = sys.argv[1]
+try:
+    d = json.load(open("gpurun_out/scale_sweep/%s.json" % tag))
+    dp = d.get("data_parallel") or {}
+    print("%-28s %9.1f audio-s/s  %6.2f ms/step  devices %s  wait ms %s" % (tag, d["value"], d["ms_per_step"], dp.get("distinct_devices"), dp.get("comm_wait_ms_per_rank")))
+except Exception as e:
+    print(tag, "FAILED", e)
+PY
+}
+for cu in 0 8 16; do run cus${cu}_bucket32 WAVLM_DP_RESERVED_CUS=$cu WAVLM_DP_BUCKET_MIB=32; done
+for mb in 16 64; do run cus8_bucket${mb} WAVLM_DP_RESERVED_CUS=8 WAVLM_DP_BUCKET_MIB=$mb; done
+for n in 1 2 4; do [ $n -lt $N ] && N_SAVE=$N && N=$n && run n${n}_default WAVLM_DP_RESERVED_CUS=8 && N=$N_SAVE; done

@@ -8,6 +8,11 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // P = 2^0 = 1, which bf16 holds exactly; relative to a stale reference it is 2^frac and rounds like every other term.  The
 // 12-layer gradient comparison with the fp32 oracle (tests/test_bf16_e2e_gpu.py) keeps its median (1.52e-2 against
 // 1.59e-2 relative L2) but its worst tensor moves from 3.2e-2 to 4.4e-2 of a 4e-2 bound -- not worth 5 us per layer.
+#if !defined(WAVLM_EXPERIMENTAL)   // lab-bench switches exist only in -DWAVLM_EXPERIMENTAL builds (tools/probe/build_probe.py)
+#undef FA_FWD_LAZY
+#undef FA_FWD_THETA
+#undef FA_DQ_PK
+#endif
 #ifndef FA_FWD_LAZY
 #define FA_FWD_LAZY 0
 #endif

@@ -42,6 +42,11 @@
 
 #include "tile_loaders.hpp"
 
+// Lab-bench switches exist only in builds made with -DWAVLM_EXPERIMENTAL (tools/probe/build_probe.py).
+#if !defined(WAVLM_EXPERIMENTAL)
+#undef PP_PROBE
+#undef PP_DMA_RD
+#endif
 #ifndef PP_PROBE
 // 0 in the product build.  Timing probes (tools/probe/build_probe.py; results are wrong by construction): bit 0 drops the
 // LDS fragment reads, bit 1 the DMA, bit 2 three quarters of the MFMAs, bit 3 makes the DMA source hot and contiguous,

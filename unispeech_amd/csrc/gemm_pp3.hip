@@ -22,9 +22,12 @@
 
 #include "tile_loaders.hpp"
 
+// Lab-bench switches exist only in builds made with -DWAVLM_EXPERIMENTAL (tools/probe/build_probe.py); the product build
+// has P3_PROBE == 0.  Timing probes (results are wrong by construction): bit 0 skips the K loop and the prologue DMA.
+#if !defined(WAVLM_EXPERIMENTAL)
+#undef P3_PROBE
+#endif
 #ifndef P3_PROBE
-// 0 in the product build.  Timing probes (tools/probe/build_probe.py pp3:<tag>:-DP3_PROBE=<bits>; results are wrong by
-// construction): bit 0 skips the K loop and the prologue DMA (tile set-up + epilogue only)
 #define P3_PROBE 0
 #endif
 #define P3_AU 8192
@@ -490,11 +493,12 @@ static int pp3_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
   p.nbatch = nbatch;
   p.vtotal = p.tiles_m * p.tiles_n * nbatch * p.split_k;
   const int pgrid = 256 - g_pp_reserved_cus;
-  static const bool persistent = !(getenv("WAVLM_PP3_PERSISTENT") && getenv("WAVLM_PP3_PERSISTENT")[0] == '0');  // A/B switch
-  dim3 grid((unsigned)(!persistent || p.vtotal < pgrid ? p.vtotal : pgrid), 1, 1);
-  // WAVLM_PP3_SKEW=n: start phases 0..3 x n x ~3.9 us (s_sleep 127) for launches of >= 2 rounds (experiment switch)
+  dim3 grid((unsigned)(p.vtotal < pgrid ? p.vtotal : pgrid), 1, 1);   // persistent: a tile's epilogue stores drain under the next tile's DMA
+#if defined(WAVLM_EXPERIMENTAL)
+  // WAVLM_PP3_SKEW=n: start phases 0..3 x n x ~3.9 us (s_sleep 127) for launches of >= 2 rounds (measured: no gain, profiles/HISTORY.md)
   static const int skew = getenv("WAVLM_PP3_SKEW") ? atoi(getenv("WAVLM_PP3_SKEW")) : 0;
-  p.skew = (persistent && skew > 0 && p.vtotal >= 2 * pgrid) ? skew : 0;
+  p.skew = (skew > 0 && p.vtotal >= 2 * pgrid) ? skew : 0;
+#endif
   constexpr int smem = 2 * P3_STAGE;
   static bool done[5] = {false, false, false, false, false};
 #define PP_CASE(E) case E: { \

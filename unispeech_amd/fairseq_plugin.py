@@ -181,11 +181,16 @@ def _w2v_classes():
     return W2VModel, W2VCriterion, W2VCfg, W2VCritCfg
 
 
-def register(override: bool = False):
+def register(override: bool = False, fp16_as_bf16=None):
     """Call once per mode (importing the package via --user-dir does the default one).  Returns (model_cls,
     criterion_cls).  override=False registers the `*_mi355x` names; override=True ALSO replaces the built-in
     `wavlm` / `hubert` / `unispeech_sat` / `ils_hubert` model entries and the `wavlm` / `hubert` criteria in fairseq's
-    registries, so that an unmodified recipe (`--arch wavlm --criterion wavlm`) runs on the HIP kernels."""
+    registries, so that an unmodified recipe (`--arch wavlm --criterion wavlm`) runs on the HIP kernels.
+    fp16_as_bf16 (None = leave as the environment set it): an unmodified `--fp16` recipe runs on the bf16 kernels with the
+    reference's loss-scaling protocol instead of raising (unispeech_amd/precision.py)."""
+    if fp16_as_bf16 is not None:
+        from . import precision
+        precision.set_fp16_as_bf16(fp16_as_bf16)
     from fairseq.criterions import register_criterion
     from fairseq.models import register_model
     Model, Criterion, ModelCfg, CritCfg = _classes()
@@ -221,7 +226,9 @@ def register(override: bool = False):
             @classmethod
             def build_optimizer(cls, cfg, params, **kwargs):
                 oname = getattr(cfg.optimizer, "_name", "adam")
-                if getattr(cfg.common, "bf16", False) and oname in ("adam", "adam_mi355x"):
+                from . import precision
+                low = getattr(cfg.common, "bf16", False) or (getattr(cfg.common, "fp16", False) and precision.fp16_as_bf16())
+                if low and oname in ("adam", "adam_mi355x"):
                     return FP16Standin.build_optimizer(cfg, params, **kwargs)
                 return orig_fp16.build_optimizer(cfg, params, **kwargs)
 

@@ -37,14 +37,6 @@ CHAIN_CONSUMERS = os.environ.get("WAVLM_CHAIN_CONSUMERS", "1") == "1"
 _WG = os.environ.get("WAVLM_WGRAD_GROUPING", "auto")
 WGRAD_GROUPING = _WG != "0"
 SINK_LISTENERS = []  # callables(tensor): told which arena slice a backward kernel has just accumulated into (dp.GradReducer)
-# WAVLM_WGRAD_STREAM=1: the grouped weight-gradient launches run on a side HIP stream.  They are off the critical path of
-# backward (nothing but the optimizer / the gradient reducer reads dW), a grouped launch leaves 40 of 256 CUs idle for its
-# whole duration and every kernel of the main chain has a tail: with a second queue the scheduler fills those with the
-# other stream's workgroups.  The side stream waits for the point at which the layer's last dy was produced; the optimizer
-# step / reducer finish wait for the side stream (flush_wgrad_groups); operands are kept alive across streams with
-# record_stream; the side stream has its own split-K workspace.
-WGRAD_STREAM = os.environ.get("WAVLM_WGRAD_STREAM", "0") == "1"
-_WG_SIDE = {}  # device index -> side stream
 
 
 def h2d(a, dev):
@@ -148,7 +140,6 @@ class WgradGroup:
     whatever is left, so a member that never receives a gradient cannot strand the others."""
     __slots__ = ("expected", "items", "sinks", "fired")
     pending = []
-    side_pending = False  # side-stream launches not yet joined by the main stream
     deferred = set()  # data_ptr of every sink slice whose accumulation is queued but not yet enqueued on the stream
 
     def __init__(self, expected):
@@ -171,46 +162,30 @@ class WgradGroup:
         self.fired = True
         if self in WgradGroup.pending:
             WgradGroup.pending.remove(self)
-        def launch():
-            # Members are packed, in arrival order, into sub-groups whose tiles still fit ONE round of the persistent grid
-            # with a split >= 2 (ops.grouped_split): Base: all four dW of a layer (108 tiles); Large: fc2 | fc1 | out_proj +
-            # q|k|v (64 tiles each) -- out_proj alone needs a split of 16 (16 fp32 slabs for a 1024 x 1024 output).
-            n = self.items[0][0].shape[0]
-            kt = (n + 63) // 64
-            tl = [((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in self.items]
-            groups, cur, cur_t = [], [], 0
-            for it, t in zip(self.items, tl):
-                if cur and (n == 0 or ops.grouped_split(cur_t + t, kt) < 2 or len(cur) == 4):
-                    groups.append(cur)
-                    cur, cur_t = [], 0
-                cur.append(it)
-                cur_t += t
-            if cur:
+        # Members are packed, in arrival order, into sub-groups whose tiles still fit ONE round of the persistent grid
+        # with a split >= 2 (ops.grouped_split): Base: all four dW of a layer (108 tiles); Large: fc2 | fc1 | out_proj +
+        # q|k|v (64 tiles each) -- out_proj alone needs a split of 16 (16 fp32 slabs for a 1024 x 1024 output).
+        n = self.items[0][0].shape[0]
+        kt = (n + 63) // 64
+        tl = [((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in self.items]
+        groups, cur, cur_t = [], [], 0
+        for it, t in zip(self.items, tl):
+            if cur and (n == 0 or ops.grouped_split(cur_t + t, kt) < 2 or len(cur) == 4):
                 groups.append(cur)
-            for grp in groups:
-                if len(grp) == 1 or n == 0:
-                    for dy2d, x2d, out in grp:
-                        _linear_bwd_w(dy2d, x2d, out.dtype, out=out)
-                else:
-                    ops.gemm_wgrad_grouped(grp, grp[0][2].dtype)
-            for sk in self.sinks:  # (on the side stream: a reducer orders its all-reduce behind THIS stream's work)
-                WgradGroup.deferred.discard(sk.data_ptr())
-                _sink_written(sk)
-
-        dev = self.items[0][0].device
-        if WGRAD_STREAM and dev.type == "cuda":
-            side = _WG_SIDE.get(dev.index)
-            if side is None:
-                side = _WG_SIDE[dev.index] = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                launch()
-            for dy2d, x2d, _ in self.items:  # the allocator must not hand these blocks out again before the side stream is done
-                dy2d.record_stream(side)
-                x2d.record_stream(side)
-            WgradGroup.side_pending = True
-        else:
-            launch()
+                cur, cur_t = [], 0
+            cur.append(it)
+            cur_t += t
+        if cur:
+            groups.append(cur)
+        for grp in groups:
+            if len(grp) == 1 or n == 0:
+                for dy2d, x2d, out in grp:
+                    _linear_bwd_w(dy2d, x2d, out.dtype, out=out)
+            else:
+                ops.gemm_wgrad_grouped(grp, grp[0][2].dtype)
+        for sk in self.sinks:
+            WgradGroup.deferred.discard(sk.data_ptr())
+            _sink_written(sk)
         self.items, self.sinks = [], []
 
 
@@ -222,14 +197,9 @@ def grad_write_deferred(grad_view):
 
 
 def flush_wgrad_groups():
-    """fire what is still queued and, with side-stream weight gradients, make the current stream wait for them: called by
-    every reader of the gradient arena (optimizer step / norm, reducer finish)"""
+    """fire what is still queued: called by every reader of the gradient arena (optimizer step / norm, reducer finish)"""
     for g in list(WgradGroup.pending):
         g.fire()
-    if WgradGroup.side_pending:
-        WgradGroup.side_pending = False
-        for idx, side in _WG_SIDE.items():
-            torch.cuda.current_stream(idx).wait_stream(side)
 
 
 class BiasGradToken:
@@ -570,18 +540,21 @@ class ConvStackFn(torch.autograd.Function):
         ctx.specs = specs
         ctx.act = act
         ctx.nl = len(specs)
-        ctx.wbs = wbs
+        ctx.has_wb = wbs is not None
         for i, W in enumerate(weights):
             if ctx.needs_input_grad[3 + i]:
                 _sink_use(W)
-        ctx.save_for_backward(*xs, *us, *weights)
+        # the back-propagation weight images travel through autograd's saved-tensor machinery like every other saved tensor
+        # (version checks, saved_tensors_hooks; released with the graph)
+        ctx.save_for_backward(*xs, *us, *weights, *(wbs or ()))
         return cur
 
     @staticmethod
     def backward(ctx, dy):
         nl, specs = ctx.nl, ctx.specs
         saved = ctx.saved_tensors
-        xs, us, weights = saved[:nl], saved[nl:2 * nl], saved[2 * nl:]
+        xs, us, weights = saved[:nl], saved[nl:2 * nl], saved[2 * nl:3 * nl]
+        wb_flat = saved[3 * nl:] if ctx.has_wb else None
         B = dy.shape[0]
         dev = dy.device
         grads = [None] * nl
@@ -628,6 +601,7 @@ class ConvStackFn(torch.autograd.Function):
                 fpp, Tpp = 0, T_in
                 nxt = torch.empty((B, T_in, Cin), dtype=dy.dtype, device=dev)
                 aux = None
+            wb_views = ops.conv_phase_views(wb_flat[i], Cout, Cin, k, s)
             for r in range(s):
                 Jr = J[r]
                 if Jr == 0:
@@ -636,7 +610,7 @@ class ConvStackFn(torch.autograd.Function):
                 # with a Python list builds the index tensor on the host and copies it with a blocking H2D transfer, i.e.
                 # a stream synchronisation in the middle of backward (measured: the launch thread stalled 23 ms here
                 # every step and lost all its run-ahead for the rest of the step)
-                Wb = ctx.wbs[i][r]   # [Cin, Jr * Cout], taps of the phase newest first (ops.conv_weights_relayout)
+                Wb = wb_views[r]   # [Cin, Jr * Cout], taps of the phase newest first (ops.conv_weights_relayout)
                 Mr = (T_in - r + s - 1) // s
                 ops.gemm(P, Wb, nxt, Mr, Cin, Jr * Cout, lda=Cout, ldb=Jr * Cout, ldc=s * Cin, batch=(B, 1),
                          a_off=(fp - Jr + 1) * Cout, sA=(Tp * Cout, 0), c_off=(fpp + r) * Cin, sC=(Tpp * Cin, 0),

@@ -280,28 +280,33 @@ def _conv_desc(weights, specs):
 
 def conv_weights_relayout(weights, specs, want_bwd):
     """GEMM operand images of the extractor's Conv1d weights, all layers in one launch.  weights: [Cout, Cin, k] tensors,
-    specs: [(k, stride)].  Returns (Wf list [Cout, k * Cin], Wb list of per-phase lists [Cin, J_r * Cout] or None)."""
+    specs: [(k, stride)].  Returns (Wf list [Cout, k * Cin], Wb flat buffers [Cin * Cout * k] or None): the stride-phase
+    images of layer l are views of its flat buffer (conv_phase_views)."""
     d = _conv_desc(weights, specs)
-    Wf, Wb, keep = [], [], []
+    Wf, Wb = [], []
     for l, (W, (k, s_)) in enumerate(zip(weights, specs)):
         Cout, Cin, _ = W.shape
         f = torch.empty((Cout, k * Cin), dtype=W.dtype, device=W.device)
         d.Wf[l] = f.data_ptr()
         Wf.append(f)
         if want_bwd:
-            J = [len(range(r, k, s_)) for r in range(s_)]
             flat = torch.empty(Cin * Cout * k, dtype=W.dtype, device=W.device)
             d.Wb[l] = flat.data_ptr()
-            views, off = [], 0
-            for Jr in J:
-                views.append(flat[off:off + Cin * Jr * Cout].view(Cin, Jr * Cout))
-                off += Cin * Jr * Cout
-            Wb.append(views)
-            keep.append(flat)
+            Wb.append(flat)
         else:
             d.Wb[l] = None
     check(_lib.lib().wavlm_conv_weights_relayout(C.byref(d), stream()), "wavlm_conv_weights_relayout")
     return Wf, (Wb if want_bwd else None)
+
+
+def conv_phase_views(flat, Cout, Cin, k, s_):
+    """the s_ stride-phase images [Cin, J_r * Cout] (taps of phase r newest first) inside a layer's flat Wb buffer"""
+    views, off = [], 0
+    for r in range(s_):
+        Jr = len(range(r, k, s_))
+        views.append(flat[off:off + Cin * Jr * Cout].view(Cin, Jr * Cout))
+        off += Cin * Jr * Cout
+    return views
 
 
 def conv_wgrad_scatter(grads, dWf, specs, accumulate):

@@ -75,6 +75,8 @@ class FusedAdam:
             off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
         self.offsets = [off_of[id(p)] for p in self.params]
         self.numel = off
+        # what was packed (tests / logs: a deep-copied model whose tags were lost would show 0 here)
+        self.packed_groups = len(self._group_span)
         self.flat_param = torch.zeros(off, dtype=dtype, device=dev)
         self.flat_grad = torch.zeros(off, dtype=dtype, device=dev)
         with torch.no_grad():
@@ -218,6 +220,51 @@ class FusedAdam:
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
 
 
+class DynamicLossScaler:
+    """The reference's loss-scale schedule (optim/dynamic_loss_scaler.py:7-70), kept for `--fp16` recipes run with the
+    fp16-as-bf16 switch (precision.py): multiply the loss by `loss_scale`; a non-finite gradient norm is an overflow --
+    the scale is divided by `scale_factor` (not below `threshold`) once the share of overflowing updates since the last
+    rescale reaches `tolerance`, and OverflowError tells the Trainer to skip the update (FloatingPointError once the scale
+    would fall to `min_loss_scale`); `scale_window` updates after the last overflow the scale is multiplied again."""
+
+    def __init__(self, init_scale=2.0 ** 15, scale_factor=2.0, scale_window=2000, tolerance=0.0, threshold=None,
+                 min_loss_scale=1e-4):
+        self.loss_scale, self.scale_factor, self.scale_window = init_scale, scale_factor, scale_window
+        self.tolerance, self.threshold, self.min_loss_scale = tolerance, threshold, min_loss_scale
+        self._iter, self._last_overflow_iter, self._last_rescale_iter, self._overflows_since_rescale = 0, -1, -1, 0
+
+    def scale(self, outputs):
+        return self.loss_scale * outputs
+
+    def update(self):
+        """after a completed update: grow the scale every `scale_window` updates without an overflow"""
+        if (self._iter - self._last_overflow_iter) % self.scale_window == 0:
+            self.loss_scale *= self.scale_factor
+            self._last_rescale_iter = self._iter
+        self._iter += 1
+
+    def check_overflow(self, grad_norm):
+        if not (grad_norm == float("inf") or grad_norm != grad_norm):
+            return
+        before = self.loss_scale
+        since = self._iter - self._last_rescale_iter
+        self._last_overflow_iter = self._iter
+        self._overflows_since_rescale += 1
+        if self._overflows_since_rescale / float(since) >= self.tolerance:
+            self.loss_scale /= self.scale_factor
+            if self.threshold is not None:
+                self.loss_scale = max(self.loss_scale, self.threshold)
+            self._last_rescale_iter = self._iter
+            self._overflows_since_rescale = 0
+        if self.loss_scale <= self.min_loss_scale:
+            self.loss_scale = before
+            raise FloatingPointError("Minimum loss scale reached ({}). Your loss is probably exploding. Try lowering the "
+                                     "learning rate, using gradient clipping or increasing the batch size."
+                                     .format(self.min_loss_scale))
+        self._iter += 1
+        raise OverflowError("setting loss scale to: " + str(self.loss_scale))
+
+
 class FairseqFusedAdam:
     """The fairseq Trainer's optimizer seam over FusedAdam: every method `trainer.py` calls on `self.optimizer`
     (optim/fairseq_optimizer.py:97-130 and the bf16 wrapper optim/fp16_optimizer.py:106-289 that trainer.py:296-316
@@ -230,7 +277,7 @@ class FairseqFusedAdam:
 
     cfg: the optimizer config (`cfg.optimizer` of the reference: lr list, adam_betas, adam_eps, weight_decay)."""
 
-    def __init__(self, cfg, params):
+    def __init__(self, cfg, params, scaler=None):
         self.cfg = cfg
         betas = getattr(cfg, "adam_betas", (0.9, 0.999))
         if isinstance(betas, str):
@@ -243,7 +290,9 @@ class FairseqFusedAdam:
                                clip_norm=0.0)
         self._mult_dev = None    # a factor that arrived as a device tensor (sample_size kept on the device)
         self._max_norm = 0.0
-        self.scaler = None       # bf16: no loss scaling (fp16_optimizer.py:248-250); trainer.py:711,947 probe for it
+        # bf16: no loss scaling (fp16_optimizer.py:248-250); trainer.py:711,947 probe for it.  A DynamicLossScaler only when
+        # an --fp16 recipe runs under the fp16-as-bf16 switch (precision.py)
+        self.scaler = scaler
         from . import dp
         dp.bind_live_wrappers(self.fused)
 
@@ -251,9 +300,25 @@ class FairseqFusedAdam:
     def build_optimizer(cls, cfg, params, **kwargs):
         """the signature `optim.FP16Optimizer.build_optimizer(self.cfg, params)` is called with (trainer.py:312): the FULL
         config; the registry path `optim.build_optimizer(cfg.optimizer, params)` constructs the class directly"""
-        if getattr(getattr(cfg, "common", None), "fp16", False) and not getattr(cfg.common, "bf16", False):
-            raise NotImplementedError("unispeech_amd: fp16 with dynamic loss scaling is not supported on the MI355X path; "
-                                      "run bf16 (cfg.common.bf16=True, INTEGRATION.md section 1)")
+        common = getattr(cfg, "common", None)
+        if getattr(common, "fp16", False) and not getattr(common, "bf16", False):
+            from . import precision
+            if not precision.fp16_as_bf16():
+                raise NotImplementedError(precision.MESSAGE)
+            # fp16_optimizer.py:241-268: the scaler of an --fp16 run, window from the data-parallel size when not given
+            window = getattr(common, "fp16_scale_window", None)
+            if window is None:
+                dt, opt_ = getattr(cfg, "distributed_training", None), getattr(cfg, "optimization", None)
+                uf = list(getattr(opt_, "update_freq", [1]))
+                if len(uf) > 1:
+                    raise ValueError("--fp16-scale-window must be given explicitly when using a custom --update-freq schedule")
+                dp_size = int(getattr(dt, "distributed_world_size", 1) / getattr(common, "model_parallel_size", 1))
+                window = int(2 ** 14 / dp_size / uf[0])
+            scaler = DynamicLossScaler(init_scale=getattr(common, "fp16_init_scale", 2 ** 7), scale_window=window,
+                                       tolerance=getattr(common, "fp16_scale_tolerance", 0.0),
+                                       threshold=getattr(common, "threshold_loss_scale", None),
+                                       min_loss_scale=getattr(common, "min_loss_scale", 1e-4))
+            return cls(cfg.optimizer, params, scaler=scaler)
         return cls(cfg.optimizer, params)
 
     # -- what the Trainer reads ------------------------------------------------------------------------------------
@@ -288,6 +353,8 @@ class FairseqFusedAdam:
 
     # -- the step sequence of trainer.py:697-860 -------------------------------------------------------------------
     def backward(self, loss):
+        if self.scaler is not None:
+            loss = self.scaler.scale(loss)   # fp16_optimizer.py:112-120; 1 / loss_scale is in the deferred factor (zero_grad)
         loss.backward()
 
     def all_reduce_grads(self, module):
@@ -315,6 +382,10 @@ class FairseqFusedAdam:
         if self._mult_dev is not None:
             n = n * self._mult_dev.abs()
         self._max_norm = float(max_norm) if max_norm else 0.0
+        if self.scaler is not None:
+            # fp16_optimizer.py:199-206: with a loss scaler the overflow check reads the norm on the host (the reference
+            # synchronises here too) and raises OverflowError before anything is updated
+            self.scaler.check_overflow(float(n))
         return n.reshape(())
 
     def step(self, closure=None, scale=1.0, groups=None):
@@ -322,10 +393,14 @@ class FairseqFusedAdam:
             raise NotImplementedError("closure / parameter groups are not supported by the fused update")
         self.fused.step(grad_mult=1.0 / float(scale), grad_mult_dev=self._mult_dev, max_norm=self._max_norm)
         self._mult_dev, self._max_norm = None, 0.0
+        if self.scaler is not None:
+            self.scaler.update()             # fp16_optimizer.py:218-219
 
     def zero_grad(self):
         self.fused.zero_grad()
         self._mult_dev, self._max_norm = None, 0.0
+        if self.scaler is not None:          # fp16_optimizer.py:238-239: the next backward's gradients carry loss_scale
+            self.fused.pending_mult = 1.0 / float(self.scaler.loss_scale)
 
     # -- checkpoints (trainer.py:373-411, 511-543) ------------------------------------------------------------------
     def state_dict(self):

@@ -243,7 +243,10 @@ class Wav2Vec2Model(nn.Module):
         return None
 
     def half(self):
-        raise NotImplementedError("unispeech_amd: fp16 is not supported on the MI355X path; use bf16 (INTEGRATION.md)")
+        from . import precision
+        if precision.fp16_as_bf16():   # explicit switch: an unmodified --fp16 recipe on bf16 kernels (precision.py)
+            return self.to(torch.bfloat16)
+        raise NotImplementedError(precision.MESSAGE)
 
     @property
     def feat_grad_scale(self):

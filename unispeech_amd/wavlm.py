@@ -181,11 +181,32 @@ class MultiheadAttention(nn.Module):
         if gru_rel_pos:
             self.grep_linear = nn.Linear(self.head_dim, 8)
             self.grep_a = nn.Parameter(torch.ones(1, num_heads, 1, 1))
+        self._tag_pack_owner()
+        self.reset_parameters()
+
+    def _tag_pack_owner(self):
         # an optimizer built from a bare parameter list (the fairseq Trainer's) finds the packed q|k|v groups through this tag
         for lin in (self.q_proj, self.k_proj, self.v_proj):
             lin.weight._wl_pack_owner = self
             lin.bias._wl_pack_owner = self
-        self.reset_parameters()
+
+    def __setstate__(self, state):
+        """copy.deepcopy / pickle (EMA copies, fairseq's model copying): nn.Parameter.__deepcopy__ drops Python attributes,
+        so the copy's q|k|v parameters are re-tagged with THEIR owner, and views into the original's arenas are dropped
+        (the copy packs again when an optimizer is built over it)"""
+        super().__setstate__(state)
+        self.__dict__.pop("_packed_w", None)
+        self.__dict__.pop("_packed_b", None)
+        self.__dict__.pop("_wl_binding", None)
+        self._packed = None
+        self._tag_pack_owner()
+
+    def _apply(self, fn, recurse=True):
+        """module conversion (.to / .cuda / .bfloat16) may replace the Parameter objects (overwrite_module_params_on_conversion):
+        tag whatever objects are there afterwards"""
+        out = super()._apply(fn, recurse)
+        self._tag_pack_owner()
+        return out
 
     def reset_parameters(self):
         g = 1 / math.sqrt(2)
@@ -604,10 +625,12 @@ class WavLM(nn.Module):
 
     def half(self):
         """the reference recipes pass --fp16 (trainer.py:86-89 then calls model.half()); the gfx950 kernels compute in
-        bf16 (MFMA, fp32 accumulate, no loss scaling needed) or fp32 -- fail here, not at the first kernel launch"""
-        raise NotImplementedError(
-            "unispeech_amd: fp16 is not supported on the MI355X path; run bf16 instead (cfg.common.bf16=True with "
-            "cfg.common.tpu=False -- see INTEGRATION.md section 1, 'Precision') or fp32")
+        bf16 (MFMA, fp32 accumulate) or fp32.  Default: fail here, not at the first kernel launch.  With the explicit
+        fp16-as-bf16 switch (unispeech_amd/precision.py) the model becomes bf16."""
+        from . import precision
+        if precision.fp16_as_bf16():
+            return self.to(torch.bfloat16)
+        raise NotImplementedError(precision.MESSAGE)
 
     # -- host-side pieces -------------------------------------------------------------------------------------
     def compute_mask(self, B, T, padding_mask):
