@@ -290,8 +290,8 @@ def pin_rank_cores(local_rank, local_world):
 
 def busy_and_enqueue(step, reps=5):
     """(gpu_busy_ms, host_enqueue_ms) of one step, medians over `reps`: the GPU is first parked on a spin kernel
-    (torch.cuda._sleep) and one un-measured step (which also brings the clocks back up after the spin), the measured step is
-    enqueued behind them -- the launch thread is never waiting for the GPU and the GPU never for the launch thread -- and
+    (torch.cuda._sleep) and two un-measured steps (so that the measured one sees the clocks of a steady stream of steps),
+    the measured step is enqueued behind them -- the launch thread is never waiting for the GPU and the GPU never for the launch thread -- and
     two events around it give the time the GPU needs when nothing starves it; the host clock around the same call gives
     what the launch thread needs to enqueue it.  ms_per_step of the timed region within a few % of gpu_busy = the step is
     GPU-bound on this box; ms_per_step ~ host_enqueue = launch-bound."""
@@ -304,7 +304,11 @@ def busy_and_enqueue(step, reps=5):
     busy, host = [], []
     for _ in range(reps):
         torch.cuda.synchronize()
-        torch.cuda._sleep(int(per_ms * 80))   # ~80 ms + one step: longer than any host needs to enqueue two steps
+        # a short spin gives the host its head start, then TWO unmeasured steps: the part is power-limited, a step that
+        # follows an idle (spinning) GPU runs ~4 % faster than one in a steady stream of steps (measured: 33.1 against
+        # 34.5 ms) -- the measured step must see the same clocks as the timed region's steps
+        torch.cuda._sleep(int(per_ms * 20))
+        step()
         step()
         e0.record()
         t0 = time.perf_counter()

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void gate_bwd64_kernel(const float* __restrict
   const int D = H * 64, CPR = 8 * H, NCH = 2 * CPR;
   const int PW = 128 + 2 + H;
   const int sub = lane & 7;
-  for (int i = threadIdx.x; i < PW; i += 256) sm[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * PW; i += 256) sm[i] = 0.f;
   float wa[8], wb[8], dwa[8], dwb[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -419,22 +419,26 @@ __global__ __launch_bounds__(256) void gate_bwd64_kernel(const float* __restrict
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) { dwa[e] += __shfl_xor(dwa[e], o, 64); dwb[e] += __shfl_xor(dwb[e], o, 64); }
   }
+  // per-wave slots, summed in wave order below: the block's partial row is the same bits in every run (one shared slot
+  // with LDS atomics from four waves summed in arrival order -- run-to-run differences in the last bit of the gate's
+  // parameter gradients)
+  float* smw = sm + wave * PW;
   if (lane < 8) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { atomicAdd(&sm[sub * 8 + e], dwa[e]); atomicAdd(&sm[64 + sub * 8 + e], dwb[e]); }
+    for (int e = 0; e < 8; ++e) { smw[sub * 8 + e] = dwa[e]; smw[64 + sub * 8 + e] = dwb[e]; }
   }
   dba = wave_sum(dba); dbb = wave_sum(dbb);
-  if (lane == 0) { atomicAdd(&sm[128], dba); atomicAdd(&sm[129], dbb); }
+  if (lane == 0) { smw[128] = dba; smw[129] = dbb; }
   if (sub == 0) {
 #pragma unroll
     for (int i = 0; i < GATE_MAXI; ++i) {
       const int q = lane + 64 * i;
-      if (q < NCH) atomicAdd(&sm[130 + ((q % CPR) >> 3)], da[i]);
+      if (q < NCH) atomicAdd(&smw[130 + ((q % CPR) >> 3)], da[i]);   // (collisions only inside the wave: fixed lane order)
     }
   }
   __syncthreads();
   float* out = part + (long)blockIdx.x * PW;
-  for (int i = threadIdx.x; i < PW; i += 256) out[i] = sm[i];
+  for (int i = threadIdx.x; i < PW; i += 256) out[i] = (sm[i] + sm[PW + i]) + (sm[2 * PW + i] + sm[3 * PW + i]);
 }
 
 // ---- head_dim 64, H = 4 NI (12 or 16 heads): the row pair of a step is exactly NI chunks per lane -----------------
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(256) void gate_bwd64p_kernel(const float* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long nbt = (long)B * Tn, npair = (nbt + 1) >> 1;
   const int sub = lane & 7;
-  for (int i = threadIdx.x; i < PW; i += 256) sm[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * PW; i += 256) sm[i] = 0.f;
   float wa[8], wb[8], dwa[8], dwb[8];
   gate_weights(W, sub, wa, wb);
 #pragma unroll
@@ -647,19 +651,20 @@ __global__ __launch_bounds__(256) void gate_bwd64p_kernel(const float* __restric
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) { dwa[e] += __shfl_xor(dwa[e], o, 64); dwb[e] += __shfl_xor(dwb[e], o, 64); }
   }
+  float* smw = sm + wave * PW;   // per-wave slots, summed in wave order (deterministic; see gate_bwd64_kernel)
   if (lane < 8) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { atomicAdd(&sm[sub * 8 + e], dwa[e]); atomicAdd(&sm[64 + sub * 8 + e], dwb[e]); }
+    for (int e = 0; e < 8; ++e) { smw[sub * 8 + e] = dwa[e]; smw[64 + sub * 8 + e] = dwb[e]; }
   }
   dba = wave_sum(dba); dbb = wave_sum(dbb);
-  if (lane == 0) { atomicAdd(&sm[128], dba); atomicAdd(&sm[129], dbb); }
+  if (lane == 0) { smw[128] = dba; smw[129] = dbb; }
   if (sub == 0) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) atomicAdd(&sm[130 + hsel[i]], da[i]);
+    for (int i = 0; i < NI; ++i) atomicAdd(&smw[130 + hsel[i]], da[i]);
   }
   __syncthreads();
   float* out = part + (long)blockIdx.x * PW;
-  for (int i = threadIdx.x; i < PW; i += 256) out[i] = sm[i];
+  for (int i = threadIdx.x; i < PW; i += 256) out[i] = (sm[i] + sm[PW + i]) + (sm[2 * PW + i] + sm[3 * PW + i]);
 }
 
 // partial layout per block: [2*hd (dWa, dWb)] [2 (dba, dbb)] [H (da)]
