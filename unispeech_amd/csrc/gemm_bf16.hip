@@ -310,6 +310,20 @@ bool gemm_pp_ok(const wavlm_gemm_desc* d);                       // gemm_pp.hip
 int gemm_pp_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);
 bool gemm_pp3_ok(const wavlm_gemm_desc* d);                      // gemm_pp3.hip
 int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);
+int gemm_w4_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);  // gemm_w4.hip (same shapes as gemm_pp)
+int gemm_w4_launch_grouped(GemmP& p, hipStream_t st);
+// which 256 x 256 kernel takes a launch: the eight-wave ping-pong (gemm_pp.hip) or the four-wave one (gemm_w4.hip).
+// WAVLM_GEMM_W4: 0 never | 1 always | unset: by shape (see w4_takes)
+static int w4_mode() { static const int m = getenv("WAVLM_GEMM_W4") ? atoi(getenv("WAVLM_GEMM_W4")) : -1; return m; }
+static bool w4_takes(const wavlm_gemm_desc* d, bool grouped) {
+  const int m = w4_mode();
+  if (m == 0) return false;
+  if (m == 1) return true;
+  // measured (tools/w4_ab.py, same process, alternating): the four-wave kernel wins where BOTH operands are K-strided
+  // (weight gradients: the transposing ds_read_b64_tr_b16 form, 2 LDS instructions per fragment -- 8192^3 TT 914 -> 819 us)
+  // and loses 3-8 % on K-contiguous operands and on the epilogue-heavy conv forward
+  return grouped || (d->transA && d->transB);
+}
 
 // fraction of a CU-round's MFMA work that is useful for a BM x BN tiling on 256 CUs (edge waste x round quantisation)
 static double tile_efficiency(const wavlm_gemm_desc* d, int nbatch, int BM, int BN) {
@@ -499,10 +513,12 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
     { const int ec = gemm_epilogue_class(d, vec); if (ec == 3) p.gtab = gelu_tab4_get(st);
       if (d->colsum && (ec == 2 || ec == 4)) { p.colsum_part = (float*)d->workspace; csum_rows = (d->M + 191) / 192; }
       rc = gemm_pp3_launch(p, nbatch, d->transA != 0, d->transB != 0, ec, st); }
-  else if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) {
+  else if ((g_gemm_variant == 3 || g_gemm_variant == 5 || (g_gemm_variant == 0 && d->N >= 256)) && gemm_pp_ok(d)) {
     const int ec = gemm_epilogue_class(d, vec); if (ec == 3) p.gtab = gelu_tab4_get(st);
     if (d->colsum && (ec == 2 || ec == 4)) { p.colsum_part = (float*)d->workspace; csum_rows = (d->M + 255) / 256; }
-    rc = gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, ec, st);
+    rc = (g_gemm_variant == 5 || (g_gemm_variant == 0 && w4_takes(d, false)))
+             ? gemm_w4_launch(p, nbatch, d->transA != 0, d->transB != 0, ec, st)
+             : gemm_pp_launch(p, nbatch, d->transA != 0, d->transB != 0, ec, st);
   }
   else if (!d->transA && !d->transB) rc = launch_t<false, false>(p, nbatch, vec, st);
   else if (!d->transA && d->transB) rc = launch_t<false, true>(p, nbatch, vec, st);
@@ -572,7 +588,7 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
     for (int i = 0; i < n; ++i) by += 2.0 * ((double)d[i].M * d[i].K + (double)d[i].N * d[i].K) + 2.0 * 2.0 * d[i].M * d[i].N;
     g_prof.bytes[pi] = by;
   }
-  int rc = gemm_pp_launch_grouped(p, st);
+  int rc = w4_takes(d, true) ? gemm_w4_launch_grouped(p, st) : gemm_pp_launch_grouped(p, st);
   if (rc == WL_OK) {
     RedGrpP r;
     r.n = n; r.S = p.split_k; r.base[0] = 0;
