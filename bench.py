@@ -128,9 +128,10 @@ def cpu_baseline():
         loss.backward()
         return time.time() - t0
 
-    ncpu = os.cpu_count() or 1
+    from unispeech_amd import hostenv
+    ncpu = hostenv.usable_cpus()   # cores the container may actually use (cgroup quota: 16 of the GPU box's 256)
     # never the full core count of a big host: 256 OpenMP threads on these many small ops ran the 3 s probe in 170 s
-    # (against 0.45 s on 8 threads) on the GPU box
+    # (against 0.45 s on 8 threads) on the GPU box -- the container is throttled to its quota
     cands = sorted({c for c in (4, 8, 16, 32) if c <= ncpu}) or [1]
     old = torch.get_num_threads()
     sweep = {}
@@ -165,7 +166,8 @@ def cpu_baseline_extract():
             O.extract_features(sd, cfg, wav)
         return time.time() - t0
 
-    ncpu = os.cpu_count() or 1
+    from unispeech_amd import hostenv
+    ncpu = hostenv.usable_cpus()
     cands = sorted({c for c in (4, 8, 16, 32) if c <= ncpu}) or [1]
     old = torch.get_num_threads()
     torch.set_num_threads(cands[0])
@@ -380,7 +382,9 @@ def main():
             dist.init_process_group(backend)
 
     from unispeech_amd import functional as WF
-    from unispeech_amd import ops
+    from unispeech_amd import hostenv, ops
+    # the launch thread must not share a throttled cgroup with a 256-thread OpenMP pool (unispeech_amd/hostenv.py)
+    host_threads = hostenv.cap_threads(4)
     from unispeech_amd.dp import DataParallelWavLM
     from unispeech_amd.optim import FusedAdam
     from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainModel
@@ -621,7 +625,8 @@ def main():
             "ms_per_step": round(ms_per_step, 2),
             "gpu_busy_ms_per_step": None if gpu_busy_ms is None else round(gpu_busy_ms, 2),
             "host_enqueue_ms_per_step": None if host_enq_ms is None else round(host_enq_ms, 2),
-            "host_cores_pinned": pinned, "settle_steps": settle,
+            "host_cores_pinned": pinned, "host_threads": host_threads, "host_cpu_quota": hostenv.cpu_quota(),
+            "settle_steps": settle,
             "settle_host_ms": None if settle_host_ms is None else round(settle_host_ms, 2),
             "ms_per_step_unsettled": None if unsettled_ms is None else round(unsettled_ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",

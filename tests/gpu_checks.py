@@ -212,6 +212,19 @@ def check_gemm_pp3():
     return check_gemm_pp(4, "gemm_pp3")
 
 
+def check_gemm_w4():
+    """the four-wave 256 x 256 kernel (csrc/gemm_w4.hip, variant 5: 128 x 128 accumulators per wave, fragment reads
+    software-pipelined between the MFMAs) on the same cases as the eight-wave kernel it shares its LDS image with, plus the
+    fused column sums / GELU' epilogue and the grouped launch"""
+    out = check_gemm_pp(5, "gemm_w4")
+    ops.gemm_set_variant(5)
+    try:
+        out += [("[w4] " + n, e, t) for n, e, t in check_gemm_colsum()]
+    finally:
+        ops.gemm_set_variant(0)
+    return out
+
+
 def check_gemm_race():
     """the same ping-pong launch repeated gives bit-identical output (an LDS hazard between the asynchronous operand DMA
     and the fragment reads would show as run-to-run differences); step-sized shapes, both tile shapes, split-K"""
@@ -1002,7 +1015,7 @@ def check_activations():
 
 
 GROUPS = {
-    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
+    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_w4": check_gemm_w4, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
     "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv, "gemm_colsum": check_gemm_colsum,
     "linear_ffn": check_linear_ffn, "activations": check_activations, "loss": check_loss, "adam": check_adam, "dropout_exact": check_dropout_exact,
 }

@@ -74,7 +74,7 @@ def _frames(T, cfg):
 
 def _oracle_threads():
     # 128 host threads are slower than 16-32 for these sizes (bench.py's cpu_baseline sweep)
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    torch.set_num_threads(min(32, __import__("unispeech_amd.hostenv", fromlist=["x"]).usable_cpus()))  # within the container's CPU quota (hostenv.py)
 
 
 def test_bf16_step_loss_and_all_gradients_vs_fp32_oracle():

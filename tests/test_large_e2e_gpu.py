@@ -71,7 +71,7 @@ def test_large_width_bf16_step_vs_fp32_oracle(name, layers):
     from unispeech_amd.masking import compute_mask_indices
     from unispeech_amd.optim import FusedAdam
     from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainConfig, WavLMPretrainModel
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    torch.set_num_threads(min(32, __import__("unispeech_amd.hostenv", fromlist=["x"]).usable_cpus()))  # within the container's CPU quota (hostenv.py)
     d = dict(SAT if name == "sat_large" else LARGE)
     d["encoder_layers"] = layers
     if layers == 24 and name == "sat_large":

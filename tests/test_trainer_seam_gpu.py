@@ -152,7 +152,7 @@ def test_trainer_step_sequence_world2_vs_oracle(dtype_name):
         p.join(timeout=60)
 
     # ---- the oracle's version of the same 2-worker update
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    torch.set_num_threads(min(32, __import__("unispeech_amd.hostenv", fromlist=["x"]).usable_cpus()))  # within the container's CPU quota (hostenv.py)
     d = _cfg_dict()
     cfg = WavLMPretrainConfig(**{k: v for k, v in d.items() if k in WavLMPretrainConfig.__dataclass_fields__})
     torch.manual_seed(0)

@@ -911,6 +911,20 @@ int wavlm_gate_bwd(const float* dgate, const void* x, const void* W, const void*
 #undef GBP4
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
+  {
+    // deferred finishing (one encoder block's backward collects them, common.hpp): the partial row is [dWa hd][dWb hd][dba]
+    // [dbb][da H]; grep_linear's eight rows are four copies of dWa then four of dWb (gate_bwd_finish_kernel), its bias alike
+    const float* part = (const float*)workspace;
+    const int PW = 2 * hd + 2 + H, acc = accumulate_params & 1;
+    if (wl_fin_add(part, (int)grid, PW, hd, dW, param_dtype, acc, 4, hd)) {
+      const uint64_t es = wl_esize(param_dtype);
+      bool ok = wl_fin_add(part + hd, (int)grid, PW, hd, (char*)dW + 4ull * hd * es, param_dtype, acc, 4, hd);
+      ok = ok && wl_fin_add(part + 2 * hd, (int)grid, PW, 1, dbias, param_dtype, acc, 4, 1);
+      ok = ok && wl_fin_add(part + 2 * hd + 1, (int)grid, PW, 1, (char*)dbias + 4ull * es, param_dtype, acc, 4, 1);
+      ok = ok && wl_fin_add(part + 2 * hd + 2, (int)grid, PW, H, dgrep_a, param_dtype, acc);
+      return ok ? WL_OK : WL_EINVAL;
+    }
+  }
   WL_LAUNCH(gate_bwd_finish_kernel, dim3((unsigned)((2 * hd + 2 + H + 15) / 16)), dim3(1024), 0, st, (const float*)workspace,
                      (int)grid, (int)H, (int)hd, dW, dbias, dgrep_a, (int)param_dtype, (int)(accumulate_params & 1));
   rc = wl_check_launch();

@@ -744,7 +744,7 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
   if (dbias) {  // [B * nqt * 4] partial rows x 3 * H * 64 columns -> the bias gradient ((+)= in its own dtype)
     const int rcb = wl_colsum_finish(p.dbias_part, B * nqt * 4, 3 * H * FA_HD, dbias, dbias_dtype, dbias_accumulate, st);
     if (rcb != WL_OK) return rcb;
-    if (dbias_accumulate) wl_notify_grad(dbias, (uint64_t)3 * H * FA_HD * wl_esize(dbias_dtype), stream);
+    if (dbias_accumulate && !wl_fin_active()) wl_notify_grad(dbias, (uint64_t)3 * H * FA_HD * wl_esize(dbias_dtype), stream);
   }
   if (tab)
     WL_LAUNCH(fa_dtab_reduce_kernel, dim3((unsigned)((Lp / 4 + 15) / 16), (unsigned)H), dim3(1024), 0, st,

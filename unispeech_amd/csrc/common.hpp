@@ -237,3 +237,19 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
                          void* stream);
 // rowops.hip: out[c] (+)= sum over nblk rows of part[nblk][n]
 int wl_colsum_finish(const float* part, int nblk, int n, void* out, int out_dtype, int accumulate, hipStream_t st);
+
+// ---- deferred finishing launches (rowops.hip) ----
+// Kernels that reduce over rows leave per-block partial rows and need a small finishing launch (pure load latency, ~5 us,
+// ~100 of them per training step).  A caller that issues a fixed sequence of such kernels (layer.hip: one encoder block's
+// backward) installs a list; while it is installed the producers APPEND their finishing work to it instead of launching,
+// and wl_fin_flush() runs everything as ONE launch.  Each segment is summed exactly as its stand-alone finishing kernel
+// would (same slices, same order): results are bit-identical.  out[r * rep_stride + c] for r < rep (the gate's 4 x replicated
+// rows), (+)= if accumulate.  The partial buffers must stay untouched until the flush.
+struct WlFinSeg { const float* part; void* out; long stride, rep_stride; int nblk, n, out_dtype, accumulate, rep, blk0; };
+#define WL_FIN_MAX 16
+struct WlFinList { WlFinSeg s[WL_FIN_MAX]; int n, blocks; };
+void wl_fin_defer(WlFinList* l);      // thread-local; nullptr ends the deferral
+bool wl_fin_active();                 // a list is installed: producers leave the listener notification to the flush
+bool wl_fin_add(const float* part, int nblk, long stride, int n, void* out, int out_dtype, int accumulate, int rep = 1,
+                long rep_stride = 0);  // false: nothing installed (or full) -- the caller launches its own finish
+int wl_fin_flush(WlFinList& l, void* stream);   // one launch for the whole list + the gradient-listener notifications

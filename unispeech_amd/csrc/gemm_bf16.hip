@@ -474,7 +474,7 @@ extern "C" uint64_t wavlm_gemm_workspace_bytes(const wavlm_gemm_desc* d) {
 static void gemm_notify(const wavlm_gemm_desc* d, bool colsum_fused, void* stream) {
   if (d->accumulate && d->batch_o <= 1 && d->batch_i <= 1)
     wl_notify_grad(d->C, ((uint64_t)(d->M - 1) * d->ldc + d->N) * wl_esize(d->c_dtype), stream);
-  if (d->colsum && d->colsum_accumulate && colsum_fused)   // (the stand-alone pass reports through wavlm_colsum)
+  if (d->colsum && d->colsum_accumulate && colsum_fused && !wl_fin_active())   // (the stand-alone pass reports through wavlm_colsum; a deferred finish through its flush)
     wl_notify_grad(d->colsum, (uint64_t)d->N * wl_esize(d->colsum_dtype), stream);
 }
 

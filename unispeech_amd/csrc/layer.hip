@@ -207,8 +207,8 @@ int wgrads(const WG* it, int cnt, int64_t n, int pdt, void* ws, uint64_t wsb, vo
 struct BwdWs {
   void *dsa, *df, *du, *dh, *dxa, *da, *dO, *dqkv;
   float* dgate;
-  void *ln_ws, *cs_ws, *attn_ws, *gate_ws, *wg_ws;
-  uint64_t ln_b, cs_b, attn_b, gate_b, wg_b, bytes;
+  void *ln_ws, *ln_ws2, *cs_ws, *cs_ws2, *attn_ws, *gate_ws, *wg_ws;   // (two LayerNorm / column-sum partial buffers: the
+  uint64_t ln_b, cs_b, attn_b, gate_b, wg_b, bytes;                     //  finishing launches are deferred to the end of the block)
 };
 BwdWs carve_bwd(const wavlm_layer_desc* d, void* base, uint64_t cap) {
   BwdWs w; memset(&w, 0, sizeof(w));
@@ -223,10 +223,10 @@ BwdWs carve_bwd(const wavlm_layer_desc* d, void* base, uint64_t cap) {
   w.dO = c.take(n * D * 2);
   w.dqkv = c.take(n * 3 * D * 2);
   if (d->tab) w.dgate = (float*)c.take((uint64_t)d->B * d->H * d->T * 4);
-  w.ln_b = wavlm_layernorm_bwd_workspace_bytes(d->D); w.ln_ws = c.take(w.ln_b);
+  w.ln_b = wavlm_layernorm_bwd_workspace_bytes(d->D); w.ln_ws = c.take(w.ln_b); w.ln_ws2 = c.take(w.ln_b);
   w.cs_b = lin_dx_colsum_ws((int64_t)n, d->F);
   if (w.cs_b < wavlm_colsum_workspace_bytes(d->D)) w.cs_b = wavlm_colsum_workspace_bytes(d->D);
-  w.cs_ws = c.take(w.cs_b);
+  w.cs_ws = c.take(w.cs_b); w.cs_ws2 = c.take(w.cs_b);
   w.attn_b = wavlm_attn_fused_bwd_workspace_bytes(d->B, d->H, d->T); w.attn_ws = c.take(w.attn_b);
   w.gate_b = wavlm_gate_bwd_workspace_bytes(d->H, 64); w.gate_ws = c.take(w.gate_b);
   const WG it[4] = {{nullptr, nullptr, nullptr, d->D, d->F}, {nullptr, nullptr, nullptr, d->F, d->D},
@@ -312,6 +312,10 @@ int wavlm_encoder_layer_bwd(const wavlm_layer_desc* d, void* stream) {
   const BwdWs w = carve_bwd(d, d->workspace, d->ws_bytes);
   if (w.bytes == ~(uint64_t)0) return WL_EINVAL;
   const bool drop = d->p_drop > 0.f;
+  // the ~8 finishing launches of the block (LayerNorm parameter sums x 2, three bias column sums, the gate's sums) become
+  // ONE at the end: the producers append to this list while it is installed (common.hpp)
+  WlFinList fin;
+  struct Defer { Defer(WlFinList* l) { wl_fin_defer(l); } ~Defer() { wl_fin_defer(nullptr); } } defer(&fin);
 
   // ---- feed-forward half
   const void* df;       // gradient of the feed-forward output
@@ -327,7 +331,7 @@ int wavlm_encoder_layer_bwd(const wavlm_layer_desc* d, void* stream) {
     // db2: normally delivered by the LayerNorm that consumed r_out (the next block's LN1 backward through db2_prev, or the
     // encoder's final LayerNorm); a caller whose r_out went elsewhere passes db2 and gets the column sums here
     if (d->db2)
-      RC(wavlm_colsum(df, n, D, D, WL_BF16, nullptr, nullptr, d->db2, pdt, 1, w.cs_ws, w.cs_b, stream));
+      RC(wavlm_colsum(df, n, D, D, WL_BF16, nullptr, nullptr, d->db2, pdt, 1, w.cs_ws2, w.cs_b, stream));
   }
   RC(lin_dx(df, d->W2, w.du, n, D, F, 4, s.u, nullptr, d->db1, pdt, w.cs_ws, w.cs_b, stream));   // du = (df W2) * gelu'(u); db1 += colsum
   RC(lin_dx(w.du, d->W1, w.dh, n, F, D, 0, nullptr, dres, nullptr, pdt, nullptr, 0, stream));     // dh = du W1 (+ dres)
@@ -337,7 +341,7 @@ int wavlm_encoder_layer_bwd(const wavlm_layer_desc* d, void* stream) {
   const void* dxres;    // gradient reaching the block input past the attention branch
   if (!d->pre_ln) {
     RC(wavlm_layernorm_bwd(w.dh, s.s1, s.mean1, s.rstd1, d->ln1_g, d->ln1_b, w.dxa, drop ? w.da : nullptr, nullptr, d->dln1_g,
-                           d->dln1_b, d->dbo, n, D, WL_BF16, pdt, 0, d->p_drop, d->seed_r1, 0.f, 0, 1.f, 1, 0, w.ln_ws, w.ln_b, stream));
+                           d->dln1_b, d->dbo, n, D, WL_BF16, pdt, 0, d->p_drop, d->seed_r1, 0.f, 0, 1.f, 1, 0, w.ln_ws2, w.ln_b, stream));
     da = drop ? w.da : w.dxa;
     dxres = w.dxa;
   } else {
@@ -367,11 +371,12 @@ int wavlm_encoder_layer_bwd(const wavlm_layer_desc* d, void* stream) {
     const void* s1 = d->r_in ? s.s1 : d->x;
     RC(wavlm_layernorm_bwd(w.dxa, s1, s.mean1, s.rstd1, d->ln1_g, d->ln1_b, d->dx, (d->r_in && drop) ? d->dr_in : nullptr, w.dsa,
                            d->dln1_g, d->dln1_b, d->r_in ? d->db2_prev : nullptr, n, D, WL_BF16, pdt, 0, d->r_in ? d->p_drop : 0.f,
-                           d->seed_r1, 0.f, 0, 1.f, 1, d->r_in ? 1 : 0, w.ln_ws, w.ln_b, stream));
+                           d->seed_r1, 0.f, 0, 1.f, 1, d->r_in ? 1 : 0, w.ln_ws2, w.ln_b, stream));
     if (d->r_in && !drop)   // without dropout the branch gradient IS dx
       RC(wavlm_axpby(d->dx, WL_BF16, d->dr_in, WL_BF16, n * D, 1.f, 0.f, stream));
   }
-  return WL_OK;
+  wl_fin_defer(nullptr);
+  return wl_fin_flush(fin, stream);
 }
 
 }  // extern "C"

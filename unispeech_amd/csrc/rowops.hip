@@ -563,6 +563,75 @@ __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __rest
   }
 }
 
+// the same reduction for a LIST of segments in one launch (deferred finishing launches, common.hpp): block -> segment by
+// its first block, then exactly colsum_finish_kernel's arithmetic
+__global__ __launch_bounds__(1024) void colsum_finish_multi_kernel(WlFinList L) {
+  __shared__ float red[64][17];
+  int si = 0;
+#pragma unroll 1
+  for (int k = 1; k < L.n; ++k) if ((int)blockIdx.x >= L.s[k].blk0) si = k;
+  const WlFinSeg& g = L.s[si];
+  const float* __restrict__ part = g.part;
+  const long stride = g.stride;
+  const int nblk = g.nblk, n = g.n;
+  const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int c = ((int)blockIdx.x - g.blk0) * 16 + col;
+  float s = 0.f;
+  if (c < n) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = slice;
+    for (; b + 192 < nblk; b += 256) {
+      s0 += part[(long)b * stride + c];
+      s1 += part[(long)(b + 64) * stride + c];
+      s2 += part[(long)(b + 128) * stride + c];
+      s3 += part[(long)(b + 192) * stride + c];
+    }
+    for (; b < nblk; b += 64) s0 += part[(long)b * stride + c];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[slice][col] = s;
+  __syncthreads();
+  if (slice < 4) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[slice * 16 + k][col];
+    red[slice * 16][col] = t;
+  }
+  __syncthreads();
+  if (slice == 0 && c < n) {
+    s = (red[0][col] + red[16][col]) + (red[32][col] + red[48][col]);
+    for (int r = 0; r < g.rep; ++r) {
+      const long idx = (long)r * g.rep_stride + c;
+      st_elem(g.out, idx, g.out_dtype, g.accumulate ? s + ld_elem(g.out, idx, g.out_dtype) : s);
+    }
+  }
+}
+
+static thread_local WlFinList* g_fin_list = nullptr;
+void wl_fin_defer(WlFinList* l) { g_fin_list = l; if (l) { l->n = 0; l->blocks = 0; } }
+bool wl_fin_active() { return g_fin_list != nullptr; }
+bool wl_fin_add(const float* part, int nblk, long stride, int n, void* out, int out_dtype, int accumulate, int rep, long rep_stride) {
+  WlFinList* l = g_fin_list;
+  if (!l || l->n >= WL_FIN_MAX || n <= 0) return false;
+  WlFinSeg& g = l->s[l->n++];
+  g.part = part; g.out = out; g.stride = stride; g.rep_stride = rep_stride; g.nblk = nblk; g.n = n; g.out_dtype = out_dtype;
+  g.accumulate = accumulate; g.rep = rep < 1 ? 1 : rep; g.blk0 = l->blocks;
+  l->blocks += (n + 15) / 16;
+  return true;
+}
+int wl_fin_flush(WlFinList& l, void* stream) {
+  if (l.n == 0) return WL_OK;
+  WL_LAUNCH(colsum_finish_multi_kernel, dim3((unsigned)l.blocks), dim3(1024), 0, (hipStream_t)stream, l);
+  const int rc = wl_check_launch();
+  if (rc == WL_OK)
+    for (int k = 0; k < l.n; ++k) {
+      const WlFinSeg& g = l.s[k];
+      if (g.accumulate) wl_notify_grad(g.out, (uint64_t)((long)(g.rep - 1) * g.rep_stride + g.n) * wl_esize(g.out_dtype), stream);
+    }
+  l.n = 0; l.blocks = 0;
+  return rc;
+}
+
 #define CS_MAXC 8  // up to 4096 columns
 // column sums of x[rows, N] (row stride ld) with optional row masks: a row is counted iff
 // (!inc || inc[row]) && (!exc || !exc[row]).  part[block][N]
@@ -904,6 +973,14 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   if (rc != WL_OK) return rc;
   const unsigned g2 = (unsigned)((D + 15) / 16);
   const int na = dr_colsum ? 3 : 2;
+  // a caller that collects finishing launches (wl_fin_defer: one encoder block's backward) gets the three sums as
+  // segments of its one launch; the flush also reports them to the gradient listener
+  if (wl_fin_add(part, (int)grid, (long)(na * D), D, dgamma, param_dtype, accumulate_params)) {
+    bool ok = wl_fin_add(part + D, (int)grid, (long)(na * D), D, dbeta, param_dtype, accumulate_params);
+    if (ok && dr_colsum) ok = wl_fin_add(part + 2 * D, (int)grid, (long)(na * D), D, dr_colsum, param_dtype, accumulate_params);
+    if (ok) return WL_OK;
+    return WL_EINVAL;   // (a full list: the caller sized WL_FIN_MAX for its sequence)
+  }
   WL_LAUNCH(colsum_finish_kernel, dim3(g2, na), dim3(1024), 0, st, part, (int)grid, (long)(na * D), (int)D, dgamma,
                      (int)param_dtype, (int)accumulate_params, (long)D, dbeta, dr_colsum);
   rc = wl_check_launch();
@@ -919,6 +996,7 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
 // out[c] (+)= sum over nblk partial rows of n floats (row stride n): the finishing launch on its own, for kernels that
 // produce the partial rows themselves (attention backward: q|k|v bias gradient)
 int wl_colsum_finish(const float* part, int nblk, int n, void* out, int out_dtype, int accumulate, hipStream_t st) {
+  if (wl_fin_add(part, nblk, (long)n, n, out, out_dtype, accumulate)) return WL_OK;   // deferred to the caller's one launch
   WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, st, part, nblk, (long)n, n, out, out_dtype,
             accumulate, 0L, (void*)nullptr, (void*)nullptr);
   return wl_check_launch();
@@ -944,6 +1022,7 @@ int wavlm_colsum(const void* x, int64_t rows, int32_t N, int64_t ld, int32_t dty
   else return WL_EINVAL;
   int rc = wl_check_launch();
   if (rc != WL_OK) return rc;
+  if (wl_fin_add(part, (int)grid, (long)N, N, out, out_dtype, accumulate)) return WL_OK;   // deferred (the flush notifies)
   WL_LAUNCH(colsum_finish_kernel, dim3((unsigned)((N + 15) / 16)), dim3(1024), 0, st, part, (int)grid, (long)N,
                      (int)N, out, (int)out_dtype, (int)accumulate, 0L, (void*)nullptr, (void*)nullptr);
   rc = wl_check_launch();

@@ -654,6 +654,25 @@ class WavLM(nn.Module):
         return x * keep.view(B, 1, C)
 
     def forward_padding_mask(self, n_frames: int, padding_mask: torch.Tensor) -> torch.Tensor:
+        """frame f is padded iff all of its samples are (WavLM/WavLM.py:306-314)"""
+        if padding_mask.device.type == "cpu" and padding_mask.dtype == torch.bool:
+            # Host copy of the mask (the launch thread's own bookkeeping): numpy, single-threaded.  The torch CPU reduction of
+            # a [32, 749, 320] mask is an OpenMP parallel region -- on a 256-core host it wakes 256 spinning threads every
+            # step, and inside a container with a CPU quota (16 CPUs on the GPU boxes) that exhausts the cgroup's quota within
+            # ~10 ms of every 100 ms period: the WHOLE process is then throttled for the rest of the period (measured: 90 ms
+            # stalls of the launch thread every 2-3 steps, 52 instead of 34.5 ms per step; profiles/r04/host_stalls.txt).
+            a = padding_mask.numpy()
+            B, T = a.shape
+            if not a.any():   # nothing padded (the common batch of a crop-to-shortest recipe): 0.4 ms instead of 0.9
+                return torch.zeros((B, n_frames), dtype=torch.bool)
+            k = T // n_frames
+            if a.flags.c_contiguous and k % 8 == 0 and T % 8 == 0:
+                # eight samples per 64-bit word: a frame is padded iff its k / 8 words are all 0x0101010101010101
+                w = a.view(np.uint64)[:, :n_frames * (k // 8)].reshape(B, n_frames, k // 8)
+                out = (w == np.uint64(0x0101010101010101)).all(-1)
+            else:
+                out = a[:, :n_frames * k].reshape(B, n_frames, k).all(-1)
+            return torch.from_numpy(out)
         extra = padding_mask.size(1) % n_frames
         if extra > 0:
             padding_mask = padding_mask[:, :-extra]
