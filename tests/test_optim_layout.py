@@ -38,3 +38,34 @@ def test_deep_copied_model_still_packs_qkv_from_a_bare_parameter_list():
     # conversion keeps the tags too
     h = copy.deepcopy(m).to(torch.bfloat16)
     assert FusedAdam(list(h.parameters())).packed_groups == 2 * n
+
+
+def test_hostenv_reads_the_cgroup_quota_and_caps_the_pools(tmp_path, monkeypatch):
+    """hostenv.usable_cpus = min(affinity, cgroup quota); cap_threads never raises the pool size and never exceeds the quota"""
+    import builtins
+    from unispeech_amd import hostenv
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            p = tmp_path / "cpu.max"
+            p.write_text(fake_open.text)
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    fake_open.text = "1600000 100000\n"
+    assert hostenv.cpu_quota() == 16.0
+    assert 1 <= hostenv.usable_cpus() <= 16
+    fake_open.text = "max 100000\n"
+    assert hostenv.cpu_quota() is None
+    fake_open.text = "50000 100000\n"          # half a CPU: still one thread
+    assert hostenv.usable_cpus() == 1
+    before = torch.get_num_threads()
+    try:
+        assert hostenv.cap_threads(4) == 1
+        fake_open.text = "1600000 100000\n"
+        torch.set_num_threads(2)
+        assert hostenv.cap_threads(4) == 2      # never raised
+    finally:
+        torch.set_num_threads(before)

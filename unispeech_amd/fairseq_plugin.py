@@ -191,6 +191,10 @@ def register(override: bool = False, fp16_as_bf16=None):
     if fp16_as_bf16 is not None:
         from . import precision
         precision.set_fp16_as_bf16(fp16_as_bf16)
+    # never more host threads than the container may run (hostenv.py: a 256-thread OpenMP pool inside a 16-CPU cgroup quota
+    # gets the whole process -- the launch thread included -- throttled ~90 ms of every 100 ms)
+    from . import hostenv
+    hostenv.cap_threads(None)
     from fairseq.criterions import register_criterion
     from fairseq.models import register_model
     Model, Criterion, ModelCfg, CritCfg = _classes()
