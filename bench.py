@@ -239,7 +239,7 @@ def live_gemm_traffic(args):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "run", "--", sys.executable,
-                   os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-settle", "--no-cpu-baseline", "--no-roofline",
+                   os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-settle", "--no-busy", "--no-cpu-baseline", "--no-roofline",
                    "--config", args.config, "--batch", str(args.batch)]
             r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -306,16 +306,19 @@ def busy_and_enqueue(step, reps=5):
     busy, host = [], []
     for _ in range(reps):
         torch.cuda.synchronize()
-        # a short spin gives the host its head start, then TWO unmeasured steps: the part is power-limited, a step that
-        # follows an idle (spinning) GPU runs ~4 % faster than one in a steady stream of steps (measured: 33.1 against
-        # 34.5 ms) -- the measured step must see the same clocks as the timed region's steps
+        # a short spin gives the host its head start; the FIRST step behind it is the one whose enqueue time is taken (the
+        # runtime's queues are empty: nothing but the launch thread's own work is in that number -- three steps deep the HIP
+        # runtime drains its command batches and the launch thread waits for the GPU); then one more unmeasured step -- the
+        # part is power-limited, a step that follows an idle (spinning) GPU runs ~4 % faster than one in a steady stream of
+        # steps (measured 33.1 against 34.5 ms), the measured step must see the clocks of the timed region -- and the step
+        # whose GPU time is taken between two events
         torch.cuda._sleep(int(per_ms * 20))
-        step()
-        step()
-        e0.record()
         t0 = time.perf_counter()
         step()
         t1 = time.perf_counter()
+        step()
+        e0.record()
+        step()
         e1.record()
         torch.cuda.synchronize()
         busy.append(e0.elapsed_time(e1))
@@ -346,6 +349,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settling steps after the warm-up")
+    ap.add_argument("--no-busy", action="store_true", help="skip the gpu_busy / host_enqueue leg (profiler passes: only the timed steps run)")
     ap.add_argument("--live-traffic", action="store_true",
                     help="collect roofline.traffic live (two rocprofv3 PMC passes of this command as subprocesses, ~1 min)")
     args = ap.parse_args()
@@ -524,7 +528,7 @@ def main():
     final_loss = float(loss.float().abs().mean().item()) if extract else float(loss.item())
     # second clock on the same build, outside the timed region: what the GPU needs for a step when the launch thread is not
     # in its way, and what the launch thread needs to enqueue one (see busy_and_enqueue)
-    gpu_busy_ms, host_enq_ms = busy_and_enqueue(step) if world == 1 else (None, None)
+    gpu_busy_ms, host_enq_ms = busy_and_enqueue(step) if (world == 1 and not args.no_busy) else (None, None)
     dp_info = None
     if world > 1:
         # evidence for the overlap of the gradient all-reduce with backward, from the driver's own run: per rank, the time

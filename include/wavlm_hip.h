@@ -11,7 +11,8 @@
  * Conventions (all entry points):
  *   - plain device pointers + sizes; no torch types; `stream` is a hipStream_t passed as void*
  *   - returns 0 on success, <0 on error (-1 bad argument, -2 launch failure); never throws,
- *     never allocates, never synchronises
+ *     never allocates, never synchronises -- with ONE exception: the first GELU-epilogue launch on a device fills a
+ *     32 KiB chord table and waits for it (once per device and process; every later launch reads one atomic pointer)
  *   - dtype codes: 0 = float32, 1 = bfloat16 (raw 16-bit)
  *   - activations are channel-last: [B, T, C] row-major ("rows" = frames, contiguous channels)
  */

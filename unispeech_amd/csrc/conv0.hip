@@ -8,6 +8,7 @@
 // traffic is: waveform read twice, activation written once.  Lane l of a wave owns channels 8l..8l+7 for all
 // time steps of the wave, so every store is one 16-byte (bf16) / 2 x 16-byte (f32) vector and a wave writes a
 // full contiguous 1 KiB / 2 KiB row.  Backward recomputes the same way (conv0 has no input gradient).
+#include <atomic>
 #include "common.hpp"
 #include "conv0_shared.hpp"
 #include "../../include/wavlm_hip.h"
@@ -61,18 +62,22 @@ __global__ void gelu_tab_init_kernel() {
 // per device, thread-safe, and complete before the first user on ANY stream (same scheme as gelu_tab4_get, gemm_bf16.hip)
 static const float2* gelu_tab_get(hipStream_t st) {
   static std::mutex mu;
-  static const float2* ptr[WL_MAX_DEVICES] = {};
+  static std::atomic<const float2*> ptr[WL_MAX_DEVICES];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WL_MAX_DEVICES) return nullptr;
+  const float2* p = ptr[dev].load(std::memory_order_acquire);
+  if (p) return p;   // steady state: no lock
   std::lock_guard<std::mutex> lk(mu);
-  if (!ptr[dev]) {
+  p = ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
     void* a = nullptr;
     if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_gelu_tab)) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(gelu_tab_init_kernel, dim3(GT_N / 256), dim3(256), 0, st);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return nullptr;
-    ptr[dev] = (const float2*)a;
+    p = (const float2*)a;
+    ptr[dev].store(p, std::memory_order_release);
   }
-  return ptr[dev];
+  return p;
 }
 static int gelu_tab_ensure(hipStream_t st) { return gelu_tab_get(st) ? WL_OK : WL_ELAUNCH; }
 // copy one table (16 KiB) into LDS; the caller synchronises

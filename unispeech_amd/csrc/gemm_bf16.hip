@@ -15,6 +15,8 @@
 // Tile 128 x {128,64} x 64, 4 waves (2x2), each wave FM x FN 32x32 accumulators, register-staged
 // double buffering (global loads for tile t+1 are in flight while tile t is multiplied), one
 // barrier per K tile.
+#include <atomic>
+
 #include "gemm_common.hpp"
 
 #include "tile_loaders.hpp"
@@ -351,18 +353,24 @@ __global__ void gelu_tab4_init_kernel() {
 // pointer cached before the fill had run could be read unfilled by a first GELU-epilogue GEMM on another stream).
 static const float4* gelu_tab4_get(hipStream_t st) {
   static std::mutex mu;
-  static const float4* ptr[WL_MAX_DEVICES] = {};
+  static std::atomic<const float4*> ptr[WL_MAX_DEVICES];   // zero-initialised; published with release once filled
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WL_MAX_DEVICES) return nullptr;
+  const float4* p = ptr[dev].load(std::memory_order_acquire);
+  if (p) return p;   // every launch after the first per device: one atomic load, no lock, no runtime call besides hipGetDevice
+  // first GELU-epilogue launch on this device: fill the table and WAIT for it (the one place the library synchronises: a
+  // pointer published before the fill had run could be read unfilled by a GEMM on another stream)
   std::lock_guard<std::mutex> lk(mu);
-  if (!ptr[dev]) {
+  p = ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
     void* a = nullptr;
     if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_gelu_tab4)) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(gelu_tab4_init_kernel, dim3(GT4_N / 256), dim3(256), 0, st);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return nullptr;
-    ptr[dev] = (const float4*)a;
+    p = (const float4*)a;
+    ptr[dev].store(p, std::memory_order_release);
   }
-  return ptr[dev];
+  return p;
 }
 
 // the same table for the other translation units of the library (posconv_direct.hip)
