@@ -581,12 +581,12 @@ def main():
             # HBM bytes per GEMM launch: counters cannot be read from inside the run.  --live-traffic collects them NOW with
             # two rocprofv3 PMC passes of this same command in subprocesses (FETCH_SIZE x 2 on gfx950, WRITE_SIZE, each with
             # --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes); the default reads the passes
-            # committed with this round's build (tools/gpu_pmc.sh -> profiles/r03/gemm_hbm_traffic.json) and says so
+            # committed with this round's build (tools/gpu_pmc.sh -> profiles/r04/gemm_hbm_traffic.json) and says so
             traffic, traffic_src = None, None
             if args.live_traffic and world == 1:
                 traffic, traffic_src = live_gemm_traffic(args)
             if traffic is None and args.config == "base":
-                for rnd in ("r03", "r02", "r01"):
+                for rnd in ("r04", "r03", "r02", "r01"):
                     tj = os.path.join(ROOT, "profiles", rnd, "gemm_hbm_traffic.json")
                     if os.path.exists(tj):
                         try:

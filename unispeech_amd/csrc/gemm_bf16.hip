@@ -314,17 +314,17 @@ bool gemm_pp3_ok(const wavlm_gemm_desc* d);                      // gemm_pp3.hip
 int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);
 int gemm_w4_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);  // gemm_w4.hip (same shapes as gemm_pp)
 int gemm_w4_launch_grouped(GemmP& p, hipStream_t st);
-// which 256 x 256 kernel takes a launch: the eight-wave ping-pong (gemm_pp.hip) or the four-wave one (gemm_w4.hip).
-// WAVLM_GEMM_W4: 0 never | 1 always | unset: by shape (see w4_takes)
-static int w4_mode() { static const int m = getenv("WAVLM_GEMM_W4") ? atoi(getenv("WAVLM_GEMM_W4")) : -1; return m; }
+// which 256 x 256 kernel takes a launch: the eight-wave ping-pong (gemm_pp.hip, the default) or the four-wave one
+// (gemm_w4.hip).  WAVLM_GEMM_W4: unset / 0 never | 1 every launch the 256 x 256 kernel takes | 2 only launches with BOTH
+// operands K-strided (weight gradients, incl. the grouped launch).  Measured (profiles/r04/gemm_w4_ab.txt): mode 2 wins 10 %
+// on an 8192^3 K-strided problem and nothing at the step level (gpu_busy 33.60 / 33.75 ms against 33.62 / 33.78 ms), mode 1
+// loses 3-8 % on K-contiguous operands -- so the default stays the eight-wave kernel.
+static int w4_mode() { static const int m = getenv("WAVLM_GEMM_W4") ? atoi(getenv("WAVLM_GEMM_W4")) : 0; return m; }
 static bool w4_takes(const wavlm_gemm_desc* d, bool grouped) {
   const int m = w4_mode();
-  if (m == 0) return false;
   if (m == 1) return true;
-  // measured (tools/w4_ab.py, same process, alternating): the four-wave kernel wins where BOTH operands are K-strided
-  // (weight gradients: the transposing ds_read_b64_tr_b16 form, 2 LDS instructions per fragment -- 8192^3 TT 914 -> 819 us)
-  // and loses 3-8 % on K-contiguous operands and on the epilogue-heavy conv forward
-  return grouped || (d->transA && d->transB);
+  if (m == 2) return grouped || (d->transA && d->transB);
+  return false;
 }
 
 // fraction of a CU-round's MFMA work that is useful for a BM x BN tiling on 256 CUs (edge waste x round quantisation)
