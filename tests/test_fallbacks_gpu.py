@@ -50,8 +50,12 @@ def _run(env_extra):
 def test_environment_switches_select_an_implementation_not_a_result():
     assert torch.cuda.is_available()
     ref = _run({})
-    for name in ("WAVLM_POSCONV_DIRECT", "WAVLM_CONV0_BWD_MFMA", "WAVLM_FUSE_BIAS_COLSUM", "WAVLM_CHAIN_CONSUMERS"):
-        got = _run({name: "0"})
+    for name, val in (("WAVLM_POSCONV_DIRECT", "0"), ("WAVLM_CONV0_BWD_MFMA", "0"), ("WAVLM_FUSE_BIAS_COLSUM", "0"),
+                      ("WAVLM_CHAIN_CONSUMERS", "0"),
+                      ("WAVLM_LAYER_FUSED", "0"),    # round 4: one autograd node per kernel instead of per encoder block
+                      ("WAVLM_GEMM_W4", "1"),        # round 4: the four-wave 256 x 256 GEMM wherever the eight-wave one runs
+                      ("WAVLM_GEMM_W4", "2")):       # ... only for K-strided x K-strided launches (weight gradients)
+        got = _run({name: val})
         # same arithmetic in another order / another kernel: bf16 rounding-level agreement
         assert abs(got["loss"] - ref["loss"]) <= 2e-3 * abs(ref["loss"]), (name, got, ref)
         assert abs(got["gnorm"] - ref["gnorm"]) <= 2e-2 * abs(ref["gnorm"]), (name, got, ref)
