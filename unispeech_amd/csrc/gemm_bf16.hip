@@ -314,16 +314,17 @@ bool gemm_pp3_ok(const wavlm_gemm_desc* d);                      // gemm_pp3.hip
 int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);
 int gemm_w4_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);  // gemm_w4.hip (same shapes as gemm_pp)
 int gemm_w4_launch_grouped(GemmP& p, hipStream_t st);
-// which 256 x 256 kernel takes a launch: the eight-wave ping-pong (gemm_pp.hip, the default) or the four-wave one
-// (gemm_w4.hip).  WAVLM_GEMM_W4: unset / 0 never | 1 every launch the 256 x 256 kernel takes | 2 only launches with BOTH
-// operands K-strided (weight gradients, incl. the grouped launch).  Measured (profiles/r04/gemm_w4_ab.txt): mode 2 wins 10 %
-// on an 8192^3 K-strided problem and nothing at the step level (gpu_busy 33.60 / 33.75 ms against 33.62 / 33.78 ms), mode 1
-// loses 3-8 % on K-contiguous operands -- so the default stays the eight-wave kernel.
-static int w4_mode() { static const int m = getenv("WAVLM_GEMM_W4") ? atoi(getenv("WAVLM_GEMM_W4")) : 0; return m; }
+// which 256 x 256 kernel takes a launch: the eight-wave ping-pong (gemm_pp.hip) or the four-wave one (gemm_w4.hip).
+// WAVLM_GEMM_W4: unset = the grouped weight-gradient launch only | 0 never | 1 every launch the 256 x 256 kernel takes |
+// 2 every launch with BOTH operands K-strided.  Measured (profiles/r04/gemm_w4_ab.txt): the grouped launch of a block's four
+// weight gradients (one K batch, 188 steady K steps per work item) runs 306 us against 335 us; the conv stack's weight
+// gradients (32 K batches with a K tail each: no steady steps) 343 against 307 us; K-contiguous operands lose 3-8 %.
+static int w4_mode() { static const int m = getenv("WAVLM_GEMM_W4") ? atoi(getenv("WAVLM_GEMM_W4")) : 3; return m; }
 static bool w4_takes(const wavlm_gemm_desc* d, bool grouped) {
   const int m = w4_mode();
   if (m == 1) return true;
   if (m == 2) return grouped || (d->transA && d->transB);
+  if (m == 3) return grouped;
   return false;
 }
 

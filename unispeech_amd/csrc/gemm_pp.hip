@@ -71,7 +71,11 @@ struct PPCursor {  // position of one half-tile stream in the flattened (K-batch
   int kt;          // K-tile index inside the current K batch
 };
 
-template <bool TA, bool TB, int EP, bool GRP = false>
+// TAILS: the launch has several K batches that each end in a K tail (K % 64 != 0, KB > 1: the conv stack's weight
+// gradients, 32 batches of 375 K tiles).  Its steady-state DMA issue then carries the zero-page form of a tail piece behind a
+// uniform branch, so the whole K range runs the steady schedule; without TAILS such launches fall back to the general form
+// for every step (the branch costs the tail-free launches ~2 % when it is compiled in, hence a separate instantiation).
+template <bool TA, bool TB, int EP, bool GRP = false, bool TAILS = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 * PP_STAGE
 
@@ -211,6 +215,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                  :: "s"(lds_dst), "v"(voff32), "s"(sbase) : "memory", "m0");  // m0: so that the K-tail's builtin DMA re-initialises it
   };
+  // the same with a full 64-bit per-lane address (K-tail pieces: lanes past the end of K fetch the zero page).  asm, not the
+  // builtin: with a builtin LDS-DMA anywhere in the K loop the compiler drains vmcnt(0) before every later LDS read
+  auto dma16_v = [&](const char* lane_ptr, unsigned char* ldst) __attribute__((always_inline)) {
+    const unsigned lds_dst = (unsigned)(unsigned long)(las_ptr)ldst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                 :: "s"(lds_dst), "v"(lane_ptr) : "memory", "m0");
+  };
   auto issue_gen = [&](auto which_c, int stage) __attribute__((always_inline)) {
     constexpr int W = decltype(which_c)::value;
     constexpr int OP = W >> 1;
@@ -259,7 +270,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     // (written as asm: through the builtin the zero-extension of the offset is hoisted out of the loop as eight 64-bit
     // register pairs and every DMA costs a v_lshl_add_u64 -- or, with the offset hidden from the optimiser, a v_mov_b32
     // -- between two MFMAs.  M0 = LDS destination of the wave's 1 KiB piece; one wait state after writing it.)
-    dma16(src, voff[W][j], dst + j * 1024);
+    // TAILS instantiation: a K-tail tile takes the zero-page form of this one piece (asm, 64-bit per-lane address).
+    if (TAILS && c.kt == kt_per - 1) {
+      const bool in = kidx[OP][j] < kv_last;
+      const char* sp = in ? src + voff[W][j] : (const char*)g_pp_zero;
+      dma16_v(sp, dst + j * 1024);
+    } else {
+      dma16(src, voff[W][j], dst + j * 1024);
+    }
 #endif
     if (j == 1) {  // scalar cursor work hides behind the MFMAs around it
       c.off += OP ? stepB : stepA;
@@ -526,9 +544,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
     // steady steps: everything prefetched (up to tile t+2) is a full tile of the same K batch
+    // (K batches without a K tail are steady too: the in-section issue carries the cursor wrap; TAILS: the zero-page piece too)
     const int has_tail = (kv_last < 64 && t1 == P.KB * kt_per) ? 1 : 0;
-    // (K batches without a K tail are steady too: the in-section issue carries the cursor wrap)
-    const int n_steady = (kv_last == 64 || P.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
+    const int n_steady = TAILS ? (max(0, nt - 2) & ~1)
+                               : ((kv_last == 64 || P.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0);
     int t = 0;
     if (n_steady > 0) {
       k_step(I0{}, std::true_type{}, 0, std::true_type{});
@@ -681,6 +700,18 @@ static int pp_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
       done[E] = true; \
     } \
     WL_LAUNCH((gemm_pp_kernel<TA, TB, E>), grid, dim3(512), smem, st, p); } break;
+  if constexpr (TA && TB) {
+    // weight gradients over K batches with a K tail each (conv stack): the steady-schedule instantiation
+    if (ep == 1 && p.KB > 1 && (p.K & 63) != 0) {
+      static bool done_t = false;
+      if (!done_t) {
+        if (hipFuncSetAttribute((const void*)gemm_pp_kernel<true, true, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return WL_ELAUNCH;
+        done_t = true;
+      }
+      WL_LAUNCH((gemm_pp_kernel<true, true, 1, false, true>), grid, dim3(512), smem, st, p);
+      return wl_check_launch();
+    }
+  }
   switch (ep) { PP_CASE(0) PP_CASE(1) PP_CASE(2) PP_CASE(3) default: PP_CASE(4) }
 #undef PP_CASE
   return wl_check_launch();

@@ -40,7 +40,8 @@ typedef __attribute__((address_space(3))) w4_bf16x4_t* w4_lds_b4_ptr;
 
 struct W4Cursor { long off; int kt; };
 
-template <bool TA, bool TB, int EP, bool GRP = false>
+// TAILS: as in gemm_pp.hip -- K batches that each end in a K tail run the steady schedule (zero-page form of a tail piece)
+template <bool TA, bool TB, int EP, bool GRP = false, bool TAILS = false>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 * W4_STAGE
 
@@ -190,7 +191,16 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
     constexpr int W = decltype(which_c)::value;
     constexpr int OP = W >> 1;
     const char* src = (OP ? Bb : Ab) + cur[W].off * 2;
-    dma16(src, voff[W][jj], piece_dst(W, stage, jj));
+    if (TAILS && cur[W].kt == kt_per - 1) {
+      // asm with a 64-bit per-lane address, not the builtin: a builtin LDS-DMA anywhere in the K loop makes the compiler
+      // drain vmcnt(0) before every later LDS read
+      const bool in = kidx[OP][jj] < kv_last;
+      const char* sp = in ? src + voff[W][jj] : (const char*)g_w4_zero;
+      const unsigned lds_dst = (unsigned)(unsigned long)(las_ptr)piece_dst(W, stage, jj);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_dst), "v"(sp) : "memory", "m0");
+    } else {
+      dma16(src, voff[W][jj], piece_dst(W, stage, jj));
+    }
     if (jj == 3) advance(which_c);
   };
   using I0 = std::integral_constant<int, 0>;
@@ -347,8 +357,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int s = 0; s < 4; ++s) { at[f][s] = rd_a(0, f, s); bl[0][f][s] = rd_b(2 * W4_HB, f, s); }
+    // steady: tiles t+1 and t+2 exist, are full, and share a tail-free K range (K batches without a tail are steady too: the
+    // in-section issue carries the cursor wrap)
     const int has_tail = (kv_last < 64 && t1 == P.KB * kt_per) ? 1 : 0;
-    const int n_steady = (kv_last == 64 || P.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0;
+    const int n_steady = TAILS ? (max(0, nt - 2) & ~1)
+                               : ((kv_last == 64 || P.KB == 1) ? max(0, nt - 2 - has_tail) & ~1 : 0);
     int t = 0;
     for (; t < n_steady; t += 2) {
       k_step(I0{}, std::true_type{}, t);
@@ -471,6 +484,17 @@ static int w4_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
       done[E] = true; \
     } \
     WL_LAUNCH((gemm_w4_kernel<TA, TB, E>), grid, dim3(256), smem, st, p); } break;
+  if constexpr (TA && TB) {
+    if (ep == 1 && p.KB > 1 && (p.K & 63) != 0) {   // K batches with a K tail each (conv stack weight gradients)
+      static bool done_t = false;
+      if (!done_t) {
+        if (hipFuncSetAttribute((const void*)gemm_w4_kernel<true, true, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return WL_ELAUNCH;
+        done_t = true;
+      }
+      WL_LAUNCH((gemm_w4_kernel<true, true, 1, false, true>), grid, dim3(256), smem, st, p);
+      return wl_check_launch();
+    }
+  }
   switch (ep) { W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) default: W4_CASE(4) }
 #undef W4_CASE
   return wl_check_launch();
