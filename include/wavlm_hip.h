@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 16
+#define WAVLM_HIP_ABI_VERSION 17
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -440,6 +440,9 @@ double wavlm_prof_collect_bytes(int dtype);
 #define WL_PROF_LN_FWD 5
 #define WL_PROF_LN_BWD 6
 int wavlm_prof_collect_class(int cls, double* total_ms, double* total_flops, double* total_bytes);
+/* one text line per recorded wavlm_gemm launch into `path`: M N K KB trans epi split batches ms gflop (tools/gemm_step_table.py:
+ * which shapes of a real step sit where against the MFMA peak).  Returns the number of lines, < 0 on error. */
+int wavlm_prof_dump(const char* path);
 
 #ifdef __cplusplus
 }

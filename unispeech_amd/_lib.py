@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVLM_HIP_LIB") or os.path.join(_HERE, "lib", "libwavlm_hip.so")
 
 _lib = None
-ABI_VERSION = 16  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 17  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
 
 F32, BF16 = 0, 1
 
@@ -167,6 +167,7 @@ SIGNATURES = {
     "wavlm_prof_collect": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wavlm_prof_collect_bytes": (C.c_double, [c_i32]),
     "wavlm_prof_collect_class": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "wavlm_prof_dump": (c_i32, [C.c_char_p]),
 }
 
 _ERR = {-1: "invalid argument", -2: "kernel launch failure", -3: "out of memory"}

@@ -312,6 +312,16 @@ bool gemm_pp_ok(const wavlm_gemm_desc* d);                       // gemm_pp.hip
 int gemm_pp_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);
 bool gemm_pp3_ok(const wavlm_gemm_desc* d);                      // gemm_pp3.hip
 int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);
+bool gemm_h2_ok(const wavlm_gemm_desc* d, int ec);                // gemm_h2.hip: 192 x 192 x 32, two workgroups per CU (short K)
+int gemm_h2_launch(GemmP& p, bool transB, int ep, hipStream_t st);
+// WAVLM_GEMM_H2: 0 never | 1 wherever the shape fits (gemm_h2_ok) | unset: by measurement (h2_takes)
+static int h2_mode() { static const int m = getenv("WAVLM_GEMM_H2") ? atoi(getenv("WAVLM_GEMM_H2")) : -1; return m; }
+static bool h2_takes(const wavlm_gemm_desc* d, int ec) {
+  const int m = h2_mode();
+  if (m == 0 || !gemm_h2_ok(d, ec)) return false;
+  if (m == 1) return true;
+  return false;
+}
 int gemm_w4_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);  // gemm_w4.hip (same shapes as gemm_pp)
 int gemm_w4_launch_grouped(GemmP& p, hipStream_t st);
 // which 256 x 256 kernel takes a launch: the eight-wave ping-pong (gemm_pp.hip) or the four-wave one (gemm_w4.hip).
@@ -387,6 +397,7 @@ static struct {
   double bytes[PROF_MAX];  // algorithmic HBM bytes: each operand / output / epilogue tensor touched once
   int dtype[PROF_MAX];
   int cls[PROF_MAX];       // WL_PROF_* kernel class (0 = wavlm_gemm)
+  int shape[PROF_MAX][8];  // wavlm_gemm launches: M, N, K, KB, transA | transB << 1, epi, split_k, batches
   int created;
 } g_prof;
 
@@ -419,7 +430,13 @@ static int prof_begin(const wavlm_gemm_desc* d, hipStream_t st) {
   const double b_el = (double)d->N * d->K * kb;
   const double bytes = nb * (a_el * es + mn * cs * (d->accumulate ? 2.0 : 1.0) + (d->aux ? mn * 2.0 : 0.0) + (d->res ? mn * 2.0 : 0.0)) +
                        ((d->sB_o || d->sB_i) ? nb : 1.0) * b_el * es;
-  return wl_prof_begin(WL_PROF_GEMM, d->dtype, flops, bytes, st);
+  const int pi = wl_prof_begin(WL_PROF_GEMM, d->dtype, flops, bytes, st);
+  if (pi >= 0) {
+    int* sh = g_prof.shape[pi];
+    sh[0] = d->M; sh[1] = d->N; sh[2] = d->K; sh[3] = d->KB < 1 ? 1 : d->KB; sh[4] = (d->transA ? 1 : 0) | (d->transB ? 2 : 0);
+    sh[5] = d->epi | (d->aux ? 8 : 0) | (d->res ? 16 : 0) | (d->colsum ? 32 : 0); sh[6] = d->split_k < 1 ? 1 : d->split_k; sh[7] = (int)nb;
+  }
+  return pi;
 }
 static void prof_end(int i, hipStream_t st) { wl_prof_end(i, st); }
 
@@ -438,6 +455,24 @@ extern "C" int wavlm_prof_collect(int dtype, double* total_ms, double* total_flo
   }
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
+  return cnt;
+}
+// one line per recorded wavlm_gemm launch: "M N K KB trans epi split batches ms gflop" (trans: bit 0 A, bit 1 B K-strided; epi:
+// low 3 bits the epilogue, +8 aux, +16 residual, +32 fused column sums).  Blocks until the launches have finished.
+extern "C" int wavlm_prof_dump(const char* path) {
+  FILE* f = fopen(path, "w");
+  if (!f) return WL_EINVAL;
+  int cnt = 0;
+  for (int i = 0; i < g_prof.n; ++i) {
+    if (g_prof.cls[i] != WL_PROF_GEMM) continue;
+    if (hipEventSynchronize(g_prof.ev1[i]) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev0[i], g_prof.ev1[i]) != hipSuccess) continue;
+    const int* sh = g_prof.shape[i];
+    fprintf(f, "%d %d %d %d %d %d %d %d %.4f %.3f\n", sh[0], sh[1], sh[2], sh[3], sh[4], sh[5], sh[6], sh[7], t, g_prof.flops[i] * 1e-9);
+    ++cnt;
+  }
+  fclose(f);
   return cnt;
 }
 // algorithmic HBM bytes of the same launches (no synchronisation)
@@ -516,7 +551,13 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   int rc;
   int csum_rows = 0;  // > 0: the kernel left that many partial rows of column sums in the workspace
   const bool vec = vec_epilogue_ok(d);
-  if ((g_gemm_variant == 4 && gemm_pp3_ok(d)) ||
+  if (g_gemm_variant == 6 ? gemm_h2_ok(d, gemm_epilogue_class(d, vec)) : (g_gemm_variant == 0 && h2_takes(d, gemm_epilogue_class(d, vec)))) {
+    const int ec = gemm_epilogue_class(d, vec);
+    if (ec == 3) p.gtab = gelu_tab4_get(st);
+    if (d->colsum && (ec == 2 || ec == 4)) { p.colsum_part = (float*)d->workspace; csum_rows = (d->M + 191) / 192; }
+    rc = gemm_h2_launch(p, d->transB != 0, ec, st);
+  }
+  else if ((g_gemm_variant == 4 && gemm_pp3_ok(d)) ||
       (g_gemm_variant == 0 && d->N >= 384 && gemm_pp3_ok(d) && gemm_pp_ok(d) &&
        tile_efficiency(d, nbatch, 192, 384) > 1.06 * tile_efficiency(d, nbatch, 256, 256)))  // measured at 24 k rows: N = 768 (+25 %), 2304 (+10 % at K = 768), 3072 (+6 %) go to 192 x 384; N = 2048 and the conv stack (N = 512) stay
     { const int ec = gemm_epilogue_class(d, vec); if (ec == 3) p.gtab = gelu_tab4_get(st);
@@ -596,6 +637,8 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
     double by = 0.0;
     for (int i = 0; i < n; ++i) by += 2.0 * ((double)d[i].M * d[i].K + (double)d[i].N * d[i].K) + 2.0 * 2.0 * d[i].M * d[i].N;
     g_prof.bytes[pi] = by;
+    int* sh = g_prof.shape[pi];
+    sh[0] = -n; sh[1] = 0; sh[2] = d->K; sh[3] = 1; sh[4] = 3; sh[5] = 0; sh[6] = d->split_k; sh[7] = n;   // M = -members: a grouped launch
   }
   int rc = w4_takes(d, true) ? gemm_w4_launch_grouped(p, st) : gemm_pp_launch_grouped(p, st);
   if (rc == WL_OK) {
