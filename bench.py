@@ -352,6 +352,9 @@ def main():
     ap.add_argument("--no-busy", action="store_true", help="skip the gpu_busy / host_enqueue leg (profiler passes: only the timed steps run)")
     ap.add_argument("--live-traffic", action="store_true",
                     help="collect roofline.traffic live (two rocprofv3 PMC passes of this command as subprocesses, ~1 min)")
+    ap.add_argument("--reserved-cus", type=int, default=-1,
+                    help="1 GPU: shrink the persistent GEMM grids by this many CUs as the data-parallel reducer does "
+                         "(WAVLM_DP_RESERVED_CUS) -- what the reservation alone costs a rank")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -380,6 +383,10 @@ def main():
     pinned = pin_rank_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL gets as many channels (= workgroups = CUs) as the persistent GEMM grids leave free (unispeech_amd/dp.py)
+        from unispeech_amd.dp import reserved_channels
+        if reserved_channels() > 0:
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(reserved_channels()))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -389,6 +396,8 @@ def main():
     from unispeech_amd import hostenv, ops
     # the launch thread must not share a throttled cgroup with a 256-thread OpenMP pool (unispeech_amd/hostenv.py)
     host_threads = hostenv.cap_threads(4)
+    if args.reserved_cus >= 0 and world == 1:
+        ops.set_reserved_cus(args.reserved_cus)
     from unispeech_amd.dp import DataParallelWavLM
     from unispeech_amd.optim import FusedAdam
     from unispeech_amd.pretrain import WavLMCriterion, WavLMPretrainModel
@@ -630,6 +639,7 @@ def main():
             "gpu_busy_ms_per_step": None if gpu_busy_ms is None else round(gpu_busy_ms, 2),
             "host_enqueue_ms_per_step": None if host_enq_ms is None else round(host_enq_ms, 2),
             "host_cores_pinned": pinned, "host_threads": host_threads, "host_cpu_quota": hostenv.cpu_quota(),
+            "reserved_cus": ops.get_reserved_cus(),
             "settle_steps": settle,
             "settle_host_ms": None if settle_host_ms is None else round(settle_host_ms, 2),
             "ms_per_step_unsettled": None if unsettled_ms is None else round(unsettled_ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -292,7 +292,10 @@ def check_gemm_grouped():
     256-wide kernel does not take (sequential fall-back inside the library)."""
     out = []
     dtype, tol = torch.bfloat16, TOLBF
+    # (n = 5003 with the Base shapes, n = 9000 with ragged tiles: balanced launches -- main workgroups + tail workgroups, see
+    #  gemm_common.hpp: gemm_sk_plan; the others: the one-round split)
     for n, shapes in [(1000, [(520, 264), (256, 768)]), (2500, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
+                      (5003, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]), (9000, [(2000, 1032), (1288, 1032)]),
                       (777, [(264, 392), (512, 256), (304, 520)]), (300, [(64, 48), (96, 64)])]:
         items, refs = [], []
         for k, (N, K) in enumerate(shapes):

@@ -17,6 +17,8 @@ for a in sys.argv[1:] or ["1", "2", "3", "4"]:
     src = "gemm_pp.hip"
     if a.startswith("pp3:"):
         src, a = "gemm_pp3.hip", a[4:]
+    elif a.startswith("h2:"):  # h2:<tag>:-DH2_PIPE=0,... builds gemm_h2.hip with the defines
+        src, a = "gemm_h2.hip", a[3:]
     elif a.startswith("row:"):  # row:<tag>:-DLN_PF2=1 builds rowops.hip with the defines
         src, a = "rowops.hip", a[4:]
     elif a.startswith("attn:"):  # attn:<tag>:-DFA_FWD_LAZY=1,... builds attn_fused.hip (forward + dQ kernels) with the defines

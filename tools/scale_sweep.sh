@@ -24,6 +24,6 @@ except Exception as e:
     print(tag, "FAILED", e)
 PY
 }
-for cu in 0 8 16; do run cus${cu}_bucket32 WAVLM_DP_RESERVED_CUS=$cu WAVLM_DP_BUCKET_MIB=32; done
-for mb in 16 64; do run cus8_bucket${mb} WAVLM_DP_RESERVED_CUS=8 WAVLM_DP_BUCKET_MIB=$mb; done
-for n in 1 2 4; do [ $n -lt $N ] && N_SAVE=$N && N=$n && run n${n}_default WAVLM_DP_RESERVED_CUS=8 && N=$N_SAVE; done
+for cu in 0 4 6 8 16; do run cus${cu}_bucket32 WAVLM_DP_RESERVED_CUS=$cu WAVLM_DP_BUCKET_MIB=32; done
+for mb in 16 64; do run cus6_bucket${mb} WAVLM_DP_RESERVED_CUS=6 WAVLM_DP_BUCKET_MIB=$mb; done
+for n in 1 2 4; do [ $n -lt $N ] && N_SAVE=$N && N=$n && run n${n}_default WAVLM_DP_RESERVED_CUS=6 && N=$N_SAVE; done

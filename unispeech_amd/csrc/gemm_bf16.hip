@@ -338,12 +338,14 @@ static bool w4_takes(const wavlm_gemm_desc* d, bool grouped) {
   return false;
 }
 
-// fraction of a CU-round's MFMA work that is useful for a BM x BN tiling on 256 CUs (edge waste x round quantisation)
+// fraction of a round's MFMA work that is useful for a BM x BN tiling on the persistent grid (256 CUs minus those left to the
+// RCCL kernels): edge waste x round quantisation
 static double tile_efficiency(const wavlm_gemm_desc* d, int nbatch, int BM, int BN) {
   const long tm = (d->M + BM - 1) / BM, tn = (d->N + BN - 1) / BN;
   const long tiles = tm * tn * nbatch * (d->split_k < 1 ? 1 : d->split_k);
   const double useful = ((double)d->M * d->N) / ((double)tm * BM * tn * BN);
-  return useful * (double)tiles / (256.0 * (double)((tiles + 255) / 256));
+  const long G = 256 - wavlm_get_reserved_cus();
+  return useful * (double)tiles / ((double)G * (double)((tiles + G - 1) / G));
 }
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -620,6 +622,21 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
   }
   GemmP p = make_gemm_params(d);
   p.ngrp = n;
+  // `split_k` = slabs the workspaces hold.  The one-round split (the largest with tiles x split <= grid) is used when it fills
+  // the grid exactly; otherwise, with one more slab, the balanced launch (gemm_common.hpp: gemm_sk_plan): the CUs the one-round
+  // split leaves idle take the K tail of every tile (Base: 108 tiles x 2 = 216 of 256 CUs busy -> 256).  Opt-in (WAVLM_WGRAD_STREAMK=1):
+  // measured neutral at the launch and the step level (profiles/r04/ab_wgrad_balanced_*.txt).
+  long tiles_all = 0;
+  for (int i = 0; i < n; ++i) tiles_all += (long)((d[i].M + 255) / 256) * ((d[i].N + 255) / 256);
+  const int G = 256 - wavlm_get_reserved_cus();
+  static const bool sk_on = [] { const char* e = getenv("WAVLM_WGRAD_STREAMK"); return e && *e == '1'; }();
+  const int ksteps = (d->K + 63) / 64;
+  GemmSk plan;
+  const bool sk = sk_on && w4_takes(d, true) && tiles_all * (long)ksteps >= 8l * G && gemm_sk_plan(tiles_all, ksteps, G, plan) &&
+                  d->split_k >= plan.s + 1;
+  if (sk) p.split_k = plan.s + 1;
+  else if (sk_on && !getenv("WAVLM_WGRAD_SPLIT") && G / tiles_all >= 2 && d->split_k == G / tiles_all + 1)
+    p.split_k = (int)(G / tiles_all);   // the spare slab stays unused: the one-round split fills the grid or nothing is to be won
   int vb = 0;
   double flops = 0.0;
   for (int i = 0; i < 4; ++i) {
@@ -627,10 +644,16 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
     GemmGrp& g = p.grp[i];
     g.A = e->A; g.B = e->B; g.ws = (float*)e->workspace; g.lda = e->lda; g.ldb = e->ldb; g.M = e->M; g.N = e->N;
     g.tiles_m = (e->M + 255) / 256; g.tiles_n = (e->N + 255) / 256;
-    g.vbase = i < n ? vb : 0x7fffffff;
-    if (i < n) { vb += g.tiles_m * g.tiles_n * p.split_k; flops += 2.0 * e->M * e->N * (double)e->K; }
+    g.vbase = i < n ? vb : 0x7fffffff;   // first work item of the member (balanced launch: its first tile)
+    if (i < n) { vb += g.tiles_m * g.tiles_n * (sk ? 1 : p.split_k); flops += 2.0 * e->M * e->N * (double)e->K; }
   }
   p.vtotal = vb;
+  if (sk) {
+    p.sk_ks = ksteps; p.sk_wgs = G; p.sk_tiles = (int)tiles_all; p.sk_s = plan.s; p.sk_lm = plan.Lm;
+    p.vtotal = G * plan.q;
+    static const bool spread = [] { const char* e = getenv("WAVLM_SK_SPREAD"); return !(e && *e == '0'); }();
+    p.sk_spread = spread && (plan.s * tiles_all) % 8 == 0 && plan.R % 8 == 0 && G % 8 == 0;
+  }
   const int pi = prof_begin(d, st);
   if (pi >= 0) {
     g_prof.flops[pi] = flops;
@@ -638,7 +661,7 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
     for (int i = 0; i < n; ++i) by += 2.0 * ((double)d[i].M * d[i].K + (double)d[i].N * d[i].K) + 2.0 * 2.0 * d[i].M * d[i].N;
     g_prof.bytes[pi] = by;
     int* sh = g_prof.shape[pi];
-    sh[0] = -n; sh[1] = 0; sh[2] = d->K; sh[3] = 1; sh[4] = 3; sh[5] = 0; sh[6] = d->split_k; sh[7] = n;   // M = -members: a grouped launch
+    sh[0] = -n; sh[1] = 0; sh[2] = d->K; sh[3] = 1; sh[4] = 3; sh[5] = 0; sh[6] = sk ? 0 : p.split_k; sh[7] = n;   // M = -members: a grouped launch; split 0 = balanced
   }
   int rc = w4_takes(d, true) ? gemm_w4_launch_grouped(p, st) : gemm_pp_launch_grouped(p, st);
   if (rc == WL_OK) {

@@ -22,10 +22,41 @@ struct GemmP {
   int vtotal, nbatch, skew;  // persistent launch (ping-pong kernels): virtual block count, batch count, start skew
   int patch_m;               // split-K work order: tile-row patch height (0: tiles only, split outermost)
   int ngrp;                  // > 0: grouped launch, the problems are grp[0 .. ngrp) (A/B/M/N/lda/ldb/ws above are unused)
+  int sk_ks, sk_wgs, sk_tiles, sk_s, sk_lm, sk_spread;  // sk_ks > 0: balanced grouped launch (gemm_sk_plan): K steps per tile, workgroups, tiles of all members, main splits, main run
   const float4* gtab;        // GELU / GELU' chord table in global memory (fast epilogue 3 copies it to LDS), or null
   float* colsum_part;        // fused column sums of C (ping-pong kernels, fast epilogues): partial rows [tiles_m][N], or null
   GemmGrp grp[4];
 };
+
+// Balanced grouped weight-gradient launch.  T tiles (all members), KS K steps each, G workgroups, s = G / T: the one-round
+// split runs T * s workgroups and leaves R = G - T * s CUs idle (Base: 108 x 2 = 216 of 256).  Here the T * s MAIN workgroups
+// take the K steps [j Lm, (j + 1) Lm) of their tile, j < s -- in the same order and lockstep as the one-round split, which is
+// what lets the tiles of a row / column share their operand panels in L2 -- and the R TAIL workgroups the last
+// KS - s Lm steps of ceil(T / R) tiles each, one after the other; Lm is chosen so that both kinds finish together
+// (c = what a tile's prologue + epilogue cost, in K steps).  Every tile has s + 1 partial sums (slabs).
+// (A plain stream-K partition -- the tile-major line of K steps cut into G equal runs -- was built first and measured 40 %
+//  SLOWER than the one-round split, profiles/r04/ab_streamk_tile_major.txt: neighbouring workgroups then work at different
+//  K offsets, no operand panel is ever shared, and the launch becomes HBM-bound at 2.65 GB instead of 0.59 GB.)
+#define GEMM_SK_SEG_COST 8
+struct GemmSk { int s, R, q, Lm; };   // main splits, tail workgroups, tiles per tail workgroup (max), main run length
+static inline bool gemm_sk_plan(long T, long KS, int G, GemmSk& k) {
+  if (T <= 0 || T >= G) return false;
+  k.s = (int)(G / T); k.R = (int)(G - T * k.s);
+  if (k.R == 0 || k.s < 1) return false;
+  k.q = (int)((T + k.R - 1) / k.R);
+  static const long c_env = [] { const char* e = getenv("WAVLM_SK_SEG_COST"); return e && *e ? atol(e) : 0l; }();   // lab switch
+  const long c = c_env > 0 ? c_env : GEMM_SK_SEG_COST;
+  const long L0 = (k.q * (KS + c) - c) / (1 + (long)k.s * k.q);   // main run == tail workgroup's total, rounded down
+  long Lm = 0, best = 0;
+  for (long L = L0; L <= L0 + 1; ++L) {
+    if (L < 8 || KS - L * k.s < 1) continue;
+    const long tail = k.q * (KS - L * k.s + c), cost = L + c > tail ? L + c : tail;
+    if (Lm == 0 || cost < best) { Lm = L; best = cost; }
+  }
+  if (Lm == 0 || best * 100 > 97 * ((KS + k.s - 1) / k.s + c)) return false;   // not worth a third kind of slab
+  k.Lm = (int)Lm;
+  return true;
+}
 
 static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
   GemmP p;
@@ -44,6 +75,7 @@ static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
   p.split_k = d->split_k < 1 ? 1 : d->split_k;
   p.ws = (float*)d->workspace;
   p.tiles_m = 0; p.tiles_n = 0; p.vtotal = 0; p.nbatch = 1; p.skew = 0; p.patch_m = 0; p.ngrp = 0;
+  p.sk_ks = 0; p.sk_wgs = 0; p.sk_tiles = 0; p.sk_s = 0; p.sk_lm = 0; p.sk_spread = 0;
   return p;
 }
 

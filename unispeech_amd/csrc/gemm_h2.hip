@@ -30,6 +30,12 @@
 #define H2_OPB (192 * 64)           // bytes of one operand image per stage (either layout)
 #define H2_STAGE (2 * H2_OPB)       // 24576
 #define H2_NSTAGE 3
+#ifndef H2_PIPE
+#define H2_PIPE 1   // lab switches: software-pipelined K loop; s_setprio around the MFMA groups
+#endif
+#ifndef H2_PRIO
+#define H2_PRIO 0
+#endif
 #define H2_SMEM (H2_NSTAGE * H2_STAGE)   // 73728
 
 typedef __attribute__((ext_vector_type(4))) __bf16 h2_bf16x4_t;
@@ -153,6 +159,62 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- K loop
+#if H2_PRIO
+#define H2_PRIO_HI() __builtin_amdgcn_s_setprio(1)
+#define H2_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define H2_PRIO_HI()
+#define H2_PRIO_LO()
+#endif
+  // the second workgroup of a CU (blocks 256 .. 511 of the launch: the dispatcher fills every CU once before it doubles up)
+  // starts late, so that the pair is out of phase -- one in its K loop while the other stores (lab switch WAVLM_H2_SKEW)
+  if (p.skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
+#if H2_PIPE
+  // Software-pipelined: the fragments of K half s = 0 of tile t + 1 are read under the MFMAs of half 1 of tile t, those of
+  // half 1 under the MFMAs of half 0; the wave meets the others once per tile, in the middle of it: by then it has read all
+  // of tile t (stage t % 3 is free for tile t + 3) and tile t + 1 must have landed.
+  issue_tile(0);
+  if (nt > 1) issue_tile(1);
+  if (nt > 2) issue_tile(2);
+  if (nt > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8_t f0a[3], f0b[3], f1a[3], f1b[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) { f0a[b] = rd_a(0, b, 0); f0b[b] = rd_b(0, b, 0); }
+  // (each MFMA group issues its first MFMA BEFORE the reads of the next fragments: the compiler's wait for the group's own
+  //  fragments then sees nothing younger in the LDS queue)
+#define H2_MFMA_GROUP(FA, FB, READS)                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                                   \
+  H2_PRIO_HI();                                                                                        \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0], FB[0], acc[0][0], 0, 0, 0);                \
+  __builtin_amdgcn_sched_barrier(0);                                                                   \
+  READS                                                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                        \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                      \
+      if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], FB[j], acc[i][j], 0, 0, 0); \
+  H2_PRIO_LO();                                                                                        \
+  __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < nt; ++t) {
+    const int sb = (t % H2_NSTAGE) * H2_STAGE;
+    H2_MFMA_GROUP(f0a, f0b, _Pragma("unroll") for (int b = 0; b < 3; ++b) { f1a[b] = rd_a(sb, b, 1); f1b[b] = rd_b(sb, b, 1); })
+    const bool more = t + 1 < nt;
+    const int sn = ((t + 1) % H2_NSTAGE) * H2_STAGE;
+    if (more) {
+      if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 3 < nt) issue_tile(t % H2_NSTAGE);
+    }
+    // (unconditional: behind the last tile these read a stale stage and nobody uses them -- a branch around the reads would make
+    //  the compiler's wait counts those of the path without them)
+    H2_MFMA_GROUP(f1a, f1b, _Pragma("unroll") for (int b = 0; b < 3; ++b) { f0a[b] = rd_a(sn, b, 0); f0b[b] = rd_b(sn, b, 0); })
+  }
+#undef H2_MFMA_GROUP
+#else
   issue_tile(0);
   if (nt > 1) issue_tile(1);
   for (int t = 0; t < nt; ++t) {
@@ -168,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmP p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int b = 0; b < 3; ++b) { fa[b][s] = rd_a(sb, b, s); fb[b][s] = rd_b(sb, b, s); }
+    H2_PRIO_HI();
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -175,7 +238,9 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    H2_PRIO_LO();
   }
+#endif
   __syncthreads();
 
   // ---- epilogue: 16-row half blocks through the wave's LDS slice -> 16-byte row vectors
@@ -277,6 +342,8 @@ int gemm_h2_launch(GemmP& p, bool transB, int ep, hipStream_t st) {
   p.tiles_m = (p.M + H2_BM - 1) / H2_BM;
   p.tiles_n = (p.N + H2_BN - 1) / H2_BN;
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+  static const int skew = [] { const char* e = getenv("WAVLM_H2_SKEW"); return e ? atoi(e) : 0; }();
+  p.skew = skew;
   static bool done[2][5] = {};
 #define H2_CASE(TB_, E) { \
     if (!done[TB_][E]) { \

@@ -48,20 +48,50 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
   const int ntile = p.tiles_m * p.tiles_n;
   for (int vid = blockIdx.x; vid < p.vtotal; vid += gridDim.x) {
   int tm, tn, z, split;
+  int sk_t0 = 0, sk_t1 = 0;
   GemmP q = p;
   if constexpr (GRP) {
-    const int nv = p.vtotal;
-    const int q8 = nv >> 3, rem = nv & 7, xcd = vid & 7, idx = vid >> 3;
-    const int item = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + idx;
-    const int g = (item >= p.grp[1].vbase) + (item >= p.grp[2].vbase) + (item >= p.grp[3].vbase);
+    int item, local, g;
+    if (p.sk_ks > 0) {
+      // balanced launch (gemm_common.hpp: gemm_sk_plan): vid = physical workgroup + G * (which of a tail workgroup's tiles)
+      const int G = p.sk_wgs, T = p.sk_tiles, S = p.sk_s;
+      const int wp = vid % G, seg = vid / G;
+      const int q8 = G >> 3, rem = G & 7, xcd = wp & 7, idx = wp >> 3;
+      if (p.sk_spread) {   // every XCD hosts S T / 8 main and R / 8 tail workgroups (both divisible: checked on the host)
+        const int mx = S * T / 8, tx = (G - S * T) / 8;
+        item = idx < mx ? xcd * mx + idx : S * T + xcd * tx + (idx - mx);
+      } else
+      item = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + idx;   // as the one-round split: neighbouring tiles share an XCD
+      int tile_all;
+      if (item < S * T) {
+        if (seg > 0) continue;
+        split = item / T; tile_all = item - split * T;
+        sk_t0 = split * p.sk_lm; sk_t1 = sk_t0 + p.sk_lm;
+      } else {
+        const int e = item - S * T, R = G - S * T;
+        const int first = (int)((long)e * T / R), last = (int)((long)(e + 1) * T / R);
+        tile_all = first + seg;
+        if (tile_all >= last) continue;
+        split = S; sk_t0 = S * p.sk_lm; sk_t1 = p.sk_ks;
+      }
+      g = (tile_all >= p.grp[1].vbase) + (tile_all >= p.grp[2].vbase) + (tile_all >= p.grp[3].vbase);
+      local = tile_all;
+    } else {
+      const int nv = p.vtotal;
+      const int q8 = nv >> 3, rem = nv & 7, xcd = vid & 7, idx = vid >> 3;
+      item = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + idx;
+      g = (item >= p.grp[1].vbase) + (item >= p.grp[2].vbase) + (item >= p.grp[3].vbase);
+      local = item;
+    }
 #define W4_SEL(F) (g == 0 ? p.grp[0].F : g == 1 ? p.grp[1].F : g == 2 ? p.grp[2].F : p.grp[3].F)
     q.A = W4_SEL(A); q.B = W4_SEL(B); q.ws = W4_SEL(ws); q.lda = W4_SEL(lda); q.ldb = W4_SEL(ldb);
     q.M = W4_SEL(M); q.N = W4_SEL(N); q.tiles_m = W4_SEL(tiles_m); q.tiles_n = W4_SEL(tiles_n);
-    const int local = item - W4_SEL(vbase);
+    local -= W4_SEL(vbase);
 #undef W4_SEL
     const int nt_g = q.tiles_m * q.tiles_n;
-    split = local / nt_g;
-    const int tile = local - split * nt_g;
+    int tile;
+    if (p.sk_ks > 0) tile = local;
+    else { split = local / nt_g; tile = local - split * nt_g; }
     tm = tile / q.tiles_n; tn = tile - tm * q.tiles_n;
     z = 0;
   } else
@@ -102,7 +132,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
   const int kt_per = (P.K + 63) >> 6;
   const int kv_last = P.K - (kt_per - 1) * 64;
   int t0, t1;
-  gemm_split_range(P.KB * kt_per, P.split_k, split, t0, t1);
+  if (GRP && p.sk_ks > 0) { t0 = sk_t0; t1 = sk_t1; }
+  else gemm_split_range(P.KB * kt_per, P.split_k, split, t0, t1);
   t0 = __builtin_amdgcn_readfirstlane(t0); t1 = __builtin_amdgcn_readfirstlane(t1);
   const int nt = t1 - t0;
 
@@ -509,7 +540,7 @@ int gemm_w4_launch_grouped(GemmP& p, hipStream_t st) {
   }
   p.patch_m = 0; p.skew = 0; p.nbatch = 1;
   const int pgrid = 256 - g_pp_reserved_cus;
-  dim3 grid((unsigned)(p.vtotal < pgrid ? p.vtotal : pgrid), 1, 1);
+  dim3 grid((unsigned)(p.sk_ks > 0 ? p.sk_wgs : p.vtotal < pgrid ? p.vtotal : pgrid), 1, 1);
   WL_LAUNCH((gemm_w4_kernel<true, true, 1, true>), grid, dim3(256), smem, st, p);
   return wl_check_launch();
 }

@@ -126,18 +126,29 @@ int env_int(const char* name, int dflt) { const char* e = getenv(name); return e
 
 // split-K factor of a grouped launch: the largest that keeps tiles * split within ONE round of the 256-block persistent
 // grid (measured: every extra round costs a slab store and a pipeline refill per CU); 0 = run the members singly
+// blocks of a persistent GEMM grid (== ops.grid_blocks): the data-parallel reducer keeps some CUs free for RCCL
+long grid_blocks() { return 256 - wavlm_get_reserved_cus(); }
 int grouped_split(long tiles, long ktiles) {
   static const int forced = env_int("WAVLM_WGRAD_SPLIT", 0);
   if (forced > 0) return forced < 2 ? 2 : forced;
-  long s = 256 / (tiles > 0 ? tiles : 1);
+  long s = grid_blocks() / (tiles > 0 ? tiles : 1);
   if (s > ktiles / 8) s = ktiles / 8;
   if (s > 64) s = 64;
   return s >= 2 ? (int)s : 0;
 }
+// `split_k` of a grouped launch's members = slabs per member: the one-round split; the balanced launch (gemm_common.hpp:
+// gemm_sk_plan, WAVLM_WGRAD_STREAMK=1) needs one more (== ops.grouped_slabs)
+int grouped_slabs(long tiles, long ktiles) {
+  static const bool sk = env_int("WAVLM_WGRAD_STREAMK", 0) != 0 && env_int("WAVLM_WGRAD_SPLIT", 0) <= 0;
+  int split = grouped_split(tiles, ktiles); if (split < 2) split = 2;
+  const long G = grid_blocks();
+  if (sk && tiles < G && tiles * ktiles >= 8 * G) { const int s = (int)(G / tiles) + 1; if (s > split) split = s; }
+  return split;
+}
 int single_split(int M, int N, long ktiles) {
   if (M >= 256 && N >= 256) {
     const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-    long s = 256 / tiles; if (s < 1) s = 1;
+    long s = grid_blocks() / tiles; if (s < 1) s = 1;
     if (s > ktiles / 8) s = ktiles / 8;
     if (s > 64) s = 64;
     return s < 1 ? 1 : (int)s;
@@ -158,7 +169,7 @@ uint64_t wg_ws_bytes(const WG* it, int cnt, int64_t n) {  // upper bound over ev
   const long kt = (long)((n + 63) / 64);
   for (int i = 0; i < cnt; ++i) {
     int s = single_split(it[i].N, it[i].K, kt);
-    const int gs = grouped_split((long)((it[i].N + 255) / 256) * ((it[i].K + 255) / 256), kt);  // alone in a group: the largest split it can see
+    const int gs = grouped_slabs((long)((it[i].N + 255) / 256) * ((it[i].K + 255) / 256), kt);  // alone in a group: the most slabs it can see
     if (gs > s) s = gs;
     tot += rup256((uint64_t)s * it[i].N * it[i].K * 4);
   }
@@ -180,7 +191,7 @@ int wgrads(const WG* it, int cnt, int64_t n, int pdt, void* ws, uint64_t wsb, vo
     const int m = j - i;
     Carver c(ws, wsb);
     if (m >= 2) {
-      int split = grouped_split(tiles, kt); if (split < 2) split = 2;
+      const int split = grouped_slabs(tiles, kt);
       wavlm_gemm_desc g[4];
       for (int k = 0; k < m; ++k) {
         wg_desc(g[k], it[i + k], n, pdt, split);

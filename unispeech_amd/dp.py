@@ -25,6 +25,12 @@ import torch
 import torch.distributed as dist
 
 
+def reserved_channels():
+    """CUs the persistent GEMM grids leave to RCCL == the number of channels RCCL should be limited to (WAVLM_DP_RESERVED_CUS)"""
+    import os
+    return max(0, min(64, int(os.environ.get("WAVLM_DP_RESERVED_CUS", "6"))))
+
+
 class GradReducer:
     def __init__(self, params, flat_grad, offsets, process_group=None, bucket_bytes=32 << 20):
         self.params = list(params)
@@ -38,10 +44,13 @@ class GradReducer:
         if self.is_cuda and self.enabled:
             # a persistent 256-block GEMM owns every CU (128 KiB of LDS + all VGPRs per block), so an all-reduce launched
             # on the side stream would only start at the next kernel boundary: persistent grids shrink to 256 - n and
-            # leave n CUs (default 8 = one per XCD) to the RCCL kernels while backward is still running
-            import os
+            # leave n CUs to the RCCL kernels while backward is still running.  Default 6: the activation GEMMs at
+            # 32 x 15 s / 32 x 20 s have 125 row tiles, i.e. 250 / 500 / 750 / 1000 / 2000 tiles -- whole rounds of a
+            # 250-block grid; measured on one rank (profiles/r04/reserved_cus_*.txt).  The RCCL kernels must not
+            # take MORE than n CUs either (a channel = a workgroup = a CU; the next persistent grid would then run a second
+            # round): reserved_channels() is what the launcher puts into NCCL_MAX_NCHANNELS before the communicator exists.
             from . import ops
-            ops.set_reserved_cus(int(os.environ.get("WAVLM_DP_RESERVED_CUS", "8")))
+            ops.set_reserved_cus(reserved_channels())
         # buckets = disjoint contiguous arena ranges, cut walking the arena from its END (gradients of the last layers
         # are produced first).  The walk is in arena-offset order, not parameter order: the optimizer lays packed
         # groups (q|k|v) out of registration order, and ranges cut by parameter index could overlap there.

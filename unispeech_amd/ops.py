@@ -115,7 +115,7 @@ def gemm_wgrad_grouped(items, w_dtype):
     dev = _dev(items[0][0])
     n = items[0][0].shape[0]
     tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _ in items)
-    split = max(2, grouped_split(tiles, (n + 63) // 64))  # (callers that only group when one round fits: WgradGroup.fire)
+    split = grouped_slabs(tiles, (n + 63) // 64)  # (callers that only group when one round fits: WgradGroup.fire)
     L = _lib.lib()
     descs = (GemmDesc * len(items))()
     need = []
@@ -142,7 +142,7 @@ def gemm_wgrad_grouped(items, w_dtype):
     check(L.wavlm_gemm_grouped(descs, len(items), stream()), "wavlm_gemm_grouped[%d]" % len(items))
 
 
-def grouped_split(tiles, ktiles, grid=256):
+def grouped_split(tiles, ktiles, grid=None):
     """split-K factor of a grouped weight-gradient launch, or 0 when the members should run as single launches.
     Measured (profiles/r03/envab_wg.txt, Base: 108 tiles x 375 K-steps per layer, same box): ONE round of tiles * split work
     items is what pays -- split 2 (216 items) 335 us per layer against 349 us for the four single launches + 28 us less slab
@@ -152,8 +152,30 @@ def grouped_split(tiles, ktiles, grid=256):
     forced = os.environ.get("WAVLM_WGRAD_SPLIT")
     if forced:
         return max(2, int(forced))
+    grid = grid or grid_blocks()
     s = min(grid // max(tiles, 1), ktiles // 8, 64)
     return s if s >= 2 else 0
+
+
+def grid_blocks():
+    """blocks of a persistent GEMM grid: one per CU minus what the data-parallel reducer keeps free for the RCCL kernels
+    (wavlm_set_reserved_cus).  Every split-K choice aims at ONE round of THIS many blocks: with 8 CUs reserved, the 252 work
+    items a 256-CU split produces run as a full round plus a round of four (measured: +17 % step time,
+    profiles/r04/reserved_cus_base_before.txt)."""
+    return 256 - get_reserved_cus()
+
+
+def grouped_slabs(tiles, ktiles, grid=None):
+    """`split_k` of the members of a grouped weight-gradient launch = fp32 slabs each member's workspace holds: the one-round
+    split, or with WAVLM_WGRAD_STREAMK=1 one more, so that the library can hand the CUs that split leaves idle (Base: 108 tiles
+    x 2 = 216 of 256) the K tail of every tile (csrc/gemm_common.hpp: gemm_sk_plan).  Off by default: measured neutral
+    (profiles/r04/ab_wgrad_balanced_*.txt) -- the launch is not bound by how many CUs take part."""
+    grid = grid or grid_blocks()
+    split = max(2, grouped_split(tiles, ktiles, grid))
+    if (os.environ.get("WAVLM_WGRAD_STREAMK", "0") == "1" and not os.environ.get("WAVLM_WGRAD_SPLIT") and tiles < grid
+            and tiles * ktiles >= 8 * grid):
+        return max(split, grid // tiles + 1)
+    return split
 
 
 def pick_split(M, N, ktiles, nbatch=1, target_blocks=768):
@@ -162,7 +184,7 @@ def pick_split(M, N, ktiles, nbatch=1, target_blocks=768):
     blocks per CU) at `target_blocks`."""
     if M >= 256 and N >= 256:
         tiles = ((M + 255) // 256) * ((N + 255) // 256) * nbatch
-        s = max(1, 256 // tiles)
+        s = max(1, grid_blocks() // tiles)
         return max(1, min(s, ktiles // 8, 64))
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * nbatch
     s = max(1, min(ktiles, (target_blocks + tiles - 1) // tiles))
