@@ -606,7 +606,7 @@ def main():
                         except Exception:
                             traffic = None
             roof = {"bound": "mfma",
-                    "kernel": "bf16 MFMA GEMM family (gemm_pp_kernel 256x256, gemm_pp3_kernel 192x384, gemm_bf16_kernel "
+                    "kernel": "bf16 MFMA GEMM family (gemm_pp_kernel / gemm_w4_kernel 256x256, gemm_pp3_kernel 192x384, gemm_bf16_kernel "
                               "128-wide): every dense contraction of the step that goes through wavlm_gemm (all but the fused "
                               "attention and the direct pos_conv kernels)",
                     "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -85,7 +85,7 @@ def _worker(rank, world, port, q, grouped):
         # the side stream (it waits for exactly that point) precedes the end of backward by this many milliseconds
         lead = [ev.elapsed_time(end_bwd) for _, ev in dp.reducer.trace[:early]]
         from unispeech_amd import ops as _ops
-        assert _ops.get_reserved_cus() == 8, "persistent GEMM grids must leave CUs to the collectives (dp.GradReducer)"
+        assert _ops.get_reserved_cus() == 6, "persistent GEMM grids must leave CUs to the collectives (dp.GradReducer)"
         assert dp.reducer.comm_stream is not None and [b for b, _ in dp.reducer.trace] == list(range(len(dp.reducer.trace)))
         assert len(lead) == early and sum(1 for x in lead if x > 0.02) >= early // 2, lead
         assert abs(opt.pending_mult - 1.0 / world) < 1e-12   # the wrapper's average rides in the deferred factor
