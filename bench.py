@@ -612,6 +612,9 @@ def main():
                     "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (avg over the step's GEMM launches, PMC)",
+                    "power_note": "measured, not live (profiles/r04/power_probe.txt): every GEMM of the step runs the socket at its "
+                                  "1400 W limit (clock traded against active CUs); the vendor library's 8192^3 reaches 1402 TFLOP/s "
+                                  "= 0.56 of `peak` inside that envelope",
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(alg_bytes / max(n_l, 1)),
                     "launches_per_step": n_l, "gemm_ms_per_step": round(ms, 3),
