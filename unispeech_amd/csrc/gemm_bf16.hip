@@ -350,16 +350,15 @@ static double tile_efficiency(const wavlm_gemm_desc* d, int nbatch, int BM, int 
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// GELU / GELU' chord table of the fast GELU epilogue (gemm_common.hpp gelu_both_tab); filled once per process
+// chord table of the normal CDF for the fast GELU epilogue (gemm_common.hpp gelu_both_tab); filled once per process and device
 __device__ float4 g_gelu_tab4[GT4_N];
 __global__ void gelu_tab4_init_kernel() {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= GT4_N) return;
-  const double h = 16.0 / GT4_N, x0 = -8.0 + i * h, x1 = x0 + h;
-  auto f = [](double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752440)); };
-  auto d = [](double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)) + x * 0.39894228040143267794 * exp(-0.5 * x * x); };
-  const double s0 = (f(x1) - f(x0)) / h, s1 = (d(x1) - d(x0)) / h;
-  g_gelu_tab4[i] = make_float4((float)s0, (float)(f(x0) - s0 * x0), (float)s1, (float)(d(x0) - s1 * x0));
+  if (i >= GT2_N) return;
+  const double h = 16.0 / GT2_N, x0 = -8.0 + i * h, x1 = x0 + h;
+  auto cdf = [](double x) { return 0.5 * erfc(-x * 0.70710678118654752440); };   // (erfc: no cancellation in the left tail)
+  const double a = (cdf(x1) - cdf(x0)) / h;
+  reinterpret_cast<float2*>(g_gelu_tab4)[i] = make_float2((float)a, (float)(cdf(x0) - a * x0));
 }
 // Per device (hipGetSymbolAddress resolves against the CURRENT device's copy of the module), under a mutex, and the host
 // waits for the init kernel once: the table is then visible to every stream and thread that asks for it afterwards (a
@@ -378,7 +377,7 @@ static const float4* gelu_tab4_get(hipStream_t st) {
   if (!p) {
     void* a = nullptr;
     if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_gelu_tab4)) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(gelu_tab4_init_kernel, dim3(GT4_N / 256), dim3(256), 0, st);
+    hipLaunchKernelGGL(gelu_tab4_init_kernel, dim3(GT2_N / 256), dim3(256), 0, st);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return nullptr;
     p = (const float4*)a;
     ptr[dev].store(p, std::memory_order_release);

@@ -201,17 +201,24 @@ __device__ __forceinline__ void gemm_store8(const GemmP& p, int zo, int zi, int 
 // The generic gemm_store8 decides all of that per 8-element chunk at run time; with one block per CU the epilogue is
 // exposed, and the probe in tools/gemm_epi_probe.py showed it bound by the CU's own instruction stream (7.5 us per tile
 // even with 8 CUs active), not by the HBM write burst.
-// GELU and GELU' together from one 16-byte LDS read: cell i of the table holds the chords (slope, intercept) of gelu
-// and of gelu' over [x_i, x_i + h), h = 16 / GT4_N, x_0 = -8 (see conv0.hip for the error bound: 8e-6 absolute at 2048
-// cells; the outputs here are bf16).  The erf evaluation (v_rcp, v_exp, ~12 more VALU) on every element of fc1's and
-// the conv stack's outputs ran in the EXPOSED epilogue of one-block-per-CU GEMMs: ~45 us of a 199 us fc1 launch.
-#define GT4_N 2048
-__device__ __forceinline__ float gelu_both_tab(const float4* tab, float x, float& grad) {
-  float u = fmaf(x, GT4_N / 16.0f, 8.0f * (GT4_N / 16.0f));
-  u = __builtin_amdgcn_fmed3f(u, 0.f, (float)(GT4_N - 1));
-  const float4 t = tab[(int)u];
-  grad = fmaf(t.z, x, t.w);
-  return fmaf(t.x, x, t.y);
+// GELU and GELU' together from one 8-byte LDS read: cell i of the table holds the chord (slope a, intercept b) of the normal
+// CDF Phi over [x_i, x_i + h), h = 16 / GT2_N, x_0 = -8:  Phi(x) ~ a x + b,  gelu(x) = x Phi(x),  gelu'(x) = Phi(x) + x phi(x)
+// with phi = Phi' ~ a (the chord's slope is phi at the cell's midpoint).  Errors at 4096 cells: Phi 4.6e-7, gelu 1e-6 absolute;
+// gelu' <= |x^2 phi(x)| h / 2 = 5.7e-4 absolute (a seventh of bf16's half ulp at 1: the outputs here are bf16).  The table is
+// the same 32 KiB as the float4 form it replaces (chords of gelu AND gelu' per cell, 2048 cells: 16 bytes per lookup -- the
+// random 16-byte reads of eight waves were half of the epilogue's LDS time).  The erf evaluation (v_rcp, v_exp, ~12 more
+// VALU) on every element of fc1's and the conv stack's outputs ran in the EXPOSED epilogue of one-block-per-CU GEMMs: ~45 us
+// of a 199 us fc1 launch.
+#define GT4_N 2048            // float4 cells of the table's storage (32 KiB)
+#define GT2_N (2 * GT4_N)     // chord cells
+__device__ __forceinline__ float gelu_both_tab(const float4* tab4, float x, float& grad) {
+  const float2* tab = reinterpret_cast<const float2*>(tab4);
+  float u = fmaf(x, GT2_N / 16.0f, 8.0f * (GT2_N / 16.0f));
+  u = __builtin_amdgcn_fmed3f(u, 0.f, (float)(GT2_N - 1));
+  const float2 t = tab[(int)u];
+  const float ph = fmaf(t.x, x, t.y);
+  grad = fmaf(x, t.x, ph);
+  return x * ph;
 }
 const float4* wl_gelu_tab4(hipStream_t st);  // device address of the table (gemm_bf16.hip; filled on first use)
 // every thread of the block: global table -> LDS (32 KiB); the caller synchronises before and after
