@@ -76,7 +76,11 @@ int wavlm_gemm(const wavlm_gemm_desc* d, void* stream);
 /* n descriptors in one call.  Weight-gradient-shaped problems (transA && transB, same K and split_k >= 2, no epilogue
  * extras, each with its own workspace) run as ONE grouped split-K launch + one slab reduction each -- the four dW of an
  * encoder layer (modules.py q/k/v/out_proj, WavLM.py:732-737 fc1/fc2) share the reduction length B*T; anything else is
- * executed as n wavlm_gemm calls.  Results are identical either way. */
+ * executed as n wavlm_gemm calls.  Results are identical either way.  Callers should pick `split_k` so that all members' tiles x
+ * split_k fit ONE round of the persistent grid (256 CUs minus wavlm_set_reserved_cus: what unispeech_amd/ops.py grouped_split
+ * and csrc/layer.hip do).  Under WAVLM_WGRAD_STREAMK=1 `split_k` may be one larger than that (= the fp32 slabs the workspace
+ * holds): the library then runs a balanced partition in which the CUs the one-round split leaves idle take the K tail of
+ * every tile (measured neutral: off by default). */
 int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
