@@ -23,6 +23,10 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #ifndef FA_DQ_PK
 #define FA_DQ_PK 1
 #endif
+// FA_FWD_BIAS_IN_C: the forward's Toeplitz bias rides in the C operand of the score MFMAs (see the tile loop)
+#ifndef FA_FWD_BIAS_IN_C
+#define FA_FWD_BIAS_IN_C 1
+#endif
 
 // ------------------------------------------------------------------------------------------------- forward
 template <bool DROP>
@@ -56,6 +60,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
     for (int jp = threadIdx.x; jp < (p.Tkb >> 1); jp += 256) colw[jp] = fa_col_word(p.s1, (unsigned)jp);
   // everything below lives in the log2 domain: x2 = log2(e) * (scale * s + gate * rel), p = 2^(x2 - m2)
   const float g2 = p.gate ? p.gate[(long)bh * T + ic] * FA_LOG2E : 0.f;
+#if FA_FWD_BIAS_IN_C
+  const float g2s = g2 / p.sc2;
+#endif
   const unsigned roww = fa_row_word(p.s0, (unsigned)(bh * T + ic));
   const float* trow = tabs + (T - 1 - ic);  // trow[j] = rel[h, j - i]
 
@@ -87,6 +94,27 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
     const unsigned* cwp = colw + ((j0 + 4 * hi) >> 1);  // j0 + 4 hi is even, r walks in pairs
     // S^T = K Q^T
     f32x16_t s[2];
+#if FA_FWD_BIAS_IN_C
+    // the Toeplitz bias (and the key mask of edge tiles) enters as the C operand of the score MFMAs, in units of 1 / sc2: the
+    // element pass is then max, fma (x sc2 - m), 2^x -- one VALU instruction per score less than bias-fma + subtract
+    const bool edge = (p.kpm != nullptr) || (j0 + FA_BKV > T);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      if (!edge) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[f][r] = g2s * trow[j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          s[f][r] = fmaf(g2s, trow[j], kb[j]);   // kb is 0 or -inf: scale-free
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s[f], 0, 0, 0);
+    }
+#else
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
 #pragma unroll
@@ -95,6 +123,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
       for (int kk = 0; kk < 4; ++kk)
         s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s[f], 0, 0, 0);
     }
+#endif
 #if FA_FWD_LAZY
     // Lazy running maximum: the scores come out of the bias fma already relative to the row's reference `mref` (the
     // subtraction rides in the fma's addend), and the reference moves only when a tile's maximum exceeds it by more than
@@ -157,6 +186,31 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
       }
     l += wl_sum_xor32(rs2[0] + rs2[1]);
 #else
+#if FA_FWD_BIAS_IN_C
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[f][r]);
+    tmax = wl_max_xor32(tmax) * p.sc2;          // sc2 > 0: the maximum commutes with the scale
+    const float m_new = fmaxf(m, tmax);
+    const bool dead = (m_new == -INFINITY);
+    const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
+    const float nmsub = dead ? 0.f : -m_new;  // dead rows: every x is -inf -> 2^(-inf) = 0
+    float rs = 0.f;
+    U4 pf[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[f][r], p.sc2, nmsub));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[f][r + 1], p.sc2, nmsub));
+        rs += p0 + p1;
+        unsigned pk = pack_bf16(p0, p1);
+        if constexpr (DROP) pk &= fa_keepmask2(fa_mix(roww + cwp[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]), p.k2);
+        pf[f][r >> 3].u[(r & 7) >> 1] = pk;
+      }
+#else
     // scores -> log2 domain with the Toeplitz bias; key padding / keys past T only on edge tiles
     float tmax = -INFINITY;
     const bool edge = (p.kpm != nullptr) || (j0 + FA_BKV > T);
@@ -202,6 +256,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
         }
         pf[f][r >> 3].u[(r & 7) >> 1] = pk;
       }
+#endif
     rs = wl_sum_xor32(rs);
     l = l * alpha + rs;
     m = m_new;
