@@ -27,6 +27,11 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #ifndef FA_FWD_BIAS_IN_C
 #define FA_FWD_BIAS_IN_C 1
 #endif
+// FA_DQ_BIAS_IN_C: the same in the dQ kernel (bias - lse: no instruction less there, the fma only moves in front of the
+// MFMAs).  Measured 215 -> 219 us (profiles/r04/ab_attn_bwd_bias_in_c.txt): OFF.
+#ifndef FA_DQ_BIAS_IN_C
+#define FA_DQ_BIAS_IN_C 0
+#endif
 
 // ------------------------------------------------------------------------------------------------- forward
 template <bool DROP>
@@ -400,6 +405,9 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   const float g = p.gate ? p.gate[(long)bh * T + ic] : 0.f;
   const float g2 = g * FA_LOG2E;
   const float nlse2 = valid_i ? p.log2sc - p.lse[(long)bh * T + ic] * FA_LOG2E : -INFINITY;  // P * sc = 2^(x + nlse2)
+#if FA_DQ_BIAS_IN_C
+  const float g2s = g2 / p.sc2, nlse2s = nlse2 / p.sc2;
+#endif
   const unsigned roww = fa_row_word(p.s0, (unsigned)(bh * T + ic));
   const float* trow = tabs + (T - 1 - ic);
   // skew write base of this lane: row (31 - rho + 4 hi), column rho (bf16)
@@ -500,6 +508,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
           if (DROP && !(r & 1)) cww[f][r >> 1] = (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1];
         }
     }
+    const bool edge = (p.kpm != nullptr) || (j0 + FA_BKV > T);
     U4 dsf0[2], dsf1[2];  // (two arrays, not dsf[2][2]: the 2-D array of unions is not split into registers)
     f32x16_t s[2], dp[2];
     // (block index as a type: a run-time index into s / dp / dsf would put the arrays into scratch)
@@ -507,8 +516,22 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     using F1 = std::integral_constant<int, 1>;
     auto scores = [&](auto fc) __attribute__((always_inline)) {
       constexpr int f = decltype(fc)::value;
+#if FA_DQ_BIAS_IN_C
+      // bias - lse (and the key mask of edge tiles) as the C operand of the score MFMAs, in units of 1 / sc2: the fma leaves
+      // the dependent chain behind the MFMAs (P = 2^(sc2 s))
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float tv;
+        if constexpr (PF) tv = tvv[f][r]; else tv = trow[j];
+        float c = fmaf(g2s, tv, nlse2s);
+        if (edge) c += kb[j];
+        s[f][r] = c; dp[f][r] = 0.f;
+      }
+#else
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[f][r] = 0.f; dp[f][r] = 0.f; }
+#endif
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s[f], 0, 0, 0);
@@ -531,9 +554,13 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
           const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;  // r even: j, j + 1 are this pair's keys
           f32x2_t tv2;
           if constexpr (PF) tv2 = f32x2_t{tvv[f][r], tvv[f][r + 1]}; else tv2 = f32x2_t{trow[j], trow[j + 1]};
+#if FA_DQ_BIAS_IN_C
+          const f32x2_t x2 = f32x2_t{s[f][r], s[f][r + 1]} * f32x2_t{p.sc2, p.sc2};
+#else
           f32x2_t x2 = __builtin_elementwise_fma(f32x2_t{s[f][r], s[f][r + 1]}, f32x2_t{p.sc2, p.sc2},
                                                  __builtin_elementwise_fma(f32x2_t{g2, g2}, tv2, f32x2_t{nlse2, nlse2}));
           if constexpr (EDGE) x2 += f32x2_t{kb[j], kb[j + 1]};
+#endif
           const f32x2_t pe2 = f32x2_t{__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
           f32x2_t dp2 = f32x2_t{dp[f][r], dp[f][r + 1]};
           if constexpr (DROP) {
@@ -551,8 +578,12 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
           const int j = j0 + 32 * f + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
           float tv;
           if constexpr (PF) tv = tvv[f][rr]; else tv = trow[j];
+#if FA_DQ_BIAS_IN_C
+          const float x = s[f][rr] * p.sc2;
+#else
           float x = fmaf(s[f][rr], p.sc2, fmaf(g2, tv, nlse2));  // x - lse as two fmas (the -lse rides in the bias term)
           if constexpr (EDGE) x += kb[j];
+#endif
           const float pe = __builtin_amdgcn_exp2f(x);  // 0 for masked keys (-inf) and rows past T (nlse2 = -inf)
           float dpe = dp[f][rr];
           if constexpr (DROP) dpe = (e ? fa_keep_hi(w, p.ths) : fa_keep_lo(w, p.ths)) ? dpe : 0.f;
@@ -581,7 +612,6 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
         for (int s2 = 0; s2 < 2; ++s2)
           dq[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kbuf(cur), ktr, f2, f, s2), (f == 0 ? dsf0[s2] : dsf1[s2]).b, dq[f2], 0, 0, 0);
     };
-    const bool edge = (p.kpm != nullptr) || (j0 + FA_BKV > T);
 #if FA_DQ_BOTH
     // both 32-key blocks' score MFMAs first: 16 independent MFMAs in flight, then 32 elements of VALU, then 8 MFMAs
     scores(F0{}); scores(F1{});

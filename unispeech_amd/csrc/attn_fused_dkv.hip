@@ -4,6 +4,13 @@
 // f32 VALU measured 228 -> 202 us per launch here (the forward is indifferent, the dQ kernel 4 % slower without it).
 #include "attn_fused.hpp"
 
+// FA_DKV_BIAS_IN_C: bias - lse as the C operand of the score MFMAs (as in the forward, attn_fused.hip).  No instruction less
+// here (the two fmas become fma + multiply) and the bias reads move in front of the MFMAs: measured 196 -> 211 us
+// (profiles/r04/ab_attn_bwd_bias_in_c.txt): OFF.
+#ifndef FA_DKV_BIAS_IN_C
+#define FA_DKV_BIAS_IN_C 0
+#endif
+
 // ------------------------------------------------------------------------------------ backward 2/2: dK, dV
 // Lane owns a KEY column; scores are in the untransposed layout S[q][kv] so that the query contraction of
 // dV^T = dO^T P and dK^T = Q^T dS finds its k-slots in the lane's registers.
@@ -58,9 +65,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
       const int ii = it * FA_BQ1 + t;
       const bool ok = ii < T;
       const long o = (long)bh * T + (ok ? ii : T - 1);
+#if FA_DKV_BIAS_IN_C
+      // bias - lse enters as the C operand of the score MFMAs, in units of 1 / sc2 (P * sc = 2^(sc2 s))
+      rowv[st * 256 + t] = ok ? (p.log2sc - p.lse[o] * FA_LOG2E) / p.sc2 : -INFINITY;
+      rowv[st * 256 + 128 + t] = p.gate ? p.gate[o] * FA_LOG2E / p.sc2 : 0.f;
+#else
       rowv[st * 256 + t] = ok ? p.log2sc - p.lse[o] * FA_LOG2E : -INFINITY;  // P * sc = 2^(x + this); -inf: rows past T
-      rowv[st * 256 + 64 + t] = p.delta[o] * p.inv_sc;
       rowv[st * 256 + 128 + t] = p.gate ? p.gate[o] * FA_LOG2E : 0.f;
+#endif
+      rowv[st * 256 + 64 + t] = p.delta[o] * p.inv_sc;
       rowv[st * 256 + 192 + t] = __uint_as_float(fa_row_word(p.s0, (unsigned)o));
     }
   };
@@ -85,8 +98,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
     for (int f = 0; f < 2; ++f) {
       U4 pf[2], dsf[2];
       f32x16_t s, dp;
+#if FA_DKV_BIAS_IN_C
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int il0 = 32 * f + 8 * q4 + 4 * hi;
+        const float4 lse4 = *reinterpret_cast<const float4*>(rv + il0);
+        const float4 gat4 = *reinterpret_cast<const float4*>(rv + 128 + il0);
+        const float* tq = tcol - (iq0 + il0);
+        s[4 * q4] = fmaf(gat4.x, tq[0], lse4.x);
+        s[4 * q4 + 1] = fmaf(gat4.y, tq[-1], lse4.y);
+        s[4 * q4 + 2] = fmaf(gat4.z, tq[-2], lse4.z);
+        s[4 * q4 + 3] = fmaf(gat4.w, tq[-3], lse4.w);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#else
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#endif
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(qbuf(cur), 32 * f + kl, kk, hi), kf[kk].b, s, 0, 0, 0);
@@ -97,20 +126,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
         // registers 4 q4 .. 4 q4 + 3 of a block are four consecutive query rows: per-row scalars come as 16-byte
         // LDS vectors; the Toeplitz entries rel[j - i] run downwards in i
         const int il0 = 32 * f + 8 * q4 + 4 * hi;
-        const float4 lse4 = *reinterpret_cast<const float4*>(rv + il0);
         const float4 del4 = *reinterpret_cast<const float4*>(rv + 64 + il0);
-        const float4 gat4 = *reinterpret_cast<const float4*>(rv + 128 + il0);
         const uint4 row4 = *reinterpret_cast<const uint4*>(rv + 192 + il0);
-        const float lsev[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, delv[4] = {del4.x, del4.y, del4.z, del4.w};
-        const float gatv[4] = {gat4.x, gat4.y, gat4.z, gat4.w};
+        const float delv[4] = {del4.x, del4.y, del4.z, del4.w};
         const unsigned roww[4] = {row4.x, row4.y, row4.z, row4.w};
+#if !FA_DKV_BIAS_IN_C
+        const float4 lse4 = *reinterpret_cast<const float4*>(rv + il0);
+        const float4 gat4 = *reinterpret_cast<const float4*>(rv + 128 + il0);
+        const float lsev[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
+        const float gatv[4] = {gat4.x, gat4.y, gat4.z, gat4.w};
         const float* tq = tcol - (iq0 + il0);
+#endif
         float pv[4], dsv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int rr = 4 * q4 + e;
           // x - lse as two fmas (the -lse rides in the bias term)
+#if FA_DKV_BIAS_IN_C
+          const float pe = __builtin_amdgcn_exp2f(s[rr] * p.sc2);  // rows past T: -inf -> 0
+#else
           const float pe = __builtin_amdgcn_exp2f(fmaf(s[rr], p.sc2, fmaf(gatv[e], tq[-e], lsev[e])));  // rows past T: -inf -> 0
+#endif
           float pd = pe;
           if constexpr (DROP) {
             const unsigned w = fa_mix(roww[e] + cw);
