@@ -101,3 +101,17 @@ run("this library 8192^3 NT (gemm_pp)", lambda: ops.gemm(a8, b8, c8, 8192, 8192,
 ops.gemm_set_variant(5)
 run("this library 8192^3 NT (gemm_w4)", lambda: ops.gemm(a8, b8, c8, 8192, 8192, 8192, lda=8192, ldb=8192, ldc=8192), 2.0 * 8192 ** 3)
 ops.gemm_set_variant(0)
+# fused attention and a LayerNorm at the step's shapes: which of the non-GEMM families sit at the power limit too
+B_, T_, H_, hd_ = 32, 749, 12, 64
+qkv = (0.5 * torch.randn(B_, T_, 3 * H_ * hd_, device=dev)).to(bf)
+gate = 1 + 0.5 * torch.rand(B_, H_, T_, device=dev)
+tab = 0.5 * torch.randn(H_, 2 * T_ - 1, device=dev)
+dO = torch.randn(B_, T_, H_ * hd_, device=dev).to(bf)
+fl = 4.0 * B_ * H_ * T_ * T_ * hd_
+O_, lse_ = ops.attn_fused_fwd(qkv, gate, tab, None, H_, hd_ ** -0.5, 0.1, 1234)
+run("fused attention forward (12 heads, T = 749, dropout 0.1)", lambda: ops.attn_fused_fwd(qkv, gate, tab, None, H_, hd_ ** -0.5, 0.1, 1234), fl)
+run("fused attention backward (dQ + dK/dV + reduction)", lambda: ops.attn_fused_bwd(qkv, O_, dO, lse_, gate, tab, None, H_, hd_ ** -0.5, 0.1, 1234), 2.5 * fl)
+x_ = torch.randn(n, 768, device=dev).to(bf)
+r_ = torch.randn(n, 768, device=dev).to(bf)
+gm_, bt_ = torch.ones(768, device=dev).to(bf), torch.zeros(768, device=dev).to(bf)
+run("LayerNorm forward + residual [23968 x 768] (HBM-bound)", lambda: ops.layernorm_fwd(x_, r_, gm_, bt_, 1e-5), 0.0)
