@@ -96,8 +96,18 @@ def test_fp16_optimizer_build_follows_the_switch_and_keeps_the_scaling_protocol(
         assert opt.scaler.loss_scale == 64
         opt.zero_grad()
         assert opt.fused.pending_mult == 1.0 / 64
+        # checkpoints carry the loss scale (fp16_optimizer.py:79, 90-91): a resumed --fp16 run continues at 64, not at 128
+        sd = opt.state_dict()
+        assert sd["loss_scale"] == 64
+        opt2 = FairseqFusedAdam.build_optimizer(cfg, list(net.parameters()))
+        assert opt2.scaler.loss_scale == 128
+        opt2.load_state_dict(sd)
+        assert opt2.scaler.loss_scale == 64 and "loss_scale" in sd      # (the caller's dict is not modified)
         # bf16 runs keep scaler None (fp16_optimizer.py:248-250)
         cfg.common.bf16 = True
-        assert FairseqFusedAdam.build_optimizer(cfg, list(torch.nn.Linear(8, 8).parameters())).scaler is None
+        net_b = torch.nn.Linear(8, 8)
+        opt_b = FairseqFusedAdam.build_optimizer(cfg, list(net_b.parameters()))
+        assert opt_b.scaler is None and "loss_scale" not in opt_b.state_dict()
+        opt_b.load_state_dict(dict(opt_b.state_dict(), loss_scale=32.0))    # an --fp16 checkpoint resumed with --bf16: key ignored
     finally:
         precision.set_fp16_as_bf16(old)

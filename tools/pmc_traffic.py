@@ -33,12 +33,17 @@ rows.sort(reverse=True)
 print("%-60s %8s %12s %12s %12s" % ("kernel", "launches", "fetch MB/st", "write MB/st", "MB/launch"))
 for tot, k, n, f, w in rows[:25]:
     print("%-60s %8.1f %12.1f %12.1f %12.2f" % (k[:60], n / steps, f / steps / 1e6, w / steps / 1e6, tot / max(n, 1) / 1e6))
-g = [(k, n, f, w) for _, k, n, f, w in rows if k.startswith("gemm_pp") or k.startswith("gemm_bf16") or k.startswith("gemm_splitk")]
+# EVERY kernel of the GEMM family (gemm_pp / gemm_pp3 / gemm_w4 / gemm_h2 / gemm_bf16 + the split-K reductions that serve
+# them): selected by the common prefix, not by a list of names -- round 4's list missed gemm_w4_kernel, the step's largest
+# GEMM kernel.  The launch count (split-K reductions excluded: they are part of their GEMM's launch
+# in the library's own record) must equal bench.py's roofline.launches_per_step; bench.py checks that.
+g = [(k, n, f, w) for _, k, n, f, w in rows if k.startswith("gemm_")]
 n = sum(x[1] for x in g if not x[0].startswith("gemm_splitk")); f = sum(x[2] for x in g); w = sum(x[3] for x in g)
 out = {"gemm_launches_per_step": n / steps, "gemm_fetch_bytes_per_step": f / steps, "gemm_write_bytes_per_step": w / steps,
        "gemm_hbm_bytes_per_launch": (f + w) / max(n, 1),
+       "kernels": {k: {"launches_per_step": n_ / steps, "hbm_bytes_per_launch": (f_ + w_) / max(n_, 1)} for k, n_, f_, w_ in g},
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); "
-               "split-K reduce kernels' traffic is included in the bytes, not in the launch count"}
+               "every kernel whose name starts with gemm_; split-K reduce kernels' traffic is included in the bytes, not in the launch count"}
 print(json.dumps(out))
 if len(sys.argv) > 4:
     json.dump(out, open(sys.argv[4], "w"), indent=1)

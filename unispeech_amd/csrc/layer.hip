@@ -176,7 +176,9 @@ uint64_t wg_ws_bytes(const WG* it, int cnt, int64_t n) {  // upper bound over ev
   return tot;
 }
 int wgrads(const WG* it, int cnt, int64_t n, int pdt, void* ws, uint64_t wsb, void* stream) {
-  static const bool grouping = env_int("WAVLM_WGRAD_GROUPING", 1) != 0;
+  // anything but the literal "0" is on -- as unispeech_amd/functional.py reads it (atoi("auto") would be 0: the fused block
+  // would silently stop grouping while the composed path still groups, and the two paths would no longer issue the same kernels)
+  static const bool grouping = [] { const char* e = getenv("WAVLM_WGRAD_GROUPING"); return !(e && e[0] == '0' && !e[1]); }();
   const long kt = (long)((n + 63) / 64);
   int i = 0;
   while (i < cnt) {

@@ -31,6 +31,35 @@ def reserved_channels():
     return max(0, min(64, int(os.environ.get("WAVLM_DP_RESERVED_CUS", "6"))))
 
 
+def cap_rccl_channels(world=None, log=False):
+    """NCCL_MAX_NCHANNELS = the CUs the persistent GEMM grids leave free, set BEFORE the communicator exists.  The variable is
+    process-wide (it caps every RCCL communicator of the process, not only the gradient all-reduce), so: only for a
+    data-parallel run (`world` > 1, or WORLD_SIZE > 1 in the launcher's environment when `world` is None), never over a
+    value the user exported, and said out loud -- including when it is too late (torch.distributed already initialised:
+    RCCL may then take more CUs than the persistent grids leave free).  Returns the value in force or None.
+    The cap is a HYPOTHESIS (one channel = one workgroup = one CU; 332 MB per rank and step through 6 channels is an
+    untested bandwidth assumption: DESIGN.md section 5); `bench.py --gpus N` measures both settings when the wait is long."""
+    import os
+    import sys
+    n = reserved_channels()
+    if world is None:
+        world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    if n <= 0 or world <= 1:
+        return os.environ.get("NCCL_MAX_NCHANNELS")
+    if "NCCL_MAX_NCHANNELS" in os.environ:
+        return os.environ["NCCL_MAX_NCHANNELS"]
+    if dist.is_available() and dist.is_initialized():
+        if log:
+            print("[unispeech_amd] torch.distributed is already initialised: NCCL_MAX_NCHANNELS=%d can no longer be applied "
+                  "(RCCL may occupy more CUs than WAVLM_DP_RESERVED_CUS=%d leaves free)" % (n, n), file=sys.stderr)
+        return None
+    os.environ["NCCL_MAX_NCHANNELS"] = str(n)
+    if log:
+        print("[unispeech_amd] NCCL_MAX_NCHANNELS=%d for this process (= WAVLM_DP_RESERVED_CUS; export NCCL_MAX_NCHANNELS "
+              "yourself to override)" % n, file=sys.stderr)
+    return str(n)
+
+
 class GradReducer:
     def __init__(self, params, flat_grad, offsets, process_group=None, bucket_bytes=32 << 20):
         self.params = list(params)

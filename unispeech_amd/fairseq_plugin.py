@@ -198,10 +198,8 @@ def register(override: bool = False, fp16_as_bf16=None):
     if override:
         # data-parallel runs through the stand-in wrapper: RCCL may take as many channels (= CUs) as the persistent GEMM grids
         # leave free (dp.py); --user-dir is imported before distributed_utils.distributed_init creates the communicator
-        import os
-        from .dp import reserved_channels
-        if reserved_channels() > 0:
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(reserved_channels()))
+        from .dp import cap_rccl_channels
+        cap_rccl_channels(log=True)
     from fairseq.criterions import register_criterion
     from fairseq.models import register_model
     Model, Criterion, ModelCfg, CritCfg = _classes()

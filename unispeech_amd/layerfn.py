@@ -11,6 +11,7 @@ being the bottleneck.  Here a block costs the launch thread two allocations, one
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -82,11 +83,17 @@ class _Binding:
                 and self.key == (pk[0].data_ptr(), pk[1].data_ptr(), g.data_ptr(), layer.fc2.weight.data_ptr()))
 
 
+# layer -> _Binding.  Kept OUTSIDE the module's state: a _Binding holds a ctypes descriptor with pointer fields, which
+# neither copy.deepcopy (EMA / teacher copies of a model that has already trained) nor pickle accept ("ctypes objects
+# containing pointers cannot be pickled"); a copy of the model simply starts without bindings and builds its own.
+_BINDINGS = weakref.WeakKeyDictionary()
+
+
 def binding(layer):
-    b = layer.__dict__.get("_wl_binding")
+    b = _BINDINGS.get(layer)
     if b is None or not b.valid_for(layer):
         b = _Binding(layer)
-        layer.__dict__["_wl_binding"] = b
+        _BINDINGS[layer] = b
     return b
 
 

@@ -404,9 +404,17 @@ class FairseqFusedAdam:
 
     # -- checkpoints (trainer.py:373-411, 511-543) ------------------------------------------------------------------
     def state_dict(self):
-        return self.fused.fairseq_state_dict()
+        sd = self.fused.fairseq_state_dict()
+        if self.scaler is not None:          # fp16_optimizer.py:79: a resumed --fp16 run continues at its loss scale
+            sd["loss_scale"] = self.scaler.loss_scale
+        return sd
 
     def load_state_dict(self, state_dict, optimizer_overrides=None):
+        if "loss_scale" in state_dict:       # fp16_optimizer.py:90-91 (ignored without a scaler, as a --bf16 resume does)
+            state_dict = dict(state_dict)
+            ls = state_dict.pop("loss_scale")
+            if self.scaler is not None:
+                self.scaler.loss_scale = ls
         self.fused.load_fairseq_state_dict(state_dict)
         self.fused.sync_master_from_params()
         if optimizer_overrides:

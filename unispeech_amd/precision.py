@@ -12,9 +12,15 @@ fp32 master weights in the optimizer).  Two behaviours, chosen explicitly:
     reference's loss-scaling PROTOCOL around the bf16 kernels: the loss is multiplied by `scaler.loss_scale` before
     backward, 1 / loss_scale rides in the deferred gradient factor, a non-finite gradient norm raises OverflowError (the
     Trainer skips the update, trainer.py:856-862) and halves the scale, `scale_window` clean updates double it, and
-    `optimizer.scaler.loss_scale` is there for the Trainer's logging (trainer.py:947).  bf16 has fp32's exponent range,
-    so the scale never has to come down in practice; the protocol is kept so that checkpoints, logs and the overflow path
-    of a recipe behave as they do in the reference.
+    `optimizer.scaler.loss_scale` is there for the Trainer's logging (trainer.py:947) and travels in the optimizer's
+    state dict (`loss_scale`, fp16_optimizer.py:79, 90-91).  Steady state: bf16 has fp32's exponent range, so the scale is
+    not NEEDED -- but the reference's scaler doubles it every `scale_window` clean updates without a bound, so it climbs
+    until the fp32 sum of squares of the scaled gradients overflows (scale x |g| ~ 2^64); from then on one update per window
+    is skipped and the scale halved, exactly the rhythm of a real fp16 run, only tens of thousands of updates later.  The
+    protocol is kept unmodified (no cap) so that checkpoints, logs and the overflow path of a recipe behave as they do in
+    the reference.  Cost: with a scaler the gradient-norm check reads the norm on the host every update
+    (`FairseqFusedAdam.clip_grad_norm`, as fp16_optimizer.py:199-206 does) -- one stream synchronisation per step that the
+    --bf16 path does not have; the launch thread loses its run-ahead there (launch-thread section).
 """
 import os
 

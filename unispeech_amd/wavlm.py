@@ -667,9 +667,14 @@ class WavLM(nn.Module):
                 return torch.zeros((B, n_frames), dtype=torch.bool)
             k = T // n_frames
             if a.flags.c_contiguous and k % 8 == 0 and T % 8 == 0:
-                # eight samples per 64-bit word: a frame is padded iff its k / 8 words are all 0x0101010101010101
+                # eight samples per 64-bit word: a frame is padded iff every byte of its k / 8 words is non-zero.  A bool
+                # byte is 0x01 in anything numpy / torch produce, but a mask viewed from foreign uint8 storage may carry
+                # other non-zero bytes: x | x >> 1 | ... | x >> 7 folds every byte's bits into its bit 0 (carries from the
+                # byte above land in bits 1-7, which the 0x01 mask drops)
                 w = a.view(np.uint64)[:, :n_frames * (k // 8)].reshape(B, n_frames, k // 8)
-                out = (w == np.uint64(0x0101010101010101)).all(-1)
+                if a.view(np.uint8).max() > 1:
+                    w = w | (w >> np.uint64(1)); w = w | (w >> np.uint64(2)); w = w | (w >> np.uint64(4))
+                out = ((w & np.uint64(0x0101010101010101)) == np.uint64(0x0101010101010101)).all(-1)
             else:
                 out = a[:, :n_frames * k].reshape(B, n_frames, k).all(-1)
             return torch.from_numpy(out)
