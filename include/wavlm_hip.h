@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 17
+#define WAVLM_HIP_ABI_VERSION 18
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -225,6 +225,25 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
                          const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, void* dbias,
                          int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T, int32_t head_dim,
                          float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes, void* stream);
+/* The same pair with STORED PROBABILITIES (round 5): the forward additionally writes its softmax probabilities -- fp16,
+ * relative to the running row maximum of their key tile, dropout decision in the sign bit -- and those maxima into the opaque
+ * `pstore` (wavlm_attn_fused_pstore_bytes: 4 KiB per 32 query rows x 64 keys, 453 MB per layer at B = 32, H = 12, T = 749),
+ * and the backward kernels read them instead of recomputing scores, bias, exponentials and dropout words from (q, k, lse,
+ * seed): the element pass of both backward kernels shrinks to convert / scale / multiply and each loses its score MFMA.
+ * The reference keeps the same tensor (`attn_output_weights` after dropout, F.multi_head_attention_forward under
+ * WavLM/modules.py:504-563, fp32 / fp16 [B*H, T, T]) -- here it is a memory-for-VALU trade the 288 GB part can afford.
+ * wavlm_attn_fused_pstore_bytes returns 0 for T > 1024: recompute only.
+ * pstore == NULL: exactly wavlm_attn_fused_fwd / _bwd (recompute; the low-memory mode).  A backward with pstore must be
+ * given the pstore its own forward wrote (same B, H, T, gate, tab, kpm, p_drop, seed). */
+uint64_t wavlm_attn_fused_pstore_bytes(int32_t B, int32_t H, int32_t T);
+int wavlm_attn_fused_fwd_p(const void* qkv, void* O, float* lse, const float* gate, const float* tab, const uint8_t* kpm,
+                           void* pstore, uint64_t pstore_bytes, int32_t B, int32_t H, int32_t T, int32_t head_dim, float scale,
+                           float p_drop, uint64_t seed, void* stream);
+int wavlm_attn_fused_bwd_p(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
+                           const float* tab, const uint8_t* kpm, const void* pstore, uint64_t pstore_bytes, void* dqkv,
+                           float* dgate, float* dtab, void* dbias, int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B,
+                           int32_t H, int32_t T, int32_t head_dim, float scale, float p_drop, uint64_t seed, void* workspace,
+                           uint64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * pos_conv weight side: weight_norm(dim=2) -> GEMM weight images, and its backward (WavLM/WavLM.py:514-527)
@@ -373,6 +392,8 @@ typedef struct wavlm_layer_desc {
   int32_t dtab_accumulate;         /* backward: dtab (+)= instead of = */
   float eps1, eps2, scale;         /* LayerNorm epsilons, q scaling (head_dim^-0.5) */
   float p_drop, p_attn;            /* residual dropout, attention dropout (0 in eval) */
+  int32_t attn_store_p;            /* 1: the attention keeps its probabilities in `saved` for backward (wavlm_attn_fused_fwd_p);
+                                      0: backward recomputes them (low-memory mode).  Same value in forward and backward. */
   uint64_t seed_r1, seed_r2, seed_attn;
   /* parameters (and, backward only, their gradient accumulators) */
   const void *Wqkv, *bqkv, *Wo, *bo, *W1, *b1, *W2, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;

@@ -17,6 +17,7 @@ from unispeech_amd import functional as F  # noqa: E402
 from unispeech_amd import ops  # noqa: E402
 
 DEV = "cuda"
+ATTN_STORE_P_DEFAULT = F.ATTN_STORE_P   # restored after the checks that switch the attention backward mode
 TOL32, TOLBF = 1e-4, 2e-2
 
 
@@ -571,18 +572,21 @@ def check_attention():
         qd = qkv.to(dtype).to(DEV).requires_grad_(True)
         gd, td = gate.to(DEV).requires_grad_(True), tab.to(DEV).requires_grad_(True)
         kd = kpm.to(DEV) if kpm is not None else None
-        for fused in (True, False):
+        # fused with stored probabilities (the default), fused with recomputation (WAVLM_ATTN_STORE_P=0), unfused composition
+        for fused, store in ((True, True), (True, False), (False, False)):
             F.USE_FUSED_ATTENTION = fused
+            F.ATTN_STORE_P = store
             for t in (qd, gd, td):
                 t.grad = None
             Od = F.AttnCoreFn.apply(qd, gd, td, kd, H, hd ** -0.5, 0.0, 0)
             Od.backward(dO.to(dtype).to(DEV))
-            tag = f"attn[{'fused' if fused else 'unfused'} bf16] B={B} T={T} H={H} pad={use_pad}"
+            tag = f"attn[{('fused, stored P' if store else 'fused, recompute') if fused else 'unfused'} bf16] B={B} T={T} H={H} pad={use_pad}"
             out.append((tag + " O", err(Od, Or), tol))
             out.append((tag + " dqkv", err(qd.grad, qr.grad), tol * 2))
             out.append((tag + " dgate", err(gd.grad, gr.grad), tol * 2))
             out.append((tag + " dtab", err(td.grad, tr.grad), tol * 2))
         F.USE_FUSED_ATTENTION = True
+        F.ATTN_STORE_P = ATTN_STORE_P_DEFAULT
     # fused dropout: deterministic per seed, keep fraction, and forward/backward agree on the mask
     B, T, H, hd = 1, 256, 2, 64
     D = H * hd
@@ -642,7 +646,7 @@ def check_attention():
 
 
 # ------------------------------------------------------------------------------------------- exact dropout parity
-def _attn_kernel_masks(B, H, T, p_drop, seed, gate, tab, kpm, qseed=41):
+def _attn_kernel_masks(B, H, T, p_drop, seed, gate, tab, kpm, qseed=41, store_p=False):
     """The keep mask each of the three fused attention kernels ACTUALLY applies, read out of the kernels' own results
     (no debug entry point, no re-implementation of the hash): bool [B, H, T, T] (query, key) each.
       forward   V = one-hot over a 64-key chunk  ->  O[i, u] = P_drop[i, j0 + u]: kept iff non-zero;
@@ -667,20 +671,20 @@ def _attn_kernel_masks(B, H, T, p_drop, seed, gate, tab, kpm, qseed=41):
             onehot[:, c0 + u, h * hd + u] = 1.0
         # forward: V one-hot on the key chunk
         qkv = torch.cat([qv, kv, onehot], dim=-1).contiguous()
-        O, lse = ops.attn_fused_fwd(qkv, gate, tab, kpm, H, scale, p_drop, seed)
+        O, lse, _ = ops.attn_fused_fwd(qkv, gate, tab, kpm, H, scale, p_drop, seed, store_p=store_p)
         keep_f[:, :, :, c0:c0 + n] = (O.view(B, T, H, hd)[..., :n] != 0).permute(0, 2, 1, 3).cpu()
         # dK/dV: dO one-hot on the query chunk (any V)
         qkv2 = torch.cat([qv, kv, kv], dim=-1).contiguous()
-        O2, lse2 = ops.attn_fused_fwd(qkv2, gate, tab, kpm, H, scale, p_drop, seed)
-        dqkv, _, _ = ops.attn_fused_bwd(qkv2, O2, onehot, lse2, gate, tab, kpm, H, scale, p_drop, seed)
+        O2, lse2, ps2 = ops.attn_fused_fwd(qkv2, gate, tab, kpm, H, scale, p_drop, seed, store_p=store_p)
+        dqkv, _, _ = ops.attn_fused_bwd(qkv2, O2, onehot, lse2, gate, tab, kpm, H, scale, p_drop, seed, pstore=ps2)
         dV = dqkv[..., 2 * D:].view(B, T, H, hd)[..., :n]                       # [b, j, h, u] = P_drop[i0 + u, j]
         keep_kv[:, :, c0:c0 + n, :] = (dV != 0).permute(0, 2, 3, 1).cpu()
         # dQ: K one-hot on the key chunk, V = dO = e_0
         e0 = torch.zeros(B, T, D, dtype=torch.bfloat16, device=DEV)
         e0[..., hsel] = 1.0
         qkv3 = torch.cat([qv, onehot, e0], dim=-1).contiguous()
-        O3, lse3 = ops.attn_fused_fwd(qkv3, gate, tab, kpm, H, scale, p_drop, seed)
-        dqkv3, _, _ = ops.attn_fused_bwd(qkv3, O3, e0, lse3, gate, tab, kpm, H, scale, p_drop, seed)
+        O3, lse3, ps3 = ops.attn_fused_fwd(qkv3, gate, tab, kpm, H, scale, p_drop, seed, store_p=store_p)
+        dqkv3, _, _ = ops.attn_fused_bwd(qkv3, O3, e0, lse3, gate, tab, kpm, H, scale, p_drop, seed, pstore=ps3)
         dQ = dqkv3[..., :D].view(B, T, H, hd)[..., :n]
         keep_q[:, :, :, c0:c0 + n] = (dQ > 0).permute(0, 2, 1, 3).cpu()
     if kpm is not None:
@@ -710,8 +714,11 @@ def _ref_attention_masked(qkv, gate, tab, kpm, H, scale, keep, sc):
 
 def check_dropout_exact():
     """Dropout-on is the benchmarked mode: its parity must not be statistical.  (1) The keep masks the forward, dQ and dK/dV
-    attention kernels apply are read out of the kernels themselves and must be IDENTICAL (three kernels regenerate the mask
-    independently, the dK/dV one with a different word-sharing scheme).  (2) With that mask the fused forward and backward
+    attention kernels apply are read out of the kernels themselves and must be IDENTICAL -- in the recompute mode three kernels
+    regenerate the mask independently (the dK/dV one with a different word-sharing scheme), in the stored-probability mode
+    (the default) the backward kernels take the decision from the sign bit the forward stored, through two different
+    read paths (register fragments / LDS gather + transposing read); and the storing forward must drop exactly what the
+    plain forward drops.  (2) With that mask the fused forward and backward
     are compared with the fp64 reference at the usual bf16 tolerance (multihead_attention.py:278-300 with
     dropout_p = attention_dropout).  (3) The same for the dropouts fused into the LayerNorm kernels (residual-branch
     dropout of post- and pre-LN blocks incl. the fused pre-LN residual stream, output dropout) and the dropout-add."""
@@ -734,6 +741,10 @@ def check_dropout_exact():
         out.append((tag + " keep fraction", abs(kf.float().mean().item() / nvalid - (1 - p_drop)), 0.01))
         out.append((tag + " mask fwd == dQ (mismatching elements)", float((kf != kq).sum().item()), 0.0))
         out.append((tag + " mask fwd == dK/dV (mismatching elements)", float((kf != kkv).sum().item()), 0.0))
+        sf, sq, skv = _attn_kernel_masks(B, H, T, p_drop, seed, gate, tab, kpm, store_p=True)
+        out.append((tag + " stored P: storing fwd == plain fwd (mismatching elements)", float((sf != kf).sum().item()), 0.0))
+        out.append((tag + " stored P: mask fwd == dQ (mismatching elements)", float((sf != sq).sum().item()), 0.0))
+        out.append((tag + " stored P: mask fwd == dK/dV (mismatching elements)", float((sf != skv).sum().item()), 0.0))
         # (2) numerics with the forward's own mask
         D = 64 * H
         qkv = q(gen(B, T, 3 * D, seed=11), torch.bfloat16)
@@ -744,16 +755,20 @@ def check_dropout_exact():
         tr = tc.double().requires_grad_(True) if use_tab else None
         Or = _ref_attention_masked(qr, gr, tr, kpm.cpu() if kpm is not None else None, H, 64 ** -0.5, kf, sc)
         (Or * dO.double()).sum().backward()
-        qd = qkv.to(torch.bfloat16).to(DEV).requires_grad_(True)
-        gd = gate.clone().requires_grad_(True) if use_tab else None
-        td = tab.clone().requires_grad_(True) if use_tab else None
-        Od = F.AttnCoreFn.apply(qd, gd, td, kpm, H, 64 ** -0.5, p_drop, seed)
-        Od.backward(dO.to(torch.bfloat16).to(DEV))
-        out.append((tag + " O vs fp64 with the kernel's mask", err(Od, Or), TOLBF))
-        out.append((tag + " dqkv vs fp64 with the kernel's mask", err(qd.grad, qr.grad), TOLBF * 2))
-        if use_tab:
-            out.append((tag + " dgate", err(gd.grad, gr.grad), TOLBF * 2))
-            out.append((tag + " dtab", err(td.grad, tr.grad), TOLBF * 2))
+        for store in (True, False):
+            F.ATTN_STORE_P = store
+            tg2 = tag + (" [stored P]" if store else " [recompute]")
+            qd = qkv.to(torch.bfloat16).to(DEV).requires_grad_(True)
+            gd = gate.clone().requires_grad_(True) if use_tab else None
+            td = tab.clone().requires_grad_(True) if use_tab else None
+            Od = F.AttnCoreFn.apply(qd, gd, td, kpm, H, 64 ** -0.5, p_drop, seed)
+            Od.backward(dO.to(torch.bfloat16).to(DEV))
+            out.append((tg2 + " O vs fp64 with the kernel's mask", err(Od, Or), TOLBF))
+            out.append((tg2 + " dqkv vs fp64 with the kernel's mask", err(qd.grad, qr.grad), TOLBF * 2))
+            if use_tab:
+                out.append((tg2 + " dgate", err(gd.grad, gr.grad), TOLBF * 2))
+                out.append((tg2 + " dtab", err(td.grad, tr.grad), TOLBF * 2))
+        F.ATTN_STORE_P = ATTN_STORE_P_DEFAULT
     # (3) LayerNorm-fused dropouts
     for dtype in (torch.float32, torch.bfloat16):
         tol = tol_for(dtype)

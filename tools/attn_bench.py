@@ -34,9 +34,32 @@ def timeit(fn, name, flops):
 
 
 fl = 4.0 * B * H * T * T * hd
-O, lse = ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234)
+O, lse, _ = ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234)
 timeit(lambda: ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234), "attention fwd (p=%.2f)" % p, fl)
 timeit(lambda: ops.attn_fused_bwd(qkv, O, dO, lse, gate, tab, None, H, hd ** -0.5, p, 1234), "attention bwd (dq+dkv+red)", 2.5 * fl)
+# stored probabilities (round 5): the forward writes P (fp16, sign = dropped), the backward kernels read it.  The pstore is
+# allocated once here (the training path allocates it inside the block's `saved` region).
+L_ = ops._lib.lib()
+nps = int(L_.wavlm_attn_fused_pstore_bytes(B, H, T))
+pst = torch.empty(nps, dtype=torch.uint8, device=dev)
+O_s, lse_s = torch.empty_like(O), torch.empty_like(lse)
+
+
+def fwd_store():
+    ops.check(L_.wavlm_attn_fused_fwd_p(ops.ptr(qkv), ops.ptr(O_s), ops.ptr(lse_s), ops.ptr(gate), ops.ptr(tab), None, ops.ptr(pst), nps,
+                                        B, H, T, hd, hd ** -0.5, p, 1234, ops.stream()), "fwd_p")
+
+
+fwd_store()
+torch.cuda.synchronize()
+print("stored-P forward == plain forward: O max |diff| %.3e, lse max |diff| %.3e (pstore %.1f MB)"
+      % ((O_s.float() - O.float()).abs().max().item(), (lse_s - lse).abs().max().item(), nps / 1e6), flush=True)
+timeit(fwd_store, "fwd + P store (p=%.2f)" % p, fl)
+timeit(lambda: ops.attn_fused_bwd(qkv, O_s, dO, lse_s, gate, tab, None, H, hd ** -0.5, p, 1234, pstore=pst), "bwd from stored P", 2.5 * fl)
+g_r = ops.attn_fused_bwd(qkv, O, dO, lse, gate, tab, None, H, hd ** -0.5, p, 1234)
+g_s = ops.attn_fused_bwd(qkv, O_s, dO, lse_s, gate, tab, None, H, hd ** -0.5, p, 1234, pstore=pst)
+for nm, a, b_ in zip(("dqkv", "dgate", "dtab"), g_s, g_r):
+    print("stored-P backward vs recompute backward, %s: max |diff| / max |ref| = %.3e" % (nm, (a.float() - b_.float()).abs().max().item() / b_.float().abs().max().item()), flush=True)
 if os.environ.get("ATTN_BENCH_DBIAS", "0") == "1":  # with the q|k|v bias gradient delivered by the backward kernels
     db = torch.zeros(3 * D, device=dev)
     timeit(lambda: ops.attn_fused_bwd(qkv, O, dO, lse, gate, tab, None, H, hd ** -0.5, p, 1234, dbias=db, dbias_accumulate=True),
@@ -47,6 +70,6 @@ timeit(lambda: ops.attn_fused_fwd(qkv, None, None, None, H, hd ** -0.5, 0.0, 0),
 # the template arguments in the kernel names are <DROP, TAB> / <DROP>)
 for (use_tab, pp) in ((True, 0.0), (False, p), (False, 0.0)):
     g_, t_ = (gate, tab) if use_tab else (None, None)
-    O2, lse2 = ops.attn_fused_fwd(qkv, g_, t_, None, H, hd ** -0.5, pp, 1234)
+    O2, lse2, _ = ops.attn_fused_fwd(qkv, g_, t_, None, H, hd ** -0.5, pp, 1234)
     timeit(lambda: ops.attn_fused_bwd(qkv, O2, dO, lse2, g_, t_, None, H, hd ** -0.5, pp, 1234),
            "bwd tab=%d p=%.2f" % (use_tab, pp), 2.5 * fl)

@@ -108,7 +108,7 @@ gate = 1 + 0.5 * torch.rand(B_, H_, T_, device=dev)
 tab = 0.5 * torch.randn(H_, 2 * T_ - 1, device=dev)
 dO = torch.randn(B_, T_, H_ * hd_, device=dev).to(bf)
 fl = 4.0 * B_ * H_ * T_ * T_ * hd_
-O_, lse_ = ops.attn_fused_fwd(qkv, gate, tab, None, H_, hd_ ** -0.5, 0.1, 1234)
+O_, lse_, _ = ops.attn_fused_fwd(qkv, gate, tab, None, H_, hd_ ** -0.5, 0.1, 1234)
 run("fused attention forward (12 heads, T = 749, dropout 0.1)", lambda: ops.attn_fused_fwd(qkv, gate, tab, None, H_, hd_ ** -0.5, 0.1, 1234), fl)
 run("fused attention backward (dQ + dK/dV + reduction)", lambda: ops.attn_fused_bwd(qkv, O_, dO, lse_, gate, tab, None, H_, hd_ ** -0.5, 0.1, 1234), 2.5 * fl)
 x_ = torch.randn(n, 768, device=dev).to(bf)

@@ -23,10 +23,16 @@ for a in sys.argv[1:] or ["1", "2", "3", "4"]:
         src, a = "rowops.hip", a[4:]
     elif a.startswith("attn:"):  # attn:<tag>:-DFA_FWD_LAZY=1,... builds attn_fused.hip (forward + dQ kernels) with the defines
         src, a = "attn_fused.hip", a[5:]
-    tag, defs = (a, ["-DPP_PROBE=%d" % int(a)]) if a.isdigit() else (a.split(":")[0], a.split(":")[1].split(","))
-    obj = os.path.join(B.OBJ_DIR, "%s_probe%s.o" % (src[:-4], tag))
-    subprocess.check_call([B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + ["-DWAVLM_EXPERIMENTAL"] + defs + ["-c", os.path.join(B.CSRC, src), "-o", obj])
-    objs = [os.path.join(B.OBJ_DIR, s.replace(".hip", ".o")) for s in B.SOURCES if s != src] + [obj]
+    srcs = [src]
+    if a.startswith("attn3:"):  # attn3:<tag>:-DFA_ASM_DMA=0 builds all three attention kernels (both translation units)
+        srcs, a = ["attn_fused.hip", "attn_fused_dkv.hip"], a[6:]
+    tag, defs = (a, ["-DPP_PROBE=%d" % int(a)]) if a.isdigit() else (a.split(":")[0], [d for d in a.split(":")[1].split(",") if d])
+    pobjs = []
+    for src in srcs:
+        obj = os.path.join(B.OBJ_DIR, "%s_probe%s.o" % (src[:-4], tag))
+        subprocess.check_call([B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + ["-DWAVLM_EXPERIMENTAL"] + defs + ["-c", os.path.join(B.CSRC, src), "-o", obj])
+        pobjs.append(obj)
+    objs = [os.path.join(B.OBJ_DIR, s.replace(".hip", ".o")) for s in B.SOURCES if s not in srcs] + pobjs
     # probe libraries live outside the package (unispeech_amd/lib/ ships ONLY libwavlm_hip.so): select one with WAVLM_HIP_LIB
     os.makedirs(os.path.join(ROOT, "tools", "probe", "lib"), exist_ok=True)
     out = os.path.join(ROOT, "tools", "probe", "lib", "libwavlm_hip_probe%s.so" % tag)

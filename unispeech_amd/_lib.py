@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVLM_HIP_LIB") or os.path.join(_HERE, "lib", "libwavlm_hip.so")
 
 _lib = None
-ABI_VERSION = 17  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 18  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
 
 F32, BF16 = 0, 1
 
@@ -51,6 +51,7 @@ class LayerDesc(C.Structure):
         ("B", c_i32), ("T", c_i32), ("D", c_i32), ("H", c_i32), ("F", c_i32),
         ("pre_ln", c_i32), ("param_dtype", c_i32), ("dtab_accumulate", c_i32),
         ("eps1", c_f32), ("eps2", c_f32), ("scale", c_f32), ("p_drop", c_f32), ("p_attn", c_f32),
+        ("attn_store_p", c_i32),
         ("seed_r1", c_u64), ("seed_r2", c_u64), ("seed_attn", c_u64),
         ("Wqkv", c_vp), ("bqkv", c_vp), ("Wo", c_vp), ("bo", c_vp), ("W1", c_vp), ("b1", c_vp), ("W2", c_vp), ("b2", c_vp),
         ("ln1_g", c_vp), ("ln1_b", c_vp), ("ln2_g", c_vp), ("ln2_b", c_vp),
@@ -121,6 +122,11 @@ SIGNATURES = {
     "wavlm_attn_fused_bwd_workspace_bytes": (c_u64, [c_i32, c_i32, c_i32]),
     "wavlm_attn_fused_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                      c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp, c_u64, c_vp]),
+    "wavlm_attn_fused_pstore_bytes": (c_u64, [c_i32, c_i32, c_i32]),
+    "wavlm_attn_fused_fwd_p": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u64, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32,
+                                       c_u64, c_vp]),
+    "wavlm_attn_fused_bwd_p": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                                       c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp, c_u64, c_vp]),
     "wavlm_posconv_weight_workspace_bytes": (c_u64, [c_i32, c_i32, c_i32]),
     "wavlm_posconv_weight_fwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp,
                                          c_u64, c_vp]),

@@ -34,8 +34,10 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #endif
 
 // ------------------------------------------------------------------------------------------------- forward
-template <bool DROP>
+// STORE: the probabilities (fp16, sign = dropped) and the running maxima go to p.ps for the backward (attn_fused.hpp)
+template <bool DROP, bool STORE = false>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
+  static_assert(!STORE || (FA_FWD_BIAS_IN_C && !FA_FWD_LAZY), "the probability store is written for the default forward");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   auto kbuf = [&](int st) { return smem + st * 16384; };
   auto vbuf = [&](int st) { return smem + st * 16384 + 8192; };
@@ -83,18 +85,31 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 #endif
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
   const unsigned vtr = fa_tr_base(lane);
+  // STORE: this wave's tile row of the fragment-native probability store and its column of the running maxima
+  unsigned char* pst = nullptr;
+  float* mtp = nullptr;
+  if constexpr (STORE) {
+    pst = p.ps.P16 + (((long)bh * p.ps.nq32 + (qblk * 4 + wave_u)) * p.ps.nkv) * FA_PTILE_BYTES + lane * 16;
+    mtp = p.ps.mt + (long)bh * p.ps.nkv * p.ps.Tq + (qblk * FA_BQ + 32 * wave_u + ql);
+  }
 
-  glds_tile64(base + FA_HD * H, D3, 0, T, kbuf(0), wave_u);
-  glds_tile64(base + 2 * FA_HD * H, D3, 0, T, vbuf(0), wave_u);
-  __syncthreads();
+#if FA_TILE_SRC
+  FaTileSrc ksrc, vsrc;
+  ksrc.init(base + FA_HD * H, D3, T);
+  vsrc.init(base + 2 * FA_HD * H, D3, T);
+#define FA_LOAD_KV(ROW0, KB_, VB_) do { ksrc.issue(ROW0, KB_, wave_u); vsrc.issue(ROW0, VB_, wave_u); } while (0)
+#else
+#define FA_LOAD_KV(ROW0, KB_, VB_) do { glds_tile64(base + FA_HD * H, D3, ROW0, T, KB_, wave_u); glds_tile64(base + 2 * FA_HD * H, D3, ROW0, T, VB_, wave_u); } while (0)
+#endif
+  FA_LOAD_KV(0, kbuf(0), vbuf(0));
+  fa_tile_sync();
 
   int cur = 0;
   for (int jt = 0; jt < nkv; ++jt) {
     const int j0 = jt * FA_BKV;
     const bool more = jt + 1 < nkv;
     if (more) {
-      glds_tile64(base + FA_HD * H, D3, j0 + FA_BKV, T, kbuf(cur ^ 1), wave_u);
-      glds_tile64(base + 2 * FA_HD * H, D3, j0 + FA_BKV, T, vbuf(cur ^ 1), wave_u);
+      FA_LOAD_KV(j0 + FA_BKV, kbuf(cur ^ 1), vbuf(cur ^ 1));
     }
     const unsigned* cwp = colw + ((j0 + 4 * hi) >> 1);  // j0 + 4 hi is even, r walks in pairs
     // S^T = K Q^T
@@ -204,6 +219,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
     const float nmsub = dead ? 0.f : -m_new;  // dead rows: every x is -inf -> 2^(-inf) = 0
     float rs = 0.f;
     U4 pf[2][2];
+    U4 pst16[STORE ? 2 : 1][2];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -212,9 +228,32 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
         const float p1 = __builtin_amdgcn_exp2f(fmaf(s[f][r + 1], p.sc2, nmsub));
         rs += p0 + p1;
         unsigned pk = pack_bf16(p0, p1);
-        if constexpr (DROP) pk &= fa_keepmask2(fa_mix(roww + cwp[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]), p.k2);
+        if constexpr (STORE) {
+          // fp16 pair (round towards zero: one v_cvt_pkrtz_f16_f32); the sign bit takes the drop decision, the bf16 pair of
+          // the PV product is masked with the same word
+          unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+          if constexpr (DROP) {
+            const unsigned dm = fa_dropmask2(fa_mix(roww + cwp[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]), p.k3);
+            pk &= ~dm;
+            h2 |= dm & 0x80008000u;
+          }
+          pst16[f][r >> 3].u[(r & 7) >> 1] = h2;
+        } else {
+          if constexpr (DROP) pk &= fa_keepmask2(fa_mix(roww + cwp[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]), p.k2);
+        }
         pf[f][r >> 3].u[(r & 7) >> 1] = pk;
       }
+    if constexpr (STORE && !(FA_SP_PROBE & 2)) {
+      // four coalesced 1 KiB stores per wave (every lane its own 16 bytes) + the running maximum these values are relative
+      // to.  Issued AFTER this tile's prefetch DMA: fa_tile_sync<5> lets exactly these five stay in flight.  Both halves
+      // of the wave hold the row's maximum and write the same word: one store instruction whatever the lane mask.
+      unsigned char* dstp = pst + (long)jt * FA_PTILE_BYTES;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<uint4*>(dstp + (f * 2 + s2) * 1024) = pst16[f][s2].v;
+      mtp[(long)jt * p.ps.Tq] = m_new;
+    }
 #else
     // scores -> log2 domain with the Toeplitz bias; key padding / keys past T only on edge tiles
     float tmax = -INFINITY;
@@ -280,7 +319,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
           o[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vbuf(cur), vtr, f2, f, s2), pf[f][s2].b, o[f2], 0, 0, 0);
-    __syncthreads();
+    if constexpr (STORE && (FA_SP_PROBE & 2)) {   // probe: keep the conversions alive without the stores
+      if (pst16[0][0].u[0] == 0x12345678u && pst16[1][1].u[3] == 0x9abcdef0u && pst16[0][1].u[1] == 77u && pst16[1][0].u[2] == 78u) mtp[0] = m;
+      fa_tile_sync<0>();
+    } else
+    fa_tile_sync<STORE ? 5 : 0>();
     cur ^= 1;
   }
   if (i < T) {
@@ -343,7 +386,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 #ifndef FA_DQ_OCC
 #define FA_DQ_OCC 2
 #endif
-template <bool DROP, bool TAB>
+// SP: stored probabilities (attn_fused.hpp).  The wave reads back the very fragments the forward's wave of the same rows
+// wrote (16 bytes per lane, f, s2: four coalesced 1 KiB loads per tile, issued one tile ahead) -- no score MFMA, no bias, no
+// exponential, no dropout word; Q is not needed at all.  DROP is irrelevant then (the decision is the stored sign).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <bool DROP, bool TAB, bool SP = false>
 __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per stage: K [kv][hd] 8 KB | V [kv][hd] 8 KB;  then (relative-position table present) the four waves' skew buffers
@@ -384,7 +431,8 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   float dl = 0.f;
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    qf[kk].v = *reinterpret_cast<const uint4*>(base + (long)ic * D3 + 16 * kk + 8 * hi);
+    if constexpr (!SP) qf[kk].v = *reinterpret_cast<const uint4*>(base + (long)ic * D3 + 16 * kk + 8 * hi);
+    else qf[kk].v = make_uint4(0, 0, 0, 0);
     const long oo = ((long)b * T + ic) * D + h * FA_HD + 16 * kk + 8 * hi;
     dof[kk].v = *reinterpret_cast<const uint4*>(p.dO + oo);
     U4 ov; ov.v = *reinterpret_cast<const uint4*>(p.O + oo);
@@ -397,10 +445,12 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   dl = wl_sum_xor32(dl);
   const float dls = dl * p.inv_sc;
   for (int d = threadIdx.x; d < p.Ltab; d += 256) tabs[d] = (p.tab && d < L) ? p.tab[(long)h * L + d] : 0.f;
-  for (int j = threadIdx.x; j < p.Tkb; j += 256)
-    kb[j] = (j < T && !(p.kpm && p.kpm[(long)b * T + j])) ? 0.f : -INFINITY;
-  if constexpr (DROP)
-    for (int jp = threadIdx.x; jp < (p.Tkb >> 1); jp += 256) colw[jp] = fa_col_word(p.s1, (unsigned)jp);
+  if constexpr (!SP) {
+    for (int j = threadIdx.x; j < p.Tkb; j += 256)
+      kb[j] = (j < T && !(p.kpm && p.kpm[(long)b * T + j])) ? 0.f : -INFINITY;
+    if constexpr (DROP)
+      for (int jp = threadIdx.x; jp < (p.Tkb >> 1); jp += 256) colw[jp] = fa_col_word(p.s1, (unsigned)jp);
+  }
   for (int q = threadIdx.x; q < SKEW_BYTES / 16; q += 256) reinterpret_cast<uint4*>(smem + 32768)[q] = make_uint4(0, 0, 0, 0);
   const float g = p.gate ? p.gate[(long)bh * T + ic] : 0.f;
   const float g2 = g * FA_LOG2E;
@@ -441,9 +491,37 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
 #endif
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
 
-  glds_tile64(base + D, D3, 0, T, kbuf(0), wave_u);
-  glds_tile64(base + 2 * D, D3, 0, T, vbuf(0), wave_u);
-  __syncthreads();
+  // SP: fragments and running maxima travel TWO tiles ahead in two register sets (ring A / B, the tile loop is unrolled by
+  // two so that no set is ever copied while its loads are in flight).  One tile ahead the kernel was latency-bound at
+  // 2.1 TB/s of P traffic: 16 KB in flight per workgroup, a loaded HBM round trip of ~4 us per tile.  (Deeper does not
+  // help as long as the K / V tiles arrive by DMA under the same in-order counter: the wait for the DMA of tile t + 1 at
+  // the end of tile t also waits for every load issued before it.)
+  const unsigned char* pld = nullptr;
+  const float* mtp = nullptr;
+  U4 pA0[2], pA1[2], pB0[2], pB1[2];
+  float mtA = 0.f, mtB = 0.f;
+  auto p_load = [&](int jn, U4 (&x0)[2], U4 (&x1)[2], float& mx) __attribute__((always_inline)) {
+    const unsigned char* src = pld + (long)jn * FA_PTILE_BYTES;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      x0[s2].v = *reinterpret_cast<const uint4*>(src + s2 * 1024);
+      x1[s2].v = *reinterpret_cast<const uint4*>(src + (2 + s2) * 1024);
+    }
+    mx = mtp[(long)jn * p.ps.Tq];
+  };
+  if constexpr (SP) {
+    pld = p.ps.P16 + (((long)bh * p.ps.nq32 + (qblk * 4 + wave_u)) * p.ps.nkv) * FA_PTILE_BYTES + lane * 16;
+    mtp = p.ps.mt + (long)bh * p.ps.nkv * p.ps.Tq + (qblk * FA_BQ + 32 * wave_u + ql);
+    p_load(0, pA0, pA1, mtA);
+    p_load(p.ps.nkv > 1 ? 1 : 0, pB0, pB1, mtB);
+  }
+#if FA_TILE_SRC
+  FaTileSrc ksrc, vsrc;
+  ksrc.init(base + D, D3, T);
+  vsrc.init(base + 2 * D, D3, T);
+#endif
+  FA_LOAD_KV(0, kbuf(0), vbuf(0));   // (D == FA_HD * H: the same macro as the forward's)
+  fa_tile_sync();
 
   float pend_v = 0.f;
   int pend_d = -1;
@@ -481,13 +559,30 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     pend_d = -1;
   };
   int cur = 0;
-  for (int jt = 0; jt < nkv; ++jt) {
+  // one key tile; (x0, x1, mx): SP, the register set that holds this tile's fragments and is refilled with tile jt + 2
+  auto tile_body = [&](int jt, U4 (&x0)[2], U4 (&x1)[2], float& mx) __attribute__((always_inline)) {
     const int j0 = jt * FA_BKV;
     const bool more = jt + 1 < nkv;
-    if (more) {
-      glds_tile64(base + D, D3, j0 + FA_BKV, T, kbuf(cur ^ 1), wave_u);
-      glds_tile64(base + 2 * D, D3, j0 + FA_BKV, T, vbuf(cur ^ 1), wave_u);
+    U4 pc0[2], pc1[2];
+    float ct = 0.f;
+    if constexpr (SP) {
+      // (taken out of the set BEFORE the DMA is issued: the compiler's wait for these loads then cannot catch the DMA.  The
+      // copies are asm: a plain assignment is coalesced away, the refill then lands in OTHER registers and the loop-carried
+      // set is restored by moves at the bottom of the loop -- which wait for the refill that was just issued)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          asm volatile("v_mov_b32 %0, %1" : "=v"(pc0[s2].u[e]) : "v"(x0[s2].u[e]));
+          asm volatile("v_mov_b32 %0, %1" : "=v"(pc1[s2].u[e]) : "v"(x1[s2].u[e]));
+        }
+      // P sc = |P16| 2^(mt + log2 sc - lse log2 e); rows past T: nlse2 = -inf -> 0; rows without a finite score: mt = -inf
+      ct = mx > -INFINITY ? __builtin_amdgcn_exp2f(mx + nlse2) : 0.f;
     }
+    if (more) {
+      FA_LOAD_KV(j0 + FA_BKV, kbuf(cur ^ 1), vbuf(cur ^ 1));
+    }
+    if constexpr (SP && !(FA_SP_PROBE & 1)) p_load(jt + 2 < nkv ? jt + 2 : jt, x0, x1, mx);   // (past the end: a harmless reload, no branch around the loads)
     if constexpr (TAB) flush_pending();
     if constexpr (TAB && FA_DQ_DEFER) {
       if (jt > 0) skew_sums(j0 - FA_BKV);
@@ -505,10 +600,10 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
         for (int r = 0; r < 16; ++r) {
           const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
           tvv[f][r] = trow[j];
-          if (DROP && !(r & 1)) cww[f][r >> 1] = (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1];
+          if (DROP && !SP && !(r & 1)) cww[f][r >> 1] = (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1];
         }
     }
-    const bool edge = (p.kpm != nullptr) || (j0 + FA_BKV > T);
+    const bool edge = !SP && ((p.kpm != nullptr) || (j0 + FA_BKV > T));   // (SP: masked keys carry a stored 0)
     U4 dsf0[2], dsf1[2];  // (two arrays, not dsf[2][2]: the 2-D array of unions is not split into registers)
     f32x16_t s[2], dp[2];
     // (block index as a type: a run-time index into s / dp / dsf would put the arrays into scratch)
@@ -534,7 +629,8 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
 #endif
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s[f], 0, 0, 0);
+        if constexpr (!SP)
+          s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(kbuf(cur), 32 * f + ql, kk, hi), qf[kk].b, s[f], 0, 0, 0);
         dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(vbuf(cur), 32 * f + ql, kk, hi), dof[kk].b, dp[f], 0, 0, 0);
       }
     };
@@ -545,10 +641,29 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
       for (int r = 0; r < 16; r += 2) {
         float dv[2];
         unsigned w = 0;
-        if constexpr (DROP) {
+        if constexpr (DROP && !SP) {
           if constexpr (PF) w = fa_mix(roww + cww[f][r >> 1]);
           else w = fa_mix(roww + (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]);
         }
+        if constexpr (SP) {
+          // stored pair -> signed P sc (sign = dropped); dS = keep P sc dP - P delta = max(Ps, 0) dP - |Ps| delta / sc
+          const f16x2_t h2 = __builtin_bit_cast(f16x2_t, (f == 0 ? pc0 : pc1)[r >> 3].u[(r & 7) >> 1]);
+          const f32x2_t ps2 = f32x2_t{(float)h2[0], (float)h2[1]} * f32x2_t{ct, ct};
+          const f32x2_t pk2 = f32x2_t{fmaxf(ps2[0], 0.f), fmaxf(ps2[1], 0.f)};
+          const f32x2_t pa2 = f32x2_t{__builtin_fabsf(ps2[0]), __builtin_fabsf(ps2[1])};
+          const f32x2_t ds2 = __builtin_elementwise_fma(pk2, f32x2_t{dp[f][r], dp[f][r + 1]}, -(pa2 * f32x2_t{dls, dls}));
+          dv[0] = ds2[0]; dv[1] = ds2[1];
+          if constexpr (TAB) {
+            f32x2_t tv2;
+            if constexpr (PF) tv2 = f32x2_t{tvv[f][r], tvv[f][r + 1]};
+            else { const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi; tv2 = f32x2_t{trow[j], trow[j + 1]}; }
+#if FA_DQ_PK
+            dg2 = __builtin_elementwise_fma(ds2, tv2, dg2);
+#else
+            dg = fmaf(ds2[0], tv2[0], fmaf(ds2[1], tv2[1], dg));
+#endif
+          }
+        } else
 #if FA_DQ_PK
         {
           const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;  // r even: j, j + 1 are this pair's keys
@@ -596,7 +711,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
         if constexpr (f == 0) dsf0[r >> 3].u[(r & 7) >> 1] = u2; else dsf1[r >> 3].u[(r & 7) >> 1] = u2;
         if constexpr (TAB) {  // the skew buffer takes dS itself; the gate multiplies inside the diagonal-sum MFMA
           const int dd = 32 * f + (r & 3) + 8 * (r >> 2);  // + 4 hi is in sk_w
-#if !FA_DQ_NOSKEW  // (probe: wrong d(rel), prices the skew writes)
+#if !FA_DQ_NOSKEW && !(FA_SP_PROBE & 4)  // (probe: wrong d(rel), prices the skew writes)
           sk_w[dd * 32] = (unsigned short)u2;
           sk_w[(dd + 1) * 32] = (unsigned short)(u2 >> 16);
 #endif
@@ -627,8 +742,21 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     dq_acc(F1{});
 #endif
     if constexpr (TAB && !FA_DQ_DEFER) skew_sums(j0);
-    __syncthreads();
+    // SP: the five loads of p_load were issued behind the DMA and may stay in flight across the barrier
+    fa_tile_sync<SP ? 5 : 0>();
     cur ^= 1;
+  };
+  if constexpr (SP) {
+    // whole pairs, then the odd tile: the pair loop's only back edge is B -> A (with a conditional tile B inside one loop the
+    // compiler's control-flow graph keeps a path from tile A straight back to tile A, and its wait-count pass then waits
+    // for A's refill at the top of A: loads issued one tile ago instead of two)
+    for (int pi = 0; pi < (nkv >> 1); ++pi) {
+      tile_body(2 * pi, pA0, pA1, mtA);
+      tile_body(2 * pi + 1, pB0, pB1, mtB);
+    }
+    if (nkv & 1) tile_body(nkv - 1, pA0, pA1, mtA);
+  } else {
+    for (int jt = 0; jt < nkv; ++jt) tile_body(jt, pA0, pA1, mtA);
   }
   if constexpr (TAB && FA_DQ_DEFER) skew_sums((nkv - 1) * FA_BKV);
   if constexpr (TAB) flush_pending();
@@ -729,6 +857,9 @@ static FaP fa_params(int B, int H, int T, float scale, float p_drop, uint64_t se
   p.log2sc = log2f(p.sc); p.inv_sc = 1.f / p.sc;
   p.ths = (int)p.th - 32768;
   p.k2 = (unsigned)((p.ths - 1) & 0xffff) * 0x10001u;
+  p.k3 = (unsigned)(p.ths & 0xffff) * 0x10001u;
+  p.ps.P16 = nullptr; p.ps.mt = nullptr;
+  p.ps.nq32 = ((T + FA_BQ - 1) / FA_BQ) * 4; p.ps.nkv = (T + FA_BKV - 1) / FA_BKV; p.ps.Tq = ((T + FA_BQ - 1) / FA_BQ) * FA_BQ;
   p.s0 = (unsigned)seed; p.s1 = (unsigned)(seed >> 32);
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
   p.Tkb = nkv * FA_BKV;
@@ -741,26 +872,43 @@ static FaP fa_params(int B, int H, int T, float scale, float p_drop, uint64_t se
 extern "C" {
 
 // O[B,T,H*64] = softmax(scale QK^T + gate*rel + keypad) V from packed qkv [B,T,3*H*64] (bf16); lse[B*H,T] saved
+uint64_t wavlm_attn_fused_pstore_bytes(int32_t B, int32_t H, int32_t T) {
+  if (B <= 0 || H <= 0 || T <= 0) return 0;
+  if (T > FA_PSTORE_MAX_T) return 0;   // longer sequences: recompute only (the dK/dV kernel keeps per-row scalars of all T rows in LDS)
+  return ((fa_pstore_p_bytes(B, H, T) + 255) & ~(uint64_t)255) + fa_pstore_mt_bytes(B, H, T);
+}
+
 int wavlm_attn_fused_fwd(const void* qkv, void* O, float* lse, const float* gate, const float* tab, const uint8_t* kpm,
                          int32_t B, int32_t H, int32_t T, int32_t head_dim, float scale, float p_drop, uint64_t seed,
                          void* stream) {
+  return wavlm_attn_fused_fwd_p(qkv, O, lse, gate, tab, kpm, nullptr, 0, B, H, T, head_dim, scale, p_drop, seed, stream);
+}
+
+static void fa_bind_pstore(FaP& p, void* pstore, int B, int H, int T) {
+  p.ps.P16 = (unsigned char*)pstore;
+  p.ps.mt = (float*)((unsigned char*)pstore + ((fa_pstore_p_bytes(B, H, T) + 255) & ~(uint64_t)255));
+}
+
+int wavlm_attn_fused_fwd_p(const void* qkv, void* O, float* lse, const float* gate, const float* tab, const uint8_t* kpm,
+                           void* pstore, uint64_t pstore_bytes, int32_t B, int32_t H, int32_t T, int32_t head_dim, float scale,
+                           float p_drop, uint64_t seed, void* stream) {
   if (!qkv || !O || !lse || B <= 0 || H <= 0 || T <= 0 || head_dim != FA_HD) return WL_EINVAL;
   if ((gate == nullptr) != (tab == nullptr)) return WL_EINVAL;
+  if (pstore && (T > FA_PSTORE_MAX_T || pstore_bytes < wavlm_attn_fused_pstore_bytes(B, H, T) || ((uintptr_t)pstore & 15))) return WL_EINVAL;
   FaP p = fa_params(B, H, T, scale, p_drop, seed);
   p.qkv = (const bf16_t*)qkv; p.O = (bf16_t*)O; p.lse = lse; p.gate = gate; p.tab = tab; p.kpm = kpm;
+  if (pstore) fa_bind_pstore(p, pstore, B, H, T);
   const size_t smem = 32768 + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float);
   p.nqb = (T + FA_BQ - 1) / FA_BQ;
   const dim3 grid((unsigned)(p.nqb * B * H));
   // algorithmic: QK^T and PV (2 x 2 T^2 hd per head); qkv read once, O written once, lse
   WlProfScope prof(WL_PROF_ATTN_FWD, WL_BF16, 4.0 * B * H * (double)T * T * FA_HD,
                    (double)B * T * H * FA_HD * 2.0 * 4.0 + (double)B * H * T * 4.0, (hipStream_t)stream);
-  if (p.th) {
-    if (fa_set_smem(attn_fwd_kernel<true>, smem) != WL_OK) return WL_ELAUNCH;
-    WL_LAUNCH(attn_fwd_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, p);
-  } else {
-    if (fa_set_smem(attn_fwd_kernel<false>, smem) != WL_OK) return WL_ELAUNCH;
-    WL_LAUNCH(attn_fwd_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, p);
-  }
+#define FA_FWD(DR, ST) do { if (fa_set_smem(attn_fwd_kernel<DR, ST>, smem) != WL_OK) return WL_ELAUNCH; \
+    WL_LAUNCH((attn_fwd_kernel<DR, ST>), grid, dim3(256), smem, (hipStream_t)stream, p); } while (0)
+  if (p.th) { if (pstore) FA_FWD(true, true); else FA_FWD(true, false); }
+  else { if (pstore) FA_FWD(false, true); else FA_FWD(false, false); }
+#undef FA_FWD
   return wl_check_launch();
 }
 
@@ -776,15 +924,26 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
                          const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, void* dbias,
                          int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T, int32_t head_dim,
                          float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes, void* stream) {
-  return wl_attn_fused_bwd_ex(qkv, O, dO, lse, gate, tab, kpm, dqkv, dgate, dtab, 0, dbias, dbias_dtype, dbias_accumulate, B, H, T,
-                              head_dim, scale, p_drop, seed, workspace, ws_bytes, stream);
+  return wl_attn_fused_bwd_ex(qkv, O, dO, lse, gate, tab, kpm, nullptr, dqkv, dgate, dtab, 0, dbias, dbias_dtype, dbias_accumulate,
+                              B, H, T, head_dim, scale, p_drop, seed, workspace, ws_bytes, stream);
+}
+
+int wavlm_attn_fused_bwd_p(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
+                           const float* tab, const uint8_t* kpm, const void* pstore, uint64_t pstore_bytes, void* dqkv,
+                           float* dgate, float* dtab, void* dbias, int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B,
+                           int32_t H, int32_t T, int32_t head_dim, float scale, float p_drop, uint64_t seed, void* workspace,
+                           uint64_t ws_bytes, void* stream) {
+  if (pstore && (T > FA_PSTORE_MAX_T || pstore_bytes < wavlm_attn_fused_pstore_bytes(B, H, T) || ((uintptr_t)pstore & 15))) return WL_EINVAL;
+  return wl_attn_fused_bwd_ex(qkv, O, dO, lse, gate, tab, kpm, pstore, dqkv, dgate, dtab, 0, dbias, dbias_dtype, dbias_accumulate,
+                              B, H, T, head_dim, scale, p_drop, seed, workspace, ws_bytes, stream);
 }
 
 }  // extern "C"
 
 // the same with dtab (+)= (layer.hip: the table is shared by every block of the encoder, their gradients meet in one buffer)
 int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
-                         const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, int dtab_accumulate,
+                         const float* tab, const uint8_t* kpm, const void* pstore, void* dqkv, float* dgate, float* dtab,
+                         int dtab_accumulate,
                          void* dbias, int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T,
                          int32_t head_dim, float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes,
                          void* stream) {
@@ -797,6 +956,7 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
   FaP p = fa_params(B, H, T, scale, p_drop, seed);
   p.qkv = (const bf16_t*)qkv; p.O = (bf16_t*)const_cast<void*>(O); p.lse = const_cast<float*>(lse);
   p.gate = gate; p.tab = tab; p.kpm = kpm; p.dO = (const bf16_t*)dO; p.dqkv = (bf16_t*)dqkv; p.dgate = dgate;
+  if (pstore) fa_bind_pstore(p, const_cast<void*>(pstore), B, H, T);
   const int nqt = (T + FA_BQ - 1) / FA_BQ;
   const int L = 2 * T - 1;
   p.dtab_part = (float*)workspace;
@@ -810,12 +970,14 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
   // once, dqkv written once
   WlProfScope prof(WL_PROF_ATTN_BWD, WL_BF16, 10.0 * B * H * (double)T * T * FA_HD,
                    (double)B * T * H * FA_HD * 2.0 * 8.0 + (double)B * H * T * 8.0, st);
-  if (p.th) {
-#define FA_DQ(DR, TB) do { if (fa_set_smem(attn_bwd_dq_kernel<DR, TB>, smem1) != WL_OK) return WL_ELAUNCH; \
-    WL_LAUNCH((attn_bwd_dq_kernel<DR, TB>), dim3((unsigned)(nqt * B * H)), dim3(256), smem1, st, p); } while (0)
-    if (tab) FA_DQ(true, true); else FA_DQ(true, false);
+#define FA_DQ(DR, TB, SP_) do { if (fa_set_smem(attn_bwd_dq_kernel<DR, TB, SP_>, smem1) != WL_OK) return WL_ELAUNCH; \
+    WL_LAUNCH((attn_bwd_dq_kernel<DR, TB, SP_>), dim3((unsigned)(nqt * B * H)), dim3(256), smem1, st, p); } while (0)
+  if (pstore) {   // stored probabilities: the dropout decision is the stored sign
+    if (tab) FA_DQ(false, true, true); else FA_DQ(false, false, true);
+  } else if (p.th) {
+    if (tab) FA_DQ(true, true, false); else FA_DQ(true, false, false);
   } else {
-    if (tab) FA_DQ(false, true); else FA_DQ(false, false);
+    if (tab) FA_DQ(false, true, false); else FA_DQ(false, false, false);
   }
 #undef FA_DQ
   size_t smem2 = 32768 + (size_t)(p.Ltab + 64 + 2 * 256) * sizeof(float);

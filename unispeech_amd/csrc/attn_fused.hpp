@@ -48,6 +48,13 @@ __device__ __forceinline__ unsigned fa_mix(unsigned x) { return drop_mix(x); }
 // packed-integer instructions and no compare / VCC / select:  d = sat(ths - 1 - half) is negative iff the half is kept,
 // d >> 15 (arithmetic) is the 0xffff / 0 keep mask of each half, one v_and_b32 applies both.
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
+// the complement for the stored-probability forward: 0xffff in the halves that are DROPPED (half < ths): d = sat(half - ths) is
+// negative iff the half is dropped; k3 = ths in both halves
+__device__ __forceinline__ unsigned fa_dropmask2(unsigned w, unsigned k3) {
+  s16x2_t d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, w), __builtin_bit_cast(s16x2_t, k3));
+  d = d >> (short)15;
+  return __builtin_bit_cast(unsigned, d);
+}
 __device__ __forceinline__ unsigned fa_keepmask2(unsigned w, unsigned k2) {
   s16x2_t d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, k2), __builtin_bit_cast(s16x2_t, w));
   d = d >> (short)15;
@@ -91,6 +98,49 @@ __device__ __forceinline__ bf16x8_t frag_tr(const unsigned char* tile, unsigned 
   return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// LDS-DMA of one 1 KiB piece (16 bytes per lane, lane l lands at ldst + 16 l; ldst wave-uniform).
+// FA_ASM_DMA (round 5): inline asm with its own M0 write instead of __builtin_amdgcn_global_load_lds.  With the builtin
+// anywhere in a loop the compiler drains `s_waitcnt vmcnt(0)` in front of EVERY later LDS read (it cannot tell which LDS
+// bytes the DMA writes): the "prefetch" of the next K / V tile was waited for right after it was issued, in front of the
+// first fragment read of the CURRENT tile -- every wave paid one full L2 / HBM round trip per tile and only the other
+// resident waves covered it (two or three per SIMD).  Through asm the compiler does not see a memory operation it has to
+// order; the kernels wait themselves, once, in front of the barrier that ends the tile (fa_tile_sync).  Safe against the
+// compiler's own vmcnt bookkeeping: vector memory operations return in order on gfx9, so operations it does not know of
+// can only make its counted waits wait longer, never shorter.
+#ifndef FA_ASM_DMA
+#define FA_ASM_DMA 1
+#endif
+// lab-bench probes of the stored-probability kernels (WRONG results by construction; -DWAVLM_EXPERIMENTAL builds only):
+// FA_SP_PROBE bit 0: the backward kernels do not load P16 (registers keep their first tile) -- what the HBM stream costs;
+// bit 1: the forward converts but does not store; bit 2: dQ kernel without the skew writes; bit 3: dK/dV kernel without the
+// LDS round trip of the fragments; bit 4: no wait for the tile DMA at the end of a tile (races) -- what that wait costs
+#if !defined(WAVLM_EXPERIMENTAL)
+#undef FA_SP_PROBE
+#endif
+#ifndef FA_SP_PROBE
+#define FA_SP_PROBE 0
+#endif
+__device__ __forceinline__ void fa_dma16(const void* lane_ptr, unsigned char* ldst) {
+#if FA_ASM_DMA
+  const unsigned lds_dst = (unsigned)(unsigned long)(las_ptr)ldst;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_dst), "v"(lane_ptr) : "memory", "m0");
+#else
+  __builtin_amdgcn_global_load_lds((gas_ptr)lane_ptr, (las_ptr)ldst, 16, 0, 0);
+#endif
+}
+// end of a tile iteration: this wave's DMA pieces have landed, then every wave's (N: vector memory operations issued AFTER
+// the DMA that may stay in flight -- stores of the iteration)
+template <int N = 0> __device__ __forceinline__ void fa_tile_sync() {
+#if FA_ASM_DMA && !(FA_SP_PROBE & 16)
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  // the builtin, not asm: the compiler's wait-count pass reads an explicit s_waitcnt and learns from it that ITS OWN loads
+  // (q / dO fragments fetched in the prologue) have landed -- behind an opaque asm wait it kept `s_waitcnt vmcnt(3..0)` in
+  // front of the first MFMAs of every iteration, which drained the prefetch again
+  __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14));  // vmcnt(N); expcnt / lgkmcnt fields at their maxima
+#endif
+  __syncthreads();
+}
+
 // K-contiguous [64 rows][64] tile -> LDS through LDS-DMA; rows past `nrows` are clamped (results unused/masked)
 __device__ __forceinline__ void glds_tile64(const bf16_t* base, long ld, int row0, int nrows, unsigned char* lds,
                                             int wave_u) {
@@ -100,7 +150,7 @@ __device__ __forceinline__ void glds_tile64(const bf16_t* base, long ld, int row
     const int rr = (t >> 3) + 32 * ps;
     int row = row0 + rr; if (row > nrows - 1) row = nrows - 1;
     const bf16_t* src = base + (long)row * ld + (((t & 7) ^ ((rr >> 1) & 7)) << 3);
-    __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(lds + (ps * 32 + wave_u * 8) * 128), 16, 0, 0);
+    fa_dma16(src, lds + (ps * 32 + wave_u * 8) * 128);
   }
 }
 
@@ -122,6 +172,35 @@ __device__ __forceinline__ void fa_block_map(int nqb, int BH, int& qb, int& bh) 
   }
 }
 
+// ---- stored probabilities (round 5) ---------------------------------------------------------------------------------
+// The backward kernels above recompute P = softmax(...) and the dropout decisions from (q, k, bias, lse, seed): the whole
+// element pass (bias fma, 2^x, dropout word, select) runs THREE times per layer (forward, dQ kernel, dK/dV kernel) on a
+// part whose VALU is the saturated resource of these kernels (12-21 VALU instructions per MFMA) while < 1 TB/s of its
+// 8 TB/s HBM and a few GB of its 288 GB are in use.  With a `pstore` buffer the forward writes what it holds anyway:
+//   P16[bh][q32][jt][f][s2][lane][8]   fp16, FRAGMENT-NATIVE: the 16 bytes of a lane are the forward's own B-operand
+//       fragment pf[f][s2] of key tile jt (lane = 32 hi + query row % 32 of the 32-row block q32; the eight values are keys
+//       64 jt + 32 f + 16 s2 + 4 hi + {0..3, 8..11}) -- one fully coalesced 1 KiB store per wave, f, s2.  Value = the
+//       forward's p = 2^(x - m_jt) relative to the RUNNING maximum after tile jt (<= 1: fp16 carries it with 11 bits,
+//       4x finer than the bf16 the PV product uses; values below 6e-8 flush to zero), SIGN BIT = the element was dropped.
+//   mt[bh][jt][Tq]   fp32: that running maximum (log2 domain), Tq = rows padded to 128.
+// Backward: P * sc = |P16| * 2^(mt + log2 sc - lse log2 e), keep = sign clear.  The dQ kernel reads its fragments straight
+// back into registers (same decomposition as the forward); the dK/dV kernel gathers them into LDS by LDS-DMA and reads them
+// transposed with ds_read_b64_tr_b16.  Per element: convert, scale, max(., 0), multiply, fma -- no score MFMA, no bias, no
+// exponential, no hash.  Cost: 4 KiB per (32 rows x 64 keys) = 453 MB per Base layer at 32 x 15 s (5.4 GB per step), read
+// once by each backward kernel.  Rows / keys past T: the forward writes every tile of the padded grid (clamped rows give
+// finite values), the backward zeroes them through the scale (rows) or discards them (keys).
+#define FA_PTILE_BYTES 4096
+#define FA_PSTORE_MAX_T 1024   // wavlm_attn_fused_pstore_bytes returns 0 beyond (callers then recompute)
+struct FaPstore { unsigned char* P16; float* mt; int nq32, nkv, Tq; };
+__host__ __device__ inline uint64_t fa_pstore_p_bytes(int B, int H, int T) {
+  const uint64_t nq32 = (uint64_t)((T + FA_BQ - 1) / FA_BQ) * 4, nkv = (uint64_t)((T + FA_BKV - 1) / FA_BKV);
+  return (uint64_t)B * H * nq32 * nkv * FA_PTILE_BYTES;
+}
+__host__ __device__ inline uint64_t fa_pstore_mt_bytes(int B, int H, int T) {
+  const uint64_t Tq = (uint64_t)((T + FA_BQ - 1) / FA_BQ) * FA_BQ, nkv = (uint64_t)((T + FA_BKV - 1) / FA_BKV);
+  return (uint64_t)B * H * nkv * Tq * sizeof(float);
+}
+
 struct FaP {
   const bf16_t* qkv; bf16_t* O; float* lse;
   const float* gate; const float* tab; const unsigned char* kpm;
@@ -129,6 +208,8 @@ struct FaP {
   float* dbias_part;  // optional [B * nqb * 4][3 * H * 64]: per-wave column sums of dq | dk | dv (the q|k|v bias gradient)
   int B, H, T; float scale; float sc2; unsigned th; float sc, log2sc, inv_sc; unsigned s0, s1;  // th: 16-bit keep threshold (0 = no dropout)
   int ths; unsigned k2;  // signed threshold th - 32768; (ths - 1) in both halves
+  unsigned k3;           // ths in both halves (fa_dropmask2)
+  FaPstore ps;           // stored probabilities (P16 == nullptr: recompute)
   int Ltab, Tkb;  // LDS extents: rel table (zero padded) and key bias
   int nqb;        // tiles along the sequence per (b, h) of the kernel being launched
 };
@@ -166,7 +247,41 @@ __device__ __forceinline__ void fa_wave_colsum(const f32x16_t (&a)[2], float sca
   asm volatile("" ::: "memory");  // the slice is reused by the wave's next call
 }
 
-// launcher of the dK/dV kernel (attn_fused_dkv.hip); returns a WL_* code
+// The same tile loader with the address arithmetic taken out of the tile loop: per-lane row pointers once (two 16-byte pieces
+// per lane and tile), per tile one uniform offset.  (glds_tile64 re-derives row, clamp and a 64-bit row * ld product per
+// piece: 8 quarter-rate v_mul_lo_u32 + 6 v_mad_u64_u32 per pair of tiles and iteration, ~250 cycles of every tile's ~4500.)
+// Tiles whose rows all exist (`row0 + 64 <= nrows`) take the fast path; the last, partial tile the clamping one.
+// FA_TILE_SRC: the forward / dQ / recompute dK-dV kernels through FaTileSrc as well.  Measured neutral on all of them (same-box
+// A/B, profiles/r05/ab_tilesrc.txt: they are LDS-bound, not VALU-bound) at +8 VGPRs: OFF; the stored-probability dK/dV kernel
+// uses it unconditionally.
+#ifndef FA_TILE_SRC
+#define FA_TILE_SRC 0
+#endif
+struct FaTileSrc {
+  const bf16_t* lane_ptr[2];   // row (t >> 3) + 32 ps of tile 0, this lane's (swizzled) 16-byte chunk
+  const bf16_t* base; long ld; int nrows;
+  __device__ __forceinline__ void init(const bf16_t* base_, long ld_, int nrows_) {
+    base = base_; ld = ld_; nrows = nrows_;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int rr = (t >> 3) + 32 * ps;
+      lane_ptr[ps] = base_ + (long)rr * ld_ + (((t & 7) ^ ((rr >> 1) & 7)) << 3);
+    }
+  }
+  __device__ __forceinline__ void issue(int row0, unsigned char* lds, int wave_u) const {
+    if (row0 + 64 <= nrows) {
+      const long off = (long)row0 * ld;   // uniform
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) fa_dma16(lane_ptr[ps] + off, lds + (ps * 32 + wave_u * 8) * 128);
+    } else {
+      glds_tile64(base, ld, row0, nrows, lds, wave_u);
+    }
+  }
+};
+
+// launcher of the dK/dV kernel (attn_fused_dkv.hip); returns a WL_* code.  smem: of the recompute form; the stored-P form
+// sizes its own
 int fa_launch_dkv(const FaP& p, unsigned grid, size_t smem, hipStream_t st);
 
 template <typename K> static int fa_set_smem(K kernel, size_t bytes) {

@@ -59,38 +59,59 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   const int nq = (T + FA_BQ1 - 1) / FA_BQ1;
   const unsigned qtr = fa_tr_base(lane);
 
-  auto stage_rows = [&](int it, int st) {
+  // per-row scalars of a query tile: fetched into registers BEFORE the tile's DMA is issued and written to LDS at the END of
+  // the iteration (rows_store) -- consuming a global load in the middle of the iteration makes the compiler wait for it,
+  // and vector memory operations return in order: that wait would also wait for the prefetch DMA issued behind it
+  // (raw values only in rows_load: any arithmetic on them would put the wait right behind the loads)
+  struct RowRegs { float lse, gate, delta; unsigned o; bool ok; };
+  auto rows_load = [&](int it) {
+    // every wave loads the tile's 64 rows (wave 0 stores them): no divergent branch around the loads, i.e. no merge of
+    // "loaded" and "not loaded" values that would have to wait for the loads
+    RowRegs r;
+    const int ii = it * FA_BQ1 + lane;
+    r.ok = ii < T;
+    const long o = (long)bh * T + (r.ok ? ii : T - 1);
+    r.o = (unsigned)o;
+    r.lse = p.lse[o];
+    r.delta = p.delta[o];
+    r.gate = (p.gate ? p.gate : p.lse)[o];   // (no gate: any readable address; rows_store writes 0 then)
+    return r;
+  };
+  auto rows_store = [&](const RowRegs& r, int st) {
     const int t = threadIdx.x;
     if (t < 64) {
-      const int ii = it * FA_BQ1 + t;
-      const bool ok = ii < T;
-      const long o = (long)bh * T + (ok ? ii : T - 1);
 #if FA_DKV_BIAS_IN_C
       // bias - lse enters as the C operand of the score MFMAs, in units of 1 / sc2 (P * sc = 2^(sc2 s))
-      rowv[st * 256 + t] = ok ? (p.log2sc - p.lse[o] * FA_LOG2E) / p.sc2 : -INFINITY;
-      rowv[st * 256 + 128 + t] = p.gate ? p.gate[o] * FA_LOG2E / p.sc2 : 0.f;
+      rowv[st * 256 + t] = r.ok ? (p.log2sc - r.lse * FA_LOG2E) / p.sc2 : -INFINITY;
+      rowv[st * 256 + 128 + t] = p.gate ? r.gate * FA_LOG2E / p.sc2 : 0.f;
 #else
-      rowv[st * 256 + t] = ok ? p.log2sc - p.lse[o] * FA_LOG2E : -INFINITY;  // P * sc = 2^(x + this); -inf: rows past T
-      rowv[st * 256 + 128 + t] = p.gate ? p.gate[o] * FA_LOG2E : 0.f;
+      rowv[st * 256 + t] = r.ok ? p.log2sc - r.lse * FA_LOG2E : -INFINITY;  // P * sc = 2^(x + this); -inf: rows past T
+      rowv[st * 256 + 128 + t] = p.gate ? r.gate * FA_LOG2E : 0.f;
 #endif
-      rowv[st * 256 + 64 + t] = p.delta[o] * p.inv_sc;
-      rowv[st * 256 + 192 + t] = __uint_as_float(fa_row_word(p.s0, (unsigned)o));
+      rowv[st * 256 + 64 + t] = r.delta * p.inv_sc;
+      rowv[st * 256 + 192 + t] = __uint_as_float(fa_row_word(p.s0, r.o));
     }
   };
 
-  glds_tile64(base, D3, 0, T, qbuf(0), wave_u);
-  glds_tile64(dobase, D, 0, T, dobuf(0), wave_u);
-  stage_rows(0, 0);
-  __syncthreads();
+#if FA_TILE_SRC
+  FaTileSrc qsrc, dosrc;
+  qsrc.init(base, D3, T);
+  dosrc.init(dobase, D, T);
+#define FA_LOAD_QDO(ROW0, QB_, DB_) do { qsrc.issue(ROW0, QB_, wave_u); dosrc.issue(ROW0, DB_, wave_u); } while (0)
+#else
+#define FA_LOAD_QDO(ROW0, QB_, DB_) do { glds_tile64(base, D3, ROW0, T, QB_, wave_u); glds_tile64(dobase, D, ROW0, T, DB_, wave_u); } while (0)
+#endif
+  FA_LOAD_QDO(0, qbuf(0), dobuf(0));
+  rows_store(rows_load(0), 0);
+  fa_tile_sync();
 
   int cur = 0;
   for (int it = 0; it < nq; ++it) {
     const int iq0 = it * FA_BQ1;
     const bool more = it + 1 < nq;
+    const RowRegs nextrows = rows_load(more ? it + 1 : it);   // (last iteration: a harmless reload into the dead stage)
     if (more) {
-      glds_tile64(base, D3, iq0 + FA_BQ1, T, qbuf(cur ^ 1), wave_u);
-      glds_tile64(dobase, D, iq0 + FA_BQ1, T, dobuf(cur ^ 1), wave_u);
-      stage_rows(it + 1, cur ^ 1);
+      FA_LOAD_QDO(iq0 + FA_BQ1, qbuf(cur ^ 1), dobuf(cur ^ 1));
     }
     const float* rv = rowv + cur * 256;
     // S = Q K^T, dP = dO V^T  (rows = queries of the tile, col = this lane's key)
@@ -172,7 +193,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
           dk[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qbuf(cur), qtr, f2, f, s2), dsf[s2].b, dk[f2], 0, 0, 0);
         }
     }
-    __syncthreads();
+    rows_store(nextrows, cur ^ 1);
+    fa_tile_sync();
     cur ^= 1;
   }
   if (!key_ok) {  // padded keys and keys past T
@@ -203,7 +225,278 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   }
 }
 
+
+// ------------------------------------------------------------------- backward 2/2 with stored probabilities
+// (attn_fused.hpp, "stored probabilities").  Same decomposition as above -- lane owns a key column, registers walk the
+// query rows -- but P comes from the forward's fragment store instead of S = Q K^T + bias -> 2^x -> dropout word:
+//   * the forward's lanes own QUERY rows, this kernel's lanes own KEYS: the fragments have to be transposed.  A wave needs,
+//     per 64-query tile, the 4 KiB the forward's waves of those rows wrote for ITS 32 keys (2 row blocks x 2 sixteen-key
+//     halves x 1 KiB).  They are fetched with four fully coalesced 1 KiB loads into registers, two tiles ahead (two register
+//     sets, loop unrolled by two), written to a wave-private 4 KiB LDS image when their tile comes up (four conflict-free
+//     ds_write_b128) and read back transposed: ONE ds_read_b64_tr_b16 per lane per (32-query block f, row group q4), 512
+//     contiguous bytes per wave;
+//     image: chunk = ((((f 4 + q4) 2 + g) 2 + hi) 4 + r) 2 + hi', 16 bytes each: g = 16-key half of the wave's keys, row of the
+//     32-block = 8 q4 + 4 hi + r (the MFMA row mapping), hi' = which granule pair of the forward's fragment;
+//   * the lane receives P16[i0 .. i0 + 3][own key] = registers 4 q4 .. 4 q4 + 3 of the 32 x 32 block; scale
+//     c[i] = 2^(mt[i, key tile] + log2 sc - lse[i] log2 e) (two per row: the block's 128 keys span two forward key tiles), 0 for
+//     rows past T;
+//   * dS = max(Ps, 0) dP - |Ps| delta / sc; dV takes max(Ps, 0) as bf16; K is not needed at all (no score MFMA).
+// The Q / dO tiles travel TWO tiles ahead through a three-stage LDS ring: every instruction-count lever on this kernel and
+// on its recompute twin (-40 % VALU, -25 % MFMA, three workgroups per CU instead of two, fragments two tiles ahead) left the
+// run time where it was, ~200 us -- PMC: 43 % of the wave cycles in s_waitcnt, 6 % of them for LDS: the wave waits for
+// vector memory, i.e. for the tile DMA issued at the top of the SAME tile; a tile's work (~2 us at the 1.45 GHz these
+// kernels run at) is shorter than the loaded round trip.  All vector memory operations of a wave complete IN ORDER, which
+// dictates the shape: a wait for one of them waits for everything issued before it.  So (1) the per-row scalars of ALL
+// query tiles are computed once into LDS in the prologue (a per-tile load + its wait would drag the DMA issued before it
+// along), (2) per tile the fragment loads are issued BEFORE the DMA (the compiler's own wait for the next tile's
+// fragments then leaves the youngest operations -- the DMA -- in flight), (3) the end-of-tile wait is vmcnt(8): this
+// tile's four fragment loads + four DMA instructions stay in flight, everything older (the DMA of tile it + 1) has landed.
+// LDS: 3 x (Q 8 K + dO 8 K) + 4 x 4 K (P images) + 3 x 4 K (row scalars, T <= 1024) = 76 KB: two workgroups per CU.
+typedef __fp16 f16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) f16x4_t* lds_h4_ptr;
+#define FA_DKVP_ROWS FA_PSTORE_MAX_T   // query rows (padded to 64) whose scalars fit the LDS row arrays
+#define FA_DKVP_SMEM (3 * 16384 + 16384 + 3 * FA_DKVP_ROWS * 4)
+#if FA_SP_PROBE & 32   // s_memtime stamps (shader cycles) of wave 0 of every workgroup, summed over the tiles: where a tile's time goes
+__device__ unsigned long long fa_dbg_dkv[4096][12];
+extern "C" int wavlm_probe_read_dkv(void* host_dst, uint64_t bytes) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(fa_dbg_dkv), bytes < sizeof(fa_dbg_dkv) ? bytes : sizeof(fa_dbg_dkv)) == hipSuccess ? 0 : -1;
+}
+#define FA_STAMP(K_) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[K_] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FA_STAMP(K_)
+#endif
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_p_kernel(FaP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  auto qbuf = [&](int st) { return smem + st * 16384; };
+  auto dobuf = [&](int st) { return smem + st * 16384 + 8192; };
+  float* rowc = reinterpret_cast<float*>(smem + 4 * 16384);   // [2][FA_DKVP_ROWS] c of key tile 0 / 1 of the block, then [FA_DKVP_ROWS] delta / sc
+  const int T = p.T, H = p.H;
+  int kblk, bh;
+  fa_block_map(p.nqb, p.B * H, kblk, bh);
+  const int b = bh / H, h = bh % H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int hi = lane >> 5, kl = lane & 31;
+  const int j = kblk * FA_BK1 + 32 * wave + kl;
+  const int jc = j < T ? j : T - 1;
+  const long D3 = 3L * H * FA_HD, D = (long)H * FA_HD;
+  const bf16_t* base = p.qkv + (long)b * T * D3 + h * FA_HD;
+  const bf16_t* dobase = p.dO + (long)b * T * D + h * FA_HD;
+  unsigned char* pw = smem + 3 * 16384 + wave_u * 4096;   // this wave's P16 image
+  const int nq = (T + FA_BQ1 - 1) / FA_BQ1;
+
+  // ---- per-row scalars of every query tile (see the header comment, (1))
+  {
+    const float* mtb = p.ps.mt + (long)bh * p.ps.nkv * p.ps.Tq;
+    int jt0 = 2 * kblk, jt1 = 2 * kblk + 1;
+    if (jt0 > p.ps.nkv - 1) jt0 = p.ps.nkv - 1;
+    if (jt1 > p.ps.nkv - 1) jt1 = p.ps.nkv - 1;
+    for (int ii = threadIdx.x; ii < nq * FA_BQ1; ii += 256) {
+      const bool ok = ii < T;
+      const long o = (long)bh * T + (ok ? ii : T - 1);
+      const float nl = p.log2sc - p.lse[o] * FA_LOG2E;
+      const float m0 = mtb[(long)jt0 * p.ps.Tq + ii], m1 = mtb[(long)jt1 * p.ps.Tq + ii];   // (ii < Tq: the row grid is padded to 128)
+      rowc[ii] = (ok && m0 > -INFINITY) ? __builtin_amdgcn_exp2f(m0 + nl) : 0.f;
+      rowc[FA_DKVP_ROWS + ii] = (ok && m1 > -INFINITY) ? __builtin_amdgcn_exp2f(m1 + nl) : 0.f;
+      rowc[2 * FA_DKVP_ROWS + ii] = p.delta[o] * p.inv_sc;
+    }
+  }
+
+  U4 vf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) vf[kk].v = *reinterpret_cast<const uint4*>(base + 2 * D + (long)jc * D3 + 16 * kk + 8 * hi);
+  const bool key_ok = j < T && !(p.kpm && p.kpm[(long)b * T + jc]);
+
+  f32x16_t dk[2], dv[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[f][r] = 0.f; dv[f][r] = 0.f; }
+  const unsigned qtr = fa_tr_base(lane);
+
+  // ---- P16 fetch.  Load (f, g) of a tile: the 1 KiB the forward's wave of row block 2 it + f wrote for fragment
+  // (f' = wave & 1, s2' = g) of key tile 2 kblk + (wave >> 1).  Lane l takes the chunk of (row % 32 = 8 (l >> 4) + 4 ((l >> 3) & 1)
+  // + (l & 3), half hi' = (l >> 2) & 1) -- a permutation inside the 1 KiB, chosen so that eight consecutive lanes write eight
+  // different 16-byte slots of a 128-byte LDS line (r, hi' vary fastest in the image).
+  int jt_w = 2 * kblk + (wave_u >> 1); if (jt_w > p.ps.nkv - 1) jt_w = p.ps.nkv - 1;   // (keys past the last tile are discarded)
+  const int l_r = lane & 3, l_hp = (lane >> 2) & 1, l_hi = (lane >> 3) & 1, l_q4 = lane >> 4;
+  const unsigned char* psrc = p.ps.P16 + (((long)bh * p.ps.nq32) * p.ps.nkv + jt_w) * FA_PTILE_BYTES + (wave_u & 1) * 2048 +
+                              ((8 * l_q4 + 4 * l_hi + l_r) + 32 * l_hp) * 16;
+  const long q32_stride = (long)p.ps.nkv * FA_PTILE_BYTES;
+  unsigned char* pw_st = pw + l_q4 * 512 + l_hi * 128 + l_r * 32 + l_hp * 16;   // + f 2048 + g 256
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t pA[4], pB[4];   // [f 2 + g]
+  // asm loads: the compiler does not see them, so it puts no wait of its own in front of the use of a set (its count of the
+  // operations "behind" the load cannot include the DMA instructions and would also wait for the set loaded one tile ago);
+  // the end-of-tile vmcnt(8) leaves only the current tile's eight operations in flight, so a set is complete one tile
+  // before it is used
+  auto p_load = [&](int it, u32x4_t (&x)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const unsigned char* src = psrc + (long)(2 * it + f) * q32_stride;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[f * 2]) : "v"(src) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(x[f * 2 + 1]) : "v"(src) : "memory");
+    }
+  };
+  FaTileSrc qsrc, dosrc;
+  qsrc.init(base, D3, T);
+  dosrc.init(dobase, D, T);
+  auto dma_tile = [&](int it, int st) __attribute__((always_inline)) {
+    qsrc.issue(it * FA_BQ1, qbuf(st), wave_u);
+    dosrc.issue(it * FA_BQ1, dobuf(st), wave_u);
+  };
+  // transposing read of (f, q4): lane (g = (lane >> 4) & 1, hi, i = lane & 15: row r = i >> 2, granule c4 = i & 3) addresses
+  // chunk (f, q4, g, hi, r, hi' = c4 & 1), half c4 >> 1; it receives rows r = 0..3 at key 16 g + i of the wave
+  const unsigned char* pt = pw + ((((lane >> 4) & 1) * 2 + hi) * 4 + ((lane & 15) >> 2)) * 32 + (lane & 1) * 16 + ((lane >> 1) & 1) * 8;
+
+  // every load the compiler knows of (V fragments, key mask, row scalars) has landed before the first operation it does not
+  // know of is issued: behind an explicit vmcnt(0) its wait-count pass puts no `s_waitcnt vmcnt` of its own into the tile
+  // loop (it would otherwise wait for the V fragments at their first use INSIDE the loop, i.e. drain the prefetch every tile)
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  // prologue: fragments of tiles 0 and 1, DMA of tiles 0 and 1; tile 0 has landed when at most tile 1's eight operations are
+  // still in flight
+  p_load(0, pA);
+  dma_tile(0, 0);
+  p_load(nq > 1 ? 1 : 0, pB);
+  if (nq > 1) dma_tile(1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  if (nq > 1) fa_tile_sync<8>(); else fa_tile_sync<0>();
+
+  int st = 0;   // LDS stage of the current tile
+#if FA_SP_PROBE & 32
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+  unsigned long long tprev = tstart;
+#endif
+  // one query tile; x: the register set that holds this tile's fragments and is refilled with tile it + 2
+  auto tile_body = [&](int it, u32x4_t (&x)[4]) __attribute__((always_inline)) {
+    const int iq0 = it * FA_BQ1;
+    FA_STAMP(0);   // (loop overhead / previous barrier release -> here)
+    // fragments -> the wave's LDS image (the reads of the previous tile precede these writes in the wave's LDS queue); asm,
+    // so that the stores stay in front of the refill of the same registers
+    if (!(FA_SP_PROBE & 8) || it == 0) {
+      const unsigned pw_a = (unsigned)(unsigned long)(las_ptr)pw_st;
+      asm volatile("ds_write_b128 %0, %1" :: "v"(pw_a), "v"(x[0]) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:256" :: "v"(pw_a), "v"(x[1]) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(pw_a), "v"(x[2]) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:2304" :: "v"(pw_a), "v"(x[3]) : "memory");
+    }
+    // tile it + 2: fragments first, DMA last (header comment, (2)); its stage was read last in tile it - 1
+    const bool ahead = it + 2 < nq;
+    if (!(FA_SP_PROBE & 1)) p_load(ahead ? it + 2 : it, x);   // (past the end: a harmless reload, no branch around the loads)
+    int st2 = st + 2; if (st2 >= 3) st2 -= 3;
+    if (ahead) dma_tile(it + 2, st2);
+    __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the loads to the end of the tile)
+    FA_STAMP(1);   // fragment copies + ds_write, loads and DMA issued
+    const float* rv = rowc + (wave_u >> 1) * FA_DKVP_ROWS + iq0;   // c of this wave's key tile
+    const float* rd = rowc + 2 * FA_DKVP_ROWS + iq0;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      U4 pf[2], dsf[2];
+      f32x16_t dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(dobuf(st), 32 * f + kl, kk, hi), vf[kk].b, dp, 0, 0, 0);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int il0 = 32 * f + 8 * q4 + 4 * hi;
+        const f16x4_t ph = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4_ptr)(pt + (f * 4 + q4) * 512));
+        const float4 c4 = *reinterpret_cast<const float4*>(rv + il0);
+        const float4 del4 = *reinterpret_cast<const float4*>(rd + il0);
+        const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+        const float delv[4] = {del4.x, del4.y, del4.z, del4.w};
+        float pv[4], dsv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ps = (float)ph[e] * cv[e];          // signed P sc (sign = dropped)
+          const float pk = fmaxf(ps, 0.f);                // kept
+          pv[e] = pk;
+          dsv[e] = fmaf(pk, dp[4 * q4 + e], -(__builtin_fabsf(ps) * delv[e]));
+        }
+        pf[q4 >> 1].u[2 * (q4 & 1)] = pack_bf16(pv[0], pv[1]);
+        pf[q4 >> 1].u[2 * (q4 & 1) + 1] = pack_bf16(pv[2], pv[3]);
+        dsf[q4 >> 1].u[2 * (q4 & 1)] = pack_bf16(dsv[0], dsv[1]);
+        dsf[q4 >> 1].u[2 * (q4 & 1) + 1] = pack_bf16(dsv[2], dsv[3]);
+      }
+      if (f == 0) FA_STAMP(2); else FA_STAMP(4);   // dP MFMAs + element pass of the block (waits for the MFMA results)
+#pragma unroll
+      for (int f2 = 0; f2 < 2; ++f2)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          dv[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dobuf(st), qtr, f2, f, s2), pf[s2].b, dv[f2], 0, 0, 0);
+          dk[f2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qbuf(st), qtr, f2, f, s2), dsf[s2].b, dk[f2], 0, 0, 0);
+        }
+      if (f == 0) FA_STAMP(3); else FA_STAMP(5);   // the block's eight dV / dK MFMAs issued (fragment reads waited for)
+    }
+#if FA_SP_PROBE & 32
+    if (ahead) __builtin_amdgcn_s_waitcnt(0x0f70 | 8); else __builtin_amdgcn_s_waitcnt(0x0f70 | 4);
+    FA_STAMP(6);   // vector memory wait
+    __syncthreads();
+    FA_STAMP(7);   // barrier
+    st = st + 1; if (st >= 3) st = 0;
+    return;
+#endif
+    // tile it + 1 has landed when at most this tile's eight operations (four fragment loads, four DMA instructions) are in
+    // flight; without a DMA of its own (the last two tiles) the four loads alone are younger than it
+    if (ahead) fa_tile_sync<8>(); else fa_tile_sync<4>();
+    st = st + 1; if (st >= 3) st = 0;
+  };
+  // whole pairs, then the odd tile: the pair loop's only back edge is B -> A.  (With `if (it + 1 < nq) tile B` inside one loop
+  // the compiler's control-flow graph keeps a path from tile A straight back to tile A and its wait-count pass waits for
+  // A's refill at the top of A, i.e. for everything issued so far.)
+  for (int pi = 0; pi < (nq >> 1); ++pi) {
+    tile_body(2 * pi, pA);
+    tile_body(2 * pi + 1, pB);
+  }
+  if (nq & 1) tile_body(nq - 1, pA);
+#if FA_SP_PROBE & 32
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    for (int k = 0; k < 8; ++k) fa_dbg_dkv[blockIdx.x][k] = tacc[k];
+    fa_dbg_dkv[blockIdx.x][8] = tstart;
+    fa_dbg_dkv[blockIdx.x][9] = tprev;
+    fa_dbg_dkv[blockIdx.x][10] = (unsigned long long)nq;
+  }
+#endif
+  if (!key_ok) {  // padded keys and keys past T
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[f][r] = 0.f; dv[f][r] = 0.f; }
+  }
+  __syncthreads();   // (the column-sum scratch below overlays the tiles AND the other waves' P images)
+  if (p.dbias_part) {
+    float* drow = p.dbias_part + (((long)b * p.nqb + kblk) * 4 + wave_u) * D3 + h * FA_HD;
+    fa_wave_colsum(dk, p.scale, reinterpret_cast<float*>(smem), drow + D, lane, wave_u);
+    fa_wave_colsum(dv, 1.f, reinterpret_cast<float*>(smem), drow + 2 * D, lane, wave_u);
+  }
+  if (j < T) {
+    bf16_t* dst = p.dqkv + ((long)b * T + j) * D3 + h * FA_HD;
+#pragma unroll
+    for (int f2 = 0; f2 < 2; ++f2)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        uint2 w;
+        w.x = pack_bf16(dk[f2][4 * q4] * p.scale, dk[f2][4 * q4 + 1] * p.scale);
+        w.y = pack_bf16(dk[f2][4 * q4 + 2] * p.scale, dk[f2][4 * q4 + 3] * p.scale);
+        *reinterpret_cast<uint2*>(dst + D + 32 * f2 + 8 * q4 + 4 * hi) = w;
+        w.x = pack_bf16(dv[f2][4 * q4], dv[f2][4 * q4 + 1]);
+        w.y = pack_bf16(dv[f2][4 * q4 + 2], dv[f2][4 * q4 + 3]);
+        *reinterpret_cast<uint2*>(dst + 2 * D + 32 * f2 + 8 * q4 + 4 * hi) = w;
+      }
+  }
+}
+
 int fa_launch_dkv(const FaP& p, unsigned grid, size_t smem, hipStream_t st) {
+  if (p.ps.P16) {
+    if ((p.T + FA_BQ1 - 1) / FA_BQ1 * FA_BQ1 > FA_DKVP_ROWS) return WL_EINVAL;   // (the caller falls back to recomputation)
+    size_t smem_p = FA_DKVP_SMEM;
+    if (fa_set_smem(attn_bwd_dkv_p_kernel, smem_p) != WL_OK) return WL_ELAUNCH;
+    WL_LAUNCH(attn_bwd_dkv_p_kernel, dim3(grid), dim3(256), smem_p, st, p);
+    return wl_check_launch();
+  }
   if (p.th) {
     if (fa_set_smem(attn_bwd_dkv_kernel<true>, smem) != WL_OK) return WL_ELAUNCH;
     WL_LAUNCH(attn_bwd_dkv_kernel<true>, dim3(grid), dim3(256), smem, st, p);

@@ -48,6 +48,7 @@ struct Carver {  // bump allocator over a caller-provided region (256-byte align
 struct Saved {  // forward -> backward
   float *gate, *ga, *gb, *lse, *mean1, *rstd1, *mean2, *rstd2;
   void *qkv, *O, *s1, *h1, *x1, *u, *hact, *s2;
+  void* pstore; uint64_t pstore_b;   // attention probabilities (attn_store_p)
   uint64_t bytes;
 };
 
@@ -72,6 +73,10 @@ Saved carve_saved(const wavlm_layer_desc* d, void* base) {
   s.u = c.take(n * d->F * 2);
   s.hact = c.take(n * d->F * 2);
   if (!d->pre_ln) s.s2 = c.take(n * d->D * 2);
+  if (d->attn_store_p) {   // (0 bytes: this T is not supported by the stored form -- recompute)
+    s.pstore_b = wavlm_attn_fused_pstore_bytes(d->B, d->H, d->T);
+    if (s.pstore_b) s.pstore = c.take(s.pstore_b);
+  }
   s.bytes = c.off;
   return s;
 }
@@ -292,7 +297,9 @@ int wavlm_encoder_layer_fwd(const wavlm_layer_desc* d, void* stream) {
     return WL_EINVAL;  // (ungated relative position bias: the caller takes the composed path)
   }
   RC(lin_fwd(ain, d->Wqkv, d->bqkv, s.qkv, n, 3 * D, D, pdt, 0, nullptr, stream));
-  RC(wavlm_attn_fused_fwd(s.qkv, s.O, s.lse, gate, d->tab, d->kpm, d->B, d->H, d->T, 64, d->scale, d->p_attn, d->seed_attn, stream));
+  // (inference -- d->saved == NULL -- never stores probabilities: nothing will read them)
+  RC(wavlm_attn_fused_fwd_p(s.qkv, s.O, s.lse, gate, d->tab, d->kpm, d->saved ? s.pstore : nullptr, s.pstore_b, d->B, d->H, d->T, 64,
+                            d->scale, d->p_attn, d->seed_attn, stream));
   RC(lin_fwd(s.O, d->Wo, d->bo, tmp, n, D, D, pdt, 0, nullptr, stream));
   if (!d->pre_ln) {
     RC(wavlm_layernorm_fwd(d->x, tmp, s.x1, s.s1, s.mean1, s.rstd1, d->ln1_g, d->ln1_b, n, D, d->eps1, WL_BF16, pdt, 0,
@@ -365,7 +372,7 @@ int wavlm_encoder_layer_bwd(const wavlm_layer_desc* d, void* stream) {
     dxres = nullptr;    // (pre-LN: the residual stream's gradient w.dsa joins in the LN1 backward below)
   }
   RC(lin_dx(da, d->Wo, w.dO, n, D, D, 0, nullptr, nullptr, nullptr, pdt, nullptr, 0, stream));
-  RC(wl_attn_fused_bwd_ex(s.qkv, s.O, w.dO, s.lse, d->Wgate ? s.gate : nullptr, d->tab, d->kpm, w.dqkv, w.dgate, d->dtab,
+  RC(wl_attn_fused_bwd_ex(s.qkv, s.O, w.dO, s.lse, d->Wgate ? s.gate : nullptr, d->tab, d->kpm, s.pstore, w.dqkv, w.dgate, d->dtab,
                           d->dtab_accumulate, d->dbqkv, pdt, 1, d->B, d->H, d->T, 64, d->scale, d->p_attn, d->seed_attn, w.attn_ws,
                           w.attn_b, stream));
   const void* ain = d->pre_ln ? s.h1 : d->x;

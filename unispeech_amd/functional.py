@@ -13,6 +13,13 @@ from . import ops
 
 _SEED_CTR = [0]
 USE_FUSED_ATTENTION = True  # bf16 + head_dim 64 -> fused kernels; otherwise GEMM + softmax-row-kernel composition
+# Fused attention, training: WAVLM_ATTN_STORE_P=1 makes the forward keep its probabilities (fp16, dropout decision in the sign
+# bit; 467 MB per Base layer at 32 x 15 s) and the two backward kernels read them instead of recomputing scores + bias +
+# exponentials + dropout words (include/wavlm_hip.h: wavlm_attn_fused_fwd_p).  Built, parity-tested in both modes and OFF:
+# measured on the same box the step is 0.1-0.5 ms SLOWER with it (forward +45 us per layer for the 467 MB write; backward
+# kernels unchanged at ~210 + ~200 us although they issue 40 % fewer VALU and 25 % fewer MFMA instructions) -- the backward
+# kernels are bound by LDS bandwidth, not by the element pass (profiles/r05/attn_stored_p.txt).
+ATTN_STORE_P = os.environ.get("WAVLM_ATTN_STORE_P", "0") == "1"
 
 
 def next_seed():
@@ -787,8 +794,9 @@ class AttnCoreFn(torch.autograd.Function):
             qkv_bias_tok.taken = True
             ctx.bias_sink = qkv_bias_sink
         if ctx.fused:
-            O, lse = ops.attn_fused_fwd(qkvc, gate, tab, kpm, H, scale, p_drop, seed)
-            ctx.save_for_backward(qkvc, O, lse, gate, tab, kpm)
+            store = ATTN_STORE_P and ctx.needs_input_grad[0] and torch.is_grad_enabled()
+            O, lse, pstore = ops.attn_fused_fwd(qkvc, gate, tab, kpm, H, scale, p_drop, seed, store_p=store)
+            ctx.save_for_backward(qkvc, O, lse, gate, tab, kpm, pstore)
             ctx.cfg = (B, T, D, H, hd, 0, scale, p_drop, seed)
             return O
         ld = _rup(T, 8)
@@ -808,11 +816,12 @@ class AttnCoreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dO):
         if ctx.fused:
-            qkvc, O, lse, gate, tab, kpm = ctx.saved_tensors
+            qkvc, O, lse, gate, tab, kpm, pstore = ctx.saved_tensors
             B, T, D, H, hd, _, scale, p_drop, seed = ctx.cfg
             sb = ctx.bias_sink
             dqkv, dgate, dtab = ops.attn_fused_bwd(qkvc, O, dO.contiguous(), lse, gate, tab, kpm, H, scale, p_drop, seed,
-                                                   dbias=sb.view(-1) if sb is not None else None, dbias_accumulate=True)
+                                                   dbias=sb.view(-1) if sb is not None else None, dbias_accumulate=True,
+                                                   pstore=pstore)
             if sb is not None:
                 _sink_written(sb)
             return dqkv, dgate, dtab, None, None, None, None, None, None, None

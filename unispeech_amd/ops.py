@@ -528,20 +528,27 @@ def attn_softmax_bwd(S, dP, lse, gate, tab, kpm, dS, dgate, dtab, B, H, T, ldS, 
                                    need, stream()), "wavlm_attn_softmax_bwd")
 
 
-def attn_fused_fwd(qkv, gate, tab, kpm, H, scale, p_drop, seed):
-    """fused bf16 attention forward (head_dim 64): returns (O [B,T,D], lse [B*H,T])"""
+def attn_fused_fwd(qkv, gate, tab, kpm, H, scale, p_drop, seed, store_p=False):
+    """fused bf16 attention forward (head_dim 64): returns (O [B,T,D], lse [B*H,T], pstore).  store_p: the forward also
+    writes its probabilities into `pstore` (opaque uint8 buffer) for attn_fused_bwd; otherwise pstore is None"""
     dev = _dev(qkv); _contig(qkv)
     B, T, D3 = qkv.shape
     D = D3 // 3
     O = torch.empty((B, T, D), dtype=qkv.dtype, device=dev)
     lse = torch.empty((B * H, T), dtype=torch.float32, device=dev)
-    check(_lib.lib().wavlm_attn_fused_fwd(ptr(qkv), ptr(O), ptr(lse), ptr(gate), ptr(tab), ptr(kpm), B, H, T, D // H,
-                                          float(scale), float(p_drop), int(seed), stream()), "wavlm_attn_fused_fwd")
-    return O, lse
+    L = _lib.lib()
+    pstore, nps = None, 0
+    if store_p:
+        nps = int(L.wavlm_attn_fused_pstore_bytes(B, H, T))   # 0: this T is not supported by the stored form -> recompute
+        pstore = torch.empty(nps, dtype=torch.uint8, device=dev) if nps else None
+    check(L.wavlm_attn_fused_fwd_p(ptr(qkv), ptr(O), ptr(lse), ptr(gate), ptr(tab), ptr(kpm), ptr(pstore), nps, B, H, T, D // H,
+                                   float(scale), float(p_drop), int(seed), stream()), "wavlm_attn_fused_fwd_p")
+    return O, lse, pstore
 
 
-def attn_fused_bwd(qkv, O, dO, lse, gate, tab, kpm, H, scale, p_drop, seed, dbias=None, dbias_accumulate=False):
-    """returns (dqkv, dgate, dtab); dbias [3D] (optional, any float dtype): (+)= column sums of dqkv (q|k|v bias gradient)"""
+def attn_fused_bwd(qkv, O, dO, lse, gate, tab, kpm, H, scale, p_drop, seed, dbias=None, dbias_accumulate=False, pstore=None):
+    """returns (dqkv, dgate, dtab); dbias [3D] (optional, any float dtype): (+)= column sums of dqkv (q|k|v bias gradient);
+    pstore: what attn_fused_fwd(store_p=True) returned for the same arguments (None: probabilities are recomputed)"""
     dev = _dev(qkv); _contig(dO)
     B, T, D3 = qkv.shape
     D = D3 // 3
@@ -553,10 +560,11 @@ def attn_fused_bwd(qkv, O, dO, lse, gate, tab, kpm, H, scale, p_drop, seed, dbia
     L = _lib.lib()
     need = L.wavlm_attn_fused_bwd_workspace_bytes(B, H, T)
     ws = workspace(dev, need, "attn")
-    check(L.wavlm_attn_fused_bwd(ptr(qkv), ptr(O), ptr(dO), ptr(lse), ptr(gate), ptr(tab), ptr(kpm), ptr(dqkv),
-                                 ptr(dgate), ptr(dtab), ptr(dbias), dt(dbias) if dbias is not None else 0,
-                                 int(bool(dbias_accumulate)), B, H, T, D // H, float(scale), float(p_drop), int(seed),
-                                 ptr(ws), need, stream()), "wavlm_attn_fused_bwd")
+    check(L.wavlm_attn_fused_bwd_p(ptr(qkv), ptr(O), ptr(dO), ptr(lse), ptr(gate), ptr(tab), ptr(kpm), ptr(pstore),
+                                   pstore.numel() if pstore is not None else 0, ptr(dqkv),
+                                   ptr(dgate), ptr(dtab), ptr(dbias), dt(dbias) if dbias is not None else 0,
+                                   int(bool(dbias_accumulate)), B, H, T, D // H, float(scale), float(p_drop), int(seed),
+                                   ptr(ws), need, stream()), "wavlm_attn_fused_bwd_p")
     return dqkv, dgate, dtab
 
 
