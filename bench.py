@@ -335,6 +335,39 @@ def busy_and_enqueue(step, reps=5):
     return busy[len(busy) // 2], host[len(host) // 2]
 
 
+def run_alt_pass(args, rank, world, dev):
+    """every rank starts one child `bench.py` (same rank, same GPU, new rendezvous port hosted by rank 0's child) with
+    NCCL_MAX_NCHANNELS removed and WAVLM_DP_RESERVED_CUS=0, waits for it, and rank 0 returns the child's headline numbers.
+    Failures (time-out, no line) are reported, never raised: the primary measurement is already taken."""
+    import subprocess
+    port = [_free_port() if rank == 0 else 0]
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ)
+    for k in ("NCCL_MAX_NCHANNELS", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    env.update(WAVLM_DP_RESERVED_CUS="0", MASTER_PORT=str(port[0]), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"))
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--batch", str(args.batch), "--config", args.config, "--dp-alt-pass", "never", "--no-cpu-baseline", "--no-roofline"]
+    torch.cuda.synchronize()
+    res = {"settings": {"NCCL_MAX_NCHANNELS": None, "WAVLM_DP_RESERVED_CUS": 0}}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+        if rank == 0:
+            if line is None:
+                res["error"] = "no result line (rc %d): %s" % (r.returncode, r.stderr[-300:])
+            else:
+                d = json.loads(line)
+                dp2 = d.get("data_parallel") or {}
+                res.update(value=d["value"], ms_per_step=d["ms_per_step"], comm_wait_ms_per_rank=dp2.get("comm_wait_ms_per_rank"),
+                           exposed_ms_last_bucket_rank0=dp2.get("exposed_ms_last_bucket_rank0"),
+                           allreduce_bus_gb_s_rank0=dp2.get("allreduce_bus_gb_s_rank0"), buckets_rank0=dp2.get("buckets_rank0"))
+    except Exception as e:   # noqa: BLE001 -- a diagnostic leg must not take the measurement down
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    dist.barrier()
+    return res
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -360,6 +393,9 @@ def main():
     ap.add_argument("--no-busy", action="store_true", help="skip the gpu_busy / host_enqueue leg (profiler passes: only the timed steps run)")
     ap.add_argument("--live-traffic", action="store_true",
                     help="collect roofline.traffic live (two rocprofv3 PMC passes of this command as subprocesses, ~1 min)")
+    ap.add_argument("--dp-alt-pass", choices=["auto", "always", "never"], default="auto",
+                    help="N > 1: second measurement with NCCL_MAX_NCHANNELS unset and no reserved CUs (fresh processes on the same "
+                         "GPUs); auto = when a rank waits > 1 ms for the gradient all-reduce after backward")
     ap.add_argument("--reserved-cus", type=int, default=-1,
                     help="1 GPU: shrink the persistent GEMM grids by this many CUs as the data-parallel reducer does "
                          "(WAVLM_DP_RESERVED_CUS) -- what the reservation alone costs a rank")
@@ -556,13 +592,36 @@ def main():
             step()
             torch.cuda.synchronize()
             waits.append(comm_ev[0].elapsed_time(comm_ev[1]))
+        # per-bucket picture of one step (diagnostic steps, outside the timed region): when each bucket's all-reduce was
+        # launched relative to the end of backward, how long it ran, its bus bandwidth, and what the LAST bucket (extractor +
+        # first blocks: nothing left to hide behind) leaves exposed
+        red = net.reducer
+        bucket_rows, exposed_last = None, None
+        if red.comm_stream is not None:
+            red.record_timing = True
+            per = {}
+            for _ in range(3):
+                red.timing = []
+                step()
+                torch.cuda.synchronize()
+                for (bi, nbytes, ev_l, e0, e1) in red.timing:
+                    per.setdefault(bi, []).append((nbytes, ev_l.elapsed_time(comm_ev[0]), e0.elapsed_time(e1), comm_ev[0].elapsed_time(e1)))
+            red.record_timing = False
+            busf = 2.0 * (world - 1) / world        # ring all-reduce: bytes on the busiest link per byte reduced
+            bucket_rows = []
+            for bi in sorted(per):
+                v = sorted(per[bi], key=lambda t: t[2])[len(per[bi]) // 2]
+                bucket_rows.append({"bucket": bi, "mib": round(v[0] / 2 ** 20, 1), "launched_ms_before_backward_end": round(v[1], 3),
+                                    "allreduce_ms": round(v[2], 3), "bus_gb_s": round(v[0] * busf / max(v[2], 1e-6) / 1e6, 1),
+                                    "ends_ms_after_backward_end": round(v[3], 3)})
+            if bucket_rows:
+                exposed_last = max(0.0, bucket_rows[-1]["ends_ms_after_backward_end"])
         comm_ev = None
         waits.sort()
         props = torch.cuda.get_device_properties(dev)
         ident = "%s|%s" % (getattr(props, "uuid", None), getattr(props, "pci_bus_id", local_rank))
         gathered = [None] * world
         dist.all_gather_object(gathered, {"rank": rank, "device": ident, "comm_wait_ms": round(waits[1], 3), "pinned": pinned})
-        red = net.reducer
         try:
             rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
@@ -572,8 +631,28 @@ def main():
                    "bucket_mib": round(net._bucket_bytes / 2 ** 20, 1), "reserved_cus": ops.get_reserved_cus(),
                    "grad_arena_mib": round(opt.flat_grad.numel() * opt.flat_grad.element_size() / 2 ** 20, 1),
                    "grad_sum_dtype": str(opt.flat_grad.dtype).replace("torch.", ""),
+                   "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                   # (rank 0's view, median of three diagnostic steps; bus_gb_s = bytes x 2 (N - 1) / N / time: compare with one
+                   # xGMI link, ~153 GB/s -- the cap NCCL_MAX_NCHANNELS = reserved CUs is a hypothesis)
+                   "buckets_rank0": bucket_rows, "exposed_ms_last_bucket_rank0": exposed_last,
+                   "allreduce_bus_gb_s_rank0": None if not bucket_rows else round(
+                       sum(r_["mib"] for r_ in bucket_rows) * 2 ** 20 * (2.0 * (world - 1) / world)
+                       / max(sum(r_["allreduce_ms"] for r_ in bucket_rows), 1e-6) / 1e6, 1),
                    "comm_wait_ms_per_rank": [g_["comm_wait_ms"] for g_ in sorted(gathered, key=lambda g_: g_["rank"])],
                    "host_cores_per_rank": [g_["pinned"] for g_ in sorted(gathered, key=lambda g_: g_["rank"])]}
+
+    # N > 1, self-diagnosis on the first real node (nobody could tune this beforehand: RCCL has never executed in the build
+    # environment): when a rank waits noticeably for the all-reduce after backward -- or on request -- the same measurement
+    # runs once more in FRESH processes on the same GPUs with the two untested choices reverted: NCCL_MAX_NCHANNELS unset
+    # (RCCL picks its own channel count) and no CUs reserved (full persistent grids).  Fresh processes, because RCCL reads
+    # its environment once per process.  Both results go into `data_parallel`; the headline stays the default configuration's.
+    alt = None
+    if world > 1 and dp_info is not None and args.dp_alt_pass != "never":
+        worst_wait = max(dp_info["comm_wait_ms_per_rank"])
+        if args.dp_alt_pass == "always" or worst_wait > 1.0:
+            alt = run_alt_pass(args, rank, world, dev)
+            if rank == 0:
+                dp_info["alt_pass"] = alt
 
     roof = None
     if not args.no_roofline:
@@ -675,6 +754,9 @@ def main():
             out.pop("final_loss")
             out["mean_abs_feature"] = final_loss
         if dp_info is not None:
+            a_ = dp_info.get("alt_pass")
+            if a_ and a_.get("value"):
+                dp_info["alt_pass_faster_than_default"] = bool(a_["value"] > 1.01 * value)
             out["data_parallel"] = dp_info
         if roof is not None:
             out["roofline"] = roof

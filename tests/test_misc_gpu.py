@@ -435,3 +435,36 @@ def test_bench_eight_ranks_on_one_gpu_over_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["config"]["global_batch"] == 8
     assert out["scaling"] == "weak" and out["value"] > 0 and np.isfinite(out["final_loss"])
+
+
+@pytest.mark.gpu
+def test_bench_data_parallel_self_diagnosis_and_alternative_pass():
+    """The first run on a real multi-GPU node has to explain itself: `bench.py --gpus 2` prints, per
+    gradient bucket, when its all-reduce was launched relative to the end of backward, how long it took, its bus bandwidth
+    and what the last bucket leaves exposed -- and (here forced with --dp-alt-pass always, on a node: whenever a rank waits
+    > 1 ms) repeats the measurement in fresh processes with NCCL_MAX_NCHANNELS unset and no CUs reserved, printing both in
+    ONE line.  Two ranks on one GPU over gloo: the mechanics are the same, the numbers mean nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WAVLM_SHARED_GPU="1", WAVLM_DIST_BACKEND="gloo", WAVLM_DP_BUCKET_MIB="32")
+    env.pop("NCCL_MAX_NCHANNELS", None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--batch", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline", "--dp-alt-pass", "always"], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line from rank 0: " + r.stdout[-2000:]
+    dp = json.loads(lines[0])["data_parallel"]
+    rows = dp["buckets_rank0"]
+    assert rows and [r_["bucket"] for r_ in rows] == list(range(dp["buckets"]))
+    assert abs(sum(r_["mib"] for r_ in rows) - dp["grad_arena_mib"]) < 0.2 * len(rows) + 0.5   # the buckets tile the arena
+    assert all(r_["allreduce_ms"] > 0 and r_["bus_gb_s"] > 0 for r_ in rows)
+    assert dp["exposed_ms_last_bucket_rank0"] >= 0 and dp["allreduce_bus_gb_s_rank0"] > 0
+    assert dp["rccl_max_nchannels"] == "6" and dp["reserved_cus"] == 6           # the default configuration is the headline
+    alt = dp["alt_pass"]
+    assert "error" not in alt, alt
+    assert alt["settings"] == {"NCCL_MAX_NCHANNELS": None, "WAVLM_DP_RESERVED_CUS": 0}
+    assert alt["value"] > 0 and len(alt["comm_wait_ms_per_rank"]) == 2 and alt["buckets_rank0"]
+    assert isinstance(dp["alt_pass_faster_than_default"], bool)

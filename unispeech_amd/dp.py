@@ -113,6 +113,11 @@ class GradReducer:
         # the launch) in `trace` -- tests / tools/dp_overlap.py compare it with an event recorded when backward returns
         self.record_trace = False
         self.trace = []
+        # record_timing=True (bench.py --gpus N, diagnostic steps only): per bucket (index, bytes, launch event on the compute
+        # stream, start / end events around the collective on the communication stream) in `timing` -- how early each bucket
+        # went out, how long its all-reduce took, what the last one leaves exposed behind backward
+        self.record_timing = False
+        self.timing = []
         # arena element offsets (sorted) for sink notifications: backward kernels that accumulate straight into the
         # arena (functional._sink) report the slice they wrote; a packed q|k|v slice covers three parameters
         self._offsets = list(offsets)
@@ -188,13 +193,22 @@ class GradReducer:
         view = self.flat_grad[bk["lo"]:bk["hi"]]
         self._launched[b] = True
         if self.comm_stream is not None:
-            ev = torch.cuda.Event(enable_timing=self.record_trace)
+            ev = torch.cuda.Event(enable_timing=self.record_trace or self.record_timing)
             ev.record(torch.cuda.current_stream())
             if self.record_trace:
                 self.trace.append((b, ev))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self.record_timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
+                    w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    w.wait()     # the communication stream waits for the collective's own stream: e1 then marks its end
+                    e1.record(self.comm_stream)
+                    self.timing.append((b, view.numel() * view.element_size(), ev, e0, e1))
+                    self._works.append(w)
+                else:
+                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
