@@ -226,46 +226,6 @@ def check_gemm_w4():
     return out
 
 
-def check_gemm_h2():
-    """the two-workgroups-per-CU kernel (csrc/gemm_h2.hip, variant 6: 192 x 192 x 32 tiles, three LDS stages): both B layouts,
-    ragged M / N edges, the three fast epilogues incl. bias, residual, GELU + GELU' store, x aux and the fused column sums"""
-    out = []
-    dtype, tol = torch.bfloat16, TOLBF
-    for (n, N, K) in [(2000, 768, 768), (1000, 200, 96), (392, 2304, 64), (1921, 392, 3072)]:
-        for tB in (False, True):
-            A = q(gen(n, K, seed=81), dtype)
-            W = q(gen(N, K, seed=82, scale=K ** -0.5), dtype)
-            b = q(gen(N, seed=83), dtype)
-            res = q(gen(n, N, seed=84), dtype)
-            auxi = q(gen(n, N, seed=85), dtype)
-            pre = A.double() @ W.double().t()
-            Ad = A.to(dtype).to(DEV)
-            Wd = (W.t().contiguous() if tB else W).to(dtype).to(DEV)
-            for name, epi, kw, ref in [
-                    ("bias+res", 0, dict(bias=b, res=res), pre + b.double() + res.double()),
-                    ("gelu+g'", 3, dict(bias=b), TF.gelu(pre + b.double())),
-                    ("*aux+res+csum", 4, dict(aux=auxi, res=res, colsum=True), pre * auxi.double() + res.double())]:
-                C = torch.full((n, N), float("nan"), dtype=dtype, device=DEV)
-                aux = kw["aux"].to(dtype).to(DEV) if "aux" in kw else (torch.full((n, N), float("nan"), dtype=dtype, device=DEV) if epi == 3 else None)
-                cs = torch.zeros(N, dtype=dtype, device=DEV) if kw.get("colsum") else None
-                ops.gemm_set_variant(6)
-                try:
-                    ops.gemm(Ad, Wd, C, n, N, K, lda=K, ldb=N if tB else K, ldc=N, transB=tB,
-                             bias=kw["bias"].to(dtype).to(DEV) if "bias" in kw else None, epi=epi, aux=aux, ld_aux=N,
-                             res=kw["res"].to(dtype).to(DEV) if "res" in kw else None, ld_res=N, colsum=cs, colsum_accumulate=False)
-                finally:
-                    ops.gemm_set_variant(0)
-                tag = f"gemm_h2 {n}x{N}x{K} {'NT' if tB else 'NN'} {name}"
-                out.append((tag, err(C, ref), tol))
-                if epi == 3:
-                    z = pre + b.double()
-                    gp = 0.5 * (1 + torch.erf(z * 0.7071067811865476)) + z * torch.exp(-0.5 * z * z) * 0.3989422804014327
-                    out.append((tag + " aux", err(aux, gp), tol))
-                if cs is not None:
-                    out.append((tag + " colsum", err(cs, ref.sum(0)), tol))
-    return out
-
-
 def check_gemm_race():
     """the same ping-pong launch repeated gives bit-identical output (an LDS hazard between the asynchronous operand DMA
     and the fragment reads would show as run-to-run differences); step-sized shapes, both tile shapes, split-K"""
@@ -1073,7 +1033,7 @@ def check_activations():
 
 
 GROUPS = {
-    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_w4": check_gemm_w4, "gemm_h2": check_gemm_h2, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
+    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_w4": check_gemm_w4, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
     "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv, "gemm_colsum": check_gemm_colsum,
     "linear_ffn": check_linear_ffn, "activations": check_activations, "loss": check_loss, "adam": check_adam, "dropout_exact": check_dropout_exact,
 }

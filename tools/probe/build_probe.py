@@ -11,6 +11,20 @@ sys.path.insert(0, ROOT)
 from unispeech_amd import build as B  # noqa: E402
 
 B.build_library(verbose=False)
+# `lab`: the whole library with -DWAVLM_EXPERIMENTAL + tools/probe/gemm_h2.hip -> tools/probe/lib/libwavlm_hip_lab.so: the paths the
+# product library does not carry (gemm_h2 = variant 6 / WAVLM_GEMM_H2=1, the balanced grouped weight-gradient launch
+# WAVLM_WGRAD_STREAMK=1, the lab switches of the attention kernels)
+if sys.argv[1:] == ["lab"]:
+    objs = []
+    for src in B.SOURCES + ["../../tools/probe/gemm_h2.hip"]:
+        obj = os.path.join(B.OBJ_DIR, os.path.basename(src).replace(".hip", "_lab.o"))
+        subprocess.check_call([B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + ["-DWAVLM_EXPERIMENTAL", "-c", os.path.normpath(os.path.join(B.CSRC, src)), "-o", obj])
+        objs.append(obj)
+    os.makedirs(os.path.join(ROOT, "tools", "probe", "lib"), exist_ok=True)
+    out = os.path.join(ROOT, "tools", "probe", "lib", "libwavlm_hip_lab.so")
+    subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", out] + objs)
+    print("built", out)
+    sys.exit(0)
 # arguments: <bits> (PP_PROBE value) or <tag>:-DNAME=V[,-DNAME2=V2] (free-form defines, library suffix <tag>);
 # a leading "pp3:" probes gemm_pp3.hip instead (pp3:<tag>:-DP3_PROBE=1), "attn:" attn_fused.hip
 for a in sys.argv[1:] or ["1", "2", "3", "4"]:

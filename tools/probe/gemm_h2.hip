@@ -1,3 +1,7 @@
+// LAB RECORD, not part of libwavlm_hip.so (round 5: moved out of unispeech_amd/csrc/).  Built only into the lab library:
+// `python tools/probe/build_probe.py lab` -> tools/probe/lib/libwavlm_hip_lab.so (-DWAVLM_EXPERIMENTAL), selected with
+// WAVLM_HIP_LIB; parity + timing: tools/h2_ab.py.  Measured 1-22 % slower than the one-workgroup-per-CU kernels on all eight
+// transformer shapes (profiles/r04/gemm_h2_ab.txt, gemm_h2_variants.txt).
 // bf16 MFMA GEMM for gfx950, short-K path: 192 x 192 x 32 block tile, FOUR waves (96 x 96 accumulators each), three LDS
 // stages of 24 KiB -- 72 KiB per workgroup, at most 256 registers per lane -- so that TWO workgroups are resident per CU.
 //
@@ -20,9 +24,9 @@
 //   * epilogue through the workgroup's own LDS in 16-row half blocks (25.6 KiB + the 32 KiB GELU table fit the 72 KiB).
 // Handles: no batches, no split-K, K % 32 == 0, the three fast epilogues (bias / GELU + GELU' store / x aux, + bf16
 // residual, + fused column sums); everything else stays on the other kernels.
-#include "gemm_common.hpp"
+#include "../../unispeech_amd/csrc/gemm_common.hpp"
 
-#include "tile_loaders.hpp"
+#include "../../unispeech_amd/csrc/tile_loaders.hpp"
 
 #define H2_BM 192
 #define H2_BN 192

@@ -1,12 +1,13 @@
-"""The two-workgroups-per-CU GEMM (csrc/gemm_h2.hip, variant 6) against the default dispatch (variant 0: gemm_pp3 / gemm_pp) on
+"""LAB: needs the lab library (`python tools/probe/build_probe.py lab`, then WAVLM_HIP_LIB=tools/probe/lib/libwavlm_hip_lab.so).
+The two-workgroups-per-CU GEMM (tools/probe/gemm_h2.hip, variant 6) against the default dispatch (variant 0: gemm_pp3 / gemm_pp) on
 the transformer's shapes at 24 k rows: correctness against an fp32 torch reference first (ragged M / N edges, both B layouts,
-the three fast epilogues incl. residual and fused column sums), then timing.  usage (GPU box): python tools/h2_ab.py [check|time|all]"""
+the three fast epilogues incl. residual and fused column sums), then timing.  usage (GPU box): python tools/probe/h2_ab.py [check|time|all]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from unispeech_amd import ops  # noqa: E402
 

@@ -312,6 +312,12 @@ bool gemm_pp_ok(const wavlm_gemm_desc* d);                       // gemm_pp.hip
 int gemm_pp_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);
 bool gemm_pp3_ok(const wavlm_gemm_desc* d);                      // gemm_pp3.hip
 int gemm_pp3_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);
+// Lab paths (measured slower / neutral, kept as the record of the experiments): compiled only into the lab library
+// (-DWAVLM_EXPERIMENTAL, tools/probe/build_probe.py lab); libwavlm_hip.so carries neither.
+//   * gemm_h2 (tools/probe/gemm_h2.hip): 192 x 192 x 32 tiles, two workgroups per CU; variant 6 / WAVLM_GEMM_H2=1
+//   * the balanced grouped weight-gradient launch (gemm_common.hpp: gemm_sk_plan); WAVLM_WGRAD_STREAMK=1
+#if defined(WAVLM_EXPERIMENTAL)
+#define GEMM_LAB 1
 bool gemm_h2_ok(const wavlm_gemm_desc* d, int ec);                // gemm_h2.hip: 192 x 192 x 32, two workgroups per CU (short K)
 int gemm_h2_launch(GemmP& p, bool transB, int ep, hipStream_t st);
 // WAVLM_GEMM_H2: 0 never | 1 wherever the shape fits (gemm_h2_ok) | unset: by measurement (h2_takes)
@@ -322,6 +328,9 @@ static bool h2_takes(const wavlm_gemm_desc* d, int ec) {
   if (m == 1) return true;
   return false;
 }
+#else
+#define GEMM_LAB 0
+#endif
 int gemm_w4_launch(GemmP& p, int nbatch, bool transA, bool transB, int ep, hipStream_t st);  // gemm_w4.hip (same shapes as gemm_pp)
 int gemm_w4_launch_grouped(GemmP& p, hipStream_t st);
 // which 256 x 256 kernel takes a launch: the eight-wave ping-pong (gemm_pp.hip) or the four-wave one (gemm_w4.hip).
@@ -552,13 +561,16 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
   int rc;
   int csum_rows = 0;  // > 0: the kernel left that many partial rows of column sums in the workspace
   const bool vec = vec_epilogue_ok(d);
+#if GEMM_LAB
   if (g_gemm_variant == 6 ? gemm_h2_ok(d, gemm_epilogue_class(d, vec)) : (g_gemm_variant == 0 && h2_takes(d, gemm_epilogue_class(d, vec)))) {
     const int ec = gemm_epilogue_class(d, vec);
     if (ec == 3) p.gtab = gelu_tab4_get(st);
     if (d->colsum && (ec == 2 || ec == 4)) { p.colsum_part = (float*)d->workspace; csum_rows = (d->M + 191) / 192; }
     rc = gemm_h2_launch(p, d->transB != 0, ec, st);
   }
-  else if ((g_gemm_variant == 4 && gemm_pp3_ok(d)) ||
+  else
+#endif
+  if ((g_gemm_variant == 4 && gemm_pp3_ok(d)) ||
       (g_gemm_variant == 0 && d->N >= 384 && gemm_pp3_ok(d) && gemm_pp_ok(d) &&
        tile_efficiency(d, nbatch, 192, 384) > 1.06 * tile_efficiency(d, nbatch, 256, 256)))  // measured at 24 k rows: N = 768 (+25 %), 2304 (+10 % at K = 768), 3072 (+6 %) go to 192 x 384; N = 2048 and the conv stack (N = 512) stay
     { const int ec = gemm_epilogue_class(d, vec); if (ec == 3) p.gtab = gelu_tab4_get(st);
@@ -628,7 +640,11 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
   long tiles_all = 0;
   for (int i = 0; i < n; ++i) tiles_all += (long)((d[i].M + 255) / 256) * ((d[i].N + 255) / 256);
   const int G = 256 - wavlm_get_reserved_cus();
+#if GEMM_LAB
   static const bool sk_on = [] { const char* e = getenv("WAVLM_WGRAD_STREAMK"); return e && *e == '1'; }();
+#else
+  constexpr bool sk_on = false;   // (lab library only)
+#endif
   const int ksteps = (d->K + 63) / 64;
   GemmSk plan;
   const bool sk = sk_on && w4_takes(d, true) && tiles_all * (long)ksteps >= 8l * G && gemm_sk_plan(tiles_all, ksteps, G, plan) &&

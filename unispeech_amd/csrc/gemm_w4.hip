@@ -26,6 +26,12 @@
 // barrier that opens phase q + 2, and no buffer is refilled earlier than two phases after its reads were issued.
 // B-left fragments are double-buffered by K-step parity (P4 uses B-left(t) while B-left(t+1) is being read).
 #include "gemm_common.hpp"
+// the balanced grouped launch (gemm_common.hpp: gemm_sk_plan) is a lab path: decoded only in -DWAVLM_EXPERIMENTAL builds
+#if defined(WAVLM_EXPERIMENTAL)
+#define GEMM_SK 1
+#else
+#define GEMM_SK 0
+#endif
 
 #include "tile_loaders.hpp"
 
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
   GemmP q = p;
   if constexpr (GRP) {
     int item, local, g;
-    if (p.sk_ks > 0) {
+    if ((GEMM_SK && p.sk_ks > 0)) {
       // balanced launch (gemm_common.hpp: gemm_sk_plan): vid = physical workgroup + G * (which of a tail workgroup's tiles)
       const int G = p.sk_wgs, T = p.sk_tiles, S = p.sk_s;
       const int wp = vid % G, seg = vid / G;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
 #undef W4_SEL
     const int nt_g = q.tiles_m * q.tiles_n;
     int tile;
-    if (p.sk_ks > 0) tile = local;
+    if ((GEMM_SK && p.sk_ks > 0)) tile = local;
     else { split = local / nt_g; tile = local - split * nt_g; }
     tm = tile / q.tiles_n; tn = tile - tm * q.tiles_n;
     z = 0;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
   const int kt_per = (P.K + 63) >> 6;
   const int kv_last = P.K - (kt_per - 1) * 64;
   int t0, t1;
-  if (GRP && p.sk_ks > 0) { t0 = sk_t0; t1 = sk_t1; }
+  if (GRP && (GEMM_SK && p.sk_ks > 0)) { t0 = sk_t0; t1 = sk_t1; }
   else gemm_split_range(P.KB * kt_per, P.split_k, split, t0, t1);
   t0 = __builtin_amdgcn_readfirstlane(t0); t1 = __builtin_amdgcn_readfirstlane(t1);
   const int nt = t1 - t0;
@@ -540,7 +546,7 @@ int gemm_w4_launch_grouped(GemmP& p, hipStream_t st) {
   }
   p.patch_m = 0; p.skew = 0; p.nbatch = 1;
   const int pgrid = 256 - g_pp_reserved_cus;
-  dim3 grid((unsigned)(p.sk_ks > 0 ? p.sk_wgs : p.vtotal < pgrid ? p.vtotal : pgrid), 1, 1);
+  dim3 grid((unsigned)((GEMM_SK && p.sk_ks > 0) ? p.sk_wgs : p.vtotal < pgrid ? p.vtotal : pgrid), 1, 1);
   WL_LAUNCH((gemm_w4_kernel<true, true, 1, true>), grid, dim3(256), smem, st, p);
   return wl_check_launch();
 }

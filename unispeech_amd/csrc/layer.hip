@@ -144,7 +144,11 @@ int grouped_split(long tiles, long ktiles) {
 // `split_k` of a grouped launch's members = slabs per member: the one-round split; the balanced launch (gemm_common.hpp:
 // gemm_sk_plan, WAVLM_WGRAD_STREAMK=1) needs one more (== ops.grouped_slabs)
 int grouped_slabs(long tiles, long ktiles) {
+#if defined(WAVLM_EXPERIMENTAL)   // (the balanced launch exists only in the lab library)
   static const bool sk = env_int("WAVLM_WGRAD_STREAMK", 0) != 0 && env_int("WAVLM_WGRAD_SPLIT", 0) <= 0;
+#else
+  constexpr bool sk = false;
+#endif
   int split = grouped_split(tiles, ktiles); if (split < 2) split = 2;
   const long G = grid_blocks();
   if (sk && tiles < G && tiles * ktiles >= 8 * G) { const int s = (int)(G / tiles) + 1; if (s > split) split = s; }
