@@ -58,3 +58,12 @@ c2 = timeit(lambda: ops.gemm(df, W2, du, n, F, D, lda=D, ldb=F, ldc=F, transB=Tr
 print("  -> the aux read costs %.1f us of %.1f; the fused column sums %.1f us" % (a2 - b2, a2, b2 - c2))
 print("per step (12 blocks): aux store + aux read = %.2f ms -- the most an 8-bit GELU' (half the bytes) could save is about half of that"
       % (12 * ((a - b) + (a2 - b2)) / 1e3))
+# the residual read of the dX launches that add the gradient of the tensor's other consumer (fc1's dX + LayerNorm dx; q|k|v's dX + dx)
+print("fc1 dX, 23968 x 768 x 3072 (B K-strided), + bf16 residual")
+W1t = (F ** -0.5 * torch.randn(F, D, device=dev)).to(bf)    # fc1.weight [F, D]: dX = du @ W1
+duu = (0.5 * torch.randn(n, F, device=dev)).to(bf)
+dres = (0.5 * torch.randn(n, D, device=dev)).to(bf)
+dh = torch.empty(n, D, device=dev, dtype=bf)
+r1 = timeit(lambda: ops.gemm(duu, W1t, dh, n, D, F, lda=F, ldb=D, ldc=D, transB=True, res=dres, ld_res=D), "  + residual (the step's launch)")
+r0 = timeit(lambda: ops.gemm(duu, W1t, dh, n, D, F, lda=F, ldb=D, ldc=D, transB=True), "  plain")
+print("  -> the residual read costs %.1f us of %.1f (24 such launches per step: %.2f ms)" % (r1 - r0, r1, 24 * (r1 - r0) / 1e3))

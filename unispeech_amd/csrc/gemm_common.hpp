@@ -227,9 +227,11 @@ __device__ __forceinline__ void gelu_tab_stage(const float4* g, float4* lds) {
 }
 
 // vout (optional): receives the eight final values as stored (before rounding to bf16) -- fused column sums
+// aux_pre (KIND 4, optional): the eight bf16 aux values of this chunk, already loaded by the caller (gemm_pp3's epilogue
+// issues a 32-row block's six loads before it stages the block: one round trip per block instead of one per chunk)
 template <int KIND>
 __device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi, int m, int n, const float (&acc)[8],
-                                                 const float4* tab = nullptr, float* vout = nullptr) {
+                                                 const float4* tab = nullptr, float* vout = nullptr, const uint4* aux_pre = nullptr) {
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = p.alpha * acc[e];
@@ -251,7 +253,15 @@ __device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi,
     if (p.aux) st8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, WL_BF16, gr);
   } else if constexpr (KIND == 4) {
     float u[8];
-    ld8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, WL_BF16, u);
+    if (aux_pre) {
+      const uint4 a = *aux_pre;
+      u[0] = __uint_as_float(a.x << 16); u[1] = __uint_as_float(a.x & 0xffff0000u);
+      u[2] = __uint_as_float(a.y << 16); u[3] = __uint_as_float(a.y & 0xffff0000u);
+      u[4] = __uint_as_float(a.z << 16); u[5] = __uint_as_float(a.z & 0xffff0000u);
+      u[6] = __uint_as_float(a.w << 16); u[7] = __uint_as_float(a.w & 0xffff0000u);
+    } else {
+      ld8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, WL_BF16, u);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= u[e];
   }

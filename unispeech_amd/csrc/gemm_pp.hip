@@ -41,6 +41,9 @@
 #include "gemm_common.hpp"
 
 #include "tile_loaders.hpp"
+#ifndef PP_AUX_PRELOAD
+#define PP_AUX_PRELOAD 1
+#endif
 
 // Lab-bench switches exist only in builds made with -DWAVLM_EXPERIMENTAL (tools/probe/build_probe.py).
 #if !defined(WAVLM_EXPERIMENTAL)
@@ -615,16 +618,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     constexpr bool CSUM = (EP == 2 || EP == 4) && !GRP;  // fused column sums of C (gemm_common.hpp)
     const bool csum = CSUM && P.colsum_part != nullptr;
     float cs[2] = {0.f, 0.f};
-#pragma unroll 1
-    for (int i = 0; i < 4; ++i) {
-      // constant accumulator indices in every arm: the (large) store code below is emitted once, the accumulators
-      // stay in registers
-      switch (i) {
-        case 0: stage_block(acc[0]); break;
-        case 1: stage_block(acc[1]); break;
-        case 2: stage_block(acc[2]); break;
-        default: stage_block(acc[3]); break;
-      }
+    // one 32-row block out of the staging slice: four 8-wide chunks per lane; axp (EP 4 with PP_AUX_PRELOAD): the block's aux
+    // chunks, loaded one block ahead (see gemm_pp3.hip: P3_AUX_PRELOAD)
+    auto process_block = [&](int i, const uint4 (&axp)[4]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int id = lane + 64 * q;
@@ -637,6 +633,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
           const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           if constexpr (EP == 1) gemm_store8(P, zo, zi, z, split, mm, nn, v);
+          else if constexpr (PP_AUX_PRELOAD && EP == 4 && !GRP) gemm_store8_fast<4>(P, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr, &axp[q]);
           else gemm_store8_fast<(EP == 2 ? 0 : EP)>(P, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr);
         }
         if constexpr (CSUM) {
@@ -648,6 +645,47 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
       }
       if constexpr (CSUM) {
         if (csum) gemm_colsum_block<64, EP_LD>(ep, lane, cs);
+      }
+    };
+    if constexpr (PP_AUX_PRELOAD && EP == 4 && !GRP) {
+      // the GELU' factor of the conv stack's / fc2's dX travels one 32-row block ahead in two register sets: a block's loads
+      // are issued when the block before it has been staged (profiles/r05/ab_gemm_aux_preload.txt)
+      auto aux_load = [&](int i, uint4 (&a)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int id = lane + 64 * q;
+          const int rl = id >> 3, ch = id & 7;
+          const int mm = mw + i * 32 + rl, nn = nw + ch * 8;
+          a[q] = make_uint4(0, 0, 0, 0);
+          if (mm < P.M && nn < P.N)
+            a[q] = *reinterpret_cast<const uint4*>((const bf16_t*)P.aux + (long)zo * P.sAux_o + (long)zi * P.sAux_i + (long)mm * P.ld_aux + nn);
+        }
+      };
+      uint4 a0[4], a1[4];
+      aux_load(0, a0);
+      stage_block(acc[0]);
+      aux_load(1, a1);
+      process_block(0, a0);
+      stage_block(acc[1]);
+      aux_load(2, a0);
+      process_block(1, a1);
+      stage_block(acc[2]);
+      aux_load(3, a1);
+      process_block(2, a0);
+      stage_block(acc[3]);
+      process_block(3, a1);
+    } else {
+      const uint4 none[4] = {};
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        // constant accumulator indices in every arm: the (large) store code is emitted once, the accumulators stay in registers
+        switch (i) {
+          case 0: stage_block(acc[0]); break;
+          case 1: stage_block(acc[1]); break;
+          case 2: stage_block(acc[2]); break;
+          default: stage_block(acc[3]); break;
+        }
+        process_block(i, none);
       }
     }
     if constexpr (CSUM) {

@@ -33,6 +33,12 @@
 #define P3_AU 8192
 #define P3_BB 49152
 #define P3_STAGE (3 * P3_AU + P3_BB)  // 73728
+#ifndef P3_AUX_PRELOAD
+#define P3_AUX_PRELOAD 1
+#endif
+#ifndef P3_AUX_UNROLL
+#define P3_AUX_UNROLL 0
+#endif
 
 __device__ __attribute__((aligned(256))) unsigned char g_pp3_zero[256];  // zero page for K positions past the end
 
@@ -444,36 +450,89 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
     constexpr bool CSUM = EP == 2 || EP == 4;  // fused column sums of C: plain and aux-multiplying fast epilogues
     const bool csum = CSUM && p.colsum_part != nullptr;
     float cs[2] = {0.f, 0.f};
-#pragma unroll 1
-    for (int i = 0; i < 3; ++i) {
-      switch (i) {
-        case 0: stage_block(acc[0]); break;
-        case 1: stage_block(acc[1]); break;
-        default: stage_block(acc[2]); break;
+    // one 32-row block of the wave's tile out of the staging slice: six 8-wide chunks per lane.  axp (EP 4 with
+    // P3_AUX_PRELOAD): the block's aux chunks, loaded by aux_load() ahead of time
+    // chunk q of block i: ax = its preloaded aux values (EP 4 with P3_AUX_PRELOAD)
+    auto process_chunk = [&](int i, int q, const uint4& ax) __attribute__((always_inline)) {
+      const int id = lane + 64 * q;   // 32 rows x 12 chunks
+      const int rl = id / 12, ch = id - rl * 12;
+      const int mm = mw + i * 32 + rl;
+      const int nn = nw + ch * 8;
+      float vo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (mm < p.M && nn < p.N) {
+        const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if constexpr (EP == 1) gemm_store8(p, zo, zi, z, split, mm, nn, v);
+        else if constexpr (P3_AUX_PRELOAD && EP == 4) gemm_store8_fast<4>(p, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr, &ax);
+        else gemm_store8_fast<(EP == 2 ? 0 : EP)>(p, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr);
       }
-#pragma unroll 1
-      for (int q = 0; q < 6; ++q) {  // not unrolled: with 144 accumulator registers live the store code must stay small
-        const int id = lane + 64 * q;   // 32 rows x 12 chunks
-        const int rl = id / 12, ch = id - rl * 12;
-        const int mm = mw + i * 32 + rl;
-        const int nn = nw + ch * 8;
-        float vo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (mm < p.M && nn < p.N) {
-          const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
-          const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
-          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          if constexpr (EP == 1) gemm_store8(p, zo, zi, z, split, mm, nn, v);
-          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(p, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr);
+      if constexpr (CSUM) {
+        if (csum) {
+          *reinterpret_cast<float4*>(ep + rl * EP_LD + ch * 8) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+          *reinterpret_cast<float4*>(ep + rl * EP_LD + ch * 8 + 4) = make_float4(vo[4], vo[5], vo[6], vo[7]);
         }
-        if constexpr (CSUM) {
-          if (csum) {
-            *reinterpret_cast<float4*>(ep + rl * EP_LD + ch * 8) = make_float4(vo[0], vo[1], vo[2], vo[3]);
-            *reinterpret_cast<float4*>(ep + rl * EP_LD + ch * 8 + 4) = make_float4(vo[4], vo[5], vo[6], vo[7]);
+      }
+    };
+    // one 32-row block of the wave's tile out of the staging slice: six 8-wide chunks per lane
+    auto process_block = [&](int i, const uint4 (&axp)[6]) __attribute__((always_inline)) {
+      if constexpr (P3_AUX_PRELOAD && P3_AUX_UNROLL && EP == 4) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) process_chunk(i, q, axp[q]);
+      } else {
+#pragma unroll 1
+        for (int q = 0; q < 6; ++q) {  // not unrolled: with 144 accumulator registers live the store code must stay small
+          uint4 ax = axp[0];
+          if constexpr (P3_AUX_PRELOAD && EP == 4) {   // (a chain of selects: a run-time index would put the array into scratch)
+#pragma unroll
+            for (int k = 1; k < 6; ++k) {
+              ax.x = q == k ? axp[k].x : ax.x; ax.y = q == k ? axp[k].y : ax.y;
+              ax.z = q == k ? axp[k].z : ax.z; ax.w = q == k ? axp[k].w : ax.w;
+            }
           }
+          process_chunk(i, q, ax);
         }
       }
       if constexpr (CSUM) {
         if (csum) gemm_colsum_block<96, EP_LD>(ep, lane, cs);
+      }
+    };
+    if constexpr (P3_AUX_PRELOAD && EP == 4) {
+      // The aux chunks (GELU' of fc1's / a conv layer's pre-activation, written a forward pass ago) travel one block ahead in two
+      // register sets: with the load inside the chunk loop every chunk waited for its own round trip -- 18 dependent round trips
+      // per wave and tile, 47 of the 193 us of fc2's dX launch (tools/gemm_aux_bound.py, profiles/r05/ab_gemm_aux_preload.txt).
+      // Block i + 1's six loads are issued when block i has been staged (its 48 accumulator registers are free by then).
+      auto aux_load = [&](int i, uint4 (&a)[6]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int id = lane + 64 * q;
+          const int rl = id / 12, ch = id - rl * 12;
+          const int mm = mw + i * 32 + rl, nn = nw + ch * 8;
+          a[q] = make_uint4(0, 0, 0, 0);
+          if (mm < p.M && nn < p.N)
+            a[q] = *reinterpret_cast<const uint4*>((const bf16_t*)p.aux + (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)mm * p.ld_aux + nn);
+        }
+      };
+      uint4 a0[6], a1[6];
+      aux_load(0, a0);
+      stage_block(acc[0]);
+      aux_load(1, a1);
+      process_block(0, a0);
+      stage_block(acc[1]);
+      aux_load(2, a0);
+      process_block(1, a1);
+      stage_block(acc[2]);
+      process_block(2, a0);
+    } else {
+      const uint4 none[6] = {};
+#pragma unroll 1
+      for (int i = 0; i < 3; ++i) {
+        switch (i) {
+          case 0: stage_block(acc[0]); break;
+          case 1: stage_block(acc[1]); break;
+          default: stage_block(acc[2]); break;
+        }
+        process_block(i, none);
       }
     }
     if constexpr (CSUM) {
