@@ -48,7 +48,8 @@ print("fc1 forward, 23968 x 3072 x 768")
 a = timeit(lambda: ops.gemm(x, W1, h, n, F, D, lda=D, ldb=D, ldc=F, bias=b1, epi=3, aux=g, ld_aux=F), "  bias + GELU + GELU' store (the step's launch)")
 b = timeit(lambda: ops.gemm(x, W1, h, n, F, D, lda=D, ldb=D, ldc=F, bias=b1, epi=3), "  bias + GELU, NO GELU' store (bound for any narrower store)")
 c = timeit(lambda: ops.gemm(x, W1, h, n, F, D, lda=D, ldb=D, ldc=F, bias=b1), "  bias only (plain epilogue)")
-print("  -> the aux store costs %.1f us of %.1f; the GELU arithmetic + table %.1f us" % (a - b, a, b - c))
+c0 = timeit(lambda: ops.gemm(x, W1, h, n, F, D, lda=D, ldb=D, ldc=F), "  no bias, plain")
+print("  -> the aux store costs %.1f us of %.1f; the GELU arithmetic + table %.1f us; the bias load %.1f us" % (a - b, a, b - c, c - c0))
 print("fc2 dX, 23968 x 3072 x 768 (B K-strided)")
 a2 = timeit(lambda: ops.gemm(df, W2, du, n, F, D, lda=D, ldb=F, ldc=F, transB=True, epi=4, aux=g, ld_aux=F, colsum=db1, colsum_accumulate=True),
             "  x GELU' + column sums (the step's launch)")
