@@ -98,3 +98,17 @@ def test_no_cpu_fallback():
     m = WavLM(WavLMConfig(dict(TINY)))
     with pytest.raises(_lib.WavlmHipError):
         m.extract_features(torch.randn(1, 4000))
+
+
+def test_stored_probability_buffer_size_is_a_host_function():
+    """wavlm_attn_fused_pstore_bytes needs no GPU: 4 KiB per (32 query rows x 64 keys) of the padded grid + the running maxima;
+    0 beyond T = 1024 (callers then recompute)"""
+    from unispeech_amd import _lib
+    L = _lib.lib()
+    B, H, T = 32, 12, 749
+    nq32, nkv, Tq = 6 * 4, 12, 768
+    p_bytes = B * H * nq32 * nkv * 4096
+    assert L.wavlm_attn_fused_pstore_bytes(B, H, T) == (p_bytes + 255) // 256 * 256 + B * H * nkv * Tq * 4
+    assert L.wavlm_attn_fused_pstore_bytes(1, 16, 1024) > 0
+    assert L.wavlm_attn_fused_pstore_bytes(1, 16, 1025) == 0
+    assert L.wavlm_attn_fused_pstore_bytes(0, 1, 1) == 0

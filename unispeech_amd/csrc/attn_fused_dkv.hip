@@ -358,8 +358,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_p_kernel(FaP p) {
   // still in flight
   p_load(0, pA);
   dma_tile(0, 0);
-  p_load(nq > 1 ? 1 : 0, pB);
-  if (nq > 1) dma_tile(1, 1);
+  if (nq > 1) { p_load(1, pB); dma_tile(1, 1); }
   __builtin_amdgcn_sched_barrier(0);
   if (nq > 1) fa_tile_sync<8>(); else fa_tile_sync<0>();
 
@@ -383,8 +382,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_p_kernel(FaP p) {
       asm volatile("ds_write_b128 %0, %1 offset:2304" :: "v"(pw_a), "v"(x[3]) : "memory");
     }
     // tile it + 2: fragments first, DMA last (header comment, (2)); its stage was read last in tile it - 1
+    // (NO load past the end: these are asm loads the compiler does not know of -- a "harmless reload" issued in the last
+    // tiles would still be in flight when the loop ends, the register set is dead by then, the compiler hands its registers
+    // to the epilogue, and the returning data overwrites dK on its way out: seen as non-deterministic dK for odd tile counts)
     const bool ahead = it + 2 < nq;
-    if (!(FA_SP_PROBE & 1)) p_load(ahead ? it + 2 : it, x);   // (past the end: a harmless reload, no branch around the loads)
+    if (!(FA_SP_PROBE & 1) && ahead) p_load(it + 2, x);
     int st2 = st + 2; if (st2 >= 3) st2 -= 3;
     if (ahead) dma_tile(it + 2, st2);
     __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the loads to the end of the tile)
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_p_kernel(FaP p) {
       if (f == 0) FA_STAMP(3); else FA_STAMP(5);   // the block's eight dV / dK MFMAs issued (fragment reads waited for)
     }
 #if FA_SP_PROBE & 32
-    if (ahead) __builtin_amdgcn_s_waitcnt(0x0f70 | 8); else __builtin_amdgcn_s_waitcnt(0x0f70 | 4);
+    if (ahead) __builtin_amdgcn_s_waitcnt(0x0f70 | 8); else __builtin_amdgcn_s_waitcnt(0x0f70);
     FA_STAMP(6);   // vector memory wait
     __syncthreads();
     FA_STAMP(7);   // barrier
@@ -440,8 +442,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_p_kernel(FaP p) {
     return;
 #endif
     // tile it + 1 has landed when at most this tile's eight operations (four fragment loads, four DMA instructions) are in
-    // flight; without a DMA of its own (the last two tiles) the four loads alone are younger than it
-    if (ahead) fa_tile_sync<8>(); else fa_tile_sync<4>();
+    // flight; the last two tiles issue nothing
+    if (ahead) fa_tile_sync<8>(); else fa_tile_sync<0>();
     st = st + 1; if (st >= 3) st = 0;
   };
   // whole pairs, then the odd tile: the pair loop's only back edge is B -> A.  (With `if (it + 1 < nq) tile B` inside one loop

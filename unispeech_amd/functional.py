@@ -598,11 +598,16 @@ class ConvStackFn(torch.autograd.Function):
                 kp, sp = specs[i - 1]
                 _, _, fpp, bpp = _conv_geometry(xs[i - 1].shape[1], kp, sp)
                 Tpp = fpp + T_in + bpp
-                nxt = torch.empty((B, Tpp, Cin), dtype=dy.dtype, device=dev)
-                if fpp:
-                    nxt[:, :fpp].zero_()
-                if bpp:
-                    nxt[:, fpp + T_in:].zero_()
+                # The zero pad rows in front of / behind every utterance's T_in rows: the back pad of utterance b and the front pad of
+                # utterance b + 1 are adjacent, so with bpp spare rows in front of the buffer and fpp behind it ALL pads are the
+                # B + 1 equally spaced gaps [g * Tpp, g * Tpp + bpp + fpp) of one allocation: ONE strided fill per layer
+                # (two strided fills per layer before: 9 of the step's small torch launches).
+                if fpp or bpp:
+                    big = torch.empty((B * Tpp + fpp + bpp, Cin), dtype=dy.dtype, device=dev)
+                    big.as_strided((B + 1, fpp + bpp, Cin), (Tpp * Cin, Cin, 1)).zero_()
+                    nxt = big[bpp:bpp + B * Tpp].view(B, Tpp, Cin)
+                else:
+                    nxt = torch.empty((B, Tpp, Cin), dtype=dy.dtype, device=dev)
                 aux = us[i - 1] if ctx.act else None
             else:
                 fpp, Tpp = 0, T_in
@@ -794,7 +799,7 @@ class AttnCoreFn(torch.autograd.Function):
             qkv_bias_tok.taken = True
             ctx.bias_sink = qkv_bias_sink
         if ctx.fused:
-            store = ATTN_STORE_P and ctx.needs_input_grad[0] and torch.is_grad_enabled()
+            store = ATTN_STORE_P and ctx.needs_input_grad[0]   # (grad mode is always off inside Function.forward: not a condition)
             O, lse, pstore = ops.attn_fused_fwd(qkvc, gate, tab, kpm, H, scale, p_drop, seed, store_p=store)
             ctx.save_for_backward(qkvc, O, lse, gate, tab, kpm, pstore)
             ctx.cfg = (B, T, D, H, hd, 0, scale, p_drop, seed)

@@ -256,10 +256,13 @@ class WavLMPretrainModel(WavLM):
 
         pad_cpu = None
         if padding_mask is not None:
-            padding_mask = self.forward_padding_mask(T, padding_mask)
             if padding_mask_cpu is not None:
+                # the frame mask comes from the host copy (numpy, no OpenMP) and goes up as 24 KB: the device-side reduction
+                # of the [32, 240000] sample mask was an 18 us kernel per step for a tensor the host already has
                 pad_cpu = self.forward_padding_mask(T, padding_mask_cpu)
+                padding_mask = F.h2d(pad_cpu, dev)
             else:
+                padding_mask = self.forward_padding_mask(T, padding_mask)
                 pad_cpu = padding_mask.cpu()
         x = F.dropout(x, self.dropout_input.p, self.training)
 
@@ -319,12 +322,7 @@ class WavLMPretrainModel(WavLM):
         else:
             sources = [x.reshape(B * T, -1)]
 
-        tinds = {}
-
-        def tinds_dev(d):  # label index of every kept frame, uploaded once per device
-            if d not in tinds:
-                tinds[d] = F.h2d(target_inds, d)
-            return tinds[d]
+        tinds_np = target_inds.numpy().astype(np.int64)   # label index of every kept frame (host)
 
         def head(frame_sel_np, need_grad):
             out = []
@@ -350,14 +348,21 @@ class WavLMPretrainModel(WavLM):
             proj = F.LinearFn.apply(rows, fp.weight, fp.bias)
             projs = proj.chunk(len(pairs), dim=-1) if untied else [proj] * len(pairs)
             out = []
-            idx64 = idx.long()
+            # label of selected frame s = t[b, tinds[f]] with (b, f) = divmod(idx[s], T): ONE flat index per label tensor width,
+            # computed on the host (idx_np is host data anyway) -- `t[:, tinds].reshape(-1).index_select(0, idx.long())` was
+            # five launches per head and label set
+            bsel, fsel = np.divmod(idx_np.astype(np.int64), T)
+            flat_cache = {}
             for pj, (emb, t) in zip(projs, pairs):
                 if self.target_glu is not None:
                     # wavlm.py:529-531 applies target_glu to the positives and to every negative, i.e. row by row to the
                     # label embeddings: transforming the [V, F] table once is the same computation
                     tg = self.target_glu[0]
                     emb = F.GLUFn.apply(F.LinearFn.apply(emb.contiguous(), tg.weight, tg.bias))
-                tt = t[:, tinds_dev(t.device)].reshape(-1).index_select(0, idx64).to(torch.int32)
+                Tl = int(t.size(1))
+                if Tl not in flat_cache:
+                    flat_cache[Tl] = F.h2d(bsel * Tl + tinds_np[fsel], t.device)
+                tt = t.contiguous().view(-1).index_select(0, flat_cache[Tl]).to(torch.int32)
                 loss, ncorrect = F.MaskedPredLossFn.apply(pj.contiguous(), emb, tt, self.logit_temp, need_grad)
                 out.append({"loss": loss, "correct": ncorrect, "count": S, "proj": pj, "target": tt, "label_embs": emb})
             return out
@@ -561,20 +566,31 @@ class WavLMCriterion(nn.Module):
         lw = getattr(model, "weights", None) if getattr(model, "weighted_sum", False) else None
         nw = torch.softmax(lw.float(), dim=-1) if lw is not None else None
 
+        # (the scalar arithmetic below is written so that no operation is a no-op kernel: Python's sum() starts from 0 + tensor,
+        # a weight of 1.0 is a multiply, `0.0 + x` an add -- thirteen 4.5 us launches per step forward + backward before)
         def total(heads):
             if nw is None:
-                return sum(h["loss"][0] for h in heads)
-            assert len(heads) == nw.numel(), "weighted_sum needs one loss per predicted layer"
-            return sum(nw[i] * h["loss"][0] for i, h in enumerate(heads))
+                parts = [h["loss"][0] for h in heads]
+            else:
+                assert len(heads) == nw.numel(), "weighted_sum needs one loss per predicted layer"
+                parts = [nw[i] * h["loss"][0] for i, h in enumerate(heads)]
+            t = parts[0]
+            for q in parts[1:]:
+                t = t + q
+            return t
+
+        def add_term(acc, w, t):
+            t = t if w == 1 else w * t
+            return t if (not torch.is_tensor(acc) and acc == 0.0) else acc + t
 
         if self.pred_masked_weight > 0:
-            loss = loss + self.pred_masked_weight * total(heads_m)
+            loss = add_term(loss, self.pred_masked_weight, total(heads_m))
             sample_size += heads_m[0]["count"]
         assert self.pred_nomask_weight == 0 or len(heads_u) > 0
         for i, h in enumerate(heads_u):
             logging_output[f"loss_u_{i}"] = num(h["loss"].detach()[0])
         if self.pred_nomask_weight > 0:
-            loss = loss + self.pred_nomask_weight * total(heads_u)
+            loss = add_term(loss, self.pred_nomask_weight, total(heads_u))
             sample_size += heads_u[0]["count"]
 
         if self.loss_weights is not None:
@@ -585,8 +601,8 @@ class WavLMCriterion(nn.Module):
             assert len(extra_losses) == len(weights), f"{len(extra_losses)}, {len(weights)}"
             for p, n, coef in zip(extra_losses, names, weights):
                 if coef != 0 and p is not None:
-                    p = coef * p.float().reshape(()) * sample_size
-                    loss = loss + p
+                    p = p.float().reshape(()) * (coef * sample_size)   # (hubert_criterion.py:98-105: coef * p * sample_size)
+                    loss = p if (not torch.is_tensor(loss) and loss == 0.0) else loss + p
                     logging_output[f"loss_{n}"] = num(p.detach())
 
         nsent = sample["id"].numel() if "id" in sample else sample["net_input"]["source"].size(0)
