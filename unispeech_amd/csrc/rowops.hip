@@ -885,8 +885,13 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   // (HS = the row statistics are kept; without a residual the pre-norm sum is x itself and s stays NULL -- until round 3 that
   // case fell through to the general kernels: the extractor's LayerNorms of layer_norm-mode models, the encoder's first one)
   if (ln_full_enabled() && (D == 512 || D == 768 || D == 1024) && (mean == nullptr) == (rstd == nullptr) && (!s || mean)) {
-    static const int cap = getenv("WAVLM_LN_FWD_BLOCKS") ? atoi(getenv("WAVLM_LN_FWD_BLOCKS")) : 1024;
-    const unsigned gridf = grid_for(rows, 4, (unsigned)(cap > 0 ? cap : 1024));
+    // grid cap: 1024 blocks up to 131 k rows (the encoder: measured at 23 968 rows), then one block per 128 rows up to 8192 --
+    // the extractor LayerNorms of layer_norm-mode models run over up to 1.02 M rows: 618 us at 1024 blocks, 558 at 8192
+    // (tools/ln_conv_bench.py, profiles/r05/ln_conv_sweep.txt)
+    static const int cap_env = getenv("WAVLM_LN_FWD_BLOCKS") ? atoi(getenv("WAVLM_LN_FWD_BLOCKS")) : 0;
+    long cap = cap_env > 0 ? cap_env : rows / 128;
+    if (cap_env <= 0) { if (cap < 1024) cap = 1024; if (cap > 8192) cap = 8192; }
+    const unsigned gridf = grid_for(rows, 4, (unsigned)cap);
 #define LNF_K(T, TP, VEC, NCS, HR, HS) WL_LAUNCH((layernorm_fwd_full_kernel<T, TP, VEC, NCS, HR, HS>), dim3(gridf), dim3(256), 0, st, \
     (const T*)x, (const T*)r, (T*)y, (T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (long)rows, eps, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out)
@@ -916,8 +921,19 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
   return wl_check_launch();
 }
 
-static int ln_bwd_blocks() { static const int n = getenv("WAVLM_LN_BWD_BLOCKS") ? atoi(getenv("WAVLM_LN_BWD_BLOCKS")) : LN_BWD_BLOCKS; return n > 0 && n <= 4096 ? n : LN_BWD_BLOCKS; }
-uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D) { return (uint64_t)ln_bwd_blocks() * 3 * D * sizeof(float); }
+// backward grid: LN_BWD_BLOCKS (512) up to 131 k rows, then one block per 256 rows up to 4096 (1.02 M rows x 512: 926 us at
+// 512 blocks, 737 at 4096 incl. the finish over 4096 partial rows; profiles/r05/ln_conv_sweep.txt); WAVLM_LN_BWD_BLOCKS fixes it
+#define LN_BWD_BLOCKS_MAX 4096
+static int ln_bwd_blocks_env() { static const int n = getenv("WAVLM_LN_BWD_BLOCKS") ? atoi(getenv("WAVLM_LN_BWD_BLOCKS")) : 0; return n > 0 && n <= LN_BWD_BLOCKS_MAX ? n : 0; }
+static int ln_bwd_blocks(long rows) {
+  if (ln_bwd_blocks_env()) return ln_bwd_blocks_env();
+  long n = rows / 256;
+  if (n < LN_BWD_BLOCKS) n = LN_BWD_BLOCKS;
+  if (n > LN_BWD_BLOCKS_MAX) n = LN_BWD_BLOCKS_MAX;
+  return (int)n;
+}
+// (sized for the largest grid: the row count is not known here)
+uint64_t wavlm_layernorm_bwd_workspace_bytes(int32_t D) { return (uint64_t)LN_BWD_BLOCKS_MAX * 3 * D * sizeof(float); }
 
 int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd, const void* gamma,
                         const void* beta, void* dx, void* dr, const void* dx_add, void* dgamma, void* dbeta,
@@ -935,7 +951,7 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   const double es_p = dtype == WL_BF16 ? 2.0 : 4.0;  // dy, s (+ dx_add) read, dx (+ dr) written
   WlProfScope prof(WL_PROF_LN_BWD, dtype, 12.0 * rows * D,
                    (double)rows * D * es_p * (3.0 + (dx_add ? 1.0 : 0.0) + ((dr && dr != dx) ? 1.0 : 0.0)), st);
-  const unsigned grid = grid_for(rows, 4, (unsigned)ln_bwd_blocks());
+  const unsigned grid = grid_for(rows, 4, (unsigned)ln_bwd_blocks(rows));
   float* part = (float*)workspace;
   if (ln_full_enabled() && (D == 512 || D == 768 || D == 1024)) {
 #define LNB_K(T, TP, VEC, NCS, CSF, HA, HD) WL_LAUNCH((layernorm_bwd_full_kernel<T, TP, VEC, NCS, CSF, HA, HD>), dim3(grid), dim3(256), 0, st, \
