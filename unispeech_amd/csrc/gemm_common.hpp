@@ -1,5 +1,6 @@
 // Kernel-side GEMM parameter block + the shared epilogue (bias / GELU / GELU' / residual / accumulate).
 #pragma once
+#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/wavlm_hip.h"
 
@@ -20,6 +21,7 @@ struct GemmP {
   int split_k; float* ws;
   int tiles_m, tiles_n;
   int vtotal, nbatch, skew;  // persistent launch (ping-pong kernels): virtual block count, batch count, start skew
+  int swz_r;                 // > 0: tile ids walk super-rows of swz_r tile rows column by column (gemm_tile_rc)
   int patch_m;               // split-K work order: tile-row patch height (0: tiles only, split outermost)
   int ngrp;                  // > 0: grouped launch, the problems are grp[0 .. ngrp) (A/B/M/N/lda/ldb/ws above are unused)
   int sk_ks, sk_wgs, sk_tiles, sk_s, sk_lm, sk_spread;  // sk_ks > 0: balanced grouped launch (gemm_sk_plan): K steps per tile, workgroups, tiles of all members, main splits, main run
@@ -58,6 +60,43 @@ static inline bool gemm_sk_plan(long T, long KS, int G, GemmSk& k) {
   return true;
 }
 
+// ---- tile order inside an XCD (round 5) ----
+// A persistent launch hands XCD x a contiguous run of tile ids, and per round the XCD's 32 CUs work on 32 CONSECUTIVE ids at
+// the same time -- they progress through K roughly in lockstep, so an operand panel is fetched into the XCD's L2 once per
+// round for all the tiles that share it.  With row-major ids the 32 tiles are (32 / tiles_n) rows x tiles_n columns: at
+// N = 4096 (16 column tiles of 256) two A panels and ALL sixteen B panels per round -- the PMC pass of round 5 shows 1283 MB
+// fetched per fc1 / fc2-dX launch of WavLM-Large against 598 MB algorithmic (2.1 x), 3.4 TB/s: those launches are bound by
+// that traffic.  Walking super-rows of R tile rows column by column makes the 32 tiles an R x (32 / R) block: the panels per
+// round drop from 2 + 16 to 4 + 8 (N = 4096), from 4 + 8 to 8 + 4 at 192 x 384 tiles and N = 3072 (the B panels are twice as
+// tall there).  R is chosen on the host (gemm_pick_swizzle) to minimise panel bytes per round; 0 = the row-major order.
+__host__ __device__ inline void gemm_tile_rc(int tile, int tiles_m, int tiles_n, int R, int& tm, int& tn) {
+  if (R <= 1) { tm = tile / tiles_n; tn = tile - tm * tiles_n; return; }
+  const int per = R * tiles_n;
+  const int sr = tile / per;
+  int rows = tiles_m - sr * R; if (rows > R) rows = R;
+  const int w = tile - sr * per;
+  tn = w / rows; tm = sr * R + (w - tn * rows);
+}
+// R in {1, 2, 4, 8, 16, 32} minimising (tile rows x R + tile columns x min(32 / R, tiles_n)) -- the operand rows an XCD fetches
+// per round; ties go to the smaller R (R = 1 is the row-major order itself)
+// Only where the B operand as a whole does not fit an XCD's 4 MiB L2 (b_bytes >= 6 MB: measured -- WavLM-Large's N = 4096 /
+// 3072 at K = 1024, 8 / 6 MB: fetch -13 ... -26 %, launches -3 ... -6 %; WavLM-Base's N = 3072 at K = 768, 4.7 MB: B stays
+// resident either way, fetch +4 %, time unchanged; profiles/r05/gemm_swizzle.txt).
+static inline int gemm_pick_swizzle(int tile_m, int tile_n, int tiles_m, int tiles_n, long b_bytes) {
+  static const int off = getenv("WAVLM_GEMM_SWIZZLE") && getenv("WAVLM_GEMM_SWIZZLE")[0] == '0';
+  if (off || tiles_n <= 1 || tiles_m <= 1 || b_bytes < 6l * 1000 * 1000) return 0;
+  long best = -1; int br = 0;
+  for (int R = 1; R <= 32; R *= 2) {
+    if (R > tiles_m) break;
+    int cols = (32 + R - 1) / R; if (cols > tiles_n) cols = tiles_n;
+    // rows actually covered when the block is narrower than 32 / R columns: 32 tiles = rows x cols
+    int rows = R; if (cols * R < 32) { rows = (32 + cols - 1) / cols; if (rows > tiles_m) rows = tiles_m; }
+    const long cost = (long)tile_m * rows + (long)tile_n * cols;
+    if (best < 0 || cost < best) { best = cost; br = R; }
+  }
+  return br <= 1 ? 0 : br;
+}
+
 static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
   GemmP p;
   p.A = d->A; p.B = d->B; p.C = d->C;
@@ -76,6 +115,7 @@ static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
   p.ws = (float*)d->workspace;
   p.tiles_m = 0; p.tiles_n = 0; p.vtotal = 0; p.nbatch = 1; p.skew = 0; p.patch_m = 0; p.ngrp = 0;
   p.sk_ks = 0; p.sk_wgs = 0; p.sk_tiles = 0; p.sk_s = 0; p.sk_lm = 0; p.sk_spread = 0;
+  p.swz_r = 0;
   return p;
 }
 

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     const int nt = ntile, bid = vid % ntile;
     const int q = nt >> 3, rem = nt & 7, xcd = bid & 7, idx = bid >> 3;
     const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-    tn = tile % p.tiles_n; tm = tile / p.tiles_n;
+    gemm_tile_rc(tile, p.tiles_m, p.tiles_n, p.swz_r, tm, tn);
     z = (vid / ntile) % p.nbatch; split = vid / (ntile * p.nbatch);
   } else {
     // Split-K (weight-gradient) order.  Blocks that share operand panels are the tiles of ONE split: they must sit on
@@ -721,6 +721,7 @@ static int pp_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
   p.nbatch = nbatch;
   p.vtotal = p.tiles_m * p.tiles_n * nbatch * p.split_k;
   p.patch_m = 0;
+  p.swz_r = (nbatch == 1 && p.split_k == 1 && g_pp_mode != 0) ? gemm_pick_swizzle(256, 256, p.tiles_m, p.tiles_n, (long)p.N * p.K * 2) : 0;
   if (p.split_k > 1 && nbatch == 1 && g_pp_mode != 0) {
     p.patch_m = 16 / p.tiles_n; if (p.patch_m < 1) p.patch_m = 1; if (p.patch_m > p.tiles_m) p.patch_m = p.tiles_m;
   }

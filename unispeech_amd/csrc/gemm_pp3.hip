@@ -67,7 +67,8 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
     const int q = nt >> 3, rem = nt & 7, xcd = bid & 7, idx = bid >> 3;
     tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
-  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+  int tm, tn;
+  gemm_tile_rc(tile, p.tiles_m, p.tiles_n, p.swz_r, tm, tn);
   const int z = (vid / ntile_) % p.nbatch, split = vid / (ntile_ * p.nbatch);
   const int zo = z / p.batch_i, zi = z % p.batch_i;
   const int m0 = tm * 192, n0 = tn * 384;
@@ -551,6 +552,7 @@ static int pp3_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
   p.tiles_n = (p.N + 383) / 384;
   p.nbatch = nbatch;
   p.vtotal = p.tiles_m * p.tiles_n * nbatch * p.split_k;
+  p.swz_r = (nbatch == 1 && p.split_k == 1) ? gemm_pick_swizzle(192, 384, p.tiles_m, p.tiles_n, (long)p.N * p.K * 2) : 0;
   const int pgrid = 256 - g_pp_reserved_cus;
   dim3 grid((unsigned)(p.vtotal < pgrid ? p.vtotal : pgrid), 1, 1);   // persistent: a tile's epilogue stores drain under the next tile's DMA
 #if defined(WAVLM_EXPERIMENTAL)
