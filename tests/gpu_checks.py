@@ -431,6 +431,50 @@ def check_conv0():
     return out
 
 
+def check_conv0_ln():
+    """extractor_mode 'layer_norm' block 0 at the width of the real models (C = 512: with bf16 operands the backward runs on the
+    matrix cores, conv0_bwd_mfma.hip) with conv bias, ragged chunk ends (512 frames per workgroup, 32 per tile), fewer frames
+    than one tile, a bias that moves the frame mean away from zero, and feature_grad_mult-style scaling."""
+    out = []
+    C = 512
+    for dtype in (torch.bfloat16, torch.float32):
+        tol = tol_for(dtype)
+        for (B, T, boff, gs) in [(2, 16000, 0.0, 1.0), (1, 400, 0.0, 1.0), (3, 2565, 0.5, 0.1), (1, 5175, -1.0, 1.0), (2, 95, 0.0, 1.0)]:
+            if dtype == torch.float32 and T > 3000:
+                continue
+            wav = q(gen(B, T, seed=1), dtype)
+            W = q(gen(C, 1, 10, seed=2, scale=0.4), dtype)
+            g, b = q(1 + 0.1 * gen(C, seed=3), dtype), q(0.1 * gen(C, seed=4), dtype)
+            cb = q(boff + 0.2 * gen(C, seed=6), dtype)
+            ts = [t.double().clone().requires_grad_(True) for t in (W, g, b, cb)]
+            y = TF.gelu(TF.layer_norm(TF.conv1d(wav.double().unsqueeze(1), ts[0], ts[3], stride=5).transpose(1, 2), (C,), ts[1], ts[2], 1e-5))
+            dy = q(gen(*y.shape, seed=5), dtype)
+            gr = torch.autograd.grad(y, ts, dy.double() * gs)
+            Wd, gd, bd, cd = [t.to(dtype).to(DEV) for t in (W, g, b, cb)]
+            wd = wav.to(dtype).to(DEV)
+            yd = ops.conv0_ln_gelu_fwd(wd, Wd, gd, bd, 5, 1e-5, dtype, bias=cd)
+            dW, dg, db, dcb = ops.conv0_ln_gelu_bwd(wd, Wd, gd, bd, dy.to(dtype).to(DEV), 5, 1e-5, gscale=gs, bias=cd)
+            tag = f"conv0+LN+bias[{dtype}] B={B} T={T} off={boff}"
+            out.append((tag + " y", err(yd, y), tol))
+            out.append((tag + " dW", err(dW, gr[0]), tol))
+            out.append((tag + " dgamma", err(dg, gr[1]), tol))
+            out.append((tag + " dbeta", err(db, gr[2]), tol))
+            out.append((tag + " dbias", err(dcb, gr[3]), tol))
+    # batch linearity at a size where a workgroup of the matrix-core form walks two chunks (64 rows x 8 chunks = 512 chunks on
+    # 256 CUs) and one where it walks one (32 x 8): the gradients of the whole batch are the sums over its two halves
+    B, T = 64, 4000 * 5 + 5
+    wd = gen(B, T, seed=11).to(torch.bfloat16).to(DEV)
+    Wd = gen(C, 1, 10, seed=12, scale=0.4).to(torch.bfloat16).to(DEV)
+    gd, bd, cd = [(o + 0.1 * gen(C, seed=13 + i)).to(torch.bfloat16).to(DEV) for i, o in enumerate((1.0, 0.0, 0.3))]
+    dy = torch.randn(B, 4000, C, generator=torch.Generator(device=DEV).manual_seed(7), device=DEV).to(torch.bfloat16)
+    full = ops.conv0_ln_gelu_bwd(wd, Wd, gd, bd, dy, 5, 1e-5, bias=cd)
+    ha = ops.conv0_ln_gelu_bwd(wd[:32].contiguous(), Wd, gd, bd, dy[:32].contiguous(), 5, 1e-5, bias=cd)
+    hb = ops.conv0_ln_gelu_bwd(wd[32:].contiguous(), Wd, gd, bd, dy[32:].contiguous(), 5, 1e-5, bias=cd)
+    for nm, f, a, b2 in zip(("dW", "dgamma", "dbeta", "dbias"), full, ha, hb):
+        out.append((f"conv0+LN batch linearity {nm}", err(f, a.float() + b2.float()), 1e-2))
+    return out
+
+
 def check_convstack():
     out = []
     for dtype in (torch.float32, torch.bfloat16):
@@ -1033,7 +1077,7 @@ def check_activations():
 
 
 GROUPS = {
-    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_w4": check_gemm_w4, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0,
+    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_w4": check_gemm_w4, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0, "conv0_ln": check_conv0_ln,
     "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv, "gemm_colsum": check_gemm_colsum,
     "linear_ffn": check_linear_ffn, "activations": check_activations, "loss": check_loss, "adam": check_adam, "dropout_exact": check_dropout_exact,
 }

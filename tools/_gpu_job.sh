@@ -1,4 +1,11 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "gemm or linear_ffn or convstack" 2>&1 | tail -2
-(for i in 1 2; do WAVLM_GEMM_SWIZZLE=0 python tools/gemm_swizzle_bench.py; python tools/gemm_swizzle_bench.py; done) 2>&1 | grep -v amdgpu > gpurun_out/r05_gemm_swizzle.txt; cat gpurun_out/r05_gemm_swizzle.txt
-for s in 0 1; do rm -rf /tmp/pm; WAVLM_GEMM_SWIZZLE=$s rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pm -o run -- python tools/gemm_swizzle_bench.py > /dev/null 2>&1; C=$(find /tmp/pm -name "*counter_collection.csv" | head -1); echo "== swizzle $s: FETCH_SIZE per kernel (KiB units x 2 = bytes / 512)"; python tools/pmc_sq.py $C 1 | grep "gemm_p" | head -8; done > gpurun_out/r05_gemm_swizzle_fetch.txt 2>&1; cat gpurun_out/r05_gemm_swizzle_fetch.txt
+(echo "== matrix-core form"; timeout 600 python tests/gpu_checks.py conv0_ln) > gpurun_out/r05_conv0_ln_check.txt 2>&1
+grep -v "^ok" gpurun_out/r05_conv0_ln_check.txt | tail -40; grep linearity gpurun_out/r05_conv0_ln_check.txt
+(timeout 300 python tools/conv0_ln_bench.py; WAVLM_CONV0_BWD_MFMA=0 timeout 300 python tools/conv0_ln_bench.py) 2>&1 | grep -v amdgpu > gpurun_out/r05_conv0_ln_bench.txt; cat gpurun_out/r05_conv0_ln_bench.txt
+rm -rf /tmp/pf; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf -o run -- python tools/conv0_ln_bench.py > /tmp/pf.log 2>&1
+S=$(find /tmp/pf -name "*kernel_stats.csv" | head -1); python - $S <<'PY' > gpurun_out/r05_conv0_ln_prof.txt
+import csv, sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:9]:
+    print(f"{r['Name'][:60]:60s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:9.1f} us")
+PY
+cat gpurun_out/r05_conv0_ln_prof.txt

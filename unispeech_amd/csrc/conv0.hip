@@ -692,7 +692,9 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
 uint64_t wavlm_conv0_ln_bwd_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride) {
   const long T0 = (T - C0_KW) / stride + 1;
   const uint64_t nchunk = (uint64_t)((T0 + C0_TCH_BWD - 1) / C0_TCH_BWD);
-  return (uint64_t)B * nchunk * C0_LN_NQ * C * sizeof(float);
+  const uint64_t valu = (uint64_t)B * nchunk * C0_LN_NQ * C * sizeof(float);
+  const uint64_t mfma = conv0_ln_bwd_mfma_workspace_bytes((int)B, (int)T0);  // whichever form runs (dtypes are not known here)
+  return valu > mfma ? valu : mfma;
 }
 
 // extractor_mode "layer_norm", block 0: out[B, T0, C] = gelu(LayerNorm_C(conv0(wav)))  (WavLM/WavLM.py:403-418)
@@ -738,11 +740,17 @@ int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
   // algorithmic: the incoming gradient read once + the waveform; conv recompute + weight gradient = 4 * kw flops per output
   WlProfScope prof(WL_PROF_CONV0_BWD, g_dtype, 4.0 * kw * B * (double)T0 * C,
                    (double)B * T * (wav_dtype == WL_BF16 ? 2 : 4) + (double)B * T0 * C * (g_dtype == WL_BF16 ? 2 : 4), st);
+  const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
+  if (key == 111 && C == 512 && g_conv0_bwd_mfma) {  // the matrix-core form (conv0_bwd_mfma.hip); WAVLM_CONV0_BWD_MFMA=0: the VALU form
+    const float2* tab0 = gelu_tab_get(st);
+    if (!tab0) return WL_ELAUNCH;
+    return conv0_ln_bwd_mfma_launch(wav, W, conv_bias, gamma, beta, g, dW, dconv_bias, dgamma, dbeta, workspace, (long)T, T0,
+                                    (int)stride, (int)B, eps, gscale, tab0 + GT_N, st);
+  }
   static const int occ = (getenv("WAVLM_CONV0_LN_OCC") && getenv("WAVLM_CONV0_LN_OCC")[0] == '1') ? 1 : 2;
 #define BW_O(TW, TP, TO, O) WL_LAUNCH((conv0_ln_bwd_kernel<TW, TP, TO, O>), grid, dim3(256), smem, st, (const TW*)wav, \
     (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (const TO*)g, part, (long)T, T0, (int)C, (int)stride, eps, gscale)
 #define BW(TW, TP, TO) do { if (occ == 1) BW_O(TW, TP, TO, 1); else BW_O(TW, TP, TO, 2); } while (0)
-  const int key = wav_dtype * 100 + param_dtype * 10 + g_dtype;
   if (key == 0) BW(float, float, float);
   else if (key == 111) BW(bf16_t, bf16_t, bf16_t);
   else if (key == 11) BW(float, bf16_t, bf16_t);

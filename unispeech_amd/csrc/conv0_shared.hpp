@@ -15,3 +15,9 @@
 int conv0_bwd_mfma_launch(const void* wav, const void* W, const void* gamma, const void* beta, const float* stats, const void* g,
                           float* part, float* partx, long T, int T0, int stride, float gscale, int nchunk, int B,
                           const float2* tab1, hipStream_t st);
+// LayerNorm-mode backward on the matrix cores (same instantiation): workspace size and launch (gram constants, the pass, the
+// two reduction kernels); dW / dcbias (may be null) / dgamma / dbeta are written in bf16
+uint64_t conv0_ln_bwd_mfma_workspace_bytes(int B, int T0);
+int conv0_ln_bwd_mfma_launch(const void* wav, const void* W, const void* cbias, const void* gamma, const void* beta, const void* g,
+                             void* dW, void* dcbias, void* dgamma, void* dbeta, void* workspace, long T, int T0, int stride, int B,
+                             float eps, float gscale, const float2* tab1, hipStream_t st);
