@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 18
+#define WAVLM_HIP_ABI_VERSION 19
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -172,10 +172,14 @@ int wavlm_conv0_gn_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, c
 
 /* extractor_mode = "layer_norm" (WavLM-Large), block 0: Conv1d(1 -> C, k = 10) -> LayerNorm over the C channels of each
  * frame -> GELU, channel-last (WavLM/WavLM.py:403-418 with mode "layer_norm"; Fp32LayerNorm WavLM/modules.py:31-43).
- * One fused pass forward; backward (dW, dgamma, dbeta; no input gradient) recomputes conv and statistics. */
+ * One fused pass forward; backward (dW, dgamma, dbeta; no input gradient) recomputes conv and statistics.  With bf16
+ * operands and C = 512 both run on the matrix cores; their frame statistics come from second moments of the parameters over
+ * the channels, which the forward keeps in its (small) workspace: wavlm_conv0_ln_fwd_workspace_bytes() bytes. */
+uint64_t wavlm_conv0_ln_fwd_workspace_bytes(void);
 int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, const void* conv_bias, const void* gamma,
                             const void* beta, int32_t param_dtype, void* out, int32_t out_dtype, int32_t B, int64_t T,
-                            int32_t C, int32_t kw, int32_t stride, float eps, void* stream);
+                            int32_t C, int32_t kw, int32_t stride, float eps, void* workspace, uint64_t ws_bytes,
+                            void* stream);
 uint64_t wavlm_conv0_ln_bwd_workspace_bytes(int32_t B, int64_t T, int32_t C, int32_t stride);
 /* conv_bias / dconv_bias: the Conv1d bias of conv_bias=True configurations and its gradient (both optional, [C]) */
 int wavlm_conv0_ln_gelu_bwd(const void* wav, int32_t wav_dtype, const void* W, const void* conv_bias, const void* gamma,

@@ -40,3 +40,11 @@ f = timed(lambda: ops.conv0_ln_gelu_fwd(wav, W, gm, bt, 5, 1e-5, torch.bfloat16,
 b = timed(lambda: ops.conv0_ln_gelu_bwd(wav, W, gm, bt, dy, 5, 1e-5, bias=cb))
 print(f"conv0+LN+GELU B={B} T={T} frames={B * T0} ({gb:.2f} GB): forward {f:.0f} us ({gb / f * 1e3:.2f} TB/s), "
       f"backward {b:.0f} us ({gb / b * 1e3:.2f} TB/s) [WAVLM_CONV0_BWD_MFMA={os.environ.get('WAVLM_CONV0_BWD_MFMA', '1')}]")
+# the GroupNorm-mode block (WavLM-Base) at the headline step's shape: 32 x 15 s
+Bg, Tg = 32, 240000
+wg = torch.randn(Bg, Tg, generator=g).cuda().bfloat16()
+T0g = (Tg - 10) // 5 + 1
+gbg = Bg * T0g * C * 2 / 1e9
+fg = timed(lambda: ops.conv0_gn_gelu_fwd(wg, W, gm, bt, 5, 1e-5, torch.bfloat16))
+print(f"conv0+GN+GELU B={Bg} T={Tg} frames={Bg * T0g} ({gbg:.2f} GB): forward (Gram + statistics + apply) {fg:.0f} us "
+      f"({gbg / fg * 1e3:.2f} TB/s) [WAVLM_CONV0_FWD_MFMA={os.environ.get('WAVLM_CONV0_FWD_MFMA', '1')}]")

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVLM_HIP_LIB") or os.path.join(_HERE, "lib", "libwavlm_hip.so")
 
 _lib = None
-ABI_VERSION = 18  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 19  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
 
 F32, BF16 = 0, 1
 
@@ -100,8 +100,9 @@ SIGNATURES = {
     "wavlm_conv0_gn_bwd_workspace_bytes": (c_u64, [c_i32, c_i64, c_i32, c_i32]),
     "wavlm_conv0_gn_gelu_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
                                         c_i32, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_u64, c_vp]),
+    "wavlm_conv0_ln_fwd_workspace_bytes": (c_u64, []),
     "wavlm_conv0_ln_gelu_fwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32,
-                                        c_i32, c_f32, c_vp]),
+                                        c_i32, c_f32, c_vp, c_u64, c_vp]),
     "wavlm_conv0_ln_bwd_workspace_bytes": (c_u64, [c_i32, c_i64, c_i32, c_i32]),
     "wavlm_conv0_ln_gelu_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                         c_i64, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_u64, c_vp]),

@@ -574,6 +574,7 @@ __global__ __launch_bounds__(256) void conv0_ln_bwd_finish_kernel(const float* _
 
 // WAVLM_CONV0_BWD_MFMA=0 keeps the VALU form of the GroupNorm-mode backward (A/B and fallback)
 static const bool g_conv0_bwd_mfma = [] { const char* e = getenv("WAVLM_CONV0_BWD_MFMA"); return !(e && e[0] == '0'); }();
+static const bool g_conv0_fwd_mfma = [] { const char* e = getenv("WAVLM_CONV0_FWD_MFMA"); return !(e && e[0] == '0'); }();
 
 static inline size_t seg_floats(int tch, int stride) { return (size_t)(((tch - 1) * stride + C0_KW + 3) / 4 * 4); }
 
@@ -605,20 +606,31 @@ int wavlm_conv0_gn_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
   // algorithmic: 2 * kw flops per output; the waveform read once, the output written once
   WlProfScope prof(WL_PROF_CONV0_FWD, out_dtype, 2.0 * kw * B * (double)T0 * C,
                    (double)B * T * (wav_dtype == WL_BF16 ? 2 : 4) + (double)B * T0 * C * (out_dtype == WL_BF16 ? 2 : 4), st);
-  if (wav_dtype == WL_F32)
+  int nrec = nchunk;  // partial Gram records per batch row
+  int rc;
+  if (wav_dtype == WL_F32) {
     WL_LAUNCH((conv0_gram_kernel<float>), grid, dim3(256), sm_gram, st, (const float*)wav, partx, (long)T, T0, (int)stride);
-  else
+    rc = wl_check_launch();
+  } else if (g_conv0_fwd_mfma) {  // the matrix-core form (conv0_bwd_mfma.hip): 4096 frames per record
+    rc = conv0_gram_mfma_launch(wav, partx, (long)T, T0, (int)stride, (int)B, st, &nrec);
+  } else {
     WL_LAUNCH((conv0_gram_kernel<bf16_t>), grid, dim3(256), sm_gram, st, (const bf16_t*)wav, partx, (long)T, T0, (int)stride);
-  int rc = wl_check_launch();
+    rc = wl_check_launch();
+  }
   if (rc != WL_OK) return rc;
   const dim3 gs((unsigned)((C + 255) / 256), (unsigned)B);
   if (param_dtype == WL_F32)
-    WL_LAUNCH((conv0_stats_from_gram_kernel<float>), gs, dim3(256), 0, st, partx, (const float*)W, stats, nchunk, (int)C, T0, eps);
+    WL_LAUNCH((conv0_stats_from_gram_kernel<float>), gs, dim3(256), 0, st, partx, (const float*)W, stats, nrec, (int)C, T0, eps);
   else
-    WL_LAUNCH((conv0_stats_from_gram_kernel<bf16_t>), gs, dim3(256), 0, st, partx, (const bf16_t*)W, stats, nchunk, (int)C, T0, eps);
+    WL_LAUNCH((conv0_stats_from_gram_kernel<bf16_t>), gs, dim3(256), 0, st, partx, (const bf16_t*)W, stats, nrec, (int)C, T0, eps);
 #define AP(TW, TP, TO) WL_LAUNCH((conv0_apply_kernel<TW, TP, TO>), grid, dim3(256), sm_apply, st, (const TW*)wav, \
     (const TP*)W, (const TP*)gamma, (const TP*)beta, stats, (TO*)out, (long)T, T0, (int)C, (int)stride)
   const int key = wav_dtype * 100 + param_dtype * 10 + out_dtype;
+  if (key == 111 && C == 512 && g_conv0_fwd_mfma) {  // the matrix-core form of the apply pass (conv0_bwd_mfma.hip)
+    const float2* tab0 = gelu_tab_get(st);
+    if (!tab0) return WL_ELAUNCH;
+    return conv0_gn_fwd_mfma_launch(wav, W, gamma, beta, stats, out, (long)T, T0, (int)stride, (int)B, tab0, st);
+  }
   if (key == 0) AP(float, float, float);
   else if (key == 111) AP(bf16_t, bf16_t, bf16_t);
   else if (key == 11) AP(float, bf16_t, bf16_t);
@@ -698,11 +710,15 @@ uint64_t wavlm_conv0_ln_bwd_workspace_bytes(int32_t B, int64_t T, int32_t C, int
 }
 
 // extractor_mode "layer_norm", block 0: out[B, T0, C] = gelu(LayerNorm_C(conv0(wav)))  (WavLM/WavLM.py:403-418)
+uint64_t wavlm_conv0_ln_fwd_workspace_bytes(void) { return 128 * sizeof(float); }
+
 int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, const void* conv_bias, const void* gamma,
                             const void* beta, int32_t param_dtype, void* out, int32_t out_dtype, int32_t B, int64_t T,
-                            int32_t C, int32_t kw, int32_t stride, float eps, void* stream) {
-  if (!wav || !W || !gamma || !beta || !out) return WL_EINVAL;
+                            int32_t C, int32_t kw, int32_t stride, float eps, void* workspace, uint64_t ws_bytes,
+                            void* stream) {
+  if (!wav || !W || !gamma || !beta || !out || !workspace) return WL_EINVAL;
   if (kw != C0_KW || stride < 1 || stride > 8 || C <= 0 || C > 512 || (C & 7) || B <= 0 || T < kw) return WL_EINVAL;
+  if (ws_bytes < wavlm_conv0_ln_fwd_workspace_bytes()) return WL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int T0 = (int)((T - kw) / stride + 1);
   const dim3 grid((unsigned)((T0 + C0_TCH - 1) / C0_TCH), (unsigned)B);
@@ -713,6 +729,12 @@ int wavlm_conv0_ln_gelu_fwd(const void* wav, int32_t wav_dtype, const void* W, c
 #define FW(TW, TP, TO) WL_LAUNCH((conv0_ln_fwd_kernel<TW, TP, TO>), grid, dim3(256), smem, st, (const TW*)wav, \
     (const TP*)W, (const TP*)conv_bias, (const TP*)gamma, (const TP*)beta, (TO*)out, (long)T, T0, (int)C, (int)stride, eps)
   const int key = wav_dtype * 100 + param_dtype * 10 + out_dtype;
+  if (key == 111 && C == 512 && g_conv0_fwd_mfma) {  // the matrix-core form (conv0_bwd_mfma.hip); WAVLM_CONV0_FWD_MFMA=0: this file's
+    const float2* tab0 = gelu_tab_get(st);
+    if (!tab0) return WL_ELAUNCH;
+    return conv0_ln_fwd_mfma_launch(wav, W, conv_bias, gamma, beta, out, (float*)workspace, (long)T, T0, (int)stride, (int)B, eps,
+                                    tab0, st);
+  }
   if (key == 0) FW(float, float, float);
   else if (key == 111) FW(bf16_t, bf16_t, bf16_t);
   else if (key == 11) FW(float, bf16_t, bf16_t);

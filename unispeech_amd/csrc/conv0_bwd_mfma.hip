@@ -265,7 +265,7 @@ __global__ __launch_bounds__(1024) void conv0_ln_gram_kernel(const bf16_t* __res
   const int o = tid >> 3, p = tid & 7, per = C / 8;
   if (o < 11) {
     double s = 0.0;
-    for (int c = p * per; c < (p + 1) * per; ++c) s += (double)sw[c][o];
+    for (int e = 0; e < per; ++e) s += (double)sw[e * 8 + p][o];  // (channels interleaved over the eight threads: LDS banks)
     pp[o][p] = s;
   }
   __syncthreads();
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(1024) void conv0_ln_gram_kernel(const bf16_t* __res
     const int j = o < 100 ? o / C0_KW : C0_KW, k = o < 100 ? o % C0_KW : (o < 110 ? o - 100 : C0_KW);
     const double mj = wb[j], mk = wb[k];
     double s = 0.0;
-    for (int c = p * per; c < (p + 1) * per; ++c) s += ((double)sw[c][j] - mj) * ((double)sw[c][k] - mk);
+    for (int e = 0; e < per; ++e) { const int c = e * 8 + p; s += ((double)sw[c][j] - mj) * ((double)sw[c][k] - mk); }
     pp[o][p] = s;
   }
   __syncthreads();
@@ -575,6 +575,331 @@ __global__ __launch_bounds__(512, 1) void conv0_ln_bwd_mfma_kernel(const bf16_t*
     for (int w = 0; w < 8; ++w) s += md[w * 256 + threadIdx.x];
     out[(long)C0L_NROW * C + threadIdx.x] = s;
   }
+}
+
+// ---- forward of the same block on the matrix cores ----------------------------------------------------------------------
+// The VALU form (conv0.hip: a wave owns a frame, two wave reductions per frame, 10 FMAs per output) wrote the Large step's
+// 2.1 GB at 2.6 TB/s.  Here: frame statistics from the waveform (thread = frame, the Gram form above), the conv as one MFMA per
+// 16 channels x 16 frames with the WEIGHTS as the A operand, so that D[channel][frame] leaves a lane with one frame (column
+// li) and, with tile ct's rows mapped to channels 16 (r >> 2) + 4 ct + (r & 3), sixteen CONSECUTIVE channels 16 q .. 16 q + 15
+// of the wave's 64 across its four tiles: 32 bytes per frame and lane, two 16-byte stores; the four q groups of a frame
+// fill a 128-byte line.
+#define C0F_OFF_XC 0                                // [512][16] bf16 im2col rows (taps, 1.0, zeros)
+#define C0F_OFF_ST (C0L_FR * 32)                    // [512] float2 (rstd_t, -mean_t rstd_t)
+#define C0F_OFF_TAB (C0F_OFF_ST + C0L_FR * 8)       // GELU chords
+#define C0F_OFF_SEG (C0F_OFF_TAB + GT_N * 8)        // the chunk's waveform segment, (511 * 8 + 10) samples at most
+#define C0F_SMEM (C0F_OFF_SEG + 8208)
+
+__global__ __launch_bounds__(512, 2) void conv0_ln_fwd_mfma_kernel(const bf16_t* __restrict__ wav, const bf16_t* __restrict__ W,
+    const bf16_t* __restrict__ cbias, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+    const float* __restrict__ gc, bf16_t* __restrict__ out, long T, int T0, int stride, float eps, const float2* __restrict__ gtab) {
+  constexpr int C = 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char c0sm[];
+  unsigned char* xc = c0sm + C0F_OFF_XC;
+  float2* stt = reinterpret_cast<float2*>(c0sm + C0F_OFF_ST);
+  float2* tab = reinterpret_cast<float2*>(c0sm + C0F_OFF_TAB);
+  bf16_t* seg = reinterpret_cast<bf16_t*>(c0sm + C0F_OFF_SEG);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, q = lane >> 4;
+  const int b = blockIdx.y, t0 = blockIdx.x * C0L_FR;
+  const int nt = min(C0L_FR, T0 - t0);
+  const bf16_t* wsrc = wav + (long)b * T + (long)t0 * stride;
+  const int nseg = (nt - 1) * stride + C0_KW;
+  for (int i = threadIdx.x; i < nseg; i += 512) seg[i] = wsrc[i];
+  for (int i = threadIdx.x; i < GT_N / 2; i += 512) reinterpret_cast<float4*>(tab)[i] = reinterpret_cast<const float4*>(gtab)[i];
+
+  // weights (+ conv bias as tap 10) as A fragments: row li of tile ct = channel 16 (li >> 2) + 4 ct + (li & 3) of the wave's 64
+  C0U4 wf[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int c = wave * 64 + 16 * (li >> 2) + 4 * ct + (li & 3);
+    wf[ct].v = make_uint4(0, 0, 0, 0);
+    if (q == 0) wf[ct].v = *reinterpret_cast<const uint4*>(W + (long)c * C0_KW);
+    if (q == 1) {
+      wf[ct].u[0] = *reinterpret_cast<const unsigned*>(W + (long)c * C0_KW + 8);
+      wf[ct].u[1] = cbias ? (unsigned)cbias[c] : 0u;
+    }
+  }
+  // affine of the lane's sixteen output channels wave * 64 + 16 q + (4 ct + i)
+  float gm[16], bt[16];
+  {
+    const int c0 = wave * 64 + 16 * q;
+    C0U4 g0, g1, b0, b1;
+    g0.v = *reinterpret_cast<const uint4*>(gamma + c0); g1.v = *reinterpret_cast<const uint4*>(gamma + c0 + 8);
+    b0.v = *reinterpret_cast<const uint4*>(beta + c0); b1.v = *reinterpret_cast<const uint4*>(beta + c0 + 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int sh = 16 * (e & 1);
+      gm[e] = __uint_as_float(((g0.u[e >> 1] >> sh) & 0xffffu) << 16); gm[8 + e] = __uint_as_float(((g1.u[e >> 1] >> sh) & 0xffffu) << 16);
+      bt[e] = __uint_as_float(((b0.u[e >> 1] >> sh) & 0xffffu) << 16); bt[8 + e] = __uint_as_float(((b1.u[e >> 1] >> sh) & 0xffffu) << 16);
+    }
+  }
+  __syncthreads();
+  {  // thread = frame: statistics and the im2col row
+    const int t = threadIdx.x;
+    const bool ok = t < nt;
+    unsigned xb[C0_KW];
+    float x[C0_KW];
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) { xb[k] = ok ? (unsigned)seg[t * stride + k] : 0u; x[k] = __uint_as_float(xb[k] << 16); }
+    float mean = gc[10];
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) mean = fmaf(gc[k], x[k], mean);
+    float var = gc[11];
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) {
+      float r = gc[12 + k];
+#pragma unroll
+      for (int j = 0; j < C0_KW; ++j) r = fmaf(gc[22 + k * C0_KW + j], x[j], r);
+      var = fmaf(r, x[k], var);
+    }
+    const float rstd = ok ? rsqrtf(fmaxf(var, 0.f) + eps) : 0.f;
+    stt[t] = make_float2(rstd, ok ? -mean * rstd : 0.f);
+    *reinterpret_cast<uint4*>(xc + t * 32) = make_uint4(xb[0] | (xb[1] << 16), xb[2] | (xb[3] << 16), xb[4] | (xb[5] << 16), xb[6] | (xb[7] << 16));
+    *reinterpret_cast<uint4*>(xc + t * 32 + 16) = make_uint4(xb[8] | (xb[9] << 16), ok ? 0x3f80u : 0u, 0u, 0u);
+  }
+  __syncthreads();
+
+  bf16_t* orow = out + ((long)b * T0 + t0) * C + wave * 64 + 16 * q;
+  const int nft = (nt + 31) >> 5;
+  for (int ft = 0; ft < nft; ++ft) {
+    const int f0 = 32 * ft + li, f1 = f0 + 16;
+    C0U4 x0, x1;
+    x0.v = make_uint4(0, 0, 0, 0); x1.v = x0.v;
+    if (q < 2) {
+      x0.v = *reinterpret_cast<const uint4*>(xc + f0 * 32 + q * 16);
+      x1.v = *reinterpret_cast<const uint4*>(xc + f1 * 32 + q * 16);
+    }
+    const float2 s0 = stt[f0], s1 = stt[f1];
+    unsigned o0[8], o1[8];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const c0_f32x4_t zero = c0_f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const c0_f32x4_t y0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct].b, x0.b, zero, 0, 0, 0);
+      const c0_f32x4_t y1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct].b, x1.b, zero, 0, 0, 0);
+      float z[8], u[8], r[8];
+      float2 cell[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        z[i] = fmaf(fmaf(y0[i], s0.x, s0.y), gm[4 * ct + i], bt[4 * ct + i]);
+        z[4 + i] = fmaf(fmaf(y1[i], s1.x, s1.y), gm[4 * ct + i], bt[4 * ct + i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_fmed3f(fmaf(z[i], GT_INV_H, -GT_LO * GT_INV_H), 0.f, (float)(GT_N - 1));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cell[i] = tab[(int)u[i]];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] = fmaf(cell[i].x, z[i], cell[i].y);
+      o0[2 * ct] = pack_bf16x2(r[0], r[1]); o0[2 * ct + 1] = pack_bf16x2(r[2], r[3]);
+      o1[2 * ct] = pack_bf16x2(r[4], r[5]); o1[2 * ct + 1] = pack_bf16x2(r[6], r[7]);
+    }
+    if (f0 < nt) {
+      uint4* p = reinterpret_cast<uint4*>(orow + (long)f0 * C);
+      p[0] = make_uint4(o0[0], o0[1], o0[2], o0[3]); p[1] = make_uint4(o0[4], o0[5], o0[6], o0[7]);
+    }
+    if (f1 < nt) {
+      uint4* p = reinterpret_cast<uint4*>(orow + (long)f1 * C);
+      p[0] = make_uint4(o1[0], o1[1], o1[2], o1[3]); p[1] = make_uint4(o1[4], o1[5], o1[6], o1[7]);
+    }
+  }
+}
+
+int conv0_ln_fwd_mfma_launch(const void* wav, const void* W, const void* cbias, const void* gamma, const void* beta, void* out,
+                             float* gc, long T, int T0, int stride, int B, float eps, const float2* tab0, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)conv0_ln_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C0F_SMEM) != hipSuccess)
+      return WL_ELAUNCH;
+    attr = true;
+  }
+  const int nchunk = (T0 + C0L_FR - 1) / C0L_FR;
+  WL_LAUNCH(conv0_ln_gram_kernel, dim3(1), dim3(1024), 0, st, (const bf16_t*)W, (const bf16_t*)cbias, gc, 512);
+  WL_LAUNCH(conv0_ln_fwd_mfma_kernel, dim3((unsigned)nchunk, (unsigned)B), dim3(512), C0F_SMEM, st, (const bf16_t*)wav,
+            (const bf16_t*)W, (const bf16_t*)cbias, (const bf16_t*)gamma, (const bf16_t*)beta, gc, (bf16_t*)out, T, T0, stride, eps,
+            tab0);
+  return wl_check_launch();
+}
+
+// ---- GroupNorm-mode forward (WavLM-Base: the headline step's first kernel) in the same form: the statistics are per
+// (batch row, channel) and arrive from the Gram pass (conv0.hip), so the affine is one fma with the lane's sixteen channels'
+// (rstd gamma, beta - mean rstd gamma).  The VALU form (10 FMAs per output) wrote the 1.57 GB at 3.9 TB/s.
+#define C0G_OFF_XC 0
+#define C0G_OFF_TAB (C0L_FR * 32)
+#define C0G_OFF_SEG (C0G_OFF_TAB + GT_N * 8)
+#define C0G_SMEM (C0G_OFF_SEG + 8208)
+
+__global__ __launch_bounds__(512, 2) void conv0_gn_fwd_mfma_kernel(const bf16_t* __restrict__ wav, const bf16_t* __restrict__ W,
+    const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, const float* __restrict__ stats, bf16_t* __restrict__ out,
+    long T, int T0, int stride, const float2* __restrict__ gtab) {
+  constexpr int C = 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char c0sm[];
+  unsigned char* xc = c0sm + C0G_OFF_XC;
+  float2* tab = reinterpret_cast<float2*>(c0sm + C0G_OFF_TAB);
+  bf16_t* seg = reinterpret_cast<bf16_t*>(c0sm + C0G_OFF_SEG);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, q = lane >> 4;
+  const int b = blockIdx.y, t0 = blockIdx.x * C0L_FR;
+  const int nt = min(C0L_FR, T0 - t0);
+  const bf16_t* wsrc = wav + (long)b * T + (long)t0 * stride;
+  const int nseg = (nt - 1) * stride + C0_KW;
+  for (int i = threadIdx.x; i < nseg; i += 512) seg[i] = wsrc[i];
+  for (int i = threadIdx.x; i < GT_N / 2; i += 512) reinterpret_cast<float4*>(tab)[i] = reinterpret_cast<const float4*>(gtab)[i];
+  C0U4 wf[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int c = wave * 64 + 16 * (li >> 2) + 4 * ct + (li & 3);
+    wf[ct].v = make_uint4(0, 0, 0, 0);
+    if (q == 0) wf[ct].v = *reinterpret_cast<const uint4*>(W + (long)c * C0_KW);
+    if (q == 1) wf[ct].u[0] = *reinterpret_cast<const unsigned*>(W + (long)c * C0_KW + 8);
+  }
+  float zs[16], zb[16];
+  {
+    const int c0 = wave * 64 + 16 * q;
+    C0U4 g0, g1, b0, b1;
+    g0.v = *reinterpret_cast<const uint4*>(gamma + c0); g1.v = *reinterpret_cast<const uint4*>(gamma + c0 + 8);
+    b0.v = *reinterpret_cast<const uint4*>(beta + c0); b1.v = *reinterpret_cast<const uint4*>(beta + c0 + 8);
+    const float4* sp = reinterpret_cast<const float4*>(stats + ((long)b * C + c0) * 2);  // (mean, rstd) x 16
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const C0U4& gg = e < 8 ? g0 : g1;
+      const C0U4& bb = e < 8 ? b0 : b1;
+      const int sh = 16 * (e & 1), w = (e & 7) >> 1;
+      const float gm = __uint_as_float(((gg.u[w] >> sh) & 0xffffu) << 16), bt = __uint_as_float(((bb.u[w] >> sh) & 0xffffu) << 16);
+      const float4 st2 = sp[e >> 1];
+      const float mean = (e & 1) ? st2.z : st2.x, rstd = (e & 1) ? st2.w : st2.y;
+      zs[e] = rstd * gm; zb[e] = bt - mean * rstd * gm;
+    }
+  }
+  __syncthreads();
+  {  // thread = frame: the im2col row
+    const int t = threadIdx.x;
+    const bool ok = t < nt;
+    unsigned xb[C0_KW];
+#pragma unroll
+    for (int k = 0; k < C0_KW; ++k) xb[k] = ok ? (unsigned)seg[t * stride + k] : 0u;
+    *reinterpret_cast<uint4*>(xc + t * 32) = make_uint4(xb[0] | (xb[1] << 16), xb[2] | (xb[3] << 16), xb[4] | (xb[5] << 16), xb[6] | (xb[7] << 16));
+    *reinterpret_cast<uint4*>(xc + t * 32 + 16) = make_uint4(xb[8] | (xb[9] << 16), 0u, 0u, 0u);
+  }
+  __syncthreads();
+
+  bf16_t* orow = out + ((long)b * T0 + t0) * C + wave * 64 + 16 * q;
+  const int nft = (nt + 31) >> 5;
+  for (int ft = 0; ft < nft; ++ft) {
+    const int f0 = 32 * ft + li, f1 = f0 + 16;
+    C0U4 x0, x1;
+    x0.v = make_uint4(0, 0, 0, 0); x1.v = x0.v;
+    if (q < 2) {
+      x0.v = *reinterpret_cast<const uint4*>(xc + f0 * 32 + q * 16);
+      x1.v = *reinterpret_cast<const uint4*>(xc + f1 * 32 + q * 16);
+    }
+    unsigned o0[8], o1[8];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const c0_f32x4_t zero = c0_f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const c0_f32x4_t y0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct].b, x0.b, zero, 0, 0, 0);
+      const c0_f32x4_t y1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct].b, x1.b, zero, 0, 0, 0);
+      float z[8], u[8], r[8];
+      float2 cell[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        z[i] = fmaf(y0[i], zs[4 * ct + i], zb[4 * ct + i]);
+        z[4 + i] = fmaf(y1[i], zs[4 * ct + i], zb[4 * ct + i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_fmed3f(fmaf(z[i], GT_INV_H, -GT_LO * GT_INV_H), 0.f, (float)(GT_N - 1));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cell[i] = tab[(int)u[i]];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] = fmaf(cell[i].x, z[i], cell[i].y);
+      o0[2 * ct] = pack_bf16x2(r[0], r[1]); o0[2 * ct + 1] = pack_bf16x2(r[2], r[3]);
+      o1[2 * ct] = pack_bf16x2(r[4], r[5]); o1[2 * ct + 1] = pack_bf16x2(r[6], r[7]);
+    }
+    if (f0 < nt) {
+      uint4* p = reinterpret_cast<uint4*>(orow + (long)f0 * C);
+      p[0] = make_uint4(o0[0], o0[1], o0[2], o0[3]); p[1] = make_uint4(o0[4], o0[5], o0[6], o0[7]);
+    }
+    if (f1 < nt) {
+      uint4* p = reinterpret_cast<uint4*>(orow + (long)f1 * C);
+      p[0] = make_uint4(o1[0], o1[1], o1[2], o1[3]); p[1] = make_uint4(o1[4], o1[5], o1[6], o1[7]);
+    }
+  }
+}
+
+int conv0_gn_fwd_mfma_launch(const void* wav, const void* W, const void* gamma, const void* beta, const float* stats, void* out,
+                             long T, int T0, int stride, int B, const float2* tab0, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)conv0_gn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C0G_SMEM) != hipSuccess)
+      return WL_ELAUNCH;
+    attr = true;
+  }
+  const int nchunk = (T0 + C0L_FR - 1) / C0L_FR;
+  WL_LAUNCH(conv0_gn_fwd_mfma_kernel, dim3((unsigned)nchunk, (unsigned)B), dim3(512), C0G_SMEM, st, (const bf16_t*)wav,
+            (const bf16_t*)W, (const bf16_t*)gamma, (const bf16_t*)beta, stats, (bf16_t*)out, T, T0, stride, tab0);
+  return wl_check_launch();
+}
+
+// ---- the Gram pass of the GroupNorm-mode forward on the matrix cores: Q[k] = sum_t x[s t + k], XX[j][k] = sum_t x[s t + j] x[s t + k]
+// as X'^T X' with X' = (taps, 1).  bf16 x bf16 products are exact in fp32, so this is the VALU pass's arithmetic in another
+// order.  A workgroup covers 4096 frames (the VALU form: 512, two serial LDS loops of 256 frames per sum, 62 us per step and
+// 8 x as many partial records for the statistics kernel to walk).  partx[(b * gridDim.x + blockIdx.x)][112]: Q[10], XX[10][10].
+#define C0GR_FR 4096
+__global__ __launch_bounds__(256) void conv0_gram_mfma_kernel(const bf16_t* __restrict__ wav, float* __restrict__ partx, long T,
+                                                              int T0, int stride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char c0sm[];
+  bf16_t* seg = reinterpret_cast<bf16_t*>(c0sm);
+  __shared__ float md[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, q = lane >> 4;
+  const int b = blockIdx.y, t0 = blockIdx.x * C0GR_FR;
+  const int nt = min(C0GR_FR, T0 - t0);
+  const bf16_t* wsrc = wav + (long)b * T + (long)t0 * stride;
+  const int nseg = (nt - 1) * stride + C0_KW;
+  for (int i = threadIdx.x; i < nseg; i += 256) seg[i] = wsrc[i];
+  __syncthreads();
+  c0_f32x4_t acc = c0_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nst = (nt + 31) >> 5;
+  for (int s = wave; s < nst; s += 4) {
+    C0U4 f; f.v = make_uint4(0, 0, 0, 0);
+    if (li <= C0_KW) {
+      unsigned v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int t = 32 * s + 8 * q + e;
+        v[e] = t < nt ? (li < C0_KW ? (unsigned)seg[t * stride + li] : 0x3f80u) : 0u;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f.u[e] = v[2 * e] | (v[2 * e + 1] << 16);
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b, f.b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) md[wave][(4 * q + i) * 16 + li] = acc[i];  // D[j][k]: rows j = 4 q + i, column k = li
+  __syncthreads();
+  if (threadIdx.x < 110) {
+    const int idx = threadIdx.x;
+    const int o = idx < C0_KW ? C0_KW * 16 + idx : ((idx - C0_KW) / C0_KW) * 16 + (idx - C0_KW) % C0_KW;
+    partx[((long)b * gridDim.x + blockIdx.x) * C0_NX + idx] = (md[0][o] + md[1][o]) + (md[2][o] + md[3][o]);
+  }
+}
+
+// returns the number of partial records per batch row (what conv0_stats_from_gram_kernel walks)
+int conv0_gram_mfma_launch(const void* wav, float* partx, long T, int T0, int stride, int B, hipStream_t st, int* nrec) {
+  const int nblk = (T0 + C0GR_FR - 1) / C0GR_FR;
+  const size_t smem = ((size_t)(C0GR_FR - 1) * stride + C0_KW) * 2 + 16;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)conv0_gram_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess)
+      return WL_ELAUNCH;
+    attr = true;
+  }
+  WL_LAUNCH(conv0_gram_mfma_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), smem, st, (const bf16_t*)wav, partx, T, T0, stride);
+  *nrec = nblk;
+  return wl_check_launch();
 }
 
 // red[slice][C0L_NV] (double) = sum over the workgroups slice, slice + 32, ... of their partial records

@@ -21,3 +21,11 @@ uint64_t conv0_ln_bwd_mfma_workspace_bytes(int B, int T0);
 int conv0_ln_bwd_mfma_launch(const void* wav, const void* W, const void* cbias, const void* gamma, const void* beta, const void* g,
                              void* dW, void* dcbias, void* dgamma, void* dbeta, void* workspace, long T, int T0, int stride, int B,
                              float eps, float gscale, const float2* tab1, hipStream_t st);
+// ... and the forward: gc = 128 floats of workspace (the parameters' second moments over the channels)
+int conv0_ln_fwd_mfma_launch(const void* wav, const void* W, const void* cbias, const void* gamma, const void* beta, void* out,
+                             float* gc, long T, int T0, int stride, int B, float eps, const float2* tab0, hipStream_t st);
+// GroupNorm-mode forward (apply pass) on the matrix cores; stats[B][C][2] = (mean, rstd) from the Gram pass
+int conv0_gn_fwd_mfma_launch(const void* wav, const void* W, const void* gamma, const void* beta, const float* stats, void* out,
+                             long T, int T0, int stride, int B, const float2* tab0, hipStream_t st);
+// ... and its Gram pass (bf16 waveform): partx[B][*nrec][112]
+int conv0_gram_mfma_launch(const void* wav, float* partx, long T, int T0, int stride, int B, hipStream_t st, int* nrec);

@@ -435,8 +435,11 @@ def conv0_ln_gelu_fwd(wav, W, gamma, beta, stride, eps, out_dtype, bias=None):
     Cc, _, kw = W.shape
     T0 = (T - kw) // stride + 1
     out = torch.empty((B, T0, Cc), dtype=out_dtype, device=dev)
-    check(_lib.lib().wavlm_conv0_ln_gelu_fwd(ptr(wav), dt(wav), ptr(W), ptr(bias), ptr(gamma), ptr(beta), dt(W), ptr(out),
-                                             dt(out), B, T, Cc, kw, stride, float(eps), stream()), "wavlm_conv0_ln_gelu_fwd")
+    L = _lib.lib()
+    need = L.wavlm_conv0_ln_fwd_workspace_bytes()
+    ws = workspace(dev, need)
+    check(L.wavlm_conv0_ln_gelu_fwd(ptr(wav), dt(wav), ptr(W), ptr(bias), ptr(gamma), ptr(beta), dt(W), ptr(out), dt(out), B, T,
+                                    Cc, kw, stride, float(eps), ptr(ws), need, stream()), "wavlm_conv0_ln_gelu_fwd")
     return out
 
 
