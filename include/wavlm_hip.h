@@ -110,6 +110,16 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
                         void* dr_colsum, int64_t rows, int32_t D, int32_t dtype, int32_t param_dtype, int32_t act,
                         float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float grad_scale,
                         int32_t accumulate_params, int32_t dr_incl_add, void* workspace, uint64_t ws_bytes, void* stream);
+/* The same with a segmented dx: row r of the b-th run of dx_seg_rows rows is written at row r + b * dx_seg_gap of dx (the
+ * caller zero-fills the gaps) -- the zero-padded per-utterance layout that the data-gradient GEMMs of the conv layer in
+ * front of this LayerNorm read (layer_norm extractor mode: WavLM/WavLM.py:403-418), so that no padded copy of the gradient is
+ * made.  dx_seg_rows = 0: contiguous.  D in {512, 768, 1024} only (WL_EINVAL otherwise). */
+int wavlm_layernorm_bwd_seg(const void* dy, const void* s, const float* mean, const float* rstd, const void* gamma,
+                            const void* beta, void* dx, void* dr, const void* dx_add, void* dgamma, void* dbeta,
+                            void* dr_colsum, int64_t rows, int32_t D, int32_t dtype, int32_t param_dtype, int32_t act,
+                            float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float grad_scale,
+                            int32_t accumulate_params, int32_t dr_incl_add, int32_t dx_seg_rows, int32_t dx_seg_gap,
+                            void* workspace, uint64_t ws_bytes, void* stream);
 
 /* out[c] (+)= sum over rows of x[row, c]; a row counts iff (!include || include[row]) && (!exclude || !exclude[row]).
  * Bias gradients of every nn.Linear / conv bias, and d(mask_emb) (src/fairseq/models/wavlm/wavlm.py:401). */

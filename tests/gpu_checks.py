@@ -475,6 +475,43 @@ def check_conv0_ln():
     return out
 
 
+def check_conv_ln_block():
+    """A conv block of the layer_norm extractor mode (conv -> LayerNorm over channels -> GELU, WavLM/WavLM.py:403-418) at the real
+    width: the LayerNorm's backward writes its input gradient straight into the zero-padded layout the conv's backward reads
+    (LayerNormFn grad_pad / wavlm_layernorm_bwd_seg).  Against the fp64 reference, and bit-identical to the path with the padded
+    copy (ops.LN_SEG_OK = False)."""
+    out = []
+    C = 512
+    dtype = torch.bfloat16
+    for (B, T_in, k, s_) in [(3, 101, 3, 2), (2, 64, 2, 2), (2, 37, 3, 2), (1, 200, 2, 2)]:
+        x = q(gen(B, T_in, C, seed=1), dtype)
+        W = q(gen(C, C, k, seed=2, scale=1.0 / math.sqrt(C * k)), dtype)
+        cb = q(0.1 * gen(C, seed=3), dtype)
+        g, b = q(1 + 0.1 * gen(C, seed=4), dtype), q(0.1 * gen(C, seed=5), dtype)
+        ts = [t.double().clone().requires_grad_(True) for t in (x, W, cb, g, b)]
+        yr = TF.gelu(TF.layer_norm(TF.conv1d(ts[0].transpose(1, 2), ts[1], ts[2], stride=s_).transpose(1, 2), (C,), ts[3], ts[4], 1e-5))
+        dy = q(gen(*yr.shape, seed=6), dtype)
+        gr = torch.autograd.grad(yr, ts, dy.double())
+        res = {}
+        for seg in (True, False):
+            saved = ops.LN_SEG_OK
+            ops.LN_SEG_OK = seg
+            try:
+                td = [t.to(dtype).to(DEV).requires_grad_(True) for t in (x, W, cb, g, b)]
+                v = F.ConvStackFn.apply(td[0], ((k, s_),), False, td[1], td[2])
+                y, _ = F.layer_norm(v, td[3], td[4], 1e-5, act=1, grad_pad=F.conv_grad_pad(T_in, k, s_))
+                res[seg] = (y,) + torch.autograd.grad(y, td, dy.to(dtype).to(DEV))
+            finally:
+                ops.LN_SEG_OK = saved
+        tag = f"conv+LN block B={B} T={T_in} k={k} s={s_}"
+        out.append((tag + " y", err(res[True][0], yr), TOLBF))
+        for nm, a, r in zip(("dx", "dW", "dbias", "dgamma", "dbeta"), res[True][1:], gr):
+            out.append((tag + " " + nm, err(a, r), TOLBF))
+        for nm, a, c in zip(("y", "dx", "dW", "dbias", "dgamma", "dbeta"), res[True], res[False]):
+            out.append((tag + " " + nm + " == the padded-copy path", 0.0 if torch.equal(a, c) else 1.0, 0.0))
+    return out
+
+
 def check_convstack():
     out = []
     for dtype in (torch.float32, torch.bfloat16):
@@ -1077,7 +1114,7 @@ def check_activations():
 
 
 GROUPS = {
-    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_w4": check_gemm_w4, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0, "conv0_ln": check_conv0_ln,
+    "gemm": check_gemm, "gemm_pp": check_gemm_pp, "gemm_pp3": check_gemm_pp3, "gemm_w4": check_gemm_w4, "gemm_grouped": check_gemm_grouped, "gemm_race": check_gemm_race, "layernorm": check_layernorm, "rowops": check_rowops, "conv0": check_conv0, "conv0_ln": check_conv0_ln, "conv_ln_block": check_conv_ln_block,
     "convstack": check_convstack, "attention": check_attention, "posconv": check_posconv, "gemm_colsum": check_gemm_colsum,
     "linear_ffn": check_linear_ffn, "activations": check_activations, "loss": check_loss, "adam": check_adam, "dropout_exact": check_dropout_exact,
 }

@@ -82,6 +82,9 @@ SIGNATURES = {
     "wavlm_layernorm_bwd_workspace_bytes": (c_u64, [c_i32]),
     "wavlm_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
                                     c_i32, c_i32, c_f32, c_u64, c_f32, c_u64, c_f32, c_i32, c_i32, c_vp, c_u64, c_vp]),
+    "wavlm_layernorm_bwd_seg": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
+                                        c_i32, c_i32, c_f32, c_u64, c_f32, c_u64, c_f32, c_i32, c_i32, c_i32, c_i32, c_vp, c_u64,
+                                        c_vp]),
     "wavlm_colsum_workspace_bytes": (c_u64, [c_i32]),
     "wavlm_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_u64, c_vp]),
     "wavlm_select_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),

@@ -417,11 +417,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_full_kernel(const T* __rest
     const float* __restrict__ mean_i, const float* __restrict__ rstd_i, const TP* __restrict__ gamma,
     const TP* __restrict__ beta, T* __restrict__ dx, T* __restrict__ dr, const T* __restrict__ dx_add,
     float* __restrict__ part, long rows, int act, unsigned th_in, float sc_in, unsigned long long seed_in, unsigned th_out,
-    float sc_out, unsigned long long seed_out, float grad_scale, int dr_incl_add) {
+    float sc_out, unsigned long long seed_out, float grad_scale, int dr_incl_add, int dx_tn, int dx_gap) {
   constexpr int D = VEC * 64 * NC;
   constexpr int NA = CS ? 3 : 2;
   __shared__ float red[4][NA][64 * VEC];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float ag[NC][VEC], ab[NC][VEC], gm[NC][VEC], bt[NC][VEC], ac[CS ? NC : 1][VEC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -447,8 +447,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_full_kernel(const T* __rest
     }
   };
   if (row < rows) fetch(row);
+  // dx_tn > 0: dx is written in segments of dx_tn rows with dx_gap rows between them (the zero-padded layout the conv
+  // layer's data-gradient GEMMs read: row r of segment b lands at r + b * dx_gap); scalar bookkeeping, no division per row
+  long ob = dx_tn ? row / dx_tn : 0, ot = dx_tn ? row - ob * dx_tn : 0;
   for (; row < rows; row += rstep) {
     const float mean = nmean, rstd = nrstd;
+    const long orow = row + ob * dx_gap;
+    if (dx_tn) { ot += rstep; while (ot >= dx_tn) { ot -= dx_tn; ++ob; } }
     const unsigned rw_in = th_in ? ln_drop_row(seed_in, row) : 0u, rw_out = th_out ? ln_drop_row(seed_out, row) : 0u;
     float h[NC][VEC], xh[NC][VEC], addv[HA ? NC : 1][VEC];
     float s1 = 0.f, s2 = 0.f;
@@ -479,6 +484,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_full_kernel(const T* __rest
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const long off = row * D + (lane + 64 * c) * VEC;
+      const long ooff = orow * D + (lane + 64 * c) * VEC;
       float o[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) o[e] = grad_scale * rstd * (h[c][e] - s1 - xh[c][e] * s2);  // grad_scale: input gradient only
@@ -486,12 +492,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_full_kernel(const T* __rest
         float t[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) t[e] = o[e] + addv[c][e];
-        stv<VEC>(dx + off, t);
+        stv<VEC>(dx + ooff, t);
         if (dr_incl_add) {  // the sum x + dropout(r) itself continues as the residual stream: r sees the total too
 #pragma unroll
           for (int e = 0; e < VEC; ++e) o[e] = t[e];
         }
-      } else stv<VEC>(dx + off, o);
+      } else stv<VEC>(dx + ooff, o);
       if constexpr (HD || CS) {
         if (th_in) lnf_drop_apply<VEC>(o, rw_in, cw[c], th_in, sc_in);
         if constexpr (HD) stv<VEC>(dr + off, o);
@@ -941,7 +947,21 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
                         float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float grad_scale,
                         int32_t accumulate_params, int32_t dr_incl_add, void* workspace, uint64_t ws_bytes,
                         void* stream) {
+  return wavlm_layernorm_bwd_seg(dy, s, mean, rstd, gamma, beta, dx, dr, dx_add, dgamma, dbeta, dr_colsum, rows, D, dtype,
+                                 param_dtype, act, p_in, seed_in, p_out, seed_out, grad_scale, accumulate_params, dr_incl_add,
+                                 0, 0, workspace, ws_bytes, stream);
+}
+
+int wavlm_layernorm_bwd_seg(const void* dy, const void* s, const float* mean, const float* rstd, const void* gamma,
+                            const void* beta, void* dx, void* dr, const void* dx_add, void* dgamma, void* dbeta,
+                            void* dr_colsum, int64_t rows, int32_t D, int32_t dtype, int32_t param_dtype, int32_t act,
+                            float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float grad_scale,
+                            int32_t accumulate_params, int32_t dr_incl_add, int32_t dx_seg_rows, int32_t dx_seg_gap,
+                            void* workspace, uint64_t ws_bytes, void* stream) {
   if (!dy || !s || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return WL_EINVAL;
+  if (dx_seg_rows < 0 || dx_seg_gap < 0 || (dx_seg_rows == 0 && dx_seg_gap != 0)) return WL_EINVAL;
+  // the segmented dx layout exists in the kernels of the path's own widths only
+  if (dx_seg_rows && !(ln_full_enabled() && (D == 512 || D == 768 || D == 1024))) return WL_EINVAL;
   if (rows <= 0 || D <= 0 || (D & 7) || D > LN_MAXC * 512) return WL_EINVAL;
   if (act && !beta) return WL_EINVAL;
   if (ws_bytes < wavlm_layernorm_bwd_workspace_bytes(D)) return WL_EINVAL;
@@ -956,7 +976,7 @@ int wavlm_layernorm_bwd(const void* dy, const void* s, const float* mean, const 
   if (ln_full_enabled() && (D == 512 || D == 768 || D == 1024)) {
 #define LNB_K(T, TP, VEC, NCS, CSF, HA, HD) WL_LAUNCH((layernorm_bwd_full_kernel<T, TP, VEC, NCS, CSF, HA, HD>), dim3(grid), dim3(256), 0, st, \
     (const T*)dy, (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, (const T*)dx_add, part, (long)rows, (int)act, \
-    ti, si, (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale, (int)dr_incl_add)
+    ti, si, (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale, (int)dr_incl_add, (int)dx_seg_rows, (int)dx_seg_gap)
 #define LNB_W(T, TP, CSF, HA, HD) do { if (D == 512) LNB_K(T, TP, 8, 1, CSF, HA, HD); else if (D == 768) LNB_K(T, TP, 4, 3, CSF, HA, HD); \
                                        else LNB_K(T, TP, 8, 2, CSF, HA, HD); } while (0)
 #define LNB_D(T, TP, CSF, HA) do { if (dr) LNB_W(T, TP, CSF, HA, true); else LNB_W(T, TP, CSF, HA, false); } while (0)

@@ -392,7 +392,7 @@ class LayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, r, gamma, beta, eps, act, p_in, seed_in, p_out, seed_out, grad_scale, rbias_tok=None,
-                pass_x=False, s_grad=False):
+                pass_x=False, s_grad=False, grad_pad=None):
         """s_grad (with a residual r): the second output s = x + dropout(r) is differentiable -- it IS the residual stream
         of a pre-LN block whose residual add is fused into this LayerNorm; the gradient that arrives at s is added inside
         the backward kernel and reaches r through the dropout mask as well."""
@@ -403,6 +403,10 @@ class LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(s, mean, rstd, gamma, beta)
         ctx.cfg = (act, p_in, seed_in, p_out, seed_out, grad_scale, r is not None)
         ctx.s_grad = bool(s_grad and r is not None)
+        # grad_pad = (fp, bp): x [B, T, D] is the output of a conv layer whose backward reads its incoming gradient with fp / bp
+        # zero rows around every utterance (ConvStackFn.backward) -- dx is then written in that layout at once
+        ctx.grad_pad = (tuple(grad_pad) if (grad_pad is not None and r is None and not pass_x and x.dim() == 3
+                                            and x.shape[-1] in (512, 768, 1024) and ops.LN_SEG_OK) else None)
         ctx.rbias = None
         if (rbias_tok is not None and r is not None and _sink(rbias_tok.param) is not None
                 and _sink(gamma) is not None and _sink(beta) is not None):
@@ -427,7 +431,7 @@ class LayerNormFn(torch.autograd.Function):
             if dy is None:
                 raise NotImplementedError("fused pre-LN residual: the normalised output must be used")
         if dy is None:
-            return (dx_pass,) + (None,) * 13
+            return (dx_pass,) + (None,) * 14
         if dx_pass is not None:
             dx_pass = dx_pass.contiguous()
             if dx_pass.dtype != dy.dtype:
@@ -445,7 +449,11 @@ class LayerNormFn(torch.autograd.Function):
                                                      grad_scale=grad_scale, need_dr=has_r and p_in > 0,
                                                      dgamma=sg, dbeta=sb,
                                                      dr_colsum=sc.view(-1) if sc is not None else None,
-                                                     dx_add=dx_pass, dr_incl_add=ctx.s_grad)
+                                                     dx_add=dx_pass, dr_incl_add=ctx.s_grad,
+                                                     dx_pad=ctx.grad_pad if dx_pass is None else None)
+        padded = getattr(dx, "_padded", None)
+        if padded is not None:  # handed to the conv layer's backward, which runs next (one slot: see ConvStackFn.backward)
+            _PADDED_GRAD[0] = (dx.data_ptr(), tuple(dx.shape), tuple(dx.stride()), padded, ctx.grad_pad)
         if sg is not None:
             dgamma = dbeta = None  # accumulated in place
             _sink_written(sg); _sink_written(sb)
@@ -453,15 +461,28 @@ class LayerNormFn(torch.autograd.Function):
             _sink_written(sc)
         if has_r and dr is None:
             dr = dx
-        return dx, (dr if has_r else None), dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, (dr if has_r else None), dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, *, residual=None, act=0, p_in=0.0, p_out=0.0, training=True,
-               grad_scale=1.0, residual_bias_tok=None, pass_x=False, s_grad=False):
+               grad_scale=1.0, residual_bias_tok=None, pass_x=False, s_grad=False, grad_pad=None):
     p_in = p_in if training else 0.0
     p_out = p_out if training else 0.0
     return LayerNormFn.apply(x, residual, gamma, beta, eps, act, p_in, next_seed() if p_in > 0 else 0, p_out,
-                             next_seed() if p_out > 0 else 0, grad_scale, residual_bias_tok, pass_x, s_grad)
+                             next_seed() if p_out > 0 else 0, grad_scale, residual_bias_tok, pass_x, s_grad, grad_pad)
+
+
+# The one gradient a LayerNormFn.backward has just written in a conv layer's padded layout: (data_ptr, shape, strides, the whole
+# padded buffer, (fp, bp)).  ConvStackFn.backward -- the only consumer of that gradient, and the next node autograd runs --
+# takes it if it is handed exactly that view, and empties the slot either way.
+_PADDED_GRAD = [None]
+
+
+def conv_grad_pad(T_in, k, s):
+    """(fp, bp) of the zero rows ConvStackFn.backward wants around every utterance of the gradient of a (k, s) conv layer's
+    output, for LayerNormFn's grad_pad"""
+    _, _, fp, bp = _conv_geometry(T_in, k, s)
+    return fp, bp
 
 
 # ------------------------------------------------------------------------------------- feature extractor
@@ -570,8 +591,13 @@ class ConvStackFn(torch.autograd.Function):
         k, s = specs[-1]
         T_out, J, fp, bp = _conv_geometry(xs[-1].shape[1], k, s)
         Cout = weights[-1].shape[0]
-        P, _ = ops.group_major(dy.contiguous(), us[-1] if ctx.act else None, 1, fp, fp + T_out + bp, aux_is_grad=True)
-        P = P.view(B, fp + T_out + bp, Cout)
+        slot, _PADDED_GRAD[0] = _PADDED_GRAD[0], None
+        if (slot is not None and not ctx.act and slot[0] == dy.data_ptr() and slot[1] == tuple(dy.shape)
+                and slot[2] == tuple(dy.stride()) and slot[4] == (fp, bp) and slot[3].shape == (B, fp + T_out + bp, Cout)):
+            P = slot[3]   # the LayerNorm behind this layer wrote its input gradient in the padded layout: no copy
+        else:
+            P, _ = ops.group_major(dy.contiguous(), us[-1] if ctx.act else None, 1, fp, fp + T_out + bp, aux_is_grad=True)
+            P = P.view(B, fp + T_out + bp, Cout)
         for i in range(nl - 1, -1, -1):
             k, s = specs[i]
             W = weights[i]

@@ -213,11 +213,20 @@ def layernorm_fwd(x, r, gamma, beta, eps, *, act=0, p_in=0.0, seed_in=0, p_out=0
     return y, s, mean, rstd
 
 
+# WAVLM_LN_SEG=0: LayerNorm backward never writes the padded conv-gradient layout itself (A/B: the padded copy comes back);
+# WAVLM_LN_FULL=0 (the general kernels) has no segmented form either
+LN_SEG_OK = os.environ.get("WAVLM_LN_SEG", "1") != "0" and os.environ.get("WAVLM_LN_FULL", "1") != "0"
+
+
 def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0,
-                  grad_scale=1.0, need_dr=False, dgamma=None, dbeta=None, dr_colsum=None, dx_add=None, dr_incl_add=False):
+                  grad_scale=1.0, need_dr=False, dgamma=None, dbeta=None, dr_colsum=None, dx_add=None, dr_incl_add=False,
+                  dx_pad=None):
     """returns (dx, dr, dgamma, dbeta, dr_colsum); given dgamma / dbeta (/ dr_colsum) tensors are accumulated into (+=).
     dr_colsum: True -> also return the column sums of dr (fresh tensor); a tensor -> accumulate into it (only together
-    with dgamma / dbeta tensors: the three share the accumulate flag).  dx_add: added into dx (not into dr)."""
+    with dgamma / dbeta tensors: the three share the accumulate flag).  dx_add: added into dx (not into dr).
+    dx_pad = (fp, bp) with dy of shape [B, T, D]: dx is written into a zero-padded [B, fp + T + bp, D] buffer (the layout the
+    data-gradient GEMMs of the conv layer in front of this LayerNorm read); returned dx = the [B, T, D] interior VIEW of it,
+    whose `_padded` attribute is the whole buffer."""
     dev = _dev(dy)
     _contig(dy); _contig(s)
     if dx_add is not None:
@@ -226,7 +235,21 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0,
             raise ValueError("dx_add must match dy in shape and dtype")
     D = dy.shape[-1]
     rows = dy.numel() // D
-    dx = torch.empty_like(dy)
+    seg_rows = seg_gap = 0
+    padded = None
+    if dx_pad is not None and (dx_pad[0] or dx_pad[1]):
+        fp, bp = dx_pad
+        Bn, Tn, _ = dy.shape
+        Tp = fp + Tn + bp
+        # all pads are the B + 1 equally spaced gaps of one allocation with bp spare rows in front and fp behind (see
+        # ConvStackFn.backward): one strided fill
+        big = torch.empty((Bn * Tp + fp + bp, D), dtype=dy.dtype, device=dev)
+        big.as_strided((Bn + 1, fp + bp, D), (Tp * D, D, 1)).zero_()
+        padded = big[bp:bp + Bn * Tp].view(Bn, Tp, D)
+        dx = padded[:, fp:fp + Tn]
+        seg_rows, seg_gap = Tn, fp + bp
+    else:
+        dx = torch.empty_like(dy)
     dr = torch.empty_like(dy) if need_dr else None
     acc = dgamma is not None and dbeta is not None
     if not acc:
@@ -239,10 +262,12 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, beta, *, act=0, p_in=0.0, seed_in=0,
     L = _lib.lib()
     need = L.wavlm_layernorm_bwd_workspace_bytes(D)
     ws = workspace(dev, need)
-    check(L.wavlm_layernorm_bwd(ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dr),
-                                ptr(dx_add), ptr(dgamma), ptr(dbeta), ptr(dr_colsum), rows, D, dt(dy), dt(gamma), int(act),
-                                float(p_in), int(seed_in), float(p_out), int(seed_out), float(grad_scale), int(acc),
-                                int(bool(dr_incl_add)), ptr(ws), need, stream()), "wavlm_layernorm_bwd")
+    check(L.wavlm_layernorm_bwd_seg(ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dr),
+                                    ptr(dx_add), ptr(dgamma), ptr(dbeta), ptr(dr_colsum), rows, D, dt(dy), dt(gamma), int(act),
+                                    float(p_in), int(seed_in), float(p_out), int(seed_out), float(grad_scale), int(acc),
+                                    int(bool(dr_incl_add)), seg_rows, seg_gap, ptr(ws), need, stream()), "wavlm_layernorm_bwd_seg")
+    if padded is not None:
+        dx._padded = padded
     return dx, dr, dgamma, dbeta, dr_colsum
 
 

@@ -140,7 +140,8 @@ class ConvFeatureExtractionModel(nn.Module):
                 ln = blk[2][1]
                 params = (blk[0].weight,) + ((blk[0].bias,) if has_bias else ())
                 v = F.ConvStackFn.apply(y, (spec,), False, *params)
-                y, _ = F.layer_norm(v, ln.weight, ln.bias, ln.eps, act=1)
+                # (the LayerNorm's backward writes its input gradient in the zero-padded layout this conv's backward reads)
+                y, _ = F.layer_norm(v, ln.weight, ln.bias, ln.eps, act=1, grad_pad=F.conv_grad_pad(y.shape[1], spec[0], spec[1]))
             return y
         # default mode: GroupNorm(C, C) normalises every channel over time, so block 0's Conv1d bias cancels exactly in
         # the forward and has a zero gradient; it is accepted (checkpoint compatibility) and left without a gradient
