@@ -269,15 +269,27 @@ __device__ __forceinline__ void gelu_tab_stage(const float4* g, float4* lds) {
 // vout (optional): receives the eight final values as stored (before rounding to bf16) -- fused column sums
 // aux_pre (KIND 4, optional): the eight bf16 aux values of this chunk, already loaded by the caller (gemm_pp3's epilogue
 // issues a 32-row block's six loads before it stages the block: one round trip per block instead of one per chunk)
+// bias_pre (optional): the chunk's eight bias values as floats (an LDS address); res_pre (optional): its eight bf16 residual
+// values, already loaded by the caller
+__device__ __forceinline__ void gemm_unpack8(const uint4& a, float (&u)[8]) {
+  u[0] = __uint_as_float(a.x << 16); u[1] = __uint_as_float(a.x & 0xffff0000u);
+  u[2] = __uint_as_float(a.y << 16); u[3] = __uint_as_float(a.y & 0xffff0000u);
+  u[4] = __uint_as_float(a.z << 16); u[5] = __uint_as_float(a.z & 0xffff0000u);
+  u[6] = __uint_as_float(a.w << 16); u[7] = __uint_as_float(a.w & 0xffff0000u);
+}
 template <int KIND>
 __device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi, int m, int n, const float (&acc)[8],
-                                                 const float4* tab = nullptr, float* vout = nullptr, const uint4* aux_pre = nullptr) {
+                                                 const float4* tab = nullptr, float* vout = nullptr, const uint4* aux_pre = nullptr,
+                                                 const float* bias_pre = nullptr, const uint4* res_pre = nullptr) {
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = p.alpha * acc[e];
   if (p.bias) {
     float b[8];
-    ld8_dt(p.bias, (long)zo * p.sBias_o + (long)zi * p.sBias_i + n, WL_BF16, b);
+    if (bias_pre) {
+      const float4 b0 = *reinterpret_cast<const float4*>(bias_pre), b1 = *reinterpret_cast<const float4*>(bias_pre + 4);
+      b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+    } else ld8_dt(p.bias, (long)zo * p.sBias_o + (long)zi * p.sBias_i + n, WL_BF16, b);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += b[e];
   }
@@ -294,11 +306,7 @@ __device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi,
   } else if constexpr (KIND == 4) {
     float u[8];
     if (aux_pre) {
-      const uint4 a = *aux_pre;
-      u[0] = __uint_as_float(a.x << 16); u[1] = __uint_as_float(a.x & 0xffff0000u);
-      u[2] = __uint_as_float(a.y << 16); u[3] = __uint_as_float(a.y & 0xffff0000u);
-      u[4] = __uint_as_float(a.z << 16); u[5] = __uint_as_float(a.z & 0xffff0000u);
-      u[6] = __uint_as_float(a.w << 16); u[7] = __uint_as_float(a.w & 0xffff0000u);
+      gemm_unpack8(*aux_pre, u);
     } else {
       ld8_dt(p.aux, (long)zo * p.sAux_o + (long)zi * p.sAux_i + (long)m * p.ld_aux + n, WL_BF16, u);
     }
@@ -307,7 +315,8 @@ __device__ __forceinline__ void gemm_store8_fast(const GemmP& p, int zo, int zi,
   }
   if (p.res) {  // bf16 residual (uniform branch): the gradient another consumer of the same tensor produced
     float r[8];
-    ld8_dt(p.res, (long)zo * p.sRes_o + (long)zi * p.sRes_i + (long)m * p.ld_res + n, WL_BF16, r);
+    if (res_pre) gemm_unpack8(*res_pre, r);
+    else ld8_dt(p.res, (long)zo * p.sRes_o + (long)zi * p.sRes_i + (long)m * p.ld_res + n, WL_BF16, r);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += r[e];
   }

@@ -17,6 +17,7 @@
 // q=1: A_2), so every request has >= 4 phases to land (RAW: the read follows the barrier after both groups' waits).
 // K-strided operands: A units are [64 k][64 rows] (128-B k rows, 32-B granule ^ 2*((k>>1)&1)), B is
 // [64 k][384 rows] (768-B k rows, granule ^ 2*(k&3) inside aligned groups of 8), both read with ds_read_b64_tr_b16.
+#include <type_traits>
 #include "gemm_common.hpp"
 #include <stdlib.h>
 
@@ -38,6 +39,9 @@
 #endif
 #ifndef P3_AUX_UNROLL
 #define P3_AUX_UNROLL 0
+#endif
+#ifndef P3_BIAS_PRELOAD
+#define P3_BIAS_PRELOAD 1   // the lane's three bias chunks of a tile in registers (one dependent load per CHUNK before)
 #endif
 
 __device__ __attribute__((aligned(256))) unsigned char g_pp3_zero[256];  // zero page for K positions past the end
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------
   const int mw = m0 + wm * 96, nw = n0 + wn * 96;  // wave tile origin; block i -> rows 32 i, j -> cols 32 j
+  constexpr int EPX = EP;
   if constexpr (EP == 0) {
     auto store_block = [&](const f32x16_t (&a)[3], int i) __attribute__((always_inline)) {
 #pragma unroll
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
     // GELU epilogue: chord table behind the staging slices (8 x 12800 B = 100 KiB) at 104 KiB of the 144 KiB
     const float4* tab = nullptr;
-    if constexpr (EP == 3) {
+    if constexpr (EPX == 3) {
       if (p.gtab) {
         float4* tl = reinterpret_cast<float4*>(smem + 106496);
         gelu_tab_stage(p.gtab, tl);
@@ -448,25 +453,44 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
         for (int r = 0; r < 16; ++r)
           ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] = a[j][r];
     };
-    constexpr bool CSUM = EP == 2 || EP == 4;  // fused column sums of C: plain and aux-multiplying fast epilogues
+    constexpr bool CSUM = EPX == 2 || EPX == 4;  // fused column sums of C: plain and aux-multiplying fast epilogues
     const bool csum = CSUM && p.colsum_part != nullptr;
     float cs[2] = {0.f, 0.f};
     // one 32-row block of the wave's tile out of the staging slice: six 8-wide chunks per lane.  axp (EP 4 with
     // P3_AUX_PRELOAD): the block's aux chunks, loaded by aux_load() ahead of time
     // chunk q of block i: ax = its preloaded aux values (EP 4 with P3_AUX_PRELOAD)
-    auto process_chunk = [&](int i, int q, const uint4& ax) __attribute__((always_inline)) {
+    // The tile's bias values: the wave's 96 columns once into a wave-private LDS slice (the 4 KiB between the staging slices and
+    // the table) instead of one dependent global load inside each of the tile's 18 chunks (5.5 us of a forward launch,
+    // tools/gemm_aux_bound.py); a chunk reads its eight floats back with two LDS reads.
+    float* bl = reinterpret_cast<float*>(smem + 102400) + wave * 96;
+    const bool bias_pre = P3_BIAS_PRELOAD && (EPX == 2 || EPX == 3) && p.bias != nullptr;  // (the x-aux epilogue belongs to data gradients: no bias)
+    if (bias_pre) {
+      if (lane < 12) {
+        const int n0 = nw + lane * 8;
+        float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (n0 < p.N) {
+          const uint4 raw = *reinterpret_cast<const uint4*>((const bf16_t*)p.bias + (long)zo * p.sBias_o + (long)zi * p.sBias_i + n0);
+          gemm_unpack8(raw, b8);
+        }
+        *reinterpret_cast<float4*>(bl + lane * 8) = make_float4(b8[0], b8[1], b8[2], b8[3]);
+        *reinterpret_cast<float4*>(bl + lane * 8 + 4) = make_float4(b8[4], b8[5], b8[6], b8[7]);
+      }
+    }
+    // ax: the chunk's preloaded aux values (EP 4: has_pre)
+    auto process_chunk = [&](int i, int q, const uint4& ax, auto has_pre) __attribute__((always_inline)) {
       const int id = lane + 64 * q;   // 32 rows x 12 chunks
       const int rl = id / 12, ch = id - rl * 12;
       const int mm = mw + i * 32 + rl;
       const int nn = nw + ch * 8;
+      const float* bqp = bias_pre ? bl + ch * 8 : nullptr;
       float vo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (mm < p.M && nn < p.N) {
         const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
         const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if constexpr (EP == 1) gemm_store8(p, zo, zi, z, split, mm, nn, v);
-        else if constexpr (P3_AUX_PRELOAD && EP == 4) gemm_store8_fast<4>(p, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr, &ax);
-        else gemm_store8_fast<(EP == 2 ? 0 : EP)>(p, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr);
+        if constexpr (EPX == 1) gemm_store8(p, zo, zi, z, split, mm, nn, v);
+        else if constexpr (P3_AUX_PRELOAD && EPX == 4) gemm_store8_fast<4>(p, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr, &ax, bqp);
+        else gemm_store8_fast<(EPX == 2 ? 0 : EPX)>(p, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr, nullptr, bqp);
       }
       if constexpr (CSUM) {
         if (csum) {
@@ -476,29 +500,29 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
       }
     };
     // one 32-row block of the wave's tile out of the staging slice: six 8-wide chunks per lane
-    auto process_block = [&](int i, const uint4 (&axp)[6]) __attribute__((always_inline)) {
-      if constexpr (P3_AUX_PRELOAD && P3_AUX_UNROLL && EP == 4) {
+    auto process_block = [&](int i, const uint4 (&axp)[6], auto has_pre) __attribute__((always_inline)) {
+      if constexpr (P3_AUX_PRELOAD && P3_AUX_UNROLL && EPX == 4) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) process_chunk(i, q, axp[q]);
+        for (int q = 0; q < 6; ++q) process_chunk(i, q, axp[q], has_pre);
       } else {
 #pragma unroll 1
         for (int q = 0; q < 6; ++q) {  // not unrolled: with 144 accumulator registers live the store code must stay small
           uint4 ax = axp[0];
-          if constexpr (P3_AUX_PRELOAD && EP == 4) {   // (a chain of selects: a run-time index would put the array into scratch)
+          if constexpr (decltype(has_pre)::value) {   // (a chain of selects: a run-time index would put the array into scratch)
 #pragma unroll
             for (int k = 1; k < 6; ++k) {
               ax.x = q == k ? axp[k].x : ax.x; ax.y = q == k ? axp[k].y : ax.y;
               ax.z = q == k ? axp[k].z : ax.z; ax.w = q == k ? axp[k].w : ax.w;
             }
           }
-          process_chunk(i, q, ax);
+          process_chunk(i, q, ax, has_pre);
         }
       }
       if constexpr (CSUM) {
         if (csum) gemm_colsum_block<96, EP_LD>(ep, lane, cs);
       }
     };
-    if constexpr (P3_AUX_PRELOAD && EP == 4) {
+    if constexpr (P3_AUX_PRELOAD && EPX == 4) {
       // The aux chunks (GELU' of fc1's / a conv layer's pre-activation, written a forward pass ago) travel one block ahead in two
       // register sets: with the load inside the chunk loop every chunk waited for its own round trip -- 18 dependent round trips
       // per wave and tile, 47 of the 193 us of fc2's dX launch (tools/gemm_aux_bound.py, profiles/r05/ab_gemm_aux_preload.txt).
@@ -518,23 +542,19 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(GemmP p) {
       aux_load(0, a0);
       stage_block(acc[0]);
       aux_load(1, a1);
-      process_block(0, a0);
+      process_block(0, a0, std::true_type{});
       stage_block(acc[1]);
       aux_load(2, a0);
-      process_block(1, a1);
+      process_block(1, a1, std::true_type{});
       stage_block(acc[2]);
-      process_block(2, a0);
+      process_block(2, a0, std::true_type{});
     } else {
+      // three 32-row blocks, written out: as a rolled loop over the block index (a switch selects the accumulator block) the
+      // same code ran fc1's forward launch at 131 us, written out at 127 us (profiles/r05/ab_gemm_bias_preload.txt)
       const uint4 none[6] = {};
-#pragma unroll 1
-      for (int i = 0; i < 3; ++i) {
-        switch (i) {
-          case 0: stage_block(acc[0]); break;
-          case 1: stage_block(acc[1]); break;
-          default: stage_block(acc[2]); break;
-        }
-        process_block(i, none);
-      }
+      stage_block(acc[0]); process_block(0, none, std::false_type{});
+      stage_block(acc[1]); process_block(1, none, std::false_type{});
+      stage_block(acc[2]); process_block(2, none, std::false_type{});
     }
     if constexpr (CSUM) {
       if (csum) gemm_colsum_finish<96>(p, reinterpret_cast<float*>(smem + 106496), wave, wm, lane, tm, nw, cs);
