@@ -41,6 +41,9 @@
 #include "gemm_common.hpp"
 
 #include "tile_loaders.hpp"
+#ifndef PP_BIAS_LDS
+#define PP_BIAS_LDS 1
+#endif
 #ifndef PP_AUX_PRELOAD
 #define PP_AUX_PRELOAD 1
 #endif
@@ -620,6 +623,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
     float cs[2] = {0.f, 0.f};
     // one 32-row block out of the staging slice: four 8-wide chunks per lane; axp (EP 4 with PP_AUX_PRELOAD): the block's aux
     // chunks, loaded one block ahead (see gemm_pp3.hip: P3_AUX_PRELOAD)
+#if PP_BIAS_LDS
+    // the wave's 64 bias values once per tile into a wave-private LDS slice behind the staging slices (see gemm_pp3.hip)
+    float* bl = reinterpret_cast<float*>(smem + 69632) + wave * 64;
+    const bool bias_pre = (EP == 2 || EP == 3) && P.bias != nullptr;
+    if (bias_pre) {
+      if (lane < 8) {
+        const int n0 = nw + lane * 8;
+        float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (n0 < P.N) {
+          const uint4 raw = *reinterpret_cast<const uint4*>((const bf16_t*)P.bias + (long)zo * P.sBias_o + (long)zi * P.sBias_i + n0);
+          gemm_unpack8(raw, b8);
+        }
+        *reinterpret_cast<float4*>(bl + lane * 8) = make_float4(b8[0], b8[1], b8[2], b8[3]);
+        *reinterpret_cast<float4*>(bl + lane * 8 + 4) = make_float4(b8[4], b8[5], b8[6], b8[7]);
+      }
+    }
+    const float* bqp = bias_pre ? bl + (lane & 7) * 8 : nullptr;
+#else
+    const float* bqp = nullptr;
+#endif
     auto process_block = [&](int i, const uint4 (&axp)[4]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -634,7 +657,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmP p) {
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           if constexpr (EP == 1) gemm_store8(P, zo, zi, z, split, mm, nn, v);
           else if constexpr (PP_AUX_PRELOAD && EP == 4 && !GRP) gemm_store8_fast<4>(P, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr, &axp[q]);
-          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(P, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr);
+          else gemm_store8_fast<(EP == 2 ? 0 : EP)>(P, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr, nullptr, bqp);
         }
         if constexpr (CSUM) {
           if (csum) {
