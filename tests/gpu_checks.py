@@ -428,6 +428,23 @@ def check_conv0():
             out.append((tag + " dW", err(Wd.grad, Wr2.grad), tol * 3))
             out.append((tag + " dgamma", err(gd.grad, gr2.grad), tol * 3))
             out.append((tag + " dbeta", err(bd.grad, br2.grad), tol * 3))
+    # other strides through the GroupNorm-mode kernels (the waveform segment a workgroup stages grows with the stride)
+    for st, T in ((8, 33000), (3, 9000)):
+        dtype, C, B = torch.bfloat16, 512, 2
+        wav = q(gen(B, T, seed=21), dtype)
+        W = q(gen(C, 1, 10, seed=22, scale=0.4), dtype)
+        g, b = q(1 + 0.1 * gen(C, seed=23), dtype), q(0.1 * gen(C, seed=24), dtype)
+        ts = [t.double().clone().requires_grad_(True) for t in (W, g, b)]
+        y = TF.gelu(TF.group_norm(TF.conv1d(wav.double().unsqueeze(1), ts[0], stride=st), C, ts[1], ts[2], 1e-5)).transpose(1, 2)
+        dy = q(gen(*y.shape, seed=25), dtype)
+        gr = torch.autograd.grad(y, ts, dy.double())
+        Wd, gd, bd = [t.to(dtype).to(DEV).requires_grad_(True) for t in (W, g, b)]
+        yd = F.Conv0Fn.apply(wav.to(dtype).to(DEV), Wd, gd, bd, st, 1e-5, dtype)
+        yd.backward(dy.to(dtype).to(DEV))
+        tag = f"conv0[{dtype}] stride={st} T={T}"
+        out.append((tag + " y", err(yd, y), TOLBF))
+        for nm, a, r in zip(("dW", "dgamma", "dbeta"), (Wd.grad, gd.grad, bd.grad), gr):
+            out.append((tag + " " + nm, err(a, r), TOLBF * 3))
     return out
 
 
@@ -439,7 +456,8 @@ def check_conv0_ln():
     C = 512
     for dtype in (torch.bfloat16, torch.float32):
         tol = tol_for(dtype)
-        for (B, T, boff, gs) in [(2, 16000, 0.0, 1.0), (1, 400, 0.0, 1.0), (3, 2565, 0.5, 0.1), (1, 5175, -1.0, 1.0), (2, 95, 0.0, 1.0)]:
+        for (B, T, boff, gs, st) in [(2, 16000, 0.0, 1.0, 5), (1, 400, 0.0, 1.0, 5), (3, 2565, 0.5, 0.1, 5), (1, 5175, -1.0, 1.0, 5),
+                                     (2, 95, 0.0, 1.0, 5), (2, 4106, 0.0, 1.0, 8), (1, 3001, 0.2, 1.0, 3), (2, 10, 0.0, 1.0, 5)]:
             if dtype == torch.float32 and T > 3000:
                 continue
             wav = q(gen(B, T, seed=1), dtype)
@@ -447,14 +465,14 @@ def check_conv0_ln():
             g, b = q(1 + 0.1 * gen(C, seed=3), dtype), q(0.1 * gen(C, seed=4), dtype)
             cb = q(boff + 0.2 * gen(C, seed=6), dtype)
             ts = [t.double().clone().requires_grad_(True) for t in (W, g, b, cb)]
-            y = TF.gelu(TF.layer_norm(TF.conv1d(wav.double().unsqueeze(1), ts[0], ts[3], stride=5).transpose(1, 2), (C,), ts[1], ts[2], 1e-5))
+            y = TF.gelu(TF.layer_norm(TF.conv1d(wav.double().unsqueeze(1), ts[0], ts[3], stride=st).transpose(1, 2), (C,), ts[1], ts[2], 1e-5))
             dy = q(gen(*y.shape, seed=5), dtype)
             gr = torch.autograd.grad(y, ts, dy.double() * gs)
             Wd, gd, bd, cd = [t.to(dtype).to(DEV) for t in (W, g, b, cb)]
             wd = wav.to(dtype).to(DEV)
-            yd = ops.conv0_ln_gelu_fwd(wd, Wd, gd, bd, 5, 1e-5, dtype, bias=cd)
-            dW, dg, db, dcb = ops.conv0_ln_gelu_bwd(wd, Wd, gd, bd, dy.to(dtype).to(DEV), 5, 1e-5, gscale=gs, bias=cd)
-            tag = f"conv0+LN+bias[{dtype}] B={B} T={T} off={boff}"
+            yd = ops.conv0_ln_gelu_fwd(wd, Wd, gd, bd, st, 1e-5, dtype, bias=cd)
+            dW, dg, db, dcb = ops.conv0_ln_gelu_bwd(wd, Wd, gd, bd, dy.to(dtype).to(DEV), st, 1e-5, gscale=gs, bias=cd)
+            tag = f"conv0+LN+bias[{dtype}] B={B} T={T} off={boff} stride={st}"
             out.append((tag + " y", err(yd, y), tol))
             out.append((tag + " dW", err(dW, gr[0]), tol))
             out.append((tag + " dgamma", err(dg, gr[1]), tol))
