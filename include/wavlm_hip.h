@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 19
+#define WAVLM_HIP_ABI_VERSION 20
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -450,6 +450,29 @@ int wavlm_encoder_layer_bwd(const wavlm_layer_desc* d, void* stream);
  * ------------------------------------------------------------------------------------------ */
 typedef void (*wavlm_grad_listener)(const void* base, uint64_t bytes, void* stream, void* user);
 void wavlm_dp_set_listener(wavlm_grad_listener cb, void* user);
+
+/* The transport half (ABI v20, csrc/dp_rccl.hip): one RCCL communicator per process (one process per GPU), the reference's
+ * all-reduce of the flat gradient buffer (src/fairseq/distributed/legacy_distributed_data_parallel.py:82-120,
+ * src/fairseq/distributed/utils.py:273-288) bucket by bucket, overlapped with backward:
+ *   wavlm_dp_unique_id(id128)             rank 0: a fresh ncclUniqueId (128 bytes) for the caller to hand to the other ranks
+ *                                         (over whatever it bootstraps with: MPI, a TCP store, torch.distributed)
+ *   wavlm_dp_init(rank, world, id128, average)   ncclCommInitRank on the CURRENT device + a high-priority communication
+ *                                         stream; average != 0: ncclAvg (the reference divides by the world size), else ncclSum
+ *   wavlm_dp_bucket_ready(base, count, dtype, compute_stream)   the `count` elements at `base` (WL_F32 / WL_BF16) are
+ *                                         complete in compute_stream order: all-reduced in place on the communication stream
+ *                                         behind an event on compute_stream.  Every rank reports the same buckets in the same
+ *                                         order (RCCL matches collectives by issue order).  Call it from the gradient listener.
+ *   wavlm_dp_finish(compute_stream)       compute_stream waits for every bucket reported since the last finish (before the
+ *                                         optimizer reads the gradients); no host synchronisation
+ *   wavlm_dp_destroy()
+ * RCCL is resolved at the first of these calls (the copy the process already carries, else librccl.so): libwavlm_hip.so has no
+ * link-time dependency on it.  WL_ELAUNCH (-2): RCCL missing or a HIP / RCCL call failed; WL_EINVAL (-1): bad argument, not
+ * initialised, initialised twice. */
+int wavlm_dp_unique_id(void* id128);
+int wavlm_dp_init(int32_t rank, int32_t world, const void* id128, int32_t average);
+int wavlm_dp_bucket_ready(void* base, uint64_t count, int32_t dtype, void* compute_stream);
+int wavlm_dp_finish(void* compute_stream);
+int wavlm_dp_destroy(void);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): HIP events around every wavlm_gemm launch while enabled.

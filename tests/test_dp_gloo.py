@@ -341,3 +341,83 @@ def test_in_order_issue_with_divergent_layerdrop_gloo_world8():
         p.join(timeout=60)
     for r in res:
         assert r[-1] is None and all(r[1:-1]), r
+
+
+class _RecordingTransport:
+    """stands where dp.NativeTransport (the C-ABI RCCL reducer) stands: records the protocol GradReducer drives and performs the
+    all-reduce through torch.distributed so that the results can be compared with the default transport"""
+
+    def __init__(self):
+        self.calls = []
+        self.closed = False
+
+    def bucket_ready(self, view):
+        self.calls.append(("ready", view.data_ptr(), view.numel()))
+        dist.all_reduce(view, op=dist.ReduceOp.SUM)
+
+    def finish(self):
+        self.calls.append(("finish",))
+
+    def close(self):
+        self.closed = True
+
+
+def _worker_transport(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unispeech_amd.dp import GradReducer
+    net, params, offsets, flat = _build(0)
+    tr = _RecordingTransport()
+    red = GradReducer(params, flat, offsets, bucket_bytes=1024, transport=tr)
+    assert red.comm_stream is None and red.transport is tr
+    x = torch.randn(4, 16, generator=torch.Generator().manual_seed(100 + rank))
+    refs = []
+    for r in range(world):
+        n2, p2, o2, f2 = _build(0)
+        xr = torch.randn(4, 16, generator=torch.Generator().manual_seed(100 + r))
+        n2(xr).pow(2).sum().backward()
+        refs.append(f2.clone())
+    net(x).pow(2).sum().backward()
+    red.finish()
+    ok_sum = torch.allclose(flat, refs[0] + refs[1], atol=1e-6)
+    ready = [c for c in tr.calls if c[0] == "ready"]
+    # every bucket exactly once, in bucket-index order (the order RCCL matches collectives by), each the bucket's arena range;
+    # one finish behind them
+    esz = flat.element_size()
+    want = [("ready", flat.data_ptr() + b["lo"] * esz, b["hi"] - b["lo"]) for b in red.buckets]
+    ok_proto = ready == want and tr.calls[-1] == ("finish",) and sum(c[0] == "finish" for c in tr.calls) == 1
+    # the sequence is the same on every rank
+    seqs = [None] * world
+    dist.all_gather_object(seqs, [(c[0], c[2] if len(c) > 2 else 0) for c in tr.calls])
+    ok_same = all(s == seqs[0] for s in seqs)
+    # accumulation step: nothing goes out under no_sync
+    n0 = len(tr.calls)
+    flat.zero_()
+    with red.no_sync():
+        net(x).pow(2).sum().backward()
+    ok_nosync = len(tr.calls) == n0
+    net(x).pow(2).sum().backward()
+    red.finish()
+    ok_acc = torch.allclose(flat, 2 * (refs[0] + refs[1]), atol=1e-5)
+    red.close()
+    q.put((rank, ok_sum, ok_proto, ok_same, ok_nosync, ok_acc, tr.closed))
+    dist.destroy_process_group()
+
+
+def test_reducer_drives_a_native_transport_with_the_bucket_protocol():
+    """GradReducer with a transport object (the seat of the C-ABI RCCL reducer, dp.NativeTransport / WAVLM_DP_NATIVE=1): every
+    bucket is reported once, in index order, as its arena range; one finish per step; no_sync holds everything back; close()
+    reaches the transport; results equal the torch transport's."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_transport, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert all(r[1:]), r

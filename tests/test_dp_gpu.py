@@ -122,3 +122,56 @@ def test_dp_world2_sink_gradients_sum_over_ranks(grouped):
         assert nz > 0.5, "gradient arena mostly empty"
         assert early >= nb // 2, f"only {early} of {nb} buckets were launched during backward"
         print(f"rank {rank}: {early}/{nb} buckets in flight at the end of backward, rel err {err:.2e}")
+
+
+_NATIVE_SCRIPT = r"""
+import ctypes, sys
+import torch
+sys.path.insert(0, %r)
+from unispeech_amd import _lib, ops
+L = _lib.lib()
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+ident = ctypes.create_string_buffer(128)
+assert L.wavlm_dp_bucket_ready(None, 0, 1, None) == -1            # not initialised / bad argument: WL_EINVAL, no crash
+assert L.wavlm_dp_finish(None) == -1
+rc = L.wavlm_dp_unique_id(ident)
+assert rc == 0, "RCCL could not be loaded (%%d)" %% rc
+assert any(b != 0 for b in ident.raw)
+assert L.wavlm_dp_init(0, 1, ident, 1) == 0                       # one rank, ncclAvg
+assert L.wavlm_dp_init(0, 1, ident, 1) == -1                      # one communicator per process
+# buckets of a "gradient arena" written on the compute stream, reported while later work is still queued there
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    arena = torch.zeros(3 << 20, device=dev, dtype=torch.bfloat16)
+    spin = torch.randn(4096, 4096, device=dev)
+    for _ in range(20):
+        spin = spin @ spin * 1e-4                                   # keeps the compute stream busy in front of the writes
+    arena[:1 << 20] = 1.0
+    assert L.wavlm_dp_bucket_ready(ops.ptr(arena), 1 << 20, ops.dt(arena), ops.stream()) == 0
+    arena[1 << 20:] = 2.0
+    assert L.wavlm_dp_bucket_ready(ops.ptr(arena, 1 << 20), 2 << 20, ops.dt(arena), ops.stream()) == 0
+    f32 = torch.full((1000,), 3.0, device=dev)
+    assert L.wavlm_dp_bucket_ready(ops.ptr(f32), 1000, ops.dt(f32), ops.stream()) == 0
+    assert L.wavlm_dp_finish(ops.stream()) == 0
+    total = arena.float().sum() + f32.sum()                         # ordered behind the reductions by finish()
+side.synchronize()
+want = (1 << 20) * 1.0 + (2 << 20) * 2.0 + 3000.0
+assert abs(float(total) - want) < 1e-3 * want, (float(total), want)   # world 1: sum / average = identity, in place
+assert L.wavlm_dp_finish(ops.stream()) == 0                          # nothing pending: no-op
+assert L.wavlm_dp_destroy() == 0
+assert L.wavlm_dp_destroy() == 0
+assert L.wavlm_dp_bucket_ready(ops.ptr(f32), 1000, ops.dt(f32), ops.stream()) == -1   # gone: WL_EINVAL again
+print("NATIVE_DP_OK")
+""" % (ROOT,)
+
+
+def test_c_abi_rccl_reducer_single_rank():
+    """wavlm_dp_unique_id / _init / _bucket_ready / _finish / _destroy on one GPU (an RCCL communicator of one rank): RCCL is
+    resolved at run time, buckets are reduced in place on the library's stream behind the compute stream's writes, finish()
+    orders the compute stream behind them.  In a process of its own (the communicator is process-wide)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-c", _NATIVE_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "NATIVE_DP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

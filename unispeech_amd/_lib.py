@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVLM_HIP_LIB") or os.path.join(_HERE, "lib", "libwavlm_hip.so")
 
 _lib = None
-ABI_VERSION = 19  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 20  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
 
 F32, BF16 = 0, 1
 
@@ -170,6 +170,11 @@ SIGNATURES = {
     "wavlm_encoder_layer_fwd": (c_i32, [C.POINTER(LayerDesc), c_vp]),
     "wavlm_encoder_layer_bwd": (c_i32, [C.POINTER(LayerDesc), c_vp]),
     "wavlm_dp_set_listener": (None, [c_vp, c_vp]),
+    "wavlm_dp_unique_id": (c_i32, [c_vp]),
+    "wavlm_dp_init": (c_i32, [c_i32, c_i32, c_vp, c_i32]),
+    "wavlm_dp_bucket_ready": (c_i32, [c_vp, c_u64, c_i32, c_vp]),
+    "wavlm_dp_finish": (c_i32, [c_vp]),
+    "wavlm_dp_destroy": (c_i32, []),
     "wavlm_prof_enable": (None, [c_i32]),
     "wavlm_gemm_set_variant": (None, [c_i32]),
     "wavlm_set_reserved_cus": (None, [c_i32]),

@@ -60,8 +60,55 @@ def cap_rccl_channels(world=None, log=False):
     return str(n)
 
 
+class NativeTransport:
+    """The C-ABI RCCL reducer (csrc/dp_rccl.hip: wavlm_dp_init / _bucket_ready / _finish) as the transport of GradReducer --
+    what a non-Python host would call, driven from here so that it is exercised: WAVLM_DP_NATIVE=1.  torch.distributed only
+    carries the 128-byte ncclUniqueId from rank 0 to the other ranks (the bootstrap any host has to supply).  One communicator
+    per process; buckets are all-reduced (SUM) in place on the library's own high-priority stream, each behind an event on the
+    compute stream; `finish` makes the compute stream wait for them.  No torch communication stream, no Work objects."""
+
+    def __init__(self, process_group, device):
+        import ctypes
+        from . import _lib
+        self.L = _lib.lib()
+        rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            rc = self.L.wavlm_dp_unique_id(buf)
+            if rc != 0:
+                raise RuntimeError("wavlm_dp_unique_id failed (%d): RCCL could not be loaded" % rc)
+        box = [bytes(buf.raw) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                   group=process_group)
+        self._id = ctypes.create_string_buffer(box[0], 128)
+        with torch.cuda.device(device):
+            rc = self.L.wavlm_dp_init(rank, world, self._id, 0)
+        if rc != 0:
+            raise RuntimeError("wavlm_dp_init failed (%d)" % rc)
+
+    def bucket_ready(self, view):
+        from . import ops
+        rc = self.L.wavlm_dp_bucket_ready(ops.ptr(view), view.numel(), ops.dt(view), ops.stream())
+        if rc != 0:
+            raise RuntimeError("wavlm_dp_bucket_ready failed (%d)" % rc)
+
+    def finish(self):
+        from . import ops
+        rc = self.L.wavlm_dp_finish(ops.stream())
+        if rc != 0:
+            raise RuntimeError("wavlm_dp_finish failed (%d)" % rc)
+
+    def close(self):
+        self.L.wavlm_dp_destroy()
+
+
+def native_transport_requested():
+    import os
+    return os.environ.get("WAVLM_DP_NATIVE", "0") == "1"
+
+
 class GradReducer:
-    def __init__(self, params, flat_grad, offsets, process_group=None, bucket_bytes=32 << 20):
+    def __init__(self, params, flat_grad, offsets, process_group=None, bucket_bytes=32 << 20, transport=None):
         self.params = list(params)
         self.flat_grad = flat_grad
         self.pg = process_group
@@ -69,7 +116,13 @@ class GradReducer:
         self.enabled = self.world > 1
         self.sync = True
         self.is_cuda = flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.is_cuda and self.enabled) else None
+        # transport: None = torch.distributed collectives on a side stream of torch's; an object with bucket_ready(view) /
+        # finish() / close() = the C-ABI reducer (NativeTransport; WAVLM_DP_NATIVE=1) or a test double
+        self.transport = transport
+        if self.transport is None and self.enabled and self.is_cuda and native_transport_requested():
+            self.transport = NativeTransport(process_group, flat_grad.device)
+        self.comm_stream = (torch.cuda.Stream(device=flat_grad.device)
+                            if (self.is_cuda and self.enabled and self.transport is None) else None)
         if self.is_cuda and self.enabled:
             # a persistent 256-block GEMM owns every CU (128 KiB of LDS + all VGPRs per block), so an all-reduce launched
             # on the side stream would only start at the next kernel boundary: persistent grids shrink to 256 - n and
@@ -146,6 +199,9 @@ class GradReducer:
             except ValueError:
                 pass
             self._listener = None
+        if self.transport is not None and hasattr(self.transport, "close"):
+            self.transport.close()
+            self.transport = None
         self.enabled = False
 
     def _mark(self, idx):
@@ -192,7 +248,13 @@ class GradReducer:
         bk = self.buckets[b]
         view = self.flat_grad[bk["lo"]:bk["hi"]]
         self._launched[b] = True
-        if self.comm_stream is not None:
+        if self.transport is not None:
+            if self.record_trace:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream())
+                self.trace.append((b, ev))
+            self.transport.bucket_ready(view)
+        elif self.comm_stream is not None:
             ev = torch.cuda.Event(enable_timing=self.record_trace or self.record_timing)
             ev.record(torch.cuda.current_stream())
             if self.record_trace:
@@ -235,6 +297,8 @@ class GradReducer:
             self._launch(b)
         for w in self._works:
             w.wait()
+        if self.transport is not None:
+            self.transport.finish()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._works = []
