@@ -632,6 +632,9 @@ def main():
                    "grad_arena_mib": round(opt.flat_grad.numel() * opt.flat_grad.element_size() / 2 ** 20, 1),
                    "grad_sum_dtype": str(opt.flat_grad.dtype).replace("torch.", ""),
                    "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                   # "torch": torch.distributed collectives on a side stream; "native": the library's own RCCL reducer
+                   # (wavlm_dp_*, WAVLM_DP_NATIVE=1; no per-bucket events: buckets_rank0 is null then)
+                   "transport": "native" if red.transport is not None else "torch",
                    # (rank 0's view, median of three diagnostic steps; bus_gb_s = bytes x 2 (N - 1) / N / time: compare with one
                    # xGMI link, ~153 GB/s -- the cap NCCL_MAX_NCHANNELS = reserved CUs is a hypothesis)
                    "buckets_rank0": bucket_rows, "exposed_ms_last_bucket_rank0": exposed_last,
