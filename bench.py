@@ -351,7 +351,8 @@ def run_alt_pass(args, rank, world, dev):
     torch.cuda.synchronize()
     res = {"settings": {"NCCL_MAX_NCHANNELS": None, "WAVLM_DP_RESERVED_CUS": 0}}
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        # (a child is an ordinary short run: ~1 min with start-up; the bound keeps a stuck rendezvous from holding the primary line back)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
         if rank == 0:
             if line is None:
