@@ -552,3 +552,56 @@ def test_wav2vec2_model_vs_reference_golden(golden, overrides):
     torch.manual_seed(31)
     loss2, _, _ = crit(m, sample)
     assert torch.isfinite(loss2) and abs(loss2.item() - loss.item()) < 0.2 * abs(loss.item())
+
+
+@pytest.mark.gpu
+def test_inference_keeps_parameter_derived_tensors_and_follows_parameter_changes():
+    """Under torch.no_grad() (WavLM.extract_features per call, WavLM/WavLM.py:323-375) the tensors that depend on parameters only
+    -- packed q|k|v, GEMM images of the conv-stack and pos_conv weights -- are kept between calls (functional.eval_derived).  The
+    result must be bit-identical to the uncached path, and must follow every way a parameter can change: an in-place torch
+    operation (version counter), the fused Adam step (raw pointers: functional.PARAM_EPOCH), a training step in between."""
+    import unispeech_amd.functional as F
+    from unispeech_amd.optim import FusedAdam
+    model, _sd, _cfg, crit = _base_models(2)
+    model = model.cuda().to(torch.bfloat16).eval()
+    B, T = 2, 32000
+    g = torch.Generator().manual_seed(5)
+    wav = torch.randn(B, T, generator=g).cuda().to(torch.bfloat16)
+
+    def feats(cache):
+        old = F.EVAL_CACHE
+        F.EVAL_CACHE = cache
+        try:
+            with torch.no_grad():
+                return model.extract_features(wav)[0].clone()
+        finally:
+            F.EVAL_CACHE = old
+
+    ref = feats(False)
+    a, b = feats(True), feats(True)                       # second call: everything comes from the cache
+    assert torch.equal(a, ref) and torch.equal(b, ref)
+    assert len(F._EVAL_DERIVED) > 0
+    # in-place change through torch: pos_conv's direction tensor, one conv weight, one k_proj bias
+    with torch.no_grad():
+        model.encoder.pos_conv[0].weight_v.mul_(1.5)
+        model.feature_extractor.conv_layers[2][0].weight.mul_(0.5)
+        model.encoder.layers[0].self_attn.k_proj.weight.mul_(-1.0)
+    c = feats(True)
+    assert torch.equal(c, feats(False)) and not torch.equal(c, ref)
+    # the fused optimizer moves the parameters into its arena (new addresses) and later writes them through raw pointers
+    model.train()
+    opt = FusedAdam(model.parameters(), model=model, lr=1e-2)
+    model.eval()
+    d = feats(True)
+    assert torch.equal(d, c)
+    model.train()
+    target = torch.randint(4, 504, (B, 100), generator=g).cuda()
+    sample = {"id": torch.arange(B), "net_input": {"source": wav, "padding_mask": torch.zeros(B, T, dtype=torch.bool).cuda()},
+              "target_list": [target]}
+    opt.zero_grad()
+    loss, _, _ = crit(model, sample)
+    loss.backward()
+    opt.step()
+    model.eval()
+    e = feats(True)
+    assert torch.equal(e, feats(False)) and not torch.equal(e, d)

@@ -6,6 +6,7 @@ tensors (cat / permute / contiguous of weights) and scalar bookkeeping.
 Layout: activations are channel-last [B, T, C]; the reference's [T, B, C] tensors are transposed views of these.
 """
 import os
+import weakref
 
 import torch
 
@@ -384,6 +385,37 @@ class FFNFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------- LayerNorm
+# ---- tensors derived from parameters only (packed q|k|v, GEMM images of the conv / pos_conv weights): under torch.no_grad()
+# (inference: WavLM.extract_features per call, WavLM/WavLM.py:323-375) they are kept between calls and rebuilt when a source
+# parameter changes (storage address or in-place version counter).  With autograd on nothing is cached: training changes the
+# parameters every step.  One entry per (first source parameter, tag); entries die with that parameter.
+_EVAL_DERIVED = {}   # id(first source parameter) -> (weak reference to it, {tag: (key, value)}); tensors compare elementwise, so no WeakKeyDictionary
+EVAL_CACHE = os.environ.get("WAVLM_EVAL_CACHE", "1") != "0"
+PARAM_EPOCH = [0]   # bumped by every writer that changes parameters behind torch's back (optim.FusedAdam.step)
+
+
+def eval_derived(params, tag, build, inference=None):
+    """inference: None = decide by torch.is_grad_enabled() (module code); inside a Function.forward grad mode is always off,
+    the caller passes `not any(ctx.needs_input_grad)` instead"""
+    if inference is None:
+        inference = not torch.is_grad_enabled()
+    if not inference or not EVAL_CACHE:
+        return build()
+    key = (PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+    p0 = params[0]
+    held = _EVAL_DERIVED.get(id(p0))
+    if held is None or held[0]() is not p0:
+        held = (weakref.ref(p0, lambda _r, k=id(p0): _EVAL_DERIVED.pop(k, None)), {})
+        _EVAL_DERIVED[id(p0)] = held
+    slot = held[1]
+    ent = slot.get(tag)
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    val = build()
+    slot[tag] = (key, val)
+    return val
+
+
 class LayerNormFn(torch.autograd.Function):
     """y = dropout_out(act(LN(x + dropout_in(r)))); returns (y, s) with s = the pre-norm sum (not differentiable).
     grad_scale multiplies the incoming gradient (GradMultiply at the extractor output).
@@ -553,7 +585,9 @@ class ConvStackFn(torch.autograd.Function):
         # GEMM operand images of all layers' weights in ONE launch (forward layout and, when a backward will follow, the
         # stride-phase layouts of the data-gradient GEMMs): six permute copies + twelve flip / copy pairs of torch before
         need_bwd = any(ctx.needs_input_grad)
-        wfs, wbs = ops.conv_weights_relayout([W.contiguous() for W in weights], specs, need_bwd)
+        wfs, wbs = eval_derived(list(weights), ("conv_images", tuple(specs), need_bwd),
+                                lambda: ops.conv_weights_relayout([W.contiguous() for W in weights], specs, need_bwd),
+                                inference=not need_bwd)
         for (k, s), W, bias, Wf in zip(specs, weights, biases, wfs):
             Cout, Cin, _ = W.shape
             T_in = cur.shape[1]
@@ -696,7 +730,10 @@ class PosConvFn(torch.autograd.Function):
         Cg = D // groups
         xc = x.contiguous()
         direct = POSCONV_DIRECT and ops.posconv_direct_supported(xc.dtype, Cg, K, T) and bias.dtype == xc.dtype
-        Wf, Wb, norm = ops.posconv_weight_fwd(v.contiguous(), g.contiguous().view(-1), xc.dtype, layout=1 if direct else 0)
+        Wf, Wb, norm = eval_derived([v, g], ("posconv_images", xc.dtype, direct),
+                                    lambda: ops.posconv_weight_fwd(v.contiguous(), g.contiguous().view(-1), xc.dtype,
+                                                                   layout=1 if direct else 0),
+                                    inference=not any(ctx.needs_input_grad))
         Tp = T + K - 1
         xg, _ = ops.group_major(xc, None, groups, K // 2, Tp)
         out = torch.empty_like(xc)

@@ -135,6 +135,10 @@ class FusedAdam:
                       max_norm=self.clip_norm if max_norm is None else max_norm)
         self.pending_mult = 1.0
         self._norm_fresh = False
+        # the update kernel writes the parameters through raw pointers: torch's in-place version counters do not move, so what
+        # inference keeps derived from them (functional.eval_derived) is told here
+        from . import functional
+        functional.PARAM_EPOCH[0] += 1
 
     def grad_norm(self, grad_mult=1.0):
         """host value of the (scaled) global gradient norm of the last step() / compute_grad_norm_sq() -- synchronises;

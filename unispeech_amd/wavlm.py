@@ -278,8 +278,8 @@ class MultiheadAttention(nn.Module):
             qkv = F.LinearFn.apply(x, pk[0], pk[2], pk[1], pk[3], tq, wgroup, chain)
         else:
             tq = None
-            w = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
-            b = torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0)
+            srcs = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]
+            w, b = F.eval_derived(srcs, "qkv_packed", lambda: (torch.cat(srcs[:3], dim=0), torch.cat(srcs[3:], dim=0)))
             qkv = F.LinearFn.apply(x, w, b, None, None, None, None, chain)
         if chain:
             qkv, x = qkv
