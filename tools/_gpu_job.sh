@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_model_gpu.py -q -x -k "inference_keeps or extract" 2>&1 | tail -12
-for c in 1 0 1 0; do WAVLM_EVAL_CACHE=$c python bench.py --config extract --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('cache $c', d['ms_per_step'], d['gpu_busy_ms_per_step'], d['host_enqueue_ms_per_step'])"; done
+timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu_f.txt 2>&1; tail -3 gpurun_out/pytest_gpu_f.txt
+python bench.py --config extract --steps 10 --warmup 3 2>/dev/null | tail -1 > gpurun_out/bench_extract_f.txt; cut -c1-200 gpurun_out/bench_extract_f.txt
