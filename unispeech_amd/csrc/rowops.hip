@@ -331,13 +331,24 @@ __device__ __forceinline__ void lnf_drop_apply(float (&v)[VEC], unsigned rw, con
   }
 }
 
-// HR: residual operand r present; HS: the pre-norm sum s is stored (training)
-template <typename T, typename TP, int VEC, int NC, bool HR, bool HS>
+// the GEMM epilogues' chord table of the normal CDF (gemm_bf16.hip / gemm_common.hpp: 2048 float4 = 4096 chords (slope,
+// intercept) over [-8, 8); gelu(x) = x Phi(x), |error| 1e-6): device address, filled on first use
+const float4* wl_gelu_tab4(hipStream_t st);
+#define LN_GT_CELLS 4096
+// HR: residual operand r present; HS: the pre-norm sum s is stored (training); GT: the activation is GELU by the chord table
+// staged into LDS (bf16 output only).  The erf evaluation (~18 VALU slots per element on top of LayerNorm's ~8) made the
+// LayerNorm + GELU rows of the layer_norm-mode extractor VALU-bound: 3.6 TB/s where the same kernel without it streams 4.2.
+template <typename T, typename TP, int VEC, int NC, bool HR, bool HS, bool GT = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_full_kernel(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ y,
     T* __restrict__ s, float* __restrict__ mean_o, float* __restrict__ rstd_o, const TP* __restrict__ gamma,
     const TP* __restrict__ beta, long rows, float eps, int act, unsigned th_in, float sc_in,
-    unsigned long long seed_in, unsigned th_out, float sc_out, unsigned long long seed_out) {
+    unsigned long long seed_in, unsigned th_out, float sc_out, unsigned long long seed_out, const float4* __restrict__ gtab = nullptr) {
   constexpr int D = VEC * 64 * NC;
+  __shared__ float4 gt4[GT ? LN_GT_CELLS / 2 : 1];
+  if constexpr (GT) {
+    for (int i = threadIdx.x; i < LN_GT_CELLS / 2; i += 256) gt4[i] = gtab[i];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float gm[NC][VEC], bt[NC][VEC];
 #pragma unroll
@@ -402,7 +413,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_full_kernel(const T* __rest
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float z = (v[c][e] - mean) * rstd * gm[c][e] + bt[c][e];
-        if (act) z = gelu_f(z);
+        if constexpr (GT) {
+          float u = fmaf(z, LN_GT_CELLS / 16.0f, 8.0f * (LN_GT_CELLS / 16.0f));
+          u = __builtin_amdgcn_fmed3f(u, 0.f, (float)(LN_GT_CELLS - 1));
+          const float2 t = reinterpret_cast<const float2*>(gt4)[(int)u];
+          z = z * fmaf(t.x, z, t.y);
+        } else {
+          if (act) z = gelu_f(z);
+        }
         o[e] = z;
       }
       if (th_out) lnf_drop_apply<VEC>(o, rw_out, cw[c], th_out, sc_out);
@@ -412,15 +430,23 @@ __global__ __launch_bounds__(256) void layernorm_fwd_full_kernel(const T* __rest
 }
 
 // CS: column sums of the residual-branch gradient (third partial array); HA: dx_add present; HD: dr is written
-template <typename T, typename TP, int VEC, int NC, bool CS, bool HA, bool HD>
+template <typename T, typename TP, int VEC, int NC, bool CS, bool HA, bool HD, bool GT = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_full_kernel(const T* __restrict__ dy, const T* __restrict__ s,
     const float* __restrict__ mean_i, const float* __restrict__ rstd_i, const TP* __restrict__ gamma,
     const TP* __restrict__ beta, T* __restrict__ dx, T* __restrict__ dr, const T* __restrict__ dx_add,
     float* __restrict__ part, long rows, int act, unsigned th_in, float sc_in, unsigned long long seed_in, unsigned th_out,
-    float sc_out, unsigned long long seed_out, float grad_scale, int dr_incl_add, int dx_tn, int dx_gap) {
+    float sc_out, unsigned long long seed_out, float grad_scale, int dr_incl_add, int dx_tn, int dx_gap,
+    const float4* __restrict__ gtab = nullptr) {
   constexpr int D = VEC * 64 * NC;
   constexpr int NA = CS ? 3 : 2;
   __shared__ float red[4][NA][64 * VEC];
+  // GT: gelu'(z) = Phi(z) + z phi(z) from the chord (slope ~ phi, intercept) of the normal CDF, as the GEMM epilogues do
+  // (gemm_common.hpp: |error| <= 5.7e-4 absolute, a seventh of bf16's half ulp at 1) instead of the erf evaluation
+  __shared__ float4 gt4[GT ? LN_GT_CELLS / 2 : 1];
+  if constexpr (GT) {
+    for (int i = threadIdx.x; i < LN_GT_CELLS / 2; i += 256) gt4[i] = gtab[i];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float ag[NC][VEC], ab[NC][VEC], gm[NC][VEC], bt[NC][VEC], ac[CS ? NC : 1][VEC];
 #pragma unroll
@@ -467,7 +493,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_full_kernel(const T* __rest
       for (int e = 0; e < VEC; ++e) {
         const float xhat = (sv[e] - mean) * rstd;
         float ge = g[e];
-        if (act) ge *= gelu_grad_f(xhat * gm[c][e] + bt[c][e]);
+        if constexpr (GT) {
+          const float z = fmaf(xhat, gm[c][e], bt[c][e]);
+          float u = fmaf(z, LN_GT_CELLS / 16.0f, 8.0f * (LN_GT_CELLS / 16.0f));
+          u = __builtin_amdgcn_fmed3f(u, 0.f, (float)(LN_GT_CELLS - 1));
+          const float2 t = reinterpret_cast<const float2*>(gt4)[(int)u];
+          ge *= fmaf(z, t.x, fmaf(t.x, z, t.y));
+        } else {
+          if (act) ge *= gelu_grad_f(xhat * gm[c][e] + bt[c][e]);
+        }
         ag[c][e] += ge * xhat;
         ab[c][e] += ge;
         const float hh = ge * gm[c][e];
@@ -898,6 +932,21 @@ int wavlm_layernorm_fwd(const void* x, const void* r, void* y, void* s, float* m
     long cap = cap_env > 0 ? cap_env : rows / 128;
     if (cap_env <= 0) { if (cap < 1024) cap = 1024; if (cap > 8192) cap = 8192; }
     const unsigned gridf = grid_for(rows, 4, (unsigned)cap);
+    // LayerNorm + GELU rows of the layer_norm-mode extractor (bf16, D = 512, no residual, no dropout): GELU by table
+    static const bool gt_on = !(getenv("WAVLM_LN_GELU_TAB") && getenv("WAVLM_LN_GELU_TAB")[0] == '0');
+    if (gt_on && act == 1 && dtype == WL_BF16 && param_dtype == WL_BF16 && D == 512 && !r && !(ti | to)) {
+      const float4* gtab = wl_gelu_tab4(st);
+      if (!gtab) return WL_ELAUNCH;
+      if (mean)
+        WL_LAUNCH((layernorm_fwd_full_kernel<bf16_t, bf16_t, 8, 1, false, true, true>), dim3(gridf), dim3(256), 0, st, (const bf16_t*)x,
+                  (const bf16_t*)r, (bf16_t*)y, (bf16_t*)s, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta, (long)rows, eps, (int)act,
+                  ti, si, (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, gtab);
+      else
+        WL_LAUNCH((layernorm_fwd_full_kernel<bf16_t, bf16_t, 8, 1, false, false, true>), dim3(gridf), dim3(256), 0, st, (const bf16_t*)x,
+                  (const bf16_t*)r, (bf16_t*)y, (bf16_t*)s, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta, (long)rows, eps, (int)act,
+                  ti, si, (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, gtab);
+      return wl_check_launch();
+    }
 #define LNF_K(T, TP, VEC, NCS, HR, HS) WL_LAUNCH((layernorm_fwd_full_kernel<T, TP, VEC, NCS, HR, HS>), dim3(gridf), dim3(256), 0, st, \
     (const T*)x, (const T*)r, (T*)y, (T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (long)rows, eps, (int)act, ti, si, \
     (unsigned long long)seed_in, to, so, (unsigned long long)seed_out)
@@ -973,7 +1022,17 @@ int wavlm_layernorm_bwd_seg(const void* dy, const void* s, const float* mean, co
                    (double)rows * D * es_p * (3.0 + (dx_add ? 1.0 : 0.0) + ((dr && dr != dx) ? 1.0 : 0.0)), st);
   const unsigned grid = grid_for(rows, 4, (unsigned)ln_bwd_blocks(rows));
   float* part = (float*)workspace;
-  if (ln_full_enabled() && (D == 512 || D == 768 || D == 1024)) {
+  static const bool gt_on = !(getenv("WAVLM_LN_GELU_TAB") && getenv("WAVLM_LN_GELU_TAB")[0] == '0');
+  if (ln_full_enabled() && gt_on && act == 1 && dtype == WL_BF16 && param_dtype == WL_BF16 && D == 512 && !dr && !dx_add && !dr_colsum &&
+      !(ti | to)) {
+    // LayerNorm + GELU rows of the layer_norm-mode extractor: gelu' by table
+    const float4* gtab = wl_gelu_tab4(st);
+    if (!gtab) return WL_ELAUNCH;
+    WL_LAUNCH((layernorm_bwd_full_kernel<bf16_t, bf16_t, 8, 1, false, false, false, true>), dim3(grid), dim3(256), 0, st,
+              (const bf16_t*)dy, (const bf16_t*)s, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)dx, (bf16_t*)dr,
+              (const bf16_t*)dx_add, part, (long)rows, (int)act, ti, si, (unsigned long long)seed_in, to, so,
+              (unsigned long long)seed_out, grad_scale, (int)dr_incl_add, (int)dx_seg_rows, (int)dx_seg_gap, gtab);
+  } else if (ln_full_enabled() && (D == 512 || D == 768 || D == 1024)) {
 #define LNB_K(T, TP, VEC, NCS, CSF, HA, HD) WL_LAUNCH((layernorm_bwd_full_kernel<T, TP, VEC, NCS, CSF, HA, HD>), dim3(grid), dim3(256), 0, st, \
     (const T*)dy, (const T*)s, mean, rstd, (const TP*)gamma, (const TP*)beta, (T*)dx, (T*)dr, (const T*)dx_add, part, (long)rows, (int)act, \
     ti, si, (unsigned long long)seed_in, to, so, (unsigned long long)seed_out, grad_scale, (int)dr_incl_add, (int)dx_seg_rows, (int)dx_seg_gap)
