@@ -63,3 +63,26 @@ def test_conv_grad_pad_is_the_geometry_conv_backward_uses():
     for (T_in, k, s) in [(101, 3, 2), (64, 2, 2), (37, 3, 2), (200, 2, 2), (1000, 10, 5)]:
         _, _, fp, bp = F._conv_geometry(T_in, k, s)
         assert F.conv_grad_pad(T_in, k, s) == (fp, bp)
+
+
+def test_a_function_forward_learns_from_infer_apply_whether_the_call_is_inference():
+    """inside Function.forward grad mode is always off and needs_input_grad is True for parameters even under no_grad"""
+    seen = []
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            seen.append((F._INFERENCE_CALL[0], torch.is_grad_enabled(), ctx.needs_input_grad[1]))
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            return None, None
+
+    x, w = torch.randn(3), torch.nn.Parameter(torch.randn(3))
+    F.infer_apply(Fn, x, w)
+    with torch.no_grad():
+        F.infer_apply(Fn, x, w)
+        Fn.apply(x, w)                                   # a direct apply never claims inference
+    assert seen == [(False, False, True), (True, False, True), (False, False, True)]
+    assert F._INFERENCE_CALL[0] is False

@@ -311,7 +311,10 @@ class FFNFn(torch.autograd.Function):
         n = x2d.shape[0]
         F = W1.shape[0]
         ctx.act = act
-        if act == "gelu":
+        if act == "gelu" and _INFERENCE_CALL[0] and p_act <= 0:
+            u = x2d.new_empty(0)   # inference (infer_apply under no_grad): nobody reads gelu'(pre-activation)
+            h = _linear_fwd(x2d, W1, b1, epi=3, aux=None)
+        elif act == "gelu":
             u = torch.empty((n, F), dtype=x2d.dtype, device=x2d.device)
             # without activation dropout the auxiliary tensor holds gelu'(pre-activation) (epi 3): backward multiplies
             # by it (epi 4) instead of re-evaluating erf / exp; with dropout it holds the pre-activation itself
@@ -394,9 +397,22 @@ EVAL_CACHE = os.environ.get("WAVLM_EVAL_CACHE", "1") != "0"
 PARAM_EPOCH = [0]   # bumped by every writer that changes parameters behind torch's back (optim.FusedAdam.step)
 
 
+# Inside a Function.forward grad mode is always off and ctx.needs_input_grad follows requires_grad alone (True for parameters
+# under torch.no_grad() as well): whether a call is inference is only visible at the call site.  infer_apply(Fn, ...) notes it
+# for the forward it starts; a direct Fn.apply leaves the flag False (nothing kept, backward images built): always correct.
+_INFERENCE_CALL = [False]
+
+
+def infer_apply(fn, *args):
+    _INFERENCE_CALL[0] = not torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _INFERENCE_CALL[0] = False
+
+
 def eval_derived(params, tag, build, inference=None):
-    """inference: None = decide by torch.is_grad_enabled() (module code); inside a Function.forward grad mode is always off,
-    the caller passes `not any(ctx.needs_input_grad)` instead"""
+    """inference: None = decide by torch.is_grad_enabled() (module code); a Function.forward passes _INFERENCE_CALL[0]"""
     if inference is None:
         inference = not torch.is_grad_enabled()
     if not inference or not EVAL_CACHE:
@@ -584,18 +600,20 @@ class ConvStackFn(torch.autograd.Function):
         cur = x.contiguous()
         # GEMM operand images of all layers' weights in ONE launch (forward layout and, when a backward will follow, the
         # stride-phase layouts of the data-gradient GEMMs): six permute copies + twelve flip / copy pairs of torch before
-        need_bwd = any(ctx.needs_input_grad)
+        infer = _INFERENCE_CALL[0]
+        need_bwd = any(ctx.needs_input_grad) and not infer
         wfs, wbs = eval_derived(list(weights), ("conv_images", tuple(specs), need_bwd),
                                 lambda: ops.conv_weights_relayout([W.contiguous() for W in weights], specs, need_bwd),
-                                inference=not need_bwd)
+                                inference=infer)
         for (k, s), W, bias, Wf in zip(specs, weights, biases, wfs):
             Cout, Cin, _ = W.shape
             T_in = cur.shape[1]
             T_out = (T_in - k) // s + 1
             y = torch.empty((B, T_out, Cout), dtype=cur.dtype, device=cur.device)
-            u = torch.empty_like(y) if act else y.new_empty(0)
+            keep = act and not infer   # GELU' of the pre-activation: only a backward reads it
+            u = torch.empty_like(y) if keep else y.new_empty(0)
             ops.gemm(cur, Wf, y, T_out, Cout, k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout, batch=(B, 1),
-                     sA=(T_in * Cin, 0), sC=(T_out * Cout, 0), epi=3 if act else 0, aux=u if act else None, ld_aux=Cout,
+                     sA=(T_in * Cin, 0), sC=(T_out * Cout, 0), epi=3 if act else 0, aux=u if keep else None, ld_aux=Cout,
                      sAux=(T_out * Cout, 0), bias=bias)
             xs.append(cur); us.append(u)
             cur = y
@@ -733,13 +751,14 @@ class PosConvFn(torch.autograd.Function):
         Wf, Wb, norm = eval_derived([v, g], ("posconv_images", xc.dtype, direct),
                                     lambda: ops.posconv_weight_fwd(v.contiguous(), g.contiguous().view(-1), xc.dtype,
                                                                    layout=1 if direct else 0),
-                                    inference=not any(ctx.needs_input_grad))
+                                    inference=_INFERENCE_CALL[0])
         Tp = T + K - 1
         xg, _ = ops.group_major(xc, None, groups, K // 2, Tp)
         out = torch.empty_like(xc)
-        u = torch.empty_like(xc)
+        keep = not (direct and _INFERENCE_CALL[0])   # the pre-activation: only a backward reads it
+        u = torch.empty_like(xc) if keep else xc.new_empty(0)
         if direct:  # direct convolution: the input window stays in LDS (csrc/posconv_direct.hip)
-            ops.posconv_direct(xg, Wf, out, T, K, bias=bias.contiguous(), res=xc, aux=u, gelu=True)
+            ops.posconv_direct(xg, Wf, out, T, K, bias=bias.contiguous(), res=xc, aux=u if keep else None, gelu=True)
         else:
             ops.gemm(xg, Wf, out, T, Cg, K * Cg, lda=Cg, ldb=K * Cg, ldc=D, batch=(B, groups),
                      sA=(groups * Tp * Cg, Tp * Cg), sB=(0, Cg * K * Cg), sC=(T * D, Cg), bias=bias, sBias=(0, Cg), epi=1,

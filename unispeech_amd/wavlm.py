@@ -139,7 +139,7 @@ class ConvFeatureExtractionModel(nn.Module):
             for blk, spec in zip(rest, self.specs[1:]):
                 ln = blk[2][1]
                 params = (blk[0].weight,) + ((blk[0].bias,) if has_bias else ())
-                v = F.ConvStackFn.apply(y, (spec,), False, *params)
+                v = F.infer_apply(F.ConvStackFn, y, (spec,), False, *params)
                 # (the LayerNorm's backward writes its input gradient in the zero-padded layout this conv's backward reads)
                 y, _ = F.layer_norm(v, ln.weight, ln.bias, ln.eps, act=1, grad_pad=F.conv_grad_pad(y.shape[1], spec[0], spec[1]))
             return y
@@ -149,7 +149,7 @@ class ConvFeatureExtractionModel(nn.Module):
         y = F.Conv0Fn.apply(x, conv0.weight, gn.weight, gn.bias, self.specs[0][1], gn.eps, wdt)
         params = [blk[0].weight for blk in rest] + ([blk[0].bias for blk in rest] if has_bias else [])
         if rest:
-            y = F.ConvStackFn.apply(y, tuple(self.specs[1:]), True, *params)
+            y = F.infer_apply(F.ConvStackFn, y, tuple(self.specs[1:]), True, *params)
         return y
 
 
@@ -361,7 +361,7 @@ class TransformerSentenceEncoderLayer(nn.Module):
     def _ffn(self, x, b2_tok=None, wgroup=None, chain=False):
         p = self.activation_dropout if self.training else 0.0
         fc1 = self.fc1.linear if self.activation_name == "glu" else self.fc1
-        return F.FFNFn.apply(x, fc1.weight, fc1.bias, self.fc2.weight, self.fc2.bias, p,
+        return F.infer_apply(F.FFNFn, x, fc1.weight, fc1.bias, self.fc2.weight, self.fc2.bias, p,
                              F.next_seed() if p > 0 else 0, b2_tok, wgroup, chain, self.activation_name)
 
     def forward_preln_fused(self, x, pending, key_padding_u8=None, position_table=None):
@@ -536,7 +536,7 @@ class TransformerEncoder(nn.Module):
             if not prezeroed:
                 x = F.SelectRowsFn.apply(x, None, None, kpm.view(-1))
         conv = self.pos_conv[0]
-        xs = F.PosConvFn.apply(x, conv.weight_v, conv.weight_g, conv.bias, self.conv_pos_groups)
+        xs = F.infer_apply(F.PosConvFn, x, conv.weight_v, conv.weight_g, conv.bias, self.conv_pos_groups)
         if not self.layer_norm_first:
             ln = self.layer_norm
             x, _ = F.layer_norm(xs, ln.weight, ln.bias, ln.eps, p_out=self.dropout, training=self.training)
