@@ -274,6 +274,34 @@ def live_gemm_traffic(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def secondary_lines(configs=("large", "extract"), steps=5, warmup=2):
+    """{config: {ms_per_step, value, unit, frac, ...}}: `bench.py --config <c> --steps 5 --warmup 2` in a fresh process each
+    (a crash or time-out there is reported under the config's name and cannot take the headline down)"""
+    import subprocess
+    res = {}
+    for c in configs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", c, "--steps", str(steps), "--warmup", str(warmup),
+               "--no-cpu-baseline", "--no-busy", "--no-secondary"]
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+            if line is None:
+                res[c] = {"error": "no result line (rc %d): %s" % (r.returncode, r.stderr[-300:])}
+                continue
+            d = json.loads(line)
+            roof = d.get("roofline") or {}
+            res[c] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                      "steps": d["steps"], "warmup": d["warmup"], "settle_steps": d.get("settle_steps"), "dtype": d["dtype"],
+                      "workload": d["config"]["workload"], "model_tflops": d.get("model_tflops"),
+                      "frac": roof.get("frac"), "gemm_ms_per_step": roof.get("gemm_ms_per_step"),
+                      "kernels": [{k: e.get(k) for k in ("name", "frac", "avg_call_us", "ms_per_step")} for e in roof.get("kernels", [])],
+                      "wall_s": round(time.time() - t0, 1)}
+        except Exception as e:   # noqa: BLE001 -- a side leg must not take the headline down
+            res[c] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
+
+
 def pin_rank_cores(local_rank, local_world):
     """one disjoint, contiguous block of host cores per rank (launch thread, autograd thread, HIP / RCCL helper threads of a
     rank stay off the other ranks' cores).  N = 1: nothing to separate, unless WAVLM_PIN_CORES=lo-hi asks for a block."""
@@ -392,6 +420,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settling steps after the warm-up")
     ap.add_argument("--no-busy", action="store_true", help="skip the gpu_busy / host_enqueue leg (profiler passes: only the timed steps run)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` leg (default flags, N = 1, config base: 5 steps each of --config large and --config "
+                         "extract in fresh processes on the same GPU after the headline is taken)")
     ap.add_argument("--live-traffic", action="store_true",
                     help="collect roofline.traffic live (two rocprofv3 PMC passes of this command as subprocesses, ~1 min)")
     ap.add_argument("--dp-alt-pass", choices=["auto", "always", "never"], default="auto",
@@ -452,6 +483,9 @@ def main():
         from unispeech_amd.wavlm import WavLM
         model = WavLM(extract_cfg()).to(dev).to(torch.bfloat16).eval()
         opt = net = None
+        # a frozen feature extractor: the caller states that nothing writes the parameters between calls, so the tensors derived
+        # from them alone (packed q|k|v, conv / pos_conv GEMM images) are kept (opt-in since round 6: functional.set_eval_cache)
+        WF.set_eval_cache(True)
     else:
         cfg = base_cfg(True, args.config)
         model = WavLMPretrainModel(cfg, None, [range(V)]).to(dev).to(torch.bfloat16).train()
@@ -680,20 +714,22 @@ def main():
             # HBM bytes per GEMM launch: counters cannot be read from inside the run.  --live-traffic collects them NOW with
             # two rocprofv3 PMC passes of this same command in subprocesses (FETCH_SIZE x 2 on gfx950, WRITE_SIZE, each with
             # --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes); the default reads the passes
-            # committed with this round's build (tools/gpu_pmc.sh -> profiles/r05/gemm_hbm_traffic_<config>.json) and says so
+            # committed with the latest round's build (tools/gpu_pmc.sh -> profiles/rNN/gemm_hbm_traffic_<config>.json) and says so
             traffic, traffic_src, traffic_launches = None, None, None
             if args.live_traffic and world == 1:
                 traffic, traffic_src, traffic_launches = live_gemm_traffic(args)
             if traffic is None and args.batch == BATCH_PER_GPU:
                 # the passes committed with the round's build, per config (tools/gpu_pmc.sh -> gemm_hbm_traffic_<config>.json)
-                tj = os.path.join(ROOT, "profiles", "r05", "gemm_hbm_traffic_%s.json" % args.config)
+                import glob
+                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "gemm_hbm_traffic_%s.json" % args.config)))
+                tj = cands[-1] if cands else ""
                 if os.path.exists(tj):
                     try:
                         tjd = json.load(open(tj))
                         traffic = round(tjd["gemm_hbm_bytes_per_launch"])
                         traffic_launches = tjd["gemm_launches_per_step"]
-                        traffic_src = "profiles/r05/gemm_hbm_traffic_%s.json (committed rocprofv3 PMC passes of this " \
-                                      "command, not this run; `bench.py --live-traffic` collects them live)" % args.config
+                        traffic_src = "%s (committed rocprofv3 PMC passes of this command, not this run; `bench.py " \
+                                      "--live-traffic` collects them live)" % os.path.relpath(tj, ROOT)
                     except Exception:
                         traffic = None
             roof = {"bound": "mfma",
@@ -754,10 +790,13 @@ def main():
                                   / (ms_per_step * 1e-3) / 1e12, 1),
         }
         if extract:
-            out["config"].update(dropout=0.0, attention_dropout=0.0, optimizer=None, mask_prob=0.0)
+            out["config"].update(dropout=0.0, attention_dropout=0.0, optimizer=None, mask_prob=0.0, eval_cache=True)
             out.pop("final_loss")
             out["mean_abs_feature"] = final_loss
         if dp_info is not None:
+            # what identifies the run as N ranks on N devices over RCCL, at the top level where a SCALE parser looks first
+            out.update(ranks_seen=dp_info["ranks_seen"], distinct_devices=dp_info["distinct_devices"],
+                       rccl_version=dp_info["rccl_version"], dist_backend=dp_info["backend"], dp_transport=dp_info["transport"])
             a_ = dp_info.get("alt_pass")
             if a_ and a_.get("value"):
                 dp_info["alt_pass_faster_than_default"] = bool(a_["value"] > 1.01 * value)
@@ -768,6 +807,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_cpu_baseline and extract:
             out["cpu_baseline"] = cpu_baseline_extract()
+        if (world == 1 and args.config == "base" and args.batch == BATCH_PER_GPU and not args.no_secondary
+                and args.reserved_cus < 0):
+            # the driver only ever runs the default command, so two of the five BASELINE configs would never get a
+            # driver-observed number: the headline is complete at this point (nothing below touches its timed region); the
+            # model and its arenas are released and the other configs run as ordinary short bench.py runs on the same GPU
+            del sample, wav, crit, net, opt, model
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_lines()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -112,3 +112,12 @@ def test_stored_probability_buffer_size_is_a_host_function():
     assert L.wavlm_attn_fused_pstore_bytes(1, 16, 1024) > 0
     assert L.wavlm_attn_fused_pstore_bytes(1, 16, 1025) == 0
     assert L.wavlm_attn_fused_pstore_bytes(0, 1, 1) == 0
+
+
+def test_product_library_is_not_the_lab_build():
+    """`wavlm_lab_build` exists only under -DWAVLM_EXPERIMENTAL (tools/probe/build_probe.py lab): ops.lab_build() asks the loaded
+    library, so Python's slab count for grouped weight gradients always equals csrc/layer.hip's"""
+    import ctypes
+    from unispeech_amd import _lib
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    assert not hasattr(h, "wavlm_lab_build")

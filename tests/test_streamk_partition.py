@@ -72,9 +72,14 @@ def test_exact_fit_has_no_plan():
 def test_grouped_slabs(monkeypatch):
     monkeypatch.delenv("WAVLM_WGRAD_SPLIT", raising=False)
     monkeypatch.setenv("WAVLM_WGRAD_STREAMK", "1")
-    monkeypatch.delenv("WAVLM_HIP_LIB", raising=False)
+    monkeypatch.setattr(ops, "lab_build", lambda: False)
     assert ops.grouped_slabs(108, 375, 256) == 2     # the product library has no balanced launch: the switch alone does nothing
-    monkeypatch.setenv("WAVLM_HIP_LIB", "tools/probe/lib/libwavlm_hip_lab.so")   # (the lab library, round 5)
+    # pointing WAVLM_HIP_LIB at a PRODUCT build elsewhere must not change that (the capability is asked of the loaded
+    # library -- the lab build alone exports `wavlm_lab_build` --, not inferred from the variable)
+    monkeypatch.setenv("WAVLM_HIP_LIB", "/somewhere/else/libwavlm_hip.so")
+    assert ops.grouped_slabs(108, 375, 256) == 2
+    monkeypatch.delenv("WAVLM_HIP_LIB")
+    monkeypatch.setattr(ops, "lab_build", lambda: True)   # (the lab library, round 5)
     assert ops.grouped_slabs(108, 375, 256) == 3     # Base: all four weight gradients of a block: 2 main splits + the tail
     assert ops.grouped_slabs(64, 500, 256) == 5      # Large: one more than the one-round split (used once CUs are reserved)
     assert ops.grouped_slabs(9, 16, 256) == 2        # too little work to balance: the one-round split

@@ -143,6 +143,11 @@ int grouped_split(long tiles, long ktiles) {
 }
 // `split_k` of a grouped launch's members = slabs per member: the one-round split; the balanced launch (gemm_common.hpp:
 // gemm_sk_plan, WAVLM_WGRAD_STREAMK=1) needs one more (== ops.grouped_slabs)
+#if defined(WAVLM_EXPERIMENTAL)
+// exported by the lab library ONLY: how ops.grouped_slabs learns that the balanced launch exists in the library it loaded
+// (it used to infer it from WAVLM_HIP_LIB being set, which is also how one points at a product build elsewhere)
+extern "C" int wavlm_lab_build(void) { return 1; }
+#endif
 int grouped_slabs(long tiles, long ktiles) {
 #if defined(WAVLM_EXPERIMENTAL)   // (the balanced launch exists only in the lab library)
   static const bool sk = env_int("WAVLM_WGRAD_STREAMK", 0) != 0 && env_int("WAVLM_WGRAD_SPLIT", 0) <= 0;

@@ -181,6 +181,20 @@ def _w2v_classes():
     return W2VModel, W2VCriterion, W2VCfg, W2VCritCfg
 
 
+def _invalidate_on_step(opt):
+    from . import functional
+    inner = opt.step
+
+    def step(*a, **k):
+        try:
+            return inner(*a, **k)
+        finally:
+            functional.invalidate_derived()
+
+    opt.step = step
+    return opt
+
+
 def register(override: bool = False, fp16_as_bf16=None):
     """Call once per mode (importing the package via --user-dir does the default one).  Returns (model_cls,
     criterion_cls).  override=False registers the `*_mi355x` names; override=True ALSO replaces the built-in
@@ -239,7 +253,9 @@ def register(override: bool = False, fp16_as_bf16=None):
                 low = getattr(cfg.common, "bf16", False) or (getattr(cfg.common, "fp16", False) and precision.fp16_as_bf16())
                 if low and oname in ("adam", "adam_mi355x"):
                     return FP16Standin.build_optimizer(cfg, params, **kwargs)
-                return orig_fp16.build_optimizer(cfg, params, **kwargs)
+                # the reference's optimizers write parameters through `p.data` (fp16_optimizer.py:155-165, optim/adam.py:172-226):
+                # no version counter moves, so what an opted-in inference cache keeps is dropped after every update
+                return _invalidate_on_step(orig_fp16.build_optimizer(cfg, params, **kwargs))
 
         from . import dp
 

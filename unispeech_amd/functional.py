@@ -6,6 +6,7 @@ tensors (cat / permute / contiguous of weights) and scalar bookkeeping.
 Layout: activations are channel-last [B, T, C]; the reference's [T, B, C] tensors are transposed views of these.
 """
 import os
+import threading
 import weakref
 
 import torch
@@ -64,6 +65,7 @@ _SINK_USES = {}      # arena slice (data_ptr) -> forward uses not yet matched by
 def reset_sink_uses():
     """called by the optimizer's zero_grad(): forwards whose backward never ran must not leave counts behind"""
     _SINK_USES.clear()
+    _PADDED_GRAD[0] = None   # (a LayerNorm backward whose conv layer's backward never ran must not keep ~1 GB alive)
 
 
 def _sink_use(p, explicit=None):
@@ -389,18 +391,71 @@ class FFNFn(torch.autograd.Function):
 
 # --------------------------------------------------------------------------------------------- LayerNorm
 # ---- tensors derived from parameters only (packed q|k|v, GEMM images of the conv / pos_conv weights): under torch.no_grad()
-# (inference: WavLM.extract_features per call, WavLM/WavLM.py:323-375) they are kept between calls and rebuilt when a source
-# parameter changes (storage address or in-place version counter).  With autograd on nothing is cached: training changes the
-# parameters every step.  One entry per (first source parameter, tag); entries die with that parameter.
+# (inference: WavLM.extract_features per call, WavLM/WavLM.py:323-375) they MAY be kept between calls and rebuilt when a source
+# parameter changes.  What the key can see: the storage address, torch's in-place version counter and PARAM_EPOCH (bumped by
+# invalidate_derived()).  What it CANNOT see: a write through `p.data` (a fresh alias with a version counter of its own) --
+# which is exactly how the reference's optimizers update parameters (optim/adam.py:172-226 `p.data.addcdiv_`,
+# fp16_optimizer.py:155-165 `p.data.copy_`, nag.py) and how EMA / teacher copies are usually maintained.  Therefore the cache
+# is OPT-IN (round 6; it was on by default in round 5 and served stale validation passes after such an update):
+#   * set_eval_cache(True) / `with frozen_parameters():` / WAVLM_EVAL_CACHE=1 -- the caller states that between two inference
+#     calls parameters change only through torch in-place ops on the parameter itself, this package's writers (FusedAdam,
+#     load_state_dict hooks, the fairseq plugin's optimizer wrappers: all call invalidate_derived()) or not at all;
+#   * anything else that writes through `.data` / raw pointers calls invalidate_derived() itself.
+# Worth 2 % of an extract_features call (9.37 against 9.55 ms, profiles/r05): a frozen feature extractor opts in, training
+# with periodic validation does not need to.  With autograd on nothing is ever cached.  One entry per (first source parameter,
+# tag); entries die with that parameter.
 _EVAL_DERIVED = {}   # id(first source parameter) -> (weak reference to it, {tag: (key, value)}); tensors compare elementwise, so no WeakKeyDictionary
-EVAL_CACHE = os.environ.get("WAVLM_EVAL_CACHE", "1") != "0"
-PARAM_EPOCH = [0]   # bumped by every writer that changes parameters behind torch's back (optim.FusedAdam.step)
+EVAL_CACHE = os.environ.get("WAVLM_EVAL_CACHE", "0") == "1"
+PARAM_EPOCH = [0]   # bumped by invalidate_derived(): every writer that changes parameters behind torch's back
+
+
+def invalidate_derived():
+    """every arena- / pointer- / `.data`-level parameter writer calls this (FusedAdam.step / load_state_dict / master sync,
+    the fairseq plugin's optimizer wrappers, module load_state_dict and train() / eval() transitions)"""
+    PARAM_EPOCH[0] += 1
+
+
+def set_eval_cache(on):
+    """opt into (or out of) keeping parameter-derived tensors between inference calls; returns the previous setting"""
+    global EVAL_CACHE
+    old, EVAL_CACHE = EVAL_CACHE, bool(on)
+    if not on:
+        _EVAL_DERIVED.clear()
+    return old
+
+
+class frozen_parameters:
+    """`with frozen_parameters(): feats = model.extract_features(wav)` -- the cache is on inside and emptied of nothing on
+    exit (entries stay valid for the next block as long as the keys match; invalidate_derived() drops them all)"""
+
+    def __enter__(self):
+        self._old = set_eval_cache(True)
+        return self
+
+    def __exit__(self, *exc):
+        global EVAL_CACHE
+        EVAL_CACHE = self._old
+        return False
 
 
 # Inside a Function.forward grad mode is always off and ctx.needs_input_grad follows requires_grad alone (True for parameters
 # under torch.no_grad() as well): whether a call is inference is only visible at the call site.  infer_apply(Fn, ...) notes it
 # for the forward it starts; a direct Fn.apply leaves the flag False (nothing kept, backward images built): always correct.
-_INFERENCE_CALL = [False]
+# Thread-local: a no_grad evaluation thread beside a training thread (or torch.nn.DataParallel's replicas) must not make a
+# training forward skip the stores its backward reads.
+class _InferenceFlag(threading.local):
+    def __init__(self):
+        self.on = False
+
+    # list-style access kept for the Function.forward bodies and the tests: _INFERENCE_CALL[0]
+    def __getitem__(self, i):
+        return self.on
+
+    def __setitem__(self, i, v):
+        self.on = bool(v)
+
+
+_INFERENCE_CALL = _InferenceFlag()
 
 
 def infer_apply(fn, *args):
@@ -500,7 +555,7 @@ class LayerNormFn(torch.autograd.Function):
                                                      dx_add=dx_pass, dr_incl_add=ctx.s_grad,
                                                      dx_pad=ctx.grad_pad if dx_pass is None else None)
         padded = getattr(dx, "_padded", None)
-        if padded is not None:  # handed to the conv layer's backward, which runs next (one slot: see ConvStackFn.backward)
+        if padded is not None and ctx.needs_input_grad[0]:  # handed to the conv layer's backward, which runs next (one slot: see ConvStackFn.backward)
             _PADDED_GRAD[0] = (dx.data_ptr(), tuple(dx.shape), tuple(dx.stride()), padded, ctx.grad_pad)
         if sg is not None:
             dgamma = dbeta = None  # accumulated in place

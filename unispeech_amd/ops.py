@@ -165,15 +165,22 @@ def grid_blocks():
     return 256 - get_reserved_cus()
 
 
+def lab_build():
+    """the loaded library is the lab build (tools/probe/build_probe.py lab: -DWAVLM_EXPERIMENTAL): it alone exports
+    `wavlm_lab_build`, and it alone carries the balanced grouped launch -- asked of the library itself, so that the slab count
+    chosen here always equals csrc/layer.hip: grouped_slabs of the same library"""
+    return hasattr(_lib.lib(), "wavlm_lab_build")
+
+
 def grouped_slabs(tiles, ktiles, grid=None):
     """`split_k` of the members of a grouped weight-gradient launch = fp32 slabs each member's workspace holds: the one-round
-    split.  Lab library only (WAVLM_HIP_LIB = tools/probe/lib/libwavlm_hip_lab.so) with WAVLM_WGRAD_STREAMK=1: one more, so that
+    split.  Lab library only (lab_build(): WAVLM_HIP_LIB = tools/probe/lib/libwavlm_hip_lab.so) with WAVLM_WGRAD_STREAMK=1: one more, so that
     the library can hand the CUs that split leaves idle (Base: 108 tiles x 2 = 216 of 256) the K tail of every tile
     (csrc/gemm_common.hpp: gemm_sk_plan) -- measured neutral (profiles/r04/ab_wgrad_balanced_*.txt: the launch is not bound by
     how many CUs take part), so libwavlm_hip.so does not carry that path."""
     grid = grid or grid_blocks()
     split = max(2, grouped_split(tiles, ktiles, grid))
-    if (os.environ.get("WAVLM_WGRAD_STREAMK", "0") == "1" and os.environ.get("WAVLM_HIP_LIB") and not os.environ.get("WAVLM_WGRAD_SPLIT")
+    if (os.environ.get("WAVLM_WGRAD_STREAMK", "0") == "1" and lab_build() and not os.environ.get("WAVLM_WGRAD_SPLIT")
             and tiles < grid and tiles * ktiles >= 8 * grid):
         return max(split, grid // tiles + 1)
     return split

@@ -137,8 +137,13 @@ class FusedAdam:
         self._norm_fresh = False
         # the update kernel writes the parameters through raw pointers: torch's in-place version counters do not move, so what
         # inference keeps derived from them (functional.eval_derived) is told here
+        self._params_written()
+
+    @staticmethod
+    def _params_written():
+        """every method that writes the parameters through the arena (views' version counters do not move) says so here"""
         from . import functional
-        functional.PARAM_EPOCH[0] += 1
+        functional.invalidate_derived()
 
     def grad_norm(self, grad_mult=1.0):
         """host value of the (scaled) global gradient norm of the last step() / compute_grad_norm_sq() -- synchronises;
@@ -195,6 +200,7 @@ class FusedAdam:
                     dst[o:o + sk].copy_(sd[key][so:so + sk])
         if self.lowp:
             self.flat_param.copy_(self.master)
+        self._params_written()   # (fp32 arenas too: master IS flat_param there and was just overwritten)
 
     def fairseq_state_dict(self):
         """Per-parameter state in the shape torch.optim / fairseq's Adam checkpoint it (optim/adam.py:176-195:

@@ -95,7 +95,23 @@ def init_bert_params(module):
 
 
 # ------------------------------------------------------------------------------------------ feature extractor
-class ConvFeatureExtractionModel(nn.Module):
+class _DerivedOwner:
+    """mixin of the modules whose inference path keeps tensors derived from their parameters (functional.eval_derived, opt-in):
+    every train() / eval() transition and every state-dict load drops what was kept.  The reference's optimizers write
+    parameters through `p.data` (optim/adam.py:172-226, fp16_optimizer.py:155-165), which no version counter records; the
+    Trainer calls model.train() before every update and model.eval() before every validation pass (trainer.py:697, 907), so a
+    validation pass never sees images of the weights of an earlier step."""
+
+    def train(self, mode=True):
+        F.invalidate_derived()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        F.invalidate_derived()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+
+class ConvFeatureExtractionModel(_DerivedOwner, nn.Module):
     """7 x {Conv1d(no bias) -> [GroupNorm on block 0 | LayerNorm every block] -> GELU}
     (WavLM/WavLM.py:378-504, conv_type 'default').  State-dict keys: conv_layers.{i}.0.weight,
     conv_layers.0.2.{weight,bias} (GroupNorm) or conv_layers.{i}.2.1.{weight,bias} (layer_norm mode)."""
@@ -154,7 +170,7 @@ class ConvFeatureExtractionModel(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------------- attention
-class MultiheadAttention(nn.Module):
+class MultiheadAttention(_DerivedOwner, nn.Module):
     """Self-attention with the gated relative position bias (WavLM/modules.py:303-563, the 'fast path' that all
     WavLM checkpoints were trained with).  Submodule names / order follow the reference so state dicts and seeded
     initialisation line up."""
@@ -453,7 +469,7 @@ class TransformerSentenceEncoderLayer(nn.Module):
         return (x.transpose(0, 1) if tbc else x), None, position_table
 
 
-class TransformerEncoder(nn.Module):
+class TransformerEncoder(_DerivedOwner, nn.Module):
     """pos_conv + N layers (WavLM/WavLM.py:507-612; fairseq twin src/fairseq/models/wavlm/wavlm.py:630-754)"""
 
     def __init__(self, args):
