@@ -176,7 +176,7 @@ def test_large_gradients_at_bench_batch_vs_fp32_hip_mode():
     (l32, s32, g32), (l16, s16, g16) = got[torch.float32], got[torch.bfloat16]
     assert s16 == s32
     rel = abs(l16 - l32) / abs(l32)
-    bad, rep = compare_gradients(g16, g32)
+    bad, rep = compare_gradients(g16, g32, max_tol=1e-1)   # (max-abs: see test_bf16_gradients_at_bench_batch_vs_fp32_hip_mode)
     msg = "Large 4L, 32 x 20 s (T'=999), every gradient bf16 (benchmarked path) vs fp32-HIP mode: loss %.3f vs %.3f (rel %.2e)\n  %s" % (
         l16, l32, rel, rep)
     print(msg)
