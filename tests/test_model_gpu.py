@@ -615,6 +615,9 @@ def test_inference_keeps_parameter_derived_tensors_and_follows_parameter_changes
         model.encoder.layers[1].self_attn.q_proj.weight.data.mul_(0.25)
         after = model.extract_features(wav)[0].clone()
     assert not torch.equal(before, after)
+    stale = feats(True)                       # opted in WITHOUT telling: the images kept by the calls above are served -- the
+    assert torch.equal(stale, before)         # hazard the default avoids (and why the opt-in is the caller's statement)
+    F.invalidate_derived()                    # the `.data` writer's duty under the opt-in
     f0 = feats(True)
     assert torch.equal(f0, after)
     model.feature_extractor.conv_layers[3][0].weight.data.mul_(0.5)

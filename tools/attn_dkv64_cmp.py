@@ -1,0 +1,58 @@
+"""The 64-keys-per-wave dK/dV kernel (WAVLM_ATTN_DKV64, default on) against the 32-keys-per-wave kernel of rounds 1-5 on the
+step's shapes: same formulas and rounding points, so dqkv / dbias must be BIT-IDENTICAL (dq and dgate / dtab come from the dQ
+kernel, which both paths share).  The switch is read once per process: this script re-runs itself.
+usage: python tools/attn_dkv64_cmp.py            # compares, prints one line per case"""
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CASES = [(32, 749, 12, 0.1, False), (4, 999, 16, 0.1, False), (2, 300, 2, 0.25, True), (3, 1000, 2, 0.0, True), (1, 63, 1, 0.1, False),
+         (2, 257, 3, 0.1, True)]
+
+
+def run(path):
+    from unispeech_amd import ops
+    out = {}
+    for ci, (B, T, H, p, pad) in enumerate(CASES):
+        g = torch.Generator().manual_seed(100 + ci)
+        D = 64 * H
+        qkv = (0.5 * torch.randn(B, T, 3 * D, generator=g)).to(torch.bfloat16).cuda()
+        gate = (1 + 0.5 * torch.rand(B, H, T, generator=g)).cuda()
+        tab = (0.5 * torch.randn(H, 2 * T - 1, generator=g)).cuda()
+        dO = torch.randn(B, T, D, generator=g).to(torch.bfloat16).cuda()
+        kpm = None
+        if pad:
+            kpm = torch.zeros(B, T, dtype=torch.uint8)
+            kpm[B - 1, T - min(T // 3, 100):] = 1
+            kpm = kpm.cuda()
+        O, lse, _ = ops.attn_fused_fwd(qkv, gate, tab, kpm, H, 0.125, p, 4242 + ci)
+        dbias = torch.zeros(3 * D, dtype=torch.float32, device="cuda")
+        res = ops.attn_fused_bwd(qkv, O, dO, lse, gate, tab, kpm, H, 0.125, p, 4242 + ci, dbias=dbias)
+        torch.cuda.synchronize()
+        out[ci] = [t.detach().cpu() for t in res if torch.is_tensor(t)] + [dbias.cpu()]
+    torch.save(out, path)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        run(sys.argv[1])
+        sys.exit(0)
+    paths = {}
+    for v in ("1", "0"):
+        paths[v] = "/tmp/attn_dkv64_%s.pt" % v
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), paths[v]], env=dict(os.environ, WAVLM_ATTN_DKV64=v))
+    a, b = torch.load(paths["1"]), torch.load(paths["0"])
+    bad = 0
+    for ci, case in enumerate(CASES):
+        worst = 0.0
+        same = True
+        for x, y in zip(a[ci], b[ci]):
+            same = same and torch.equal(x, y)
+            worst = max(worst, (x.float() - y.float()).abs().max().item() / (y.float().abs().max().item() + 1e-30))
+        print("B=%d T=%d H=%d p=%.2f pad=%s: %s (max rel diff %.2e)" % (*case, "bit-identical" if same else "DIFFERENT", worst))
+        bad += not same
+    sys.exit(1 if bad else 0)

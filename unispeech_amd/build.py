@@ -16,10 +16,10 @@ OBJ_DIR = os.path.join(HERE, "_build")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwavlm_hip.so")
 ARCH = "gfx950"
-SOURCES = ["layer.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_w4.hip", "gemm_pp3.hip", "gemm_f32.hip", "rowops.hip", "conv0.hip", "conv0_bwd_mfma.hip", "attn.hip", "attn_fused.hip", "attn_fused_dkv.hip", "posconv.hip", "posconv_direct.hip", "loss.hip", "vq.hip", "mixing.hip", "dp_rccl.hip",
+SOURCES = ["layer.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_w4.hip", "gemm_pp3.hip", "gemm_f32.hip", "rowops.hip", "conv0.hip", "conv0_bwd_mfma.hip", "attn.hip", "attn_fused.hip", "attn_fused_dkv.hip", "attn_fused_dkv64.hip", "posconv.hip", "posconv_direct.hip", "loss.hip", "vq.hip", "mixing.hip", "dp_rccl.hip",
            "optim.hip"]
 # per-file extra flags (see the headers of those files)
-EXTRA_FLAGS = {"attn_fused_dkv.hip": ["-fno-slp-vectorize"], "conv0_bwd_mfma.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"attn_fused_dkv.hip": ["-fno-slp-vectorize"], "attn_fused_dkv64.hip": ["-fno-slp-vectorize"], "conv0_bwd_mfma.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm", "-I", INCLUDE]
 
 

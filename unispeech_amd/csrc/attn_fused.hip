@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   }
   dl = wl_sum_xor32(dl);
   const float dls = dl * p.inv_sc;
+  const float ndls = -dls;
   for (int d = threadIdx.x; d < p.Ltab; d += 256) tabs[d] = (p.tab && d < L) ? p.tab[(long)h * L + d] : 0.f;
   if constexpr (!SP) {
     for (int j = threadIdx.x; j < p.Tkb; j += 256)
@@ -490,6 +491,15 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   f32x2_t dg2 = f32x2_t{0.f, 0.f};
 #endif
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
+  // dropout decisions of this lane's row as bit words for the 64-keys-per-wave dK/dV kernel (attn_fused.hpp: dbits): one
+  // v_addc per element while the decision sits in VCC anyway; per tile two words (32-key blocks f = 0, 1), lanes 0..31 end up
+  // with word 0 and lanes 32..63 with word 1 of the row: one store per tile, issued at the top of the next tile
+  unsigned bacc0 = 0, bacc1 = 0, pend_bits = 0;
+  int pend_bits_jt = -1;
+  unsigned* dbp = nullptr;
+  const unsigned thsv = (unsigned)p.ths;
+  if constexpr (DROP && !SP)
+    if (p.dbits) dbp = p.dbits + ((long)bh * p.db_nkb + hi) * p.db_Tq + fa_bitrow(i);
 
   // SP: fragments and running maxima travel TWO tiles ahead in two register sets (ring A / B, the tile loop is unrolled by
   // two so that no set is ever copied while its loads are in flight).  One tile ahead the kernel was latency-bound at
@@ -584,6 +594,10 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     }
     if constexpr (SP && !(FA_SP_PROBE & 1)) p_load(jt + 2 < nkv ? jt + 2 : jt, x0, x1, mx);   // (past the end: a harmless reload, no branch around the loads)
     if constexpr (TAB) flush_pending();
+    if constexpr (DROP && !SP) {
+      if (dbp && pend_bits_jt >= 0) dbp[(long)pend_bits_jt * 2 * p.db_Tq] = pend_bits;
+      pend_bits_jt = -1;
+    }
     if constexpr (TAB && FA_DQ_DEFER) {
       if (jt > 0) skew_sums(j0 - FA_BKV);
     }
@@ -679,12 +693,29 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
           const f32x2_t pe2 = f32x2_t{__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
           f32x2_t dp2 = f32x2_t{dp[f][r], dp[f][r + 1]};
           if constexpr (DROP) {
-            dp2[0] = fa_keep_lo(w, p.ths) ? dp2[0] : 0.f;
-            dp2[1] = fa_keep_hi(w, p.ths) ? dp2[1] : 0.f;
-          }
+            // keep decisions of both halves: compare (SDWA, sign-extended half against the threshold), select, and the
+            // decision shifted into the block's bit accumulator through the carry.  The select works on dP - delta (kept) against
+            // -delta (dropped) -- bit-identical to (kept ? dP : 0) - delta -- so that the first reader of the dP product's
+            // registers is an instruction the compiler's hazard recogniser sees (it does not look into inline asm)
+            const f32x2_t t2 = dp2 - f32x2_t{dls, dls};
+            float d0 = t2[0], d1 = t2[1];
+            unsigned acc = f == 0 ? bacc0 : bacc1;
+            asm("v_cmp_le_i32_sdwa vcc, %[ths], sext(%[w]) src0_sel:DWORD src1_sel:WORD_0\n\t"
+                "v_cndmask_b32_e32 %[d0], %[nd], %[d0], vcc\n\t"
+                "v_addc_co_u32_e32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                "v_cmp_le_i32_sdwa vcc, %[ths], sext(%[w]) src0_sel:DWORD src1_sel:WORD_1\n\t"
+                "v_cndmask_b32_e32 %[d1], %[nd], %[d1], vcc\n\t"
+                "v_addc_co_u32_e32 %[acc], vcc, %[acc], %[acc], vcc"
+                : [d0] "+v"(d0), [d1] "+v"(d1), [acc] "+v"(acc) : [ths] "v"(thsv), [w] "v"(w), [nd] "v"(ndls) : "vcc");
+            if constexpr (f == 0) bacc0 = acc; else bacc1 = acc;
+            const f32x2_t ds2m = pe2 * f32x2_t{d0, d1};
+            dv[0] = ds2m[0]; dv[1] = ds2m[1];
+            dg2 = __builtin_elementwise_fma(ds2m, tv2, dg2);
+          } else {
           const f32x2_t ds2 = pe2 * (dp2 - f32x2_t{dls, dls});
           dv[0] = ds2[0]; dv[1] = ds2[1];
           dg2 = __builtin_elementwise_fma(ds2, tv2, dg2);
+          }
         }
 #else
 #pragma unroll
@@ -741,6 +772,22 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     if (edge) elem_pass(F1{}, std::true_type{}); else elem_pass(F1{}, std::false_type{});
     dq_acc(F1{});
 #endif
+    if constexpr (DROP && !SP) {
+      // 16 decisions per block, first element in bit 15: reverse, spread the four 4-key runs to their key positions
+      // (r -> (r & 3) + 8 (r >> 2) + 4 hi), exchange the halves' partial words (one swap: lanes 0..31 receive word 0 of both
+      // half-waves, lanes 32..63 word 1)
+      auto spread = [&](unsigned a) __attribute__((always_inline)) {
+        unsigned x = __builtin_bitreverse32(a) >> 16;
+        x = (x | (x << 8)) & 0x00FF00FFu;
+        x = (x | (x << 4)) & 0x0F0F0F0Fu;
+        return x << (4 * hi);
+      };
+      unsigned w0 = spread(bacc0), w1 = spread(bacc1);
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(w0), "+v"(w1));
+      pend_bits = w0 | w1;
+      pend_bits_jt = jt;
+      bacc0 = 0; bacc1 = 0;
+    }
     if constexpr (TAB && !FA_DQ_DEFER) skew_sums(j0);
     // SP: the five loads of p_load were issued behind the DMA and may stay in flight across the barrier
     fa_tile_sync<SP ? 5 : 0>();
@@ -760,6 +807,8 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   }
   if constexpr (TAB && FA_DQ_DEFER) skew_sums((nkv - 1) * FA_BKV);
   if constexpr (TAB) flush_pending();
+  if constexpr (DROP && !SP)
+    if (dbp && pend_bits_jt >= 0) dbp[(long)pend_bits_jt * 2 * p.db_Tq] = pend_bits;
   if (TAB && lane < 32) {
     // the 31 diagonals past the last tile's first 64 (blocks 4, 5)
     const float v = lane < 16 ? dacc[4][0] : dacc[5][0];
@@ -859,6 +908,7 @@ static FaP fa_params(int B, int H, int T, float scale, float p_drop, uint64_t se
   p.k2 = (unsigned)((p.ths - 1) & 0xffff) * 0x10001u;
   p.k3 = (unsigned)(p.ths & 0xffff) * 0x10001u;
   p.ps.P16 = nullptr; p.ps.mt = nullptr;
+  p.dbits = nullptr; p.db_nkb = ((T + FA_BKV - 1) / FA_BKV) * 2; p.db_Tq = ((T + FA_BQ - 1) / FA_BQ) * FA_BQ;
   p.ps.nq32 = ((T + FA_BQ - 1) / FA_BQ) * 4; p.ps.nkv = (T + FA_BKV - 1) / FA_BKV; p.ps.Tq = ((T + FA_BQ - 1) / FA_BQ) * FA_BQ;
   p.s0 = (unsigned)seed; p.s1 = (unsigned)(seed >> 32);
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
@@ -916,7 +966,9 @@ uint64_t wavlm_attn_fused_bwd_workspace_bytes(int32_t B, int32_t H, int32_t T) {
   const uint64_t nqt = (uint64_t)((T + FA_BQ - 1) / FA_BQ);
   const uint64_t Lp = (2 * (uint64_t)T - 1 + 3) & ~(uint64_t)3;
   // per-wave d(rel) rows + delta + per-wave column sums of dq | dk | dv
-  return ((uint64_t)B * H * nqt * 4 * Lp + (uint64_t)B * H * T + (uint64_t)B * nqt * 4 * 3 * H * FA_HD) * sizeof(float);
+  // + the dropout bit words the dQ kernel leaves for the 64-keys-per-wave dK/dV kernel
+  const uint64_t f = ((uint64_t)B * H * nqt * 4 * Lp + (uint64_t)B * H * T + (uint64_t)B * nqt * 4 * 3 * H * FA_HD) * sizeof(float);
+  return ((f + 255) & ~(uint64_t)255) + fa_dbits_bytes(B, H, T);
 }
 
 // dqkv[B,T,3*H*64], dgate[B,H,T], dtab[H,2T-1] from dO and the forward's (qkv, O, lse)
@@ -963,6 +1015,18 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
   const int Lp = (L + 3) & ~3;
   p.delta = p.dtab_part + (long)B * H * nqt * 4 * Lp;
   if (dbias) p.dbias_part = p.delta + (long)B * H * T;
+  // the 64-keys-per-wave dK/dV kernel (round 6; WAVLM_ATTN_DKV64=0: the 32-keys-per-wave kernel of rounds 1-5) takes its
+  // dropout decisions from the dQ kernel's bit words; not with stored probabilities (their dK/dV kernel is its own)
+  static const bool dkv64_on = []() { const char* e = getenv("WAVLM_ATTN_DKV64"); return !(e && e[0] == '0'); }();
+  bool use64 = dkv64_on && !pstore;
+  if (use64) {
+    FaP q = p; q.nqb = (T + FA_K64 - 1) / FA_K64;
+    if (fa_dkv64_smem(q) > 160 * 1024) use64 = false;
+  }
+  if (use64 && p.th) {
+    const uint64_t fbytes = ((uint64_t)B * H * nqt * 4 * Lp + (uint64_t)B * H * T + (uint64_t)B * nqt * 4 * 3 * H * FA_HD) * sizeof(float);
+    p.dbits = (unsigned*)((unsigned char*)workspace + ((fbytes + 255) & ~(uint64_t)255));
+  }
   size_t smem1 = 32768 + (tab ? 4 * 6144 : 0) + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float) + 256;  // + gate fragments
   if (smem1 < FA_CS_FLOATS * sizeof(float)) smem1 = FA_CS_FLOATS * sizeof(float);
   p.nqb = nqt;
@@ -982,9 +1046,13 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
 #undef FA_DQ
   size_t smem2 = 32768 + (size_t)(p.Ltab + 64 + 2 * 256) * sizeof(float);
   if (smem2 < FA_CS_FLOATS * sizeof(float)) smem2 = FA_CS_FLOATS * sizeof(float);
-  p.nqb = (T + FA_BK1 - 1) / FA_BK1;
-  const dim3 grid2((unsigned)(p.nqb * B * H));
-  {
+  if (use64) {
+    p.nqb = (T + FA_K64 - 1) / FA_K64;
+    const int rc = fa_launch_dkv64(p, (unsigned)(p.nqb * B * H), st);
+    if (rc != WL_OK) return rc;
+  } else {
+    p.nqb = (T + FA_BK1 - 1) / FA_BK1;
+    const dim3 grid2((unsigned)(p.nqb * B * H));
     const int rc = fa_launch_dkv(p, grid2.x, smem2, st);
     if (rc != WL_OK) return rc;
   }

@@ -32,6 +32,7 @@ typedef __attribute__((address_space(3))) bf16x4_t* lds_b4_ptr;
 #define FA_BKV 64   // keys per iteration
 #define FA_BK1 128  // key rows per block (dK/dV kernel): 4 waves x 32
 #define FA_BQ1 64   // query rows per iteration (dK/dV kernel)
+#define FA_K64 256  // key rows per block of the 64-keys-per-wave dK/dV kernel (attn_fused_dkv64.hip): 4 waves x 64
 
 // Dropout mask: stateless, identical in all three kernels whichever lane holds element (i, j).
 //   word(i, j >> 1) = mix(row_word(b, h, i) + col_word(j >> 1));  keep(i, j) = 16-bit half (j & 1) of it >= th16
@@ -210,6 +211,10 @@ struct FaP {
   int ths; unsigned k2;  // signed threshold th - 32768; (ths - 1) in both halves
   unsigned k3;           // ths in both halves (fa_dropmask2)
   FaPstore ps;           // stored probabilities (P16 == nullptr: recompute)
+  // dropout decisions as bit words, written by the dQ kernel for the 64-keys-per-wave dK/dV kernel (attn_fused_dkv64.hip):
+  // dbits[(bh * db_nkb + c) * db_Tq + fa_bitrow(i)], bit k = keep(row i, key 32 c + k); db_nkb = 2 x key tiles of the dQ kernel,
+  // db_Tq = rows padded to its 128-row blocks.  nullptr: not written
+  unsigned* dbits; int db_nkb, db_Tq;
   int Ltab, Tkb;  // LDS extents: rel table (zero padded) and key bias
   int nqb;        // tiles along the sequence per (b, h) of the kernel being launched
 };
@@ -279,6 +284,18 @@ struct FaTileSrc {
     }
   }
 };
+
+// position of row i inside its group of eight in the dropout bit words: 0 4 1 5 2 6 3 7 -- rows i and i + 4 (the two half-waves
+// of the dK/dV kernel's 32 x 32 blocks) are neighbours, so that their two words form one aligned SGPR pair of a scalar load
+__host__ __device__ inline int fa_bitrow(int i) { return (i & ~7) + 2 * (i & 3) + ((i >> 2) & 1); }
+__host__ __device__ inline uint64_t fa_dbits_bytes(int B, int H, int T) {
+  const uint64_t nkb = (uint64_t)((T + FA_BKV - 1) / FA_BKV) * 2, Tq = (uint64_t)((T + FA_BQ - 1) / FA_BQ) * FA_BQ;
+  return (uint64_t)B * H * nkb * Tq * sizeof(unsigned) + 256;   // + one scalar-load line of slack behind the last word
+}
+// the 64-keys-per-wave dK/dV kernel (attn_fused_dkv64.hip); p.nqb = ceil(T / FA_K64).  WL_EINVAL: not applicable (the caller
+// launches the 32-keys-per-wave kernel)
+int fa_launch_dkv64(const FaP& p, unsigned grid, hipStream_t st);
+size_t fa_dkv64_smem(const FaP& p);
 
 // launcher of the dK/dV kernel (attn_fused_dkv.hip); returns a WL_* code.  smem: of the recompute form; the stored-P form
 // sizes its own
