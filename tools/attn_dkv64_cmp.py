@@ -1,7 +1,10 @@
-"""The 64-keys-per-wave dK/dV kernel (WAVLM_ATTN_DKV64, default on) against the 32-keys-per-wave kernel of rounds 1-5 on the
-step's shapes: same formulas and rounding points, so dqkv / dbias must be BIT-IDENTICAL (dq and dgate / dtab come from the dQ
-kernel, which both paths share).  The switch is read once per process: this script re-runs itself.
-usage: python tools/attn_dkv64_cmp.py            # compares, prints one line per case"""
+"""The dK/dV kernel variants of round 6 against the kernel of rounds 1-5 on the step's shapes: same formulas and rounding
+points, so every backward result must be BIT-IDENTICAL.
+  A: WAVLM_ATTN_DBITS=0              every kernel recomputes its dropout decisions (rounds 1-5)
+  B: default                         the dQ kernel's bit words select in the dK/dV kernel
+  C: WAVLM_ATTN_DKV64=1              + the 64-keys-per-wave dK/dV kernel
+The switches are read once per process: this script re-runs itself.
+usage: python tools/attn_dkv64_cmp.py            # compares B and C with A, prints one line per case"""
 import os
 import subprocess
 import sys
@@ -41,18 +44,20 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         run(sys.argv[1])
         sys.exit(0)
-    paths = {}
-    for v in ("1", "0"):
-        paths[v] = "/tmp/attn_dkv64_%s.pt" % v
-        subprocess.check_call([sys.executable, os.path.abspath(__file__), paths[v]], env=dict(os.environ, WAVLM_ATTN_DKV64=v))
-    a, b = torch.load(paths["1"]), torch.load(paths["0"])
+    res = {}
+    for tag, env in (("A", {"WAVLM_ATTN_DBITS": "0"}), ("B", {}), ("C", {"WAVLM_ATTN_DKV64": "1"})):
+        path = "/tmp/attn_dkv_%s.pt" % tag
+        e = {k: v for k, v in os.environ.items() if k not in ("WAVLM_ATTN_DBITS", "WAVLM_ATTN_DKV64")}
+        e.update(env)
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), path], env=e)
+        res[tag] = torch.load(path)
     bad = 0
-    for ci, case in enumerate(CASES):
-        worst = 0.0
-        same = True
-        for x, y in zip(a[ci], b[ci]):
-            same = same and torch.equal(x, y)
-            worst = max(worst, (x.float() - y.float()).abs().max().item() / (y.float().abs().max().item() + 1e-30))
-        print("B=%d T=%d H=%d p=%.2f pad=%s: %s (max rel diff %.2e)" % (*case, "bit-identical" if same else "DIFFERENT", worst))
-        bad += not same
+    for tag in ("B", "C"):
+        for ci, case in enumerate(CASES):
+            worst, same = 0.0, True
+            for x, y in zip(res[tag][ci], res["A"][ci]):
+                same = same and torch.equal(x, y)
+                worst = max(worst, (x.float() - y.float()).abs().max().item() / (y.float().abs().max().item() + 1e-30))
+            print("%s vs A  B=%d T=%d H=%d p=%.2f pad=%s: %s (max rel diff %.2e)" % (tag, *case, "bit-identical" if same else "DIFFERENT", worst))
+            bad += not same
     sys.exit(1 if bad else 0)

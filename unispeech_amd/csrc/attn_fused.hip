@@ -1015,15 +1015,18 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
   const int Lp = (L + 3) & ~3;
   p.delta = p.dtab_part + (long)B * H * nqt * 4 * Lp;
   if (dbias) p.dbias_part = p.delta + (long)B * H * T;
-  // the 64-keys-per-wave dK/dV kernel (round 6; WAVLM_ATTN_DKV64=0: the 32-keys-per-wave kernel of rounds 1-5) takes its
-  // dropout decisions from the dQ kernel's bit words; not with stored probabilities (their dK/dV kernel is its own)
-  static const bool dkv64_on = []() { const char* e = getenv("WAVLM_ATTN_DKV64"); return !(e && e[0] == '0'); }();
-  bool use64 = dkv64_on && !pstore;
+  // Round 6: the dQ kernel leaves its dropout decisions behind as bit words and the dK/dV kernel selects with them
+  // (WAVLM_ATTN_DBITS=0: every kernel recomputes its decisions, rounds 1-5).  Not with stored probabilities (the decision is the
+  // stored sign there).  WAVLM_ATTN_DKV64=1: the 64-keys-per-wave dK/dV kernel (attn_fused_dkv64.hip: built, bit-identical,
+  // measured SLOWER -- one wave per SIMD is issue-bound --, kept for the record).
+  static const bool dbits_on = []() { const char* e = getenv("WAVLM_ATTN_DBITS"); return !(e && e[0] == '0'); }();
+  static const bool dkv64_on = []() { const char* e = getenv("WAVLM_ATTN_DKV64"); return e && e[0] == '1'; }();
+  bool use64 = dkv64_on && dbits_on && !pstore;
   if (use64) {
     FaP q = p; q.nqb = (T + FA_K64 - 1) / FA_K64;
     if (fa_dkv64_smem(q) > 160 * 1024) use64 = false;
   }
-  if (use64 && p.th) {
+  if (dbits_on && !pstore && p.th) {
     const uint64_t fbytes = ((uint64_t)B * H * nqt * 4 * Lp + (uint64_t)B * H * T + (uint64_t)B * nqt * 4 * 3 * H * FA_HD) * sizeof(float);
     p.dbits = (unsigned*)((unsigned char*)workspace + ((fbytes + 255) & ~(uint64_t)255));
   }
@@ -1044,7 +1047,7 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
     if (tab) FA_DQ(false, true, false); else FA_DQ(false, false, false);
   }
 #undef FA_DQ
-  size_t smem2 = 32768 + (size_t)(p.Ltab + 64 + 2 * 256) * sizeof(float);
+  size_t smem2 = 32768 + (size_t)(p.Ltab + 64 + 2 * 448) * sizeof(float);   // (2 x FA_ROWV of attn_fused_dkv.hip)
   if (smem2 < FA_CS_FLOATS * sizeof(float)) smem2 = FA_CS_FLOATS * sizeof(float);
   if (use64) {
     p.nqb = (T + FA_K64 - 1) / FA_K64;

@@ -292,6 +292,21 @@ __host__ __device__ inline uint64_t fa_dbits_bytes(int B, int H, int T) {
   const uint64_t nkb = (uint64_t)((T + FA_BKV - 1) / FA_BKV) * 2, Tq = (uint64_t)((T + FA_BQ - 1) / FA_BQ) * FA_BQ;
   return (uint64_t)B * H * nkb * Tq * sizeof(unsigned) + 256;   // + one scalar-load line of slack behind the last word
 }
+// eight rows' words of one 32-key block = one scalar load (constant address space: the address is wave-uniform, the words were
+// written by the kernel before); words 2 e, 2 e + 1 = rows e, e + 4 of the group = the 64-bit lane mask of register "row e"
+typedef unsigned u32x8_t __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) u32x8_t* fa_mask_ptr;
+typedef fa_mask_ptr k64_mask_ptr;
+// select by an SGPR-pair lane mask: lanes whose bit is set keep `v`, the others get 0.  `v` comes straight out of v_exp_f32: on
+// gfx940+ a non-transcendental VALU instruction that reads the result of a transcendental one needs one wait state in between,
+// and the compiler's hazard recogniser does not look into inline asm (seen: the select read the register's OLD content) --
+// the s_nop is that wait state
+__device__ __forceinline__ float k64_keep(float v, unsigned lo, unsigned hi) {
+  const unsigned long m = ((unsigned long)hi << 32) | lo;
+  float r;
+  asm("s_nop 0\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+  return r;
+}
 // the 64-keys-per-wave dK/dV kernel (attn_fused_dkv64.hip); p.nqb = ceil(T / FA_K64).  WL_EINVAL: not applicable (the caller
 // launches the 32-keys-per-wave kernel)
 int fa_launch_dkv64(const FaP& p, unsigned grid, hipStream_t st);

@@ -14,15 +14,30 @@
 // ------------------------------------------------------------------------------------ backward 2/2: dK, dV
 // Lane owns a KEY column; scores are in the untransposed layout S[q][kv] so that the query contraction of
 // dV^T = dO^T P and dK^T = Q^T dS finds its k-slots in the lane's registers.
-template <bool DROP>
+// BITS (round 6, with DROP): the keep decisions come from the dQ kernel's bit words (attn_fused.hpp: dbits) instead of being
+// recomputed.  This layout pays six instructions per element for a decision (row word + column word, two-instruction mix, half
+// select, compare, select: a lane owns ONE key, so it uses one half of every 32-bit word) and a 16-byte LDS read per four rows
+// for the row words; bit k of word (row i, 32-key block c) is exactly the LANE MASK of the select for register "row i" here
+// (lanes = the 32 keys of the wave).  Two ways to use it were built:
+//   * through the scalar cache (s_load_dwordx8 per eight rows, the decision ONE v_cndmask_b32 with an SGPR-pair condition: one
+//     instruction per element instead of six).  Measured SLOWER, 214-231 us against 200 (profiles/r06/attn_dbits.txt): eight
+//     waves per CU streaming 32-byte pieces miss the small shared scalar cache, a scalar load's first use waits for
+//     lgkmcnt(0) -- scalar loads return out of order --, which also drains every LDS read in flight, and requests cannot be
+//     issued far ahead for the same reason.  (That form lives on in attn_fused_dkv64.hip.)
+//   * through the per-row LDS arrays the kernel has anyway (this form): the words of the wave's key block take the place of
+//     the dropout row words (one global load per lane and tile next to lse / delta / gate, the same 16-byte LDS read per four
+//     rows), and a decision is v_bfe_i32 (bit `key` of the row's word, sign-extended) + v_and_b32: two instructions.
+#define FA_ROWV 448   // floats per stage of the per-row arrays: lse | delta | gate | (row words, or the four waves' bit words)
+template <bool DROP, bool BITS = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
+  static_assert(DROP || !BITS, "bit words are dropout decisions");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per stage: Q [q][hd] | dO [q][hd], 8 KB each; the transposed operands of the query contraction are read from
   // the same tiles with ds_read_b64_tr_b16 (frag_tr)
   auto qbuf = [&](int st) { return smem + st * 16384; };
   auto dobuf = [&](int st) { return smem + st * 16384 + 8192; };
   float* tabs = reinterpret_cast<float*>(smem + 32768);
-  float* rowv = tabs + p.Ltab + 64;  // [2 stages][4][64]: lse * log2e, delta, gate * log2e, dropout row word of the query tile
+  float* rowv = tabs + p.Ltab + 64;  // [2 stages][FA_ROWV]: lse * log2e, delta, gate * log2e, dropout row word (BITS: the four waves' bit words) of the query tile
   const int T = p.T, H = p.H;
   int kblk, bh;
   fa_block_map(p.nqb, p.B * H, kblk, bh);
@@ -48,6 +63,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   const unsigned cw = fa_col_word(p.s1, (unsigned)(jc >> 1));
   const unsigned csh = (jc & 1) << 4;
   const float* tcol = tabs + 64 + (jc + T - 1);  // tcol[-i] = rel[h, j - i]; 64 zero floats in front absorb rows past T
+  const unsigned* bits = nullptr;   // BITS: the words of this wave's 32-key block, [row] (rows of a group of eight: 0 4 1 5 2 6 3 7)
+  if constexpr (BITS) {
+    int c = kblk * 4 + wave_u;
+    if (c > p.db_nkb - 1) c = p.db_nkb - 1;   // (blocks past the dQ kernel's key tiles hold only keys >= T: discarded)
+    bits = p.dbits + ((long)bh * p.db_nkb + c) * p.db_Tq;
+  }
   // a padded / out-of-range key is NOT masked inside the loop (one add per element): its column only feeds this lane's
   // own dK / dV rows, which are written as zeros at the end
 
@@ -63,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   // the iteration (rows_store) -- consuming a global load in the middle of the iteration makes the compiler wait for it,
   // and vector memory operations return in order: that wait would also wait for the prefetch DMA issued behind it
   // (raw values only in rows_load: any arithmetic on them would put the wait right behind the loads)
-  struct RowRegs { float lse, gate, delta; unsigned o; bool ok; };
+  struct RowRegs { float lse, gate, delta; unsigned o; bool ok; unsigned word; };
   auto rows_load = [&](int it) {
     // every wave loads the tile's 64 rows (wave 0 stores them): no divergent branch around the loads, i.e. no merge of
     // "loaded" and "not loaded" values that would have to wait for the loads
@@ -75,6 +96,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
     r.lse = p.lse[o];
     r.delta = p.delta[o];
     r.gate = (p.gate ? p.gate : p.lse)[o];   // (no gate: any readable address; rows_store writes 0 then)
+    r.word = 0;
+    if constexpr (BITS) r.word = bits[fa_bitrow(ii)];   // this WAVE's key block, row ii (rows < db_Tq: written by the dQ kernel)
     return r;
   };
   auto rows_store = [&](const RowRegs& r, int st) {
@@ -82,15 +105,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
     if (t < 64) {
 #if FA_DKV_BIAS_IN_C
       // bias - lse enters as the C operand of the score MFMAs, in units of 1 / sc2 (P * sc = 2^(sc2 s))
-      rowv[st * 256 + t] = r.ok ? (p.log2sc - r.lse * FA_LOG2E) / p.sc2 : -INFINITY;
-      rowv[st * 256 + 128 + t] = p.gate ? r.gate * FA_LOG2E / p.sc2 : 0.f;
+      rowv[st * FA_ROWV + t] = r.ok ? (p.log2sc - r.lse * FA_LOG2E) / p.sc2 : -INFINITY;
+      rowv[st * FA_ROWV + 128 + t] = p.gate ? r.gate * FA_LOG2E / p.sc2 : 0.f;
 #else
-      rowv[st * 256 + t] = r.ok ? p.log2sc - r.lse * FA_LOG2E : -INFINITY;  // P * sc = 2^(x + this); -inf: rows past T
-      rowv[st * 256 + 128 + t] = p.gate ? r.gate * FA_LOG2E : 0.f;
+      rowv[st * FA_ROWV + t] = r.ok ? p.log2sc - r.lse * FA_LOG2E : -INFINITY;  // P * sc = 2^(x + this); -inf: rows past T
+      rowv[st * FA_ROWV + 128 + t] = p.gate ? r.gate * FA_LOG2E : 0.f;
 #endif
-      rowv[st * 256 + 64 + t] = r.delta * p.inv_sc;
-      rowv[st * 256 + 192 + t] = __uint_as_float(fa_row_word(p.s0, r.o));
+      rowv[st * FA_ROWV + 64 + t] = r.delta * p.inv_sc;
+      if constexpr (!BITS) rowv[st * FA_ROWV + 192 + t] = __uint_as_float(fa_row_word(p.s0, r.o));
     }
+    if constexpr (BITS) rowv[st * FA_ROWV + 192 + t] = __uint_as_float(r.word);   // every wave its own 64 words
   };
 
 #if FA_TILE_SRC
@@ -113,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
     if (more) {
       FA_LOAD_QDO(iq0 + FA_BQ1, qbuf(cur ^ 1), dobuf(cur ^ 1));
     }
-    const float* rv = rowv + cur * 256;
+    const float* rv = rowv + cur * FA_ROWV;
     // S = Q K^T, dP = dO V^T  (rows = queries of the tile, col = this lane's key)
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -148,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
         // LDS vectors; the Toeplitz entries rel[j - i] run downwards in i
         const int il0 = 32 * f + 8 * q4 + 4 * hi;
         const float4 del4 = *reinterpret_cast<const float4*>(rv + 64 + il0);
-        const uint4 row4 = *reinterpret_cast<const uint4*>(rv + 192 + il0);
+        uint4 row4 = make_uint4(0, 0, 0, 0);
+        if constexpr (DROP) row4 = *reinterpret_cast<const uint4*>(rv + 192 + (BITS ? 64 * wave_u : 0) + il0);
         const float delv[4] = {del4.x, del4.y, del4.z, del4.w};
         const unsigned roww[4] = {row4.x, row4.y, row4.z, row4.w};
 #if !FA_DKV_BIAS_IN_C
@@ -169,7 +194,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
           const float pe = __builtin_amdgcn_exp2f(fmaf(s[rr], p.sc2, fmaf(gatv[e], tq[-e], lsev[e])));  // rows past T: -inf -> 0
 #endif
           float pd = pe;
-          if constexpr (DROP) {
+          if constexpr (BITS) {
+            // bit `key` of the row's word, sign-extended: 0 / ~0 (v_bfe_i32), applied to the bits of the probability
+            const int km = __builtin_amdgcn_sbfe(roww[e], kl, 1);
+            pd = __uint_as_float(__float_as_uint(pe) & (unsigned)km);
+          } else if constexpr (DROP) {
             const unsigned w = fa_mix(roww[e] + cw);
             const bool kp = (int)(short)((w >> csh) & 0xffffu) >= p.ths;
             pd = kp ? pe : 0.f;
@@ -499,7 +528,10 @@ int fa_launch_dkv(const FaP& p, unsigned grid, size_t smem, hipStream_t st) {
     WL_LAUNCH(attn_bwd_dkv_p_kernel, dim3(grid), dim3(256), smem_p, st, p);
     return wl_check_launch();
   }
-  if (p.th) {
+  if (p.th && p.dbits) {
+    if (fa_set_smem(attn_bwd_dkv_kernel<true, true>, smem) != WL_OK) return WL_ELAUNCH;
+    WL_LAUNCH((attn_bwd_dkv_kernel<true, true>), dim3(grid), dim3(256), smem, st, p);
+  } else if (p.th) {
     if (fa_set_smem(attn_bwd_dkv_kernel<true>, smem) != WL_OK) return WL_ELAUNCH;
     WL_LAUNCH(attn_bwd_dkv_kernel<true>, dim3(grid), dim3(256), smem, st, p);
   } else {

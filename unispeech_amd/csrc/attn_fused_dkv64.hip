@@ -37,9 +37,6 @@
 #include "attn_fused.hpp"
 
 #define FA_K64_STAGES 4
-typedef unsigned u32x8_t __attribute__((ext_vector_type(8)));
-typedef const __attribute__((address_space(4))) u32x8_t* k64_mask_ptr;
-
 // lab-bench probes (WRONG results by construction; -DWAVLM_EXPERIMENTAL builds only): K64_PROBE bit 0: no element pass (the
 // VALU work), bit 1: no MFMAs, bit 2: no mask words (no scalar loads), bit 3: no per-row / Toeplitz reads
 #if !defined(WAVLM_EXPERIMENTAL)
@@ -48,16 +45,6 @@ typedef const __attribute__((address_space(4))) u32x8_t* k64_mask_ptr;
 #ifndef K64_PROBE
 #define K64_PROBE 0
 #endif
-// select by an SGPR-pair lane mask: lanes whose bit is set keep `v`, the others get 0.  `v` comes straight out of v_exp_f32: on
-// gfx940+ a non-transcendental VALU instruction that reads the result of a transcendental one needs one wait state in between,
-// and the compiler's hazard recogniser does not look into inline asm (seen: the select read the register's OLD content) --
-// the s_nop is that wait state
-__device__ __forceinline__ float k64_keep(float v, unsigned lo, unsigned hi) {
-  const unsigned long m = ((unsigned long)hi << 32) | lo;
-  float r;
-  asm("s_nop 0\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
-  return r;
-}
 #if K64_PROBE & 2
 #define K64_MFMA(A, B, C) (C)
 #else
