@@ -363,21 +363,30 @@ def busy_and_enqueue(step, reps=5):
     return busy[len(busy) // 2], host[len(host) // 2]
 
 
-def run_alt_pass(args, rank, world, dev):
+def run_alt_pass(args, rank, world, dev, native=False):
     """every rank starts one child `bench.py` (same rank, same GPU, new rendezvous port hosted by rank 0's child) with
-    NCCL_MAX_NCHANNELS removed and WAVLM_DP_RESERVED_CUS=0, waits for it, and rank 0 returns the child's headline numbers.
-    Failures (time-out, no line) are reported, never raised: the primary measurement is already taken."""
+    NCCL_MAX_NCHANNELS removed and WAVLM_DP_RESERVED_CUS=0 -- or, native=True, with the DEFAULT channel cap / reservation and
+    the library's own RCCL reducer as the transport (WAVLM_DP_NATIVE=1: the other untested default) --, waits for it, and rank 0
+    returns the child's headline numbers.  Failures (time-out, no line) are reported, never raised: the primary measurement is
+    already taken."""
     import subprocess
     port = [_free_port() if rank == 0 else 0]
     dist.broadcast_object_list(port, src=0)
     env = dict(os.environ)
     for k in ("NCCL_MAX_NCHANNELS", "TORCHELASTIC_USE_AGENT_STORE"):
         env.pop(k, None)
-    env.update(WAVLM_DP_RESERVED_CUS="0", MASTER_PORT=str(port[0]), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"))
+    env.update(MASTER_PORT=str(port[0]), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"))
+    if native:
+        env.update(WAVLM_DP_NATIVE="1")
+        if os.environ.get("NCCL_MAX_NCHANNELS"):
+            env["NCCL_MAX_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"]
+    else:
+        env.update(WAVLM_DP_RESERVED_CUS="0")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--batch", str(args.batch), "--config", args.config, "--dp-alt-pass", "never", "--no-cpu-baseline", "--no-roofline"]
     torch.cuda.synchronize()
-    res = {"settings": {"NCCL_MAX_NCHANNELS": None, "WAVLM_DP_RESERVED_CUS": 0}}
+    res = {"settings": {"WAVLM_DP_NATIVE": 1, "NCCL_MAX_NCHANNELS": env.get("NCCL_MAX_NCHANNELS")} if native
+           else {"NCCL_MAX_NCHANNELS": None, "WAVLM_DP_RESERVED_CUS": 0}}
     try:
         # (a child is an ordinary short run: ~1 min with start-up; the bound keeps a stuck rendezvous from holding the primary line back)
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -428,6 +437,10 @@ def main():
     ap.add_argument("--dp-alt-pass", choices=["auto", "always", "never"], default="auto",
                     help="N > 1: second measurement with NCCL_MAX_NCHANNELS unset and no reserved CUs (fresh processes on the same "
                          "GPUs); auto = when a rank waits > 1 ms for the gradient all-reduce after backward")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="1 GPU: run the step through the data-parallel machinery of a rank (DataParallelWavLM over a one-rank gloo "
+                         "group: bucketed reducer on its side stream, gradient listeners, reserved CUs, the sample-size all-reduce) -- "
+                         "what the N > 1 path costs a rank before any byte crosses a link; the line carries a `data_parallel` block")
     ap.add_argument("--reserved-cus", type=int, default=-1,
                     help="1 GPU: shrink the persistent GEMM grids by this many CUs as the data-parallel reducer does "
                          "(WAVLM_DP_RESERVED_CUS) -- what the reservation alone costs a rank")
@@ -457,6 +470,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pinned = pin_rank_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    force_dp = bool(args.force_dp) and world == 1
+    if force_dp:
+        # one rank of RCCL on this GPU (an all-reduce is an in-place copy kernel then), everything else as in a real N > 1
+        # run: channel cap in the environment before the communicator exists, reducer forced on, CUs reserved
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ["WAVLM_DP_FORCE"] = "1"
+        from unispeech_amd.dp import cap_rccl_channels
+        cap_rccl_channels(2)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dp = world > 1 or force_dp   # the step runs through the data-parallel wrapper
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL gets as many channels (= workgroups = CUs) as the persistent GEMM grids leave free (unispeech_amd/dp.py)
@@ -492,7 +516,7 @@ def main():
         opt = FusedAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=10.0, model=model)
         model.instance_sampling = "device"   # UniSpeech-SAT head: draw the instance indices on the GPU (no host work per step)
         net = DataParallelWavLM(model, opt, bucket_bytes=int(float(os.environ.get("WAVLM_DP_BUCKET_MIB", "32")) * 2 ** 20)) \
-            if world > 1 else model
+            if dp else model
     sat = bool(CONFIGS[args.config].get("sat"))
     crit = WavLMCriterion(None, 1.0, 0.0, loss_weights=[10.0, 10.0, 0.0] if sat else [10.0], defer_logging=True)
 
@@ -525,7 +549,7 @@ def main():
                                                                 WF.h2d(begin_np, dev), None, True, torch.bfloat16)
         loss, ss, _ = crit(net, sample)
         loss.backward()
-        if world > 1:
+        if dp:
             if comm_ev is not None:
                 comm_ev[0].record()      # end of backward on the compute stream
             net.all_reduce_grads()   # AVERAGE over ranks (the wrapper folds 1/world into the optimizer's deferred factor)
@@ -617,7 +641,7 @@ def main():
     # in its way, and what the launch thread needs to enqueue one (see busy_and_enqueue)
     gpu_busy_ms, host_enq_ms = busy_and_enqueue(step) if (world == 1 and not args.no_busy) else (None, None)
     dp_info = None
-    if world > 1:
+    if dp:
         # evidence for the overlap of the gradient all-reduce with backward, from the driver's own run: per rank, the time
         # the compute stream waits between the end of backward and the completion of the last bucket (0 = fully hidden),
         # plus what identifies the run as N distinct devices over RCCL
@@ -689,8 +713,14 @@ def main():
         worst_wait = max(dp_info["comm_wait_ms_per_rank"])
         if args.dp_alt_pass == "always" or worst_wait > 1.0:
             alt = run_alt_pass(args, rank, world, dev)
+            # ... and the transport nobody has run on more than one rank: the reducer below Python (wavlm_dp_*), same channel
+            # cap and reservation as the headline.  It stays opt-in until a node shows it ahead
+            # (RCCL only: two ranks of the functional gloo / shared-GPU mode cannot form an RCCL communicator on one device)
+            alt_native = (run_alt_pass(args, rank, world, dev, native=True)
+                          if (dp_info["transport"] == "torch" and backend == "nccl" and os.environ.get("WAVLM_SHARED_GPU") != "1") else None)
             if rank == 0:
                 dp_info["alt_pass"] = alt
+                dp_info["alt_pass_native"] = alt_native
 
     roof = None
     if not args.no_roofline:
@@ -800,6 +830,9 @@ def main():
             a_ = dp_info.get("alt_pass")
             if a_ and a_.get("value"):
                 dp_info["alt_pass_faster_than_default"] = bool(a_["value"] > 1.01 * value)
+            n_ = dp_info.get("alt_pass_native")
+            if n_ and n_.get("value"):
+                dp_info["alt_pass_native_faster_than_default"] = bool(n_["value"] > 1.01 * value)
             out["data_parallel"] = dp_info
         if roof is not None:
             out["roofline"] = roof
@@ -817,7 +850,7 @@ def main():
             torch.cuda.empty_cache()
             out["secondary"] = secondary_lines()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

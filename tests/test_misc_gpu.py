@@ -468,3 +468,43 @@ def test_bench_data_parallel_self_diagnosis_and_alternative_pass():
     assert alt["settings"] == {"NCCL_MAX_NCHANNELS": None, "WAVLM_DP_RESERVED_CUS": 0}
     assert alt["value"] > 0 and len(alt["comm_wait_ms_per_rank"]) == 2 and alt["buckets_rank0"]
     assert isinstance(dp["alt_pass_faster_than_default"], bool)
+    assert dp.get("alt_pass_native") is None     # the native-transport pass needs RCCL with one device per rank (a node)
+    top = json.loads(lines[0])
+    assert top["ranks_seen"] == 2 and top["distinct_devices"] == 1 and top["dist_backend"] == "gloo" and top["dp_transport"] == "torch"
+
+
+@pytest.mark.gpu
+def test_bench_force_dp_prices_the_data_parallel_machinery_on_one_gpu():
+    """what the N > 1 path costs a rank BEFORE any byte crosses a link, measurable on one GPU.
+    `bench.py --force-dp` runs the headline step through DataParallelWavLM over a ONE-rank RCCL group: arena buckets
+    all-reduced on the side stream as backward produces them (an in-place copy kernel at world 1), gradient listeners, six CUs
+    reserved in every persistent GEMM grid, NCCL_MAX_NCHANNELS capped, the sample-size all-reduce.  Its ms_per_step must stay
+    within 4 % of the plain `--gpus 1` path on the same box (the reservation alone was measured at +0.5 %,
+    profiles/r04/reserved_cus_*.txt; run-to-run noise of two short runs ~1 %), the loss must be the same number, and the line
+    carries the `data_parallel` block a node run prints."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("NCCL_MAX_NCHANNELS", "WAVLM_DP_FORCE", "WAVLM_SHARED_GPU", "WAVLM_DIST_BACKEND"):
+        env.pop(k, None)
+    out = {}
+    for tag, extra in (("plain", []), ("dp", ["--force-dp"])):
+        r = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-roofline",
+                            "--no-secondary", "--no-busy", "--no-settle"] + extra, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out[tag] = json.loads(lines[0])
+    a, b = out["plain"], out["dp"]
+    dp = b["data_parallel"]
+    print("plain %.2f ms/step, through the data-parallel machinery %.2f ms/step (%+.1f %%); buckets %d, reserved CUs %d, channels %s, "
+          "comm wait %s ms" % (a["ms_per_step"], b["ms_per_step"], 100.0 * (b["ms_per_step"] / a["ms_per_step"] - 1.0), dp["buckets"],
+                               dp["reserved_cus"], dp["rccl_max_nchannels"], dp["comm_wait_ms_per_rank"]))
+    assert "data_parallel" not in a
+    assert dp["ranks_seen"] == 1 and dp["backend"] == "nccl" and dp["transport"] == "torch"
+    assert dp["buckets"] >= 4 and dp["reserved_cus"] == 6 and dp["rccl_max_nchannels"] == "6"
+    assert dp["buckets_rank0"] and all(r_["allreduce_ms"] > 0 for r_ in dp["buckets_rank0"])
+    assert abs(a["final_loss"] - b["final_loss"]) <= 2e-3 * abs(a["final_loss"])   # same seeds, same step: sums of one rank
+    assert b["ms_per_step"] <= 1.04 * a["ms_per_step"], (a["ms_per_step"], b["ms_per_step"])

@@ -113,7 +113,11 @@ class GradReducer:
         self.flat_grad = flat_grad
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.enabled = self.world > 1
+        # WAVLM_DP_FORCE=1 (bench.py --force-dp): a one-rank group still runs the whole machinery -- buckets, side stream,
+        # listeners, reserved CUs, the collective itself (an in-place copy for RCCL at world 1) --, which prices what the
+        # data-parallel path costs a rank before any byte crosses a link
+        import os
+        self.enabled = self.world > 1 or (dist.is_initialized() and os.environ.get("WAVLM_DP_FORCE", "0") == "1")
         self.sync = True
         self.is_cuda = flat_grad.is_cuda
         # transport: None = torch.distributed collectives on a side stream of torch's; an object with bucket_ready(view) /
