@@ -245,7 +245,7 @@ def live_gemm_traffic(args):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "run", "--", sys.executable,
-                   os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-settle", "--no-busy", "--no-cpu-baseline", "--no-roofline",
+                   os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-settle", "--no-busy", "--no-cpu-baseline", "--no-roofline", "--no-secondary",
                    "--config", args.config, "--batch", str(args.batch)]
             r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WAVLM_HIP_ABI_VERSION 20
+#define WAVLM_HIP_ABI_VERSION 21
 int wavlm_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -248,8 +248,15 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
  * WavLM/modules.py:504-563, fp32 / fp16 [B*H, T, T]) -- here it is a memory-for-VALU trade the 288 GB part can afford.
  * wavlm_attn_fused_pstore_bytes returns 0 for T > 1024: recompute only.
  * pstore == NULL: exactly wavlm_attn_fused_fwd / _bwd (recompute; the low-memory mode).  A backward with pstore must be
- * given the pstore its own forward wrote (same B, H, T, gate, tab, kpm, p_drop, seed). */
+ * given the pstore its own forward wrote (same B, H, T, gate, tab, kpm, p_drop, seed).
+ * BIT mode (ABI 21, round 6; opt-in, measured neutral): a pstore of exactly wavlm_attn_fused_dbits_bytes (one bit per (row, key) of
+ * the padded grid: 27 MB per layer at B = 32, H = 12, T = 749; 256-byte aligned) makes the forward store only its dropout
+ * DECISIONS -- it evaluates the hash anyway -- and both backward kernels select with the stored bits (two instructions per
+ * element) instead of evaluating the hash twice more; scores, bias and exponentials are recomputed as without a pstore.  The
+ * reference keeps the dropout mask inside F.dropout's autograd node (WavLM/modules.py:504-563 under
+ * F.multi_head_attention_forward, one byte per element). */
 uint64_t wavlm_attn_fused_pstore_bytes(int32_t B, int32_t H, int32_t T);
+uint64_t wavlm_attn_fused_dbits_bytes(int32_t B, int32_t H, int32_t T);
 int wavlm_attn_fused_fwd_p(const void* qkv, void* O, float* lse, const float* gate, const float* tab, const uint8_t* kpm,
                            void* pstore, uint64_t pstore_bytes, int32_t B, int32_t H, int32_t T, int32_t head_dim, float scale,
                            float p_drop, uint64_t seed, void* stream);
@@ -406,8 +413,9 @@ typedef struct wavlm_layer_desc {
   int32_t dtab_accumulate;         /* backward: dtab (+)= instead of = */
   float eps1, eps2, scale;         /* LayerNorm epsilons, q scaling (head_dim^-0.5) */
   float p_drop, p_attn;            /* residual dropout, attention dropout (0 in eval) */
-  int32_t attn_store_p;            /* 1: the attention keeps its probabilities in `saved` for backward (wavlm_attn_fused_fwd_p);
-                                      0: backward recomputes them (low-memory mode).  Same value in forward and backward. */
+  int32_t attn_store_p;            /* 2: the attention keeps its dropout decisions (bit words) in `saved` for backward;
+                                      1: its probabilities (wavlm_attn_fused_fwd_p); 0: backward recomputes everything
+                                      (the default).  Same value in forward and backward. */
   uint64_t seed_r1, seed_r2, seed_attn;
   /* parameters (and, backward only, their gradient accumulators) */
   const void *Wqkv, *bqkv, *Wo, *bo, *W1, *b1, *W2, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;

@@ -631,15 +631,16 @@ def check_attention():
         qd = qkv.to(dtype).to(DEV).requires_grad_(True)
         gd, td = gate.to(DEV).requires_grad_(True), tab.to(DEV).requires_grad_(True)
         kd = kpm.to(DEV) if kpm is not None else None
-        # fused with stored probabilities (the default), fused with recomputation (WAVLM_ATTN_STORE_P=0), unfused composition
-        for fused, store in ((True, True), (True, False), (False, False)):
+        # fused with stored probabilities (WAVLM_ATTN_STORE_P=1), with recomputation (=0, the default), with stored dropout bits
+        # (=bits; no dropout here: nothing is stored), unfused composition
+        for fused, store in ((True, True), (True, False), (True, "bits"), (False, False)):
             F.USE_FUSED_ATTENTION = fused
             F.ATTN_STORE_P = store
             for t in (qd, gd, td):
                 t.grad = None
             Od = F.AttnCoreFn.apply(qd, gd, td, kd, H, hd ** -0.5, 0.0, 0)
             Od.backward(dO.to(dtype).to(DEV))
-            tag = f"attn[{('fused, stored P' if store else 'fused, recompute') if fused else 'unfused'} bf16] B={B} T={T} H={H} pad={use_pad}"
+            tag = f"attn[{('fused, stored bits' if store == 'bits' else 'fused, stored P' if store else 'fused, recompute') if fused else 'unfused'} bf16] B={B} T={T} H={H} pad={use_pad}"
             out.append((tag + " O", err(Od, Or), tol))
             out.append((tag + " dqkv", err(qd.grad, qr.grad), tol * 2))
             out.append((tag + " dgate", err(gd.grad, gr.grad), tol * 2))
@@ -804,6 +805,12 @@ def check_dropout_exact():
         out.append((tag + " stored P: storing fwd == plain fwd (mismatching elements)", float((sf != kf).sum().item()), 0.0))
         out.append((tag + " stored P: mask fwd == dQ (mismatching elements)", float((sf != sq).sum().item()), 0.0))
         out.append((tag + " stored P: mask fwd == dK/dV (mismatching elements)", float((sf != skv).sum().item()), 0.0))
+        # stored dropout BITS (round 6, WAVLM_ATTN_STORE_P=bits): the forward writes its decisions as bit words, the dQ kernel reads them per
+        # row (v_bfe_i32 at the forward's bit order), the dK/dV kernel through its per-row LDS arrays (bit of the lane's key)
+        bf, bq, bkv = _attn_kernel_masks(B, H, T, p_drop, seed, gate, tab, kpm, store_p="bits")
+        out.append((tag + " stored bits: storing fwd == plain fwd (mismatching elements)", float((bf != kf).sum().item()), 0.0))
+        out.append((tag + " stored bits: mask fwd == dQ (mismatching elements)", float((bf != bq).sum().item()), 0.0))
+        out.append((tag + " stored bits: mask fwd == dK/dV (mismatching elements)", float((bf != bkv).sum().item()), 0.0))
         # (2) numerics with the forward's own mask
         D = 64 * H
         qkv = q(gen(B, T, 3 * D, seed=11), torch.bfloat16)
@@ -814,9 +821,9 @@ def check_dropout_exact():
         tr = tc.double().requires_grad_(True) if use_tab else None
         Or = _ref_attention_masked(qr, gr, tr, kpm.cpu() if kpm is not None else None, H, 64 ** -0.5, kf, sc)
         (Or * dO.double()).sum().backward()
-        for store in (True, False):
+        for store in (True, False, "bits"):
             F.ATTN_STORE_P = store
-            tg2 = tag + (" [stored P]" if store else " [recompute]")
+            tg2 = tag + (" [stored bits]" if store == "bits" else " [stored P]" if store else " [recompute]")
             qd = qkv.to(torch.bfloat16).to(DEV).requires_grad_(True)
             gd = gate.clone().requires_grad_(True) if use_tab else None
             td = tab.clone().requires_grad_(True) if use_tab else None

@@ -77,13 +77,18 @@ def _count_nodes(model_out_loss):
 
 
 @pytest.mark.parametrize("case", ["post_ln", "post_ln_padded", "post_ln_layerdrop", "pre_ln", "pre_ln_padded",
-                                  "pre_ln_sat_tap", "no_relpos", "post_ln_padded_stored_p", "pre_ln_stored_p"])
+                                  "pre_ln_sat_tap", "no_relpos", "post_ln_padded_stored_p", "pre_ln_stored_p",
+                                  "post_ln_padded_bits", "pre_ln_bits"])
 def test_fused_block_equals_composed_path_bit_for_bit(case):
     over = {}
     # *_stored_p: the attention keeps its probabilities for backward (WAVLM_ATTN_STORE_P=1): the block call carries them in
     # its `saved` region (attn_store_p in the descriptor), the composed path in a tensor of its own -- same kernels either way
-    stored = case.endswith("_stored_p")
-    case = case[:-len("_stored_p")] if stored else case
+    # *_bits: the forward keeps its dropout decisions as bit words (WAVLM_ATTN_STORE_P=bits, attn_store_p = 2); no suffix: the
+    # default -- nothing kept, the dQ kernel hands its dropout decisions to the dK/dV kernel
+    stored = False
+    for suffix, val in (("_stored_p", True), ("_bits", "bits")):
+        if case.endswith(suffix):
+            stored, case = val, case[:-len(suffix)]
     from unispeech_amd import functional as F_
     old_store = F_.ATTN_STORE_P
     F_.ATTN_STORE_P = stored

@@ -56,7 +56,15 @@ print("stored-P forward == plain forward: O max |diff| %.3e, lse max |diff| %.3e
       % ((O_s.float() - O.float()).abs().max().item(), (lse_s - lse).abs().max().item(), nps / 1e6), flush=True)
 timeit(fwd_store, "fwd + P store (p=%.2f)" % p, fl)
 timeit(lambda: ops.attn_fused_bwd(qkv, O_s, dO, lse_s, gate, tab, None, H, hd ** -0.5, p, 1234, pstore=pst), "bwd from stored P", 2.5 * fl)
+# stored dropout BITS (round 6, WAVLM_ATTN_STORE_P=bits): the forward writes its decisions (27 MB), both backward kernels read them
+O_b, lse_b, pb = ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234, store_p="bits")
+torch.cuda.synchronize()
+print("bit-storing forward == plain forward: O %s, lse %s (%.1f MB of bit words)" % (torch.equal(O_b, O), torch.equal(lse_b, lse), pb.numel() / 1e6), flush=True)
+timeit(lambda: ops.attn_fused_fwd(qkv, gate, tab, None, H, hd ** -0.5, p, 1234, store_p="bits"), "fwd + bit store (p=%.2f)" % p, fl)
+timeit(lambda: ops.attn_fused_bwd(qkv, O_b, dO, lse_b, gate, tab, None, H, hd ** -0.5, p, 1234, pstore=pb), "bwd from stored bits", 2.5 * fl)
+g_b = ops.attn_fused_bwd(qkv, O_b, dO, lse_b, gate, tab, None, H, hd ** -0.5, p, 1234, pstore=pb)
 g_r = ops.attn_fused_bwd(qkv, O, dO, lse, gate, tab, None, H, hd ** -0.5, p, 1234)
+print("stored-bits backward == recompute backward (bit for bit): %s" % all(torch.equal(a, b_) for a, b_ in zip(g_b, g_r)), flush=True)
 g_s = ops.attn_fused_bwd(qkv, O_s, dO, lse_s, gate, tab, None, H, hd ** -0.5, p, 1234, pstore=pst)
 for nm, a, b_ in zip(("dqkv", "dgate", "dtab"), g_s, g_r):
     print("stored-P backward vs recompute backward, %s: max |diff| / max |ref| = %.3e" % (nm, (a.float() - b_.float()).abs().max().item() / b_.float().abs().max().item()), flush=True)

@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 CFG=${CFG:-base}
-CMD="python bench.py --config $CFG --steps 1 --warmup 1 --no-settle --no-busy --no-cpu-baseline --no-roofline"
+CMD="python bench.py --config $CFG --steps 1 --warmup 1 --no-settle --no-busy --no-cpu-baseline --no-roofline --no-secondary"
 rocprofv3 -L 2>/dev/null | grep -oE "SQ_[A-Z_0-9]*(MFMA|VALU|BUSY|WAVE_CYCLES)[A-Z_0-9]*" | sort -u > $OUT/sq_counters_available.txt
 for P in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/$P -o run -- $CMD > $OUT/$P.log 2>&1 || echo "pass $P failed" >> $OUT/errors.txt

@@ -6,7 +6,7 @@ TAG=${1:-x}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python bench.py --steps 3 --warmup 2 --no-settle --no-busy --no-cpu-baseline --no-roofline > $OUT/bench.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python bench.py --steps 3 --warmup 2 --no-settle --no-busy --no-cpu-baseline --no-roofline --no-secondary > $OUT/bench.log 2>&1 || true
 TR=$(find $OUT/raw -name "*kernel_trace.csv" | head -1)
 ST=$(find $OUT/raw -name "*kernel_stats.csv" | head -1)
 python tools/prof_laststep.py $TR 70 > $OUT/summary.txt 2>&1 || true

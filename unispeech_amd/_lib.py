@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVLM_HIP_LIB") or os.path.join(_HERE, "lib", "libwavlm_hip.so")
 
 _lib = None
-ABI_VERSION = 20  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 21  # include/wavlm_hip.h WAVLM_HIP_ABI_VERSION this binding was written against
 
 F32, BF16 = 0, 1
 
@@ -127,6 +127,7 @@ SIGNATURES = {
     "wavlm_attn_fused_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                      c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, c_vp, c_u64, c_vp]),
     "wavlm_attn_fused_pstore_bytes": (c_u64, [c_i32, c_i32, c_i32]),
+    "wavlm_attn_fused_dbits_bytes": (c_u64, [c_i32, c_i32, c_i32]),
     "wavlm_attn_fused_fwd_p": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u64, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32,
                                        c_u64, c_vp]),
     "wavlm_attn_fused_bwd_p": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,

@@ -35,9 +35,13 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------- forward
 // STORE: the probabilities (fp16, sign = dropped) and the running maxima go to p.ps for the backward (attn_fused.hpp)
-template <bool DROP, bool STORE = false>
+// BSTORE (round 6): the dropout DECISIONS go to p.dbits as bit words (attn_fused.hpp: fa_fbit_of_key) -- the forward evaluates the
+// hash anyway; the dQ and dK/dV kernels of the backward then select with stored bits (two instructions per element) instead of
+// evaluating it twice more.  One v_lshrrev + one v_and_or per pair here, one 4-byte store per lane and tile.
+template <bool DROP, bool STORE = false, bool BSTORE = false>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
   static_assert(!STORE || (FA_FWD_BIAS_IN_C && !FA_FWD_LAZY), "the probability store is written for the default forward");
+  static_assert(!BSTORE || (DROP && !STORE && FA_FWD_BIAS_IN_C && !FA_FWD_LAZY), "the bit store is written for the default forward with dropout");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   auto kbuf = [&](int st) { return smem + st * 16384; };
   auto vbuf = [&](int st) { return smem + st * 16384 + 8192; };
@@ -85,6 +89,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 #endif
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
   const unsigned vtr = fa_tr_base(lane);
+  // BSTORE: this lane's row in the bit words; lanes 0..31 store the word of key block 2 jt, lanes 32..63 of 2 jt + 1
+  unsigned* dbp = nullptr;
+  if constexpr (BSTORE) dbp = p.dbits + ((long)bh * p.db_nkb + hi) * p.db_Tq + fa_bitrow(i);
   // STORE: this wave's tile row of the fragment-native probability store and its column of the running maxima
   unsigned char* pst = nullptr;
   float* mtp = nullptr;
@@ -220,6 +227,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
     float rs = 0.f;
     U4 pf[2][2];
     U4 pst16[STORE ? 2 : 1][2];
+    unsigned bacc[2] = {0u, 0u};
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -239,10 +247,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
           }
           pst16[f][r >> 3].u[(r & 7) >> 1] = h2;
         } else {
-          if constexpr (DROP) pk &= fa_keepmask2(fa_mix(roww + cwp[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]), p.k2);
+          if constexpr (DROP) {
+            const unsigned km = fa_keepmask2(fa_mix(roww + cwp[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]), p.k2);
+            pk &= km;
+            if constexpr (BSTORE) bacc[f] = (bacc[f] >> 1) | (km & 0x80008000u);   // the pair's decisions enter at bits 15 / 31
+          }
         }
         pf[f][r >> 3].u[(r & 7) >> 1] = pk;
       }
+    if constexpr (BSTORE) {
+      // eight pairs per block: register r sits at bit (r >> 1) + 16 (r & 1) + 8; the hi = 1 half-wave (keys + 4) moves down by 8,
+      // one swap hands lanes 0..31 both halves' word of block 0 and lanes 32..63 of block 1.  The store is issued behind this
+      // tile's prefetch DMA: fa_tile_sync<1> lets exactly it stay in flight
+      unsigned w0 = bacc[0] >> (8 * hi), w1 = bacc[1] >> (8 * hi);
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(w0), "+v"(w1));
+      dbp[(long)jt * 2 * p.db_Tq] = w0 | w1;
+    }
     if constexpr (STORE && !(FA_SP_PROBE & 2)) {
       // four coalesced 1 KiB stores per wave (every lane its own 16 bytes) + the running maximum these values are relative
       // to.  Issued AFTER this tile's prefetch DMA: fa_tile_sync<5> lets exactly these five stay in flight.  Both halves
@@ -323,7 +343,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
       if (pst16[0][0].u[0] == 0x12345678u && pst16[1][1].u[3] == 0x9abcdef0u && pst16[0][1].u[1] == 77u && pst16[1][0].u[2] == 78u) mtp[0] = m;
       fa_tile_sync<0>();
     } else
-    fa_tile_sync<STORE ? 5 : 0>();
+    fa_tile_sync<STORE ? 5 : (BSTORE ? 1 : 0)>();
     cur ^= 1;
   }
   if (i < T) {
@@ -390,8 +410,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 // wrote (16 bytes per lane, f, s2: four coalesced 1 KiB loads per tile, issued one tile ahead) -- no score MFMA, no bias, no
 // exponential, no dropout word; Q is not needed at all.  DROP is irrelevant then (the decision is the stored sign).
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-template <bool DROP, bool TAB, bool SP = false>
+// BCONS (round 6, with DROP): the keep decisions are the bit words the FORWARD wrote (p.dbits, p.db_fwd; attn_fwd_kernel BSTORE):
+// two global loads per lane and tile (its row's words of the tile's two 32-key blocks, requested one tile ahead), v_bfe_i32 +
+// v_and_b32 per element -- no row word, no column words in LDS, no mix, no compare, and no bit words to produce for the dK/dV
+// kernel (it reads the forward's too).
+template <bool DROP, bool TAB, bool SP = false, bool BCONS = false>
 __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
+  static_assert(!BCONS || (DROP && !SP), "stored bits are dropout decisions of the recompute form");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per stage: K [kv][hd] 8 KB | V [kv][hd] 8 KB;  then (relative-position table present) the four waves' skew buffers
   // (96 x 64 B each)
@@ -449,7 +474,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   if constexpr (!SP) {
     for (int j = threadIdx.x; j < p.Tkb; j += 256)
       kb[j] = (j < T && !(p.kpm && p.kpm[(long)b * T + j])) ? 0.f : -INFINITY;
-    if constexpr (DROP)
+    if constexpr (DROP && !BCONS)
       for (int jp = threadIdx.x; jp < (p.Tkb >> 1); jp += 256) colw[jp] = fa_col_word(p.s1, (unsigned)jp);
   }
   for (int q = threadIdx.x; q < SKEW_BYTES / 16; q += 256) reinterpret_cast<uint4*>(smem + 32768)[q] = make_uint4(0, 0, 0, 0);
@@ -498,8 +523,16 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   int pend_bits_jt = -1;
   unsigned* dbp = nullptr;
   const unsigned thsv = (unsigned)p.ths;
-  if constexpr (DROP && !SP)
+  if constexpr (DROP && !SP && !BCONS)
     if (p.dbits) dbp = p.dbits + ((long)bh * p.db_nkb + hi) * p.db_Tq + fa_bitrow(i);
+  // BCONS: this row's words, block 0 of tile jt at bsrc[jt * 2 * db_Tq], block 1 one db_Tq further; nxt* = the next tile's,
+  // requested at the top of the tile before (behind its K / V prefetch: the end-of-tile vmcnt(0) covers them)
+  const unsigned* bsrc = nullptr;
+  unsigned nxt0 = 0, nxt1 = 0;
+  if constexpr (BCONS) {
+    bsrc = p.dbits + (long)bh * p.db_nkb * p.db_Tq + fa_bitrow(i);
+    nxt0 = bsrc[0]; nxt1 = bsrc[p.db_Tq];
+  }
 
   // SP: fragments and running maxima travel TWO tiles ahead in two register sets (ring A / B, the tile loop is unrolled by
   // two so that no set is ever copied while its loads are in flight).  One tile ahead the kernel was latency-bound at
@@ -594,7 +627,13 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     }
     if constexpr (SP && !(FA_SP_PROBE & 1)) p_load(jt + 2 < nkv ? jt + 2 : jt, x0, x1, mx);   // (past the end: a harmless reload, no branch around the loads)
     if constexpr (TAB) flush_pending();
-    if constexpr (DROP && !SP) {
+    unsigned bw0 = 0, bw1 = 0;   // BCONS: this tile's words, the half-wave's own bits moved to positions 0..7 / 16..23
+    if constexpr (BCONS) {
+      bw0 = nxt0 >> (8 * (1 - hi)); bw1 = nxt1 >> (8 * (1 - hi));
+      const int jn = more ? jt + 1 : jt;
+      nxt0 = bsrc[(long)jn * 2 * p.db_Tq]; nxt1 = bsrc[((long)jn * 2 + 1) * p.db_Tq];
+    }
+    if constexpr (DROP && !SP && !BCONS) {
       if (dbp && pend_bits_jt >= 0) dbp[(long)pend_bits_jt * 2 * p.db_Tq] = pend_bits;
       pend_bits_jt = -1;
     }
@@ -614,7 +653,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
         for (int r = 0; r < 16; ++r) {
           const int j = j0 + 32 * f + (r & 3) + 8 * (r >> 2) + 4 * hi;
           tvv[f][r] = trow[j];
-          if (DROP && !SP && !(r & 1)) cww[f][r >> 1] = (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1];
+          if (DROP && !SP && !BCONS && !(r & 1)) cww[f][r >> 1] = (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1];
         }
     }
     const bool edge = !SP && ((p.kpm != nullptr) || (j0 + FA_BKV > T));   // (SP: masked keys carry a stored 0)
@@ -655,7 +694,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
       for (int r = 0; r < 16; r += 2) {
         float dv[2];
         unsigned w = 0;
-        if constexpr (DROP && !SP) {
+        if constexpr (DROP && !SP && !BCONS) {
           if constexpr (PF) w = fa_mix(roww + cww[f][r >> 1]);
           else w = fa_mix(roww + (colw + ((j0 + 4 * hi) >> 1))[(32 * f + (r & 3) + 8 * (r >> 2)) >> 1]);
         }
@@ -692,7 +731,16 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
 #endif
           const f32x2_t pe2 = f32x2_t{__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
           f32x2_t dp2 = f32x2_t{dp[f][r], dp[f][r + 1]};
-          if constexpr (DROP) {
+          if constexpr (BCONS) {
+            // register r = 2 t of the block sits at bit t, r + 1 at bit 16 + t of the shifted word: 0 / ~0 each, applied to dP
+            const unsigned bw = f == 0 ? bw0 : bw1;
+            const int m0 = __builtin_amdgcn_sbfe(bw, r >> 1, 1), m1 = __builtin_amdgcn_sbfe(bw, 16 + (r >> 1), 1);
+            dp2[0] = __uint_as_float(__float_as_uint(dp2[0]) & (unsigned)m0);
+            dp2[1] = __uint_as_float(__float_as_uint(dp2[1]) & (unsigned)m1);
+            const f32x2_t ds2 = pe2 * (dp2 - f32x2_t{dls, dls});
+            dv[0] = ds2[0]; dv[1] = ds2[1];
+            dg2 = __builtin_elementwise_fma(ds2, tv2, dg2);
+          } else if constexpr (DROP) {
             // keep decisions of both halves: compare (SDWA, sign-extended half against the threshold), select, and the
             // decision shifted into the block's bit accumulator through the carry.  The select works on dP - delta (kept) against
             // -delta (dropped) -- bit-identical to (kept ? dP : 0) - delta -- so that the first reader of the dP product's
@@ -772,7 +820,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     if (edge) elem_pass(F1{}, std::true_type{}); else elem_pass(F1{}, std::false_type{});
     dq_acc(F1{});
 #endif
-    if constexpr (DROP && !SP) {
+    if constexpr (DROP && !SP && !BCONS) {
       // 16 decisions per block, first element in bit 15: reverse, spread the four 4-key runs to their key positions
       // (r -> (r & 3) + 8 (r >> 2) + 4 hi), exchange the halves' partial words (one swap: lanes 0..31 receive word 0 of both
       // half-waves, lanes 32..63 word 1)
@@ -807,7 +855,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   }
   if constexpr (TAB && FA_DQ_DEFER) skew_sums((nkv - 1) * FA_BKV);
   if constexpr (TAB) flush_pending();
-  if constexpr (DROP && !SP)
+  if constexpr (DROP && !SP && !BCONS)
     if (dbp && pend_bits_jt >= 0) dbp[(long)pend_bits_jt * 2 * p.db_Tq] = pend_bits;
   if (TAB && lane < 32) {
     // the 31 diagonals past the last tile's first 64 (blocks 4, 5)
@@ -908,7 +956,7 @@ static FaP fa_params(int B, int H, int T, float scale, float p_drop, uint64_t se
   p.k2 = (unsigned)((p.ths - 1) & 0xffff) * 0x10001u;
   p.k3 = (unsigned)(p.ths & 0xffff) * 0x10001u;
   p.ps.P16 = nullptr; p.ps.mt = nullptr;
-  p.dbits = nullptr; p.db_nkb = ((T + FA_BKV - 1) / FA_BKV) * 2; p.db_Tq = ((T + FA_BQ - 1) / FA_BQ) * FA_BQ;
+  p.dbits = nullptr; p.db_fwd = 0; p.db_nkb = ((T + FA_BKV - 1) / FA_BKV) * 2; p.db_Tq = ((T + FA_BQ - 1) / FA_BQ) * FA_BQ;
   p.ps.nq32 = ((T + FA_BQ - 1) / FA_BQ) * 4; p.ps.nkv = (T + FA_BKV - 1) / FA_BKV; p.ps.Tq = ((T + FA_BQ - 1) / FA_BQ) * FA_BQ;
   p.s0 = (unsigned)seed; p.s1 = (unsigned)(seed >> 32);
   const int nkv = (T + FA_BKV - 1) / FA_BKV;
@@ -928,6 +976,13 @@ uint64_t wavlm_attn_fused_pstore_bytes(int32_t B, int32_t H, int32_t T) {
   return ((fa_pstore_p_bytes(B, H, T) + 255) & ~(uint64_t)255) + fa_pstore_mt_bytes(B, H, T);
 }
 
+// bytes of the dropout bit words (the `pstore` of the bit mode of wavlm_attn_fused_fwd_p / _bwd_p): one bit per (row, key) of the
+// padded grid, 27 MB per layer at B = 32, H = 12, T = 749
+uint64_t wavlm_attn_fused_dbits_bytes(int32_t B, int32_t H, int32_t T) {
+  if (B <= 0 || H <= 0 || T <= 0) return 0;
+  return fa_dbits_bytes(B, H, T);
+}
+
 int wavlm_attn_fused_fwd(const void* qkv, void* O, float* lse, const float* gate, const float* tab, const uint8_t* kpm,
                          int32_t B, int32_t H, int32_t T, int32_t head_dim, float scale, float p_drop, uint64_t seed,
                          void* stream) {
@@ -944,9 +999,13 @@ int wavlm_attn_fused_fwd_p(const void* qkv, void* O, float* lse, const float* ga
                            float p_drop, uint64_t seed, void* stream) {
   if (!qkv || !O || !lse || B <= 0 || H <= 0 || T <= 0 || head_dim != FA_HD) return WL_EINVAL;
   if ((gate == nullptr) != (tab == nullptr)) return WL_EINVAL;
-  if (pstore && (T > FA_PSTORE_MAX_T || pstore_bytes < wavlm_attn_fused_pstore_bytes(B, H, T) || ((uintptr_t)pstore & 15))) return WL_EINVAL;
+  // pstore_bytes == wavlm_attn_fused_dbits_bytes: the BIT mode (the forward stores its dropout decisions only)
+  const bool bitmode = pstore && pstore_bytes == fa_dbits_bytes(B, H, T);
+  if (bitmode) { if ((uintptr_t)pstore & 255) return WL_EINVAL; }
+  else if (pstore && (T > FA_PSTORE_MAX_T || pstore_bytes < wavlm_attn_fused_pstore_bytes(B, H, T) || ((uintptr_t)pstore & 15))) return WL_EINVAL;
   FaP p = fa_params(B, H, T, scale, p_drop, seed);
   p.qkv = (const bf16_t*)qkv; p.O = (bf16_t*)O; p.lse = lse; p.gate = gate; p.tab = tab; p.kpm = kpm;
+  if (bitmode) { p.dbits = (unsigned*)pstore; p.db_fwd = 1; pstore = nullptr; }
   if (pstore) fa_bind_pstore(p, pstore, B, H, T);
   const size_t smem = 32768 + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float);
   p.nqb = (T + FA_BQ - 1) / FA_BQ;
@@ -956,6 +1015,10 @@ int wavlm_attn_fused_fwd_p(const void* qkv, void* O, float* lse, const float* ga
                    (double)B * T * H * FA_HD * 2.0 * 4.0 + (double)B * H * T * 4.0, (hipStream_t)stream);
 #define FA_FWD(DR, ST) do { if (fa_set_smem(attn_fwd_kernel<DR, ST>, smem) != WL_OK) return WL_ELAUNCH; \
     WL_LAUNCH((attn_fwd_kernel<DR, ST>), grid, dim3(256), smem, (hipStream_t)stream, p); } while (0)
+  if (p.th && p.dbits) {
+    if (fa_set_smem(attn_fwd_kernel<true, false, true>, smem) != WL_OK) return WL_ELAUNCH;
+    WL_LAUNCH((attn_fwd_kernel<true, false, true>), grid, dim3(256), smem, (hipStream_t)stream, p);
+  } else
   if (p.th) { if (pstore) FA_FWD(true, true); else FA_FWD(true, false); }
   else { if (pstore) FA_FWD(false, true); else FA_FWD(false, false); }
 #undef FA_FWD
@@ -976,7 +1039,7 @@ int wavlm_attn_fused_bwd(const void* qkv, const void* O, const void* dO, const f
                          const float* tab, const uint8_t* kpm, void* dqkv, float* dgate, float* dtab, void* dbias,
                          int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T, int32_t head_dim,
                          float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes, void* stream) {
-  return wl_attn_fused_bwd_ex(qkv, O, dO, lse, gate, tab, kpm, nullptr, dqkv, dgate, dtab, 0, dbias, dbias_dtype, dbias_accumulate,
+  return wl_attn_fused_bwd_ex(qkv, O, dO, lse, gate, tab, kpm, nullptr, 0, dqkv, dgate, dtab, 0, dbias, dbias_dtype, dbias_accumulate,
                               B, H, T, head_dim, scale, p_drop, seed, workspace, ws_bytes, stream);
 }
 
@@ -985,8 +1048,9 @@ int wavlm_attn_fused_bwd_p(const void* qkv, const void* O, const void* dO, const
                            float* dgate, float* dtab, void* dbias, int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B,
                            int32_t H, int32_t T, int32_t head_dim, float scale, float p_drop, uint64_t seed, void* workspace,
                            uint64_t ws_bytes, void* stream) {
-  if (pstore && (T > FA_PSTORE_MAX_T || pstore_bytes < wavlm_attn_fused_pstore_bytes(B, H, T) || ((uintptr_t)pstore & 15))) return WL_EINVAL;
-  return wl_attn_fused_bwd_ex(qkv, O, dO, lse, gate, tab, kpm, pstore, dqkv, dgate, dtab, 0, dbias, dbias_dtype, dbias_accumulate,
+  if (pstore && pstore_bytes == fa_dbits_bytes(B, H, T)) { if ((uintptr_t)pstore & 255) return WL_EINVAL; }
+  else if (pstore && (T > FA_PSTORE_MAX_T || pstore_bytes < wavlm_attn_fused_pstore_bytes(B, H, T) || ((uintptr_t)pstore & 15))) return WL_EINVAL;
+  return wl_attn_fused_bwd_ex(qkv, O, dO, lse, gate, tab, kpm, pstore, pstore_bytes, dqkv, dgate, dtab, 0, dbias, dbias_dtype, dbias_accumulate,
                               B, H, T, head_dim, scale, p_drop, seed, workspace, ws_bytes, stream);
 }
 
@@ -994,8 +1058,8 @@ int wavlm_attn_fused_bwd_p(const void* qkv, const void* O, const void* dO, const
 
 // the same with dtab (+)= (layer.hip: the table is shared by every block of the encoder, their gradients meet in one buffer)
 int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
-                         const float* tab, const uint8_t* kpm, const void* pstore, void* dqkv, float* dgate, float* dtab,
-                         int dtab_accumulate,
+                         const float* tab, const uint8_t* kpm, const void* pstore, uint64_t pstore_bytes, void* dqkv, float* dgate,
+                         float* dtab, int dtab_accumulate,
                          void* dbias, int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T,
                          int32_t head_dim, float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes,
                          void* stream) {
@@ -1008,6 +1072,9 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
   FaP p = fa_params(B, H, T, scale, p_drop, seed);
   p.qkv = (const bf16_t*)qkv; p.O = (bf16_t*)const_cast<void*>(O); p.lse = const_cast<float*>(lse);
   p.gate = gate; p.tab = tab; p.kpm = kpm; p.dO = (const bf16_t*)dO; p.dqkv = (bf16_t*)dqkv; p.dgate = dgate;
+  // pstore of the BIT mode: the forward's dropout decisions; everything else is recomputed
+  const unsigned* fwd_bits = nullptr;
+  if (pstore && pstore_bytes == fa_dbits_bytes(B, H, T)) { fwd_bits = (const unsigned*)pstore; pstore = nullptr; }
   if (pstore) fa_bind_pstore(p, const_cast<void*>(pstore), B, H, T);
   const int nqt = (T + FA_BQ - 1) / FA_BQ;
   const int L = 2 * T - 1;
@@ -1026,6 +1093,9 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
     FaP q = p; q.nqb = (T + FA_K64 - 1) / FA_K64;
     if (fa_dkv64_smem(q) > 160 * 1024) use64 = false;
   }
+  if (fwd_bits && p.th) {
+    p.dbits = const_cast<unsigned*>(fwd_bits); p.db_fwd = 1; use64 = false;   // (the 64-keys-per-wave kernel reads lane masks: dQ-kernel words only)
+  } else
   if (dbits_on && !pstore && p.th) {
     const uint64_t fbytes = ((uint64_t)B * H * nqt * 4 * Lp + (uint64_t)B * H * T + (uint64_t)B * nqt * 4 * 3 * H * FA_HD) * sizeof(float);
     p.dbits = (unsigned*)((unsigned char*)workspace + ((fbytes + 255) & ~(uint64_t)255));
@@ -1039,6 +1109,11 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
                    (double)B * T * H * FA_HD * 2.0 * 8.0 + (double)B * H * T * 8.0, st);
 #define FA_DQ(DR, TB, SP_) do { if (fa_set_smem(attn_bwd_dq_kernel<DR, TB, SP_>, smem1) != WL_OK) return WL_ELAUNCH; \
     WL_LAUNCH((attn_bwd_dq_kernel<DR, TB, SP_>), dim3((unsigned)(nqt * B * H)), dim3(256), smem1, st, p); } while (0)
+#define FA_DQB(TB) do { if (fa_set_smem(attn_bwd_dq_kernel<true, TB, false, true>, smem1) != WL_OK) return WL_ELAUNCH; \
+    WL_LAUNCH((attn_bwd_dq_kernel<true, TB, false, true>), dim3((unsigned)(nqt * B * H)), dim3(256), smem1, st, p); } while (0)
+  if (p.th && p.db_fwd) {   // the forward's bit words: nothing to hash, nothing to produce
+    if (tab) FA_DQB(true); else FA_DQB(false);
+  } else
   if (pstore) {   // stored probabilities: the dropout decision is the stored sign
     if (tab) FA_DQ(false, true, true); else FA_DQ(false, false, true);
   } else if (p.th) {
@@ -1047,6 +1122,7 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
     if (tab) FA_DQ(false, true, false); else FA_DQ(false, false, false);
   }
 #undef FA_DQ
+#undef FA_DQB
   size_t smem2 = 32768 + (size_t)(p.Ltab + 64 + 2 * 448) * sizeof(float);   // (2 x FA_ROWV of attn_fused_dkv.hip)
   if (smem2 < FA_CS_FLOATS * sizeof(float)) smem2 = FA_CS_FLOATS * sizeof(float);
   if (use64) {

@@ -215,6 +215,9 @@ struct FaP {
   // dbits[(bh * db_nkb + c) * db_Tq + fa_bitrow(i)], bit k = keep(row i, key 32 c + k); db_nkb = 2 x key tiles of the dQ kernel,
   // db_Tq = rows padded to its 128-row blocks.  nullptr: not written
   unsigned* dbits; int db_nkb, db_Tq;
+  // db_fwd = 1: the words were written by the FORWARD (attn_fwd_kernel<true, false, true>) in ITS bit order (fa_fbit) and the dQ
+  // kernel consumes them as well; 0: written by the dQ kernel of this backward, bit k = key k of the block
+  int db_fwd;
   int Ltab, Tkb;  // LDS extents: rel table (zero padded) and key bias
   int nqb;        // tiles along the sequence per (b, h) of the kernel being launched
 };
@@ -288,6 +291,14 @@ struct FaTileSrc {
 // position of row i inside its group of eight in the dropout bit words: 0 4 1 5 2 6 3 7 -- rows i and i + 4 (the two half-waves
 // of the dK/dV kernel's 32 x 32 blocks) are neighbours, so that their two words form one aligned SGPR pair of a scalar load
 __host__ __device__ inline int fa_bitrow(int i) { return (i & ~7) + 2 * (i & 3) + ((i >> 2) & 1); }
+// Bit order of the words the forward writes.  A forward lane (row i, half-wave hi) holds the 16 keys (r & 3) + 8 (r >> 2) + 4 hi,
+// r = 0..15, of a 32-key block, walks them in pairs and shifts every pair's two decisions in from the top
+// (acc = acc >> 1 | mask & 0x80008000): register r ends at bit (r >> 1) + 16 (r & 1) + 8 of the half-wave's own word, and the
+// halves combine as hi = 0 | (hi = 1) >> 8.  fa_fbit_of_key: the bit of key k (0..31) of the block.
+__host__ __device__ inline int fa_fbit_of_key(int k) {
+  const int hi = (k >> 2) & 1, r = (k & 3) + 4 * (k >> 3);
+  return (r >> 1) + 16 * (r & 1) + 8 * (1 - hi);
+}
 __host__ __device__ inline uint64_t fa_dbits_bytes(int B, int H, int T) {
   const uint64_t nkb = (uint64_t)((T + FA_BKV - 1) / FA_BKV) * 2, Tq = (uint64_t)((T + FA_BQ - 1) / FA_BQ) * FA_BQ;
   return (uint64_t)B * H * nkb * Tq * sizeof(unsigned) + 256;   // + one scalar-load line of slack behind the last word

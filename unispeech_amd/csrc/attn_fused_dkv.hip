@@ -63,6 +63,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   const unsigned cw = fa_col_word(p.s1, (unsigned)(jc >> 1));
   const unsigned csh = (jc & 1) << 4;
   const float* tcol = tabs + 64 + (jc + T - 1);  // tcol[-i] = rel[h, j - i]; 64 zero floats in front absorb rows past T
+  // BITS: where this lane's key sits in a word: bit `key` in the dQ kernel's words, fa_fbit_of_key in the forward's
+  const unsigned kbit = (BITS && p.db_fwd) ? (unsigned)fa_fbit_of_key(kl) : (unsigned)kl;
   const unsigned* bits = nullptr;   // BITS: the words of this wave's 32-key block, [row] (rows of a group of eight: 0 4 1 5 2 6 3 7)
   if constexpr (BITS) {
     int c = kblk * 4 + wave_u;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
           float pd = pe;
           if constexpr (BITS) {
             // bit `key` of the row's word, sign-extended: 0 / ~0 (v_bfe_i32), applied to the bits of the probability
-            const int km = __builtin_amdgcn_sbfe(roww[e], kl, 1);
+            const int km = __builtin_amdgcn_sbfe(roww[e], kbit, 1);
             pd = __uint_as_float(__float_as_uint(pe) & (unsigned)km);
           } else if constexpr (DROP) {
             const unsigned w = fa_mix(roww[e] + cw);

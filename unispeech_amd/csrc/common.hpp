@@ -232,8 +232,8 @@ static inline uint64_t wl_esize(int dt) { return dt == WL_BF16 ? 2 : 4; }
 // attn_fused.hip: wavlm_attn_fused_bwd with dtab (+)= when dtab_accumulate != 0
 // (pstore: the forward's probability store, wavlm_attn_fused_fwd_p, or NULL = recompute)
 int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const float* lse, const float* gate,
-                         const float* tab, const uint8_t* kpm, const void* pstore, void* dqkv, float* dgate, float* dtab,
-                         int dtab_accumulate,
+                         const float* tab, const uint8_t* kpm, const void* pstore, uint64_t pstore_bytes, void* dqkv, float* dgate,
+                         float* dtab, int dtab_accumulate,
                          void* dbias, int32_t dbias_dtype, int32_t dbias_accumulate, int32_t B, int32_t H, int32_t T,
                          int32_t head_dim, float scale, float p_drop, uint64_t seed, void* workspace, uint64_t ws_bytes,
                          void* stream);

@@ -73,6 +73,10 @@ Saved carve_saved(const wavlm_layer_desc* d, void* base) {
   s.u = c.take(n * d->F * 2);
   s.hact = c.take(n * d->F * 2);
   if (!d->pre_ln) s.s2 = c.take(n * d->D * 2);
+  if (d->attn_store_p == 2) {   // the forward's dropout decisions as bit words (nothing to keep without attention dropout)
+    s.pstore_b = d->p_attn > 0.f ? wavlm_attn_fused_dbits_bytes(d->B, d->H, d->T) : 0;
+    if (s.pstore_b) s.pstore = c.take(s.pstore_b);
+  } else
   if (d->attn_store_p) {   // (0 bytes: this T is not supported by the stored form -- recompute)
     s.pstore_b = wavlm_attn_fused_pstore_bytes(d->B, d->H, d->T);
     if (s.pstore_b) s.pstore = c.take(s.pstore_b);
@@ -381,7 +385,7 @@ int wavlm_encoder_layer_bwd(const wavlm_layer_desc* d, void* stream) {
     dxres = nullptr;    // (pre-LN: the residual stream's gradient w.dsa joins in the LN1 backward below)
   }
   RC(lin_dx(da, d->Wo, w.dO, n, D, D, 0, nullptr, nullptr, nullptr, pdt, nullptr, 0, stream));
-  RC(wl_attn_fused_bwd_ex(s.qkv, s.O, w.dO, s.lse, d->Wgate ? s.gate : nullptr, d->tab, d->kpm, s.pstore, w.dqkv, w.dgate, d->dtab,
+  RC(wl_attn_fused_bwd_ex(s.qkv, s.O, w.dO, s.lse, d->Wgate ? s.gate : nullptr, d->tab, d->kpm, s.pstore, s.pstore_b, w.dqkv, w.dgate, d->dtab,
                           d->dtab_accumulate, d->dbqkv, pdt, 1, d->B, d->H, d->T, 64, d->scale, d->p_attn, d->seed_attn, w.attn_ws,
                           w.attn_b, stream));
   const void* ain = d->pre_ln ? s.h1 : d->x;

@@ -21,7 +21,13 @@ USE_FUSED_ATTENTION = True  # bf16 + head_dim 64 -> fused kernels; otherwise GEM
 # measured on the same box the step is 0.1-0.5 ms SLOWER with it (forward +45 us per layer for the 467 MB write; backward
 # kernels unchanged at ~210 + ~200 us although they issue 40 % fewer VALU and 25 % fewer MFMA instructions) -- the backward
 # kernels are bound by LDS bandwidth, not by the element pass (profiles/r05/attn_stored_p.txt).
-ATTN_STORE_P = os.environ.get("WAVLM_ATTN_STORE_P", "0") == "1"
+# Round 6, WAVLM_ATTN_STORE_P=bits: the forward keeps only its dropout DECISIONS (one bit per element, 27 MB per Base layer) and
+# both backward kernels select with the stored bits instead of evaluating the dropout hash (wavlm_attn_fused_dbits_bytes).  Built,
+# bit-identical, and OFF as well: the forward pays 11.5 us per layer for producing the words (it is VALU-bound: one more
+# instruction per element) and the dQ kernel gains 12 (profiles/r06/ab_attn_fwd_bits.txt).  The DEFAULT ("0") keeps nothing: the
+# dQ kernel hands its decisions to the dK/dV kernel inside the backward (csrc/attn_fused_dkv.hip, -13 us per layer for free).
+_ASP = os.environ.get("WAVLM_ATTN_STORE_P", "0")
+ATTN_STORE_P = True if _ASP == "1" else ("bits" if _ASP in ("bits", "2") else False)
 
 
 def next_seed():

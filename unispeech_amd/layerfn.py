@@ -142,7 +142,7 @@ class EncoderLayerFn(torch.autograd.Function):
         C.memmove(C.byref(d), C.byref(bd.desc), C.sizeof(d))
         d.B, d.T = B, T
         d.p_drop, d.p_attn = p_drop, p_attn
-        d.attn_store_p = int(F.ATTN_STORE_P)   # probabilities kept in `saved` for backward (functional.ATTN_STORE_P)
+        d.attn_store_p = 2 if F.ATTN_STORE_P == "bits" else int(bool(F.ATTN_STORE_P))   # what `saved` keeps of the attention (functional.ATTN_STORE_P)
         # seeds are drawn in the order the composed path draws them (same masks either way: the two paths can be compared
         # bit for bit with dropout on)
         if d.pre_ln and p_drop > 0 and rc is not None:

@@ -565,8 +565,9 @@ def attn_softmax_bwd(S, dP, lse, gate, tab, kpm, dS, dgate, dtab, B, H, T, ldS, 
 
 
 def attn_fused_fwd(qkv, gate, tab, kpm, H, scale, p_drop, seed, store_p=False):
-    """fused bf16 attention forward (head_dim 64): returns (O [B,T,D], lse [B*H,T], pstore).  store_p: the forward also
-    writes its probabilities into `pstore` (opaque uint8 buffer) for attn_fused_bwd; otherwise pstore is None"""
+    """fused bf16 attention forward (head_dim 64): returns (O [B,T,D], lse [B*H,T], pstore).  store_p True: the forward also
+    writes its probabilities into `pstore` (opaque uint8 buffer) for attn_fused_bwd; "bits": only its dropout decisions (one
+    bit per element; nothing without dropout); False: pstore is None"""
     dev = _dev(qkv); _contig(qkv)
     B, T, D3 = qkv.shape
     D = D3 // 3
@@ -574,7 +575,11 @@ def attn_fused_fwd(qkv, gate, tab, kpm, H, scale, p_drop, seed, store_p=False):
     lse = torch.empty((B * H, T), dtype=torch.float32, device=dev)
     L = _lib.lib()
     pstore, nps = None, 0
-    if store_p:
+    if store_p == "bits":
+        if p_drop > 0:
+            nps = int(L.wavlm_attn_fused_dbits_bytes(B, H, T))
+            pstore = torch.empty(nps, dtype=torch.uint8, device=dev)
+    elif store_p:
         nps = int(L.wavlm_attn_fused_pstore_bytes(B, H, T))   # 0: this T is not supported by the stored form -> recompute
         pstore = torch.empty(nps, dtype=torch.uint8, device=dev) if nps else None
     check(L.wavlm_attn_fused_fwd_p(ptr(qkv), ptr(O), ptr(lse), ptr(gate), ptr(tab), ptr(kpm), ptr(pstore), nps, B, H, T, D // H,
