@@ -609,6 +609,7 @@ extern "C" int wavlm_gemm(const wavlm_gemm_desc* d, void* stream) {
 }
 
 int gemm_pp_launch_grouped(GemmP& p, hipStream_t st);  // gemm_pp.hip
+bool gemm_w4_fixup_ok(const GemmP& p);                   // gemm_w4.hip
 
 // Several weight-gradient-shaped problems (both operands K-strided, same K and split_k >= 2, plain epilogue) as ONE
 // split-K launch of the 256 x 256 kernel plus one slab reduction per problem.  Anything else runs as n wavlm_gemm calls.
@@ -659,6 +660,7 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
     GemmGrp& g = p.grp[i];
     g.A = e->A; g.B = e->B; g.ws = (float*)e->workspace; g.lda = e->lda; g.ldb = e->ldb; g.M = e->M; g.N = e->N;
     g.tiles_m = (e->M + 255) / 256; g.tiles_n = (e->N + 255) / 256;
+    g.C = e->C; g.ldc = e->ldc; g.c_dtype = e->c_dtype; g.accumulate = e->accumulate; g.alpha = e->alpha;
     g.vbase = i < n ? vb : 0x7fffffff;   // first work item of the member (balanced launch: its first tile)
     if (i < n) { vb += g.tiles_m * g.tiles_n * (sk ? 1 : p.split_k); flops += 2.0 * e->M * e->N * (double)e->K; }
   }
@@ -678,8 +680,12 @@ extern "C" int wavlm_gemm_grouped(const wavlm_gemm_desc* d, int32_t n, void* str
     int* sh = g_prof.shape[pi];
     sh[0] = -n; sh[1] = 0; sh[2] = d->K; sh[3] = 1; sh[4] = 3; sh[5] = 0; sh[6] = sk ? 0 : p.split_k; sh[7] = n;   // M = -members: a grouped launch; split 0 = balanced
   }
+  // in-kernel fix-up (gemm_w4.hip; WAVLM_WGRAD_FIXUP=1, measured slower and off): the last workgroup of a tile to arrive adds the
+  // other splits' slabs and writes the final result -- no reduction launch, one slab round trip less per tile
+  const bool fixup = w4_takes(d, true) && gemm_w4_fixup_ok(p);
+  p.fix_epoch = fixup ? 1u : 0u; p.fix_cnt = nullptr; p.fix_flag = nullptr;
   int rc = w4_takes(d, true) ? gemm_w4_launch_grouped(p, st) : gemm_pp_launch_grouped(p, st);
-  if (rc == WL_OK) {
+  if (rc == WL_OK && !fixup) {
     RedGrpP r;
     r.n = n; r.S = p.split_k; r.base[0] = 0;
     for (int i = 0; i < 4; ++i) {

@@ -5,7 +5,9 @@
 #include "../../include/wavlm_hip.h"
 
 // one problem of a grouped split-K launch (gemm_pp.hip): operands, slab base and tile geometry; vbase = first work item
-struct GemmGrp { const void* A; const void* B; float* ws; long lda, ldb; int M, N, tiles_m, tiles_n, vbase; };
+struct GemmGrp { const void* A; const void* B; float* ws; long lda, ldb; int M, N, tiles_m, tiles_n, vbase;
+                 // the member's final epilogue (in-kernel split-K fix-up, gemm_w4.hip): C (+)= alpha * sum of the partial sums
+                 void* C; long ldc; int c_dtype, accumulate; float alpha; };
 
 struct GemmP {
   const void* A; const void* B; void* C;
@@ -24,6 +26,9 @@ struct GemmP {
   int swz_r;                 // > 0: tile ids walk super-rows of swz_r tile rows column by column (gemm_tile_rc)
   int patch_m;               // split-K work order: tile-row patch height (0: tiles only, split outermost)
   int ngrp;                  // > 0: grouped launch, the problems are grp[0 .. ngrp) (A/B/M/N/lda/ldb/ws above are unused)
+  // fix_epoch != 0 (grouped launch of gemm_w4_kernel): in-kernel split-K fix-up -- the LAST workgroup of a tile to finish its K
+  // range adds the other splits' slabs to its own partial sum and writes the final result; no reduction launch follows
+  unsigned fix_epoch; unsigned* fix_cnt; unsigned* fix_flag;
   int sk_ks, sk_wgs, sk_tiles, sk_s, sk_lm, sk_spread;  // sk_ks > 0: balanced grouped launch (gemm_sk_plan): K steps per tile, workgroups, tiles of all members, main splits, main run
   const float4* gtab;        // GELU / GELU' chord table in global memory (fast epilogue 3 copies it to LDS), or null
   float* colsum_part;        // fused column sums of C (ping-pong kernels, fast epilogues): partial rows [tiles_m][N], or null
@@ -116,6 +121,7 @@ static inline GemmP make_gemm_params(const wavlm_gemm_desc* d) {
   p.tiles_m = 0; p.tiles_n = 0; p.vtotal = 0; p.nbatch = 1; p.skew = 0; p.patch_m = 0; p.ngrp = 0;
   p.sk_ks = 0; p.sk_wgs = 0; p.sk_tiles = 0; p.sk_s = 0; p.sk_lm = 0; p.sk_spread = 0;
   p.swz_r = 0;
+  p.fix_epoch = 0; p.fix_cnt = nullptr; p.fix_flag = nullptr;
   return p;
 }
 

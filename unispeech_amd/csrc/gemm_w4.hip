@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
   const int ntile = p.tiles_m * p.tiles_n;
   for (int vid = blockIdx.x; vid < p.vtotal; vid += gridDim.x) {
   int tm, tn, z, split;
+  int fix_uid = 0;
   int sk_t0 = 0, sk_t1 = 0;
   GemmP q = p;
   if constexpr (GRP) {
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
 #define W4_SEL(F) (g == 0 ? p.grp[0].F : g == 1 ? p.grp[1].F : g == 2 ? p.grp[2].F : p.grp[3].F)
     q.A = W4_SEL(A); q.B = W4_SEL(B); q.ws = W4_SEL(ws); q.lda = W4_SEL(lda); q.ldb = W4_SEL(ldb);
     q.M = W4_SEL(M); q.N = W4_SEL(N); q.tiles_m = W4_SEL(tiles_m); q.tiles_n = W4_SEL(tiles_n);
+    q.C = W4_SEL(C); q.ldc = W4_SEL(ldc); q.c_dtype = W4_SEL(c_dtype); q.accumulate = W4_SEL(accumulate); q.alpha = W4_SEL(alpha);
     local -= W4_SEL(vbase);
 #undef W4_SEL
     const int nt_g = q.tiles_m * q.tiles_n;
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
     else { split = local / nt_g; tile = local - split * nt_g; }
     tm = tile / q.tiles_n; tn = tile - tm * q.tiles_n;
     z = 0;
+    fix_uid = item - split * nt_g;   // one id per (member, tile): members' item ranges are disjoint
   } else
   if (p.patch_m == 0) {
     const int nt = ntile, bid = vid % ntile;
@@ -412,6 +415,34 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
 #undef W4_VMWAIT
   __syncthreads();
 
+  // ---- in-kernel split-K fix-up (grouped launch, p.fix_epoch != 0): arrival order decides who finishes the tile.  A workgroup
+  // that is NOT the last to arrive writes its slab as ever and raises its flag; the LAST one waits for the others' flags --
+  // they all arrived before it, i.e. are past their K loops and wait for nobody: no cycle, whatever the grid and whoever is
+  // resident -- and adds their slabs to its own partial sum IN SPLIT ORDER (bit-identical to the reduction kernel, and the same
+  // from run to run whoever arrives last), scales, accumulates into C and stores: one slab write + read per tile less, and no
+  // reduction launch.
+  bool fix_last = false;
+  if constexpr (GRP && EP == 1) {
+    if (p.fix_epoch != 0 && !(GEMM_SK && p.sk_ks > 0)) {
+      unsigned* xch = reinterpret_cast<unsigned*>(smem);
+      if (threadIdx.x == 0) xch[0] = __hip_atomic_fetch_add(p.fix_cnt + fix_uid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      fix_last = xch[0] == (unsigned)(P.split_k - 1);
+      __syncthreads();   // (the staging below reuses smem)
+      if (fix_last) {
+        if (threadIdx.x == 0) {
+          __hip_atomic_store(p.fix_cnt + fix_uid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every split has arrived: ready for the next launch
+          for (int s_ = 0; s_ < P.split_k; ++s_) {
+            if (s_ == split) continue;
+            while (__hip_atomic_load(p.fix_flag + fix_uid * 8 + s_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.fix_epoch) __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every thread: the slabs are read from L2, not from a stale L1 line
+      }
+    }
+  }
+
   // ---- epilogue: per-wave LDS staging of a 32 x 128 row block -> 16-byte row vectors --------------------------------
   const int mw = m0 + wm * 128, nw = n0 + wn2 * 128;
   if constexpr (EP == 0) {
@@ -467,7 +498,36 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
           const float4 lo = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8);
           const float4 hi = *reinterpret_cast<const float4*>(ep + rl * EP_LD + ch * 8 + 4);
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          if constexpr (EP == 1) gemm_store8(P, zo, zi, z, split, mm, nn, v);
+          if constexpr (EP == 1) {
+            if (GRP && fix_last) {
+              const long mn = (long)P.M * P.N, at = (long)mm * P.N + nn;
+              float tot[8];
+#pragma unroll 1
+              for (int s_ = 0; s_ < P.split_k; ++s_) {
+                float src[8];
+                if (s_ == split) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) src[e] = v[e];
+                } else {
+                  const float4 a = *reinterpret_cast<const float4*>(P.ws + (long)s_ * mn + at);
+                  const float4 b = *reinterpret_cast<const float4*>(P.ws + (long)s_ * mn + at + 4);
+                  src[0] = a.x; src[1] = a.y; src[2] = a.z; src[3] = a.w; src[4] = b.x; src[5] = b.y; src[6] = b.z; src[7] = b.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tot[e] = s_ == 0 ? src[e] : tot[e] + src[e];
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) tot[e] *= P.alpha;
+              const long off = (long)mm * P.ldc + nn;
+              if (P.accumulate) {
+                float c[8];
+                ld8_dt(P.C, off, P.c_dtype, c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tot[e] += c[e];
+              }
+              st8_dt(P.C, off, P.c_dtype, tot);
+            } else gemm_store8(P, zo, zi, z, split, mm, nn, v);
+          }
           else gemm_store8_fast<(EP == 2 ? 0 : EP)>(P, zo, zi, mm, nn, v, tab, CSUM ? vo : nullptr);
         }
         if constexpr (CSUM) {
@@ -494,6 +554,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmP p) {
           if (nw + 64 + lane < P.N) dst[nw + 64 + lane] = cs[1] + other[64 + lane];
         }
       }
+    }
+  }
+  if constexpr (GRP && EP == 1) {
+    if (p.fix_epoch != 0 && !(GEMM_SK && p.sk_ks > 0) && !fix_last) {
+      __threadfence();   // this thread's slab stores are visible device-wide ...
+      __syncthreads();   // ... for every thread of the workgroup, before the flag goes up
+      if (threadIdx.x == 0)
+        __hip_atomic_store(p.fix_flag + fix_uid * 8 + split, p.fix_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
@@ -537,8 +605,30 @@ static int w4_launch_t(GemmP& p, int nbatch, int ep, hipStream_t st) {
   return wl_check_launch();
 }
 
+// in-kernel split-K fix-up: arrival counters and flags of up to 4096 (member, tile) ids x 8 splits; zero at load, counters are
+// returned to zero by the last arriver, flags carry the launch's epoch (never 0).  One grouped launch at a time per process
+// (the path has one compute stream).
+__device__ unsigned g_w4_fix_cnt[4096];
+__device__ unsigned g_w4_fix_flag[4096 * 8];
+static unsigned g_w4_fix_epoch = 0;
+bool gemm_w4_fixup_ok(const GemmP& p) {
+  // OFF by default: built, bit-identical to the reduction launch and deterministic (tools/wgrad_fixup_cmp.py), and measured
+  // SLOWER -- 402 against 338 us per Base block launch + reduction, the step +1.0 ms (profiles/r06/ab_wgrad_fixup.txt): the
+  // tiles' last arrivers all finish at the end of the launch and each reads its 256 KB of slabs through the epilogue's
+  // dependent 32-byte loads, alone on its CU, where the reduction kernel streams the same bytes with every CU in 17 us.
+  static const bool on = [] { const char* e = getenv("WAVLM_WGRAD_FIXUP"); return e && *e == '1'; }();
+  return on && p.split_k >= 2 && p.split_k <= 8 && p.vtotal <= 4096 && !(GEMM_SK && p.sk_ks > 0);
+}
 int gemm_w4_launch_grouped(GemmP& p, hipStream_t st) {
   constexpr int smem = 2 * W4_STAGE;
+  if (p.fix_epoch != 0) {   // the caller asked for the fix-up (gemm_w4_fixup_ok): bind the buffers, draw the epoch
+    static unsigned* cnt = nullptr; static unsigned* flag = nullptr;
+    if (!cnt) {
+      if (hipGetSymbolAddress((void**)&cnt, HIP_SYMBOL(g_w4_fix_cnt)) != hipSuccess || hipGetSymbolAddress((void**)&flag, HIP_SYMBOL(g_w4_fix_flag)) != hipSuccess) return WL_ELAUNCH;
+    }
+    if (++g_w4_fix_epoch == 0) g_w4_fix_epoch = 1;
+    p.fix_epoch = g_w4_fix_epoch; p.fix_cnt = cnt; p.fix_flag = flag;
+  }
   static bool done = false;
   if (!done) {
     if (hipFuncSetAttribute((const void*)gemm_w4_kernel<true, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return WL_ELAUNCH;
