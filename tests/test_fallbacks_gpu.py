@@ -59,3 +59,20 @@ def test_environment_switches_select_an_implementation_not_a_result():
         # same arithmetic in another order / another kernel: bf16 rounding-level agreement
         assert abs(got["loss"] - ref["loss"]) <= 2e-3 * abs(ref["loss"]), (name, got, ref)
         assert abs(got["gnorm"] - ref["gnorm"]) <= 2e-2 * abs(ref["gnorm"]), (name, got, ref)
+
+
+@pytest.mark.gpu
+def test_round6_opt_in_variants_are_bit_identical_to_the_default():
+    """Round 6 built four variants that were measured and left OFF; each keeps the default's arithmetic and rounding points, so
+    its results must equal the default's bit for bit (the tools re-run themselves, one process per switch):
+      * WAVLM_ATTN_DBITS=1: the dQ kernel hands its dropout decisions to the dK/dV kernel as bit words (attention dropout 0.1
+        / 0.25 / 0, padded keys, T = 63 ... 1000), and on top of it WAVLM_ATTN_DKV64=1: the 64-keys-per-wave dK/dV kernel;
+      * WAVLM_WGRAD_FIXUP=1: in-kernel split-K fix-up of the grouped weight-gradient launch (Base split 2, Large split 4, ragged
+        tiles; also identical from repetition to repetition, whoever arrives last).
+    (WAVLM_ATTN_STORE_P=bits, the forward-written words, is covered by gpu_checks.check_dropout_exact / check_attention and
+    tests/test_layer_fused_gpu.py.)"""
+    for tool in ("attn_dkv64_cmp.py", "wgrad_fixup_cmp.py"):
+        env = {k: v for k, v in os.environ.items() if k not in ("WAVLM_ATTN_DBITS", "WAVLM_ATTN_DKV64", "WAVLM_WGRAD_FIXUP")}
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, tool + "\n" + out.stdout[-3000:] + out.stderr[-2000:]
+        assert "DIFFERENT" not in out.stdout and ": False" not in out.stdout, out.stdout[-3000:]   # (the tools' own verdict words)

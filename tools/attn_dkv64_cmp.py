@@ -1,8 +1,8 @@
 """The dK/dV kernel variants of round 6 against the kernel of rounds 1-5 on the step's shapes: same formulas and rounding
 points, so every backward result must be BIT-IDENTICAL.
-  A: WAVLM_ATTN_DBITS=0              every kernel recomputes its dropout decisions (rounds 1-5)
-  B: default                         the dQ kernel's bit words select in the dK/dV kernel
-  C: WAVLM_ATTN_DKV64=1              + the 64-keys-per-wave dK/dV kernel
+  A: default                         every kernel recomputes its dropout decisions (rounds 1-5)
+  B: WAVLM_ATTN_DBITS=1              the dQ kernel's bit words select in the dK/dV kernel
+  C: + WAVLM_ATTN_DKV64=1            + the 64-keys-per-wave dK/dV kernel
 The switches are read once per process: this script re-runs itself.
 usage: python tools/attn_dkv64_cmp.py            # compares B and C with A, prints one line per case"""
 import os
@@ -45,7 +45,7 @@ if __name__ == "__main__":
         run(sys.argv[1])
         sys.exit(0)
     res = {}
-    for tag, env in (("A", {"WAVLM_ATTN_DBITS": "0"}), ("B", {}), ("C", {"WAVLM_ATTN_DKV64": "1"})):
+    for tag, env in (("A", {}), ("B", {"WAVLM_ATTN_DBITS": "1"}), ("C", {"WAVLM_ATTN_DBITS": "1", "WAVLM_ATTN_DKV64": "1"})):
         path = "/tmp/attn_dkv_%s.pt" % tag
         e = {k: v for k, v in os.environ.items() if k not in ("WAVLM_ATTN_DBITS", "WAVLM_ATTN_DKV64")}
         e.update(env)

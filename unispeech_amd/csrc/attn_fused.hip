@@ -23,6 +23,16 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #ifndef FA_DQ_PK
 #define FA_DQ_PK 1
 #endif
+// FA_FWD_MFMA_SUM (round 6, lab switch): the forward's row sums out of four all-ones MFMAs per tile (the matrix pipe is 20 % busy)
+// instead of 32 v_add_f32 + a half-wave exchange: l = sum of the bf16-ROUNDED unmasked probabilities.  Parity green, measured
+// NEUTRAL (119.8 against 119.8 us, three alternating same-box runs, profiles/r06/ab_attn_fwd_mfma_sum.txt): OFF, the numbers of
+// rounds 1-5 stay
+#if !defined(WAVLM_EXPERIMENTAL)
+#undef FA_FWD_MFMA_SUM
+#endif
+#ifndef FA_FWD_MFMA_SUM
+#define FA_FWD_MFMA_SUM 0
+#endif
 // FA_FWD_BIAS_IN_C: the forward's Toeplitz bias rides in the C operand of the score MFMAs (see the tile loop)
 #ifndef FA_FWD_BIAS_IN_C
 #define FA_FWD_BIAS_IN_C 1
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
     const float nmsub = dead ? 0.f : -m_new;  // dead rows: every x is -inf -> 2^(-inf) = 0
     float rs = 0.f;
     U4 pf[2][2];
+    U4 pu[(FA_FWD_MFMA_SUM && DROP) ? 2 : 1][2];   // the unmasked pairs (DROP: pf is masked)
     U4 pst16[STORE ? 2 : 1][2];
     unsigned bacc[2] = {0u, 0u};
 #pragma unroll
@@ -234,8 +245,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
       for (int r = 0; r < 16; r += 2) {
         const float p0 = __builtin_amdgcn_exp2f(fmaf(s[f][r], p.sc2, nmsub));
         const float p1 = __builtin_amdgcn_exp2f(fmaf(s[f][r + 1], p.sc2, nmsub));
+#if !FA_FWD_MFMA_SUM
         rs += p0 + p1;
+#endif
         unsigned pk = pack_bf16(p0, p1);
+        if constexpr (FA_FWD_MFMA_SUM && DROP) pu[f][r >> 3].u[(r & 7) >> 1] = pk;
         if constexpr (STORE) {
           // fp16 pair (round towards zero: one v_cvt_pkrtz_f16_f32); the sign bit takes the drop decision, the bf16 pair of
           // the PV product is masked with the same word
@@ -255,6 +269,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
         }
         pf[f][r >> 3].u[(r & 7) >> 1] = pk;
       }
+#if FA_FWD_MFMA_SUM
+    {
+      // D[m][q] = sum over the k-step's 16 keys of P^T[key][q] for every row m: four MFMAs cover the tile's 64 keys, both
+      // half-waves' k slots included -- no exchange; every register of the lane holds its query's sum
+      U4 ones; ones.v = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      f32x16_t lacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones.b, ((FA_FWD_MFMA_SUM && DROP) ? pu[f][s2] : pf[f][s2]).b, lacc, 0, 0, 0);
+      rs = lacc[0];
+    }
+#endif
     if constexpr (BSTORE) {
       // eight pairs per block: register r sits at bit (r >> 1) + 16 (r & 1) + 8; the hi = 1 half-wave (keys + 4) moves down by 8,
       // one swap hands lanes 0..31 both halves' word of block 0 and lanes 32..63 of block 1.  The store is issued behind this
@@ -321,7 +351,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
         pf[f][r >> 3].u[(r & 7) >> 1] = pk;
       }
 #endif
+#if !(FA_FWD_MFMA_SUM && FA_FWD_BIAS_IN_C && !FA_FWD_LAZY)
     rs = wl_sum_xor32(rs);
+#endif
     l = l * alpha + rs;
     m = m_new;
     if (__any(alpha != 1.f)) {  // the running maximum settles after the first tiles: skip the rescale then
@@ -414,9 +446,11 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 // two global loads per lane and tile (its row's words of the tile's two 32-key blocks, requested one tile ahead), v_bfe_i32 +
 // v_and_b32 per element -- no row word, no column words in LDS, no mix, no compare, and no bit words to produce for the dK/dV
 // kernel (it reads the forward's too).
-template <bool DROP, bool TAB, bool SP = false, bool BCONS = false>
+// EMIT (with DROP): the kernel leaves its dropout decisions behind as bit words for the dK/dV kernel (WAVLM_ATTN_DBITS=1).
+template <bool DROP, bool TAB, bool SP = false, bool BCONS = false, bool EMIT = false>
 __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   static_assert(!BCONS || (DROP && !SP), "stored bits are dropout decisions of the recompute form");
+  static_assert(!EMIT || (DROP && !SP && !BCONS), "bit words are emitted by the recompute form with dropout");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per stage: K [kv][hd] 8 KB | V [kv][hd] 8 KB;  then (relative-position table present) the four waves' skew buffers
   // (96 x 64 B each)
@@ -523,7 +557,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   int pend_bits_jt = -1;
   unsigned* dbp = nullptr;
   const unsigned thsv = (unsigned)p.ths;
-  if constexpr (DROP && !SP && !BCONS)
+  if constexpr (EMIT)
     if (p.dbits) dbp = p.dbits + ((long)bh * p.db_nkb + hi) * p.db_Tq + fa_bitrow(i);
   // BCONS: this row's words, block 0 of tile jt at bsrc[jt * 2 * db_Tq], block 1 one db_Tq further; nxt* = the next tile's,
   // requested at the top of the tile before (behind its K / V prefetch: the end-of-tile vmcnt(0) covers them)
@@ -633,7 +667,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
       const int jn = more ? jt + 1 : jt;
       nxt0 = bsrc[(long)jn * 2 * p.db_Tq]; nxt1 = bsrc[((long)jn * 2 + 1) * p.db_Tq];
     }
-    if constexpr (DROP && !SP && !BCONS) {
+    if constexpr (EMIT) {
       if (dbp && pend_bits_jt >= 0) dbp[(long)pend_bits_jt * 2 * p.db_Tq] = pend_bits;
       pend_bits_jt = -1;
     }
@@ -740,6 +774,12 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
             const f32x2_t ds2 = pe2 * (dp2 - f32x2_t{dls, dls});
             dv[0] = ds2[0]; dv[1] = ds2[1];
             dg2 = __builtin_elementwise_fma(ds2, tv2, dg2);
+          } else if constexpr (DROP && !EMIT) {
+            dp2[0] = fa_keep_lo(w, p.ths) ? dp2[0] : 0.f;
+            dp2[1] = fa_keep_hi(w, p.ths) ? dp2[1] : 0.f;
+            const f32x2_t ds2 = pe2 * (dp2 - f32x2_t{dls, dls});
+            dv[0] = ds2[0]; dv[1] = ds2[1];
+            dg2 = __builtin_elementwise_fma(ds2, tv2, dg2);
           } else if constexpr (DROP) {
             // keep decisions of both halves: compare (SDWA, sign-extended half against the threshold), select, and the
             // decision shifted into the block's bit accumulator through the carry.  The select works on dP - delta (kept) against
@@ -748,13 +788,15 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
             const f32x2_t t2 = dp2 - f32x2_t{dls, dls};
             float d0 = t2[0], d1 = t2[1];
             unsigned acc = f == 0 ? bacc0 : bacc1;
-            asm("v_cmp_le_i32_sdwa vcc, %[ths], sext(%[w]) src0_sel:DWORD src1_sel:WORD_0\n\t"
-                "v_cndmask_b32_e32 %[d0], %[nd], %[d0], vcc\n\t"
-                "v_addc_co_u32_e32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
-                "v_cmp_le_i32_sdwa vcc, %[ths], sext(%[w]) src0_sel:DWORD src1_sel:WORD_1\n\t"
-                "v_cndmask_b32_e32 %[d1], %[nd], %[d1], vcc\n\t"
-                "v_addc_co_u32_e32 %[acc], vcc, %[acc], %[acc], vcc"
-                : [d0] "+v"(d0), [d1] "+v"(d1), [acc] "+v"(acc) : [ths] "v"(thsv), [w] "v"(w), [nd] "v"(ndls) : "vcc");
+            // (three separate statements per half, the decision in an SGPR pair instead of VCC: one VCC chain through six
+            // instructions kept the scheduler from interleaving anything -- measured +10 us per launch)
+            unsigned long k0, k1, cdummy;
+            asm("v_cmp_le_i32_sdwa %[k], %[ths], sext(%[w]) src0_sel:DWORD src1_sel:WORD_0" : [k] "=s"(k0) : [ths] "v"(thsv), [w] "v"(w));
+            asm("v_cmp_le_i32_sdwa %[k], %[ths], sext(%[w]) src0_sel:DWORD src1_sel:WORD_1" : [k] "=s"(k1) : [ths] "v"(thsv), [w] "v"(w));
+            asm("v_cndmask_b32_e64 %[d], %[nd], %[d], %[k]" : [d] "+v"(d0) : [nd] "v"(ndls), [k] "s"(k0));
+            asm("v_cndmask_b32_e64 %[d], %[nd], %[d], %[k]" : [d] "+v"(d1) : [nd] "v"(ndls), [k] "s"(k1));
+            asm("v_addc_co_u32_e64 %[acc], %[c], %[acc], %[acc], %[k]" : [acc] "+v"(acc), [c] "=s"(cdummy) : [k] "s"(k0));
+            asm("v_addc_co_u32_e64 %[acc], %[c], %[acc], %[acc], %[k]" : [acc] "+v"(acc), [c] "=s"(cdummy) : [k] "s"(k1));
             if constexpr (f == 0) bacc0 = acc; else bacc1 = acc;
             const f32x2_t ds2m = pe2 * f32x2_t{d0, d1};
             dv[0] = ds2m[0]; dv[1] = ds2m[1];
@@ -820,7 +862,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     if (edge) elem_pass(F1{}, std::true_type{}); else elem_pass(F1{}, std::false_type{});
     dq_acc(F1{});
 #endif
-    if constexpr (DROP && !SP && !BCONS) {
+    if constexpr (EMIT) {
       // 16 decisions per block, first element in bit 15: reverse, spread the four 4-key runs to their key positions
       // (r -> (r & 3) + 8 (r >> 2) + 4 hi), exchange the halves' partial words (one swap: lanes 0..31 receive word 0 of both
       // half-waves, lanes 32..63 word 1)
@@ -855,7 +897,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   }
   if constexpr (TAB && FA_DQ_DEFER) skew_sums((nkv - 1) * FA_BKV);
   if constexpr (TAB) flush_pending();
-  if constexpr (DROP && !SP && !BCONS)
+  if constexpr (EMIT)
     if (dbp && pend_bits_jt >= 0) dbp[(long)pend_bits_jt * 2 * p.db_Tq] = pend_bits;
   if (TAB && lane < 32) {
     // the 31 diagonals past the last tile's first 64 (blocks 4, 5)
@@ -1082,11 +1124,12 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
   const int Lp = (L + 3) & ~3;
   p.delta = p.dtab_part + (long)B * H * nqt * 4 * Lp;
   if (dbias) p.dbias_part = p.delta + (long)B * H * T;
-  // Round 6: the dQ kernel leaves its dropout decisions behind as bit words and the dK/dV kernel selects with them
-  // (WAVLM_ATTN_DBITS=0: every kernel recomputes its decisions, rounds 1-5).  Not with stored probabilities (the decision is the
+  // Round 6, WAVLM_ATTN_DBITS=1: the dQ kernel leaves its dropout decisions behind as bit words and the dK/dV kernel selects with
+  // them.  Built, bit-identical, and OFF: the dK/dV kernel gains 10 us per launch and the dQ kernel pays 10 for producing the
+  // words (same-box A/B of three alternating runs each, profiles/r06/ab_attn_dq_emit_bits.txt) -- every kernel recomputes.  Not with stored probabilities (the decision is the
   // stored sign there).  WAVLM_ATTN_DKV64=1: the 64-keys-per-wave dK/dV kernel (attn_fused_dkv64.hip: built, bit-identical,
   // measured SLOWER -- one wave per SIMD is issue-bound --, kept for the record).
-  static const bool dbits_on = []() { const char* e = getenv("WAVLM_ATTN_DBITS"); return !(e && e[0] == '0'); }();
+  static const bool dbits_on = []() { const char* e = getenv("WAVLM_ATTN_DBITS"); return e && e[0] == '1'; }();
   static const bool dkv64_on = []() { const char* e = getenv("WAVLM_ATTN_DKV64"); return e && e[0] == '1'; }();
   bool use64 = dkv64_on && dbits_on && !pstore;
   if (use64) {
@@ -1116,6 +1159,11 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
   } else
   if (pstore) {   // stored probabilities: the dropout decision is the stored sign
     if (tab) FA_DQ(false, true, true); else FA_DQ(false, false, true);
+  } else if (p.th && p.dbits) {   // emit the bit words for the dK/dV kernel
+    if (tab) { if (fa_set_smem(attn_bwd_dq_kernel<true, true, false, false, true>, smem1) != WL_OK) return WL_ELAUNCH;
+               WL_LAUNCH((attn_bwd_dq_kernel<true, true, false, false, true>), dim3((unsigned)(nqt * B * H)), dim3(256), smem1, st, p); }
+    else { if (fa_set_smem(attn_bwd_dq_kernel<true, false, false, false, true>, smem1) != WL_OK) return WL_ELAUNCH;
+           WL_LAUNCH((attn_bwd_dq_kernel<true, false, false, false, true>), dim3((unsigned)(nqt * B * H)), dim3(256), smem1, st, p); }
   } else if (p.th) {
     if (tab) FA_DQ(true, true, false); else FA_DQ(true, false, false);
   } else {

@@ -14,8 +14,9 @@
 // ------------------------------------------------------------------------------------ backward 2/2: dK, dV
 // Lane owns a KEY column; scores are in the untransposed layout S[q][kv] so that the query contraction of
 // dV^T = dO^T P and dK^T = Q^T dS finds its k-slots in the lane's registers.
-// BITS (round 6, with DROP): the keep decisions come from the dQ kernel's bit words (attn_fused.hpp: dbits) instead of being
-// recomputed.  This layout pays six instructions per element for a decision (row word + column word, two-instruction mix, half
+// BITS (round 6, with DROP; WAVLM_ATTN_DBITS=1 or the forward's words, WAVLM_ATTN_STORE_P=bits): the keep decisions come from bit
+// words (attn_fused.hpp: dbits) instead of being recomputed.  This kernel gains 10-13 us per launch from it (200 -> 187-190), which
+// the producer of the words pays back (dQ kernel +10, forward +11.5: profiles/r06): off by default.  This layout pays six instructions per element for a decision (row word + column word, two-instruction mix, half
 // select, compare, select: a lane owns ONE key, so it uses one half of every 32-bit word) and a 16-byte LDS read per four rows
 // for the row words; bit k of word (row i, 32-key block c) is exactly the LANE MASK of the select for register "row i" here
 // (lanes = the 32 keys of the wave).  Two ways to use it were built:

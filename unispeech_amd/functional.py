@@ -24,8 +24,8 @@ USE_FUSED_ATTENTION = True  # bf16 + head_dim 64 -> fused kernels; otherwise GEM
 # Round 6, WAVLM_ATTN_STORE_P=bits: the forward keeps only its dropout DECISIONS (one bit per element, 27 MB per Base layer) and
 # both backward kernels select with the stored bits instead of evaluating the dropout hash (wavlm_attn_fused_dbits_bytes).  Built,
 # bit-identical, and OFF as well: the forward pays 11.5 us per layer for producing the words (it is VALU-bound: one more
-# instruction per element) and the dQ kernel gains 12 (profiles/r06/ab_attn_fwd_bits.txt).  The DEFAULT ("0") keeps nothing: the
-# dQ kernel hands its decisions to the dK/dV kernel inside the backward (csrc/attn_fused_dkv.hip, -13 us per layer for free).
+# instruction per element) and the dQ kernel gains 12 (profiles/r06/ab_attn_fwd_bits.txt).  The DEFAULT ("0") keeps nothing and
+# every kernel recomputes its decisions (WAVLM_ATTN_DBITS=1: the dQ kernel hands them to the dK/dV kernel -- neutral as well).
 _ASP = os.environ.get("WAVLM_ATTN_STORE_P", "0")
 ATTN_STORE_P = True if _ASP == "1" else ("bits" if _ASP in ("bits", "2") else False)
 
@@ -942,7 +942,7 @@ class AttnCoreFn(torch.autograd.Function):
             qkv_bias_tok.taken = True
             ctx.bias_sink = qkv_bias_sink
         if ctx.fused:
-            store = ATTN_STORE_P and ctx.needs_input_grad[0]   # (grad mode is always off inside Function.forward: not a condition)
+            store = ATTN_STORE_P if ctx.needs_input_grad[0] else False   # (grad mode is always off inside Function.forward: not a condition; `x and y` would turn "bits" into True)
             O, lse, pstore = ops.attn_fused_fwd(qkvc, gate, tab, kpm, H, scale, p_drop, seed, store_p=store)
             ctx.save_for_backward(qkvc, O, lse, gate, tab, kpm, pstore)
             ctx.cfg = (B, T, D, H, hd, 0, scale, p_drop, seed)
