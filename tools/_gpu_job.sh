@@ -1,19 +1,3 @@
 # scratch: the command of the builder's latest gpurun call (see tools/gpu_final.sh for the round's closing artefacts)
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python tests/gpu_checks.py attention 2>&1 | tail -1
-timeout 600 python tests/gpu_checks.py dropout_exact 2>&1 | tail -1
-timeout 900 python -m pytest tests/test_layer_fused_gpu.py tests/test_fallbacks_gpu.py -q -m gpu 2>&1 | tail -3
-: > gpurun_out/ab_fwd_mfma_sum.txt
-for rep in 1 2 3; do for LIB in tools/probe/lib/libwavlm_hip_probenosum.so unispeech_amd/lib/libwavlm_hip.so; do
-  rm -rf /tmp/prof_ab
-  WAVLM_HIP_LIB=$PWD/$LIB timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ab -- python tools/attn_bench.py 0.1 > /tmp/ab.log 2>&1
-  ST=$(find /tmp/prof_ab -name "*kernel_stats.csv" | head -1)
-  echo "== $LIB (rep $rep)" >> gpurun_out/ab_fwd_mfma_sum.txt
-  [ -n "$ST" ] && python - "$ST" >> gpurun_out/ab_fwd_mfma_sum.txt <<'PY'
-import csv, sys
-for r in csv.DictReader(open(sys.argv[1])):
-    if "fwd_kernel" in r["Name"]:
-        print("%-66s %6s calls  avg %9.1f us" % (r["Name"][:66], r["Calls"], float(r["AverageNs"]) / 1e3))
-PY
-done; done
-cat gpurun_out/ab_fwd_mfma_sum.txt
+cd $GRAFT_REPO_ROOT; bash tools/gpu_final.sh r6f
+timeout 600 python bench.py > gpurun_out/bench_default_r6f.txt 2>gpurun_out/bench_default_r6f.err; tail -1 gpurun_out/bench_default_r6f.txt | cut -c1-300
