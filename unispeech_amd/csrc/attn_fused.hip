@@ -435,6 +435,23 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(FaP p) {
 #ifndef FA_DQ_NOSKEW
 #define FA_DQ_NOSKEW 0
 #endif
+// FA_DQ_SKEW_ROWS (round 6): the skew buffer of the diagonal sums ROW-major, Sk[rho][c] (row = query row rho of the wave, 96 diagonals
+// + pad = 200 bytes) instead of Sk[c][rho].  A lane's four consecutive keys are then four consecutive diagonals of ITS row: one
+// 8-byte store per run at an address that is only 2-byte aligned (31 - rho + 4 hi + dd: gfx950 executes unaligned 8-byte LDS
+// stores correctly and at the aligned rate, tools/probe/lds_unaligned.hip) -- 8 ds_write_b64 per tile instead of 32 ds_write_b16;
+// the B operand [k = rho][n = c] of the diagonal-sum MFMAs is k-major then and comes through the transposing read (two
+// ds_read_b64_tr_b16 per 16-diagonal block instead of one ds_read_b128): 20 LDS instructions per tile instead of 38.  Parity green,
+// measured SLOWER: 245 against 205 us (three alternating same-box runs, profiles/r06/ab_attn_dq_skew_rows.txt) -- an unaligned
+// 8-byte store touches three banks per lane (16 lanes: 48 bank accesses for 32 banks, at least two passes) where 64 lanes' 2-byte
+// stores are one pass: the kernel is bound by LDS PASSES, not by LDS instructions.  Lab switch, OFF.
+#if !defined(WAVLM_EXPERIMENTAL)
+#undef FA_DQ_SKEW_ROWS
+#endif
+#ifndef FA_DQ_SKEW_ROWS
+#define FA_DQ_SKEW_ROWS 0
+#endif
+#define FA_SKEW_RB 200                                  // bytes per row of the row-major skew buffer
+#define FA_SKEW_WAVE (FA_DQ_SKEW_ROWS ? 32 * FA_SKEW_RB : 6144)   // bytes per wave
 #ifndef FA_DQ_OCC
 #define FA_DQ_OCC 2
 #endif
@@ -456,7 +473,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   // (96 x 64 B each)
   auto kbuf = [&](int st) { return smem + st * 16384; };
   auto vbuf = [&](int st) { return smem + st * 16384 + 8192; };
-  constexpr int SKEW_BYTES = TAB ? 4 * 6144 : 0;
+  constexpr int SKEW_BYTES = TAB ? 4 * FA_SKEW_WAVE : 0;
   float* tabs = reinterpret_cast<float*>(smem + 32768 + SKEW_BYTES);
   float* kb = tabs + p.Ltab;
   unsigned* colw = reinterpret_cast<unsigned*>(kb + p.Tkb);
@@ -472,7 +489,7 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   const int i = qblk * FA_BQ + 32 * wave + ql;
   const int ic = i < T ? i : T - 1;
   const bool valid_i = i < T;
-  unsigned char* skew = smem + 32768 + wave_u * 6144;
+  unsigned char* skew = smem + 32768 + wave_u * FA_SKEW_WAVE;
   const int ib = qblk * FA_BQ + 32 * wave_u;
   const int dlo0 = -ib - 31 + T - 1;  // diagonal of skew row 0 at tile 0 (negative for rows past the table)
   // d(rel) partial row of THIS WAVE: the finished diagonals leave as plain coalesced 256-byte stores, one per tile.
@@ -524,6 +541,11 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
   unsigned short* sk_w = reinterpret_cast<unsigned short*>(skew + (31 - ql + 4 * hi) * 64 + 2 * ql);
   // B-operand read of diagonal block cb: row 16 cb + (l & 15), 16 bytes at (l >> 4) * 16
   const unsigned char* sk_r = skew + (lane & 15) * 64 + (lane >> 4) * 16;
+  // row-major form: this lane's row rho = ql starts its runs at diagonal 31 - rho + 4 hi (+ dd); transposing read of a 16-diagonal
+  // block: lane i of a 16-lane group addresses row 8 kg + (i >> 2) (second read: + 4), diagonals 4 (i & 3) .. +3 and receives the four
+  // rows' values of diagonal i
+  const unsigned sk_w3 = (unsigned)(unsigned long)(las_ptr)(skew + ql * FA_SKEW_RB + 2 * (31 - ql + 4 * hi));
+  const unsigned char* sk_r3 = skew + (8 * (lane >> 4) + ((lane & 15) >> 2)) * FA_SKEW_RB + 8 * (lane & 3);
   // transposed A-operand read base into a K tile (see the header comment)
   const unsigned ktr = fa_tr_base(lane);
 
@@ -611,7 +633,16 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
     f32x4_t nacc[6];
 #pragma unroll
     for (int cb = 0; cb < 6; ++cb) {
-      U4 bfr; bfr.v = *reinterpret_cast<const uint4*>(sk_r + cb * 1024);
+      U4 bfr;
+#if FA_DQ_SKEW_ROWS
+      {
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(sk_r3 + cb * 32));
+        const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(sk_r3 + 4 * FA_SKEW_RB + cb * 32));
+        bfr.b = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#else
+      bfr.v = *reinterpret_cast<const uint4*>(sk_r + cb * 1024);
+#endif
       const f32x4_t cin = cb < 2 ? dacc[cb + 4] : f32x4_t{0.f, 0.f, 0.f, 0.f};
       nacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfrag.b, bfr.b, cin, 0, 0, 0);
     }
@@ -833,8 +864,17 @@ __global__ __launch_bounds__(256, FA_DQ_OCC) void attn_bwd_dq_kernel(FaP p) {
         if constexpr (TAB) {  // the skew buffer takes dS itself; the gate multiplies inside the diagonal-sum MFMA
           const int dd = 32 * f + (r & 3) + 8 * (r >> 2);  // + 4 hi is in sk_w
 #if !FA_DQ_NOSKEW && !(FA_SP_PROBE & 4)  // (probe: wrong d(rel), prices the skew writes)
+#if FA_DQ_SKEW_ROWS
+          if (r & 2) {   // the run's second pair: keys dd - 2 .. dd + 1 = four consecutive diagonals of this lane's row
+            const unsigned prev = (f == 0 ? dsf0 : dsf1)[r >> 3].u[((r & 7) >> 1) - 1];
+            const unsigned long pair = ((unsigned long)u2 << 32) | prev;
+            const unsigned a = sk_w3 + 2 * (dd - 2);
+            asm volatile("ds_write_b64 %0, %1" :: "v"(a), "v"(pair) : "memory");
+          }
+#else
           sk_w[dd * 32] = (unsigned short)u2;
           sk_w[(dd + 1) * 32] = (unsigned short)(u2 >> 16);
+#endif
 #endif
         }
       }
@@ -1143,7 +1183,7 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
     const uint64_t fbytes = ((uint64_t)B * H * nqt * 4 * Lp + (uint64_t)B * H * T + (uint64_t)B * nqt * 4 * 3 * H * FA_HD) * sizeof(float);
     p.dbits = (unsigned*)((unsigned char*)workspace + ((fbytes + 255) & ~(uint64_t)255));
   }
-  size_t smem1 = 32768 + (tab ? 4 * 6144 : 0) + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float) + 256;  // + gate fragments
+  size_t smem1 = 32768 + (tab ? 4 * FA_SKEW_WAVE : 0) + (size_t)(p.Ltab + p.Tkb + p.Tkb / 2) * sizeof(float) + 256;  // + gate fragments
   if (smem1 < FA_CS_FLOATS * sizeof(float)) smem1 = FA_CS_FLOATS * sizeof(float);
   p.nqb = nqt;
   // algorithmic: S, dP, dQ, dK, dV (5 x 2 T^2 hd per head; the kernels recompute S and dP once more); qkv, O, dO read
