@@ -37,6 +37,8 @@ for a in sys.argv[1:] or ["1", "2", "3", "4"]:
         src, a = "rowops.hip", a[4:]
     elif a.startswith("attn:"):  # attn:<tag>:-DFA_FWD_LAZY=1,... builds attn_fused.hip (forward + dQ kernels) with the defines
         src, a = "attn_fused.hip", a[5:]
+    elif a.startswith("dkv:"):  # dkv:<tag>:-DFA_DKV_RSM=0 builds attn_fused_dkv.hip (the 32-keys-per-wave dK/dV kernels) with the defines
+        src, a = "attn_fused_dkv.hip", a[4:]
     elif a.startswith("k64:"):  # k64:<tag>:-DK64_PROBE=3 builds attn_fused_dkv64.hip (64-keys-per-wave dK/dV kernel) with the defines
         src, a = "attn_fused_dkv64.hip", a[4:]
     srcs = [src]

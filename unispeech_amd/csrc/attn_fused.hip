@@ -1211,7 +1211,7 @@ int wl_attn_fused_bwd_ex(const void* qkv, const void* O, const void* dO, const f
   }
 #undef FA_DQ
 #undef FA_DQB
-  size_t smem2 = 32768 + (size_t)(p.Ltab + 64 + 2 * 448) * sizeof(float);   // (2 x FA_ROWV of attn_fused_dkv.hip)
+  size_t smem2 = 32768 + (size_t)(p.Ltab + 64) * sizeof(float) + 2 * 4096;   // (2 x FA_RSM_STAGE of attn_fused_dkv.hip, >= 2 x FA_ROWV floats)
   if (smem2 < FA_CS_FLOATS * sizeof(float)) smem2 = FA_CS_FLOATS * sizeof(float);
   if (use64) {
     p.nqb = (T + FA_K64 - 1) / FA_K64;

@@ -29,6 +29,23 @@
 //     the dropout row words (one global load per lane and tile next to lse / delta / gate, the same 16-byte LDS read per four
 //     rows), and a decision is v_bfe_i32 (bit `key` of the row's word, sign-extended) + v_and_b32: two instructions.
 #define FA_ROWV 448   // floats per stage of the per-row arrays: lse | delta | gate | (row words, or the four waves' bit words)
+// FA_DKV_RSM (round 6): the per-row scalars through the MATRIX pipe instead of 16-byte broadcast reads.  The lane owns a key, so
+// lse / gate / delta of the query rows reach its registers through LDS: three 16-byte reads per four rows, 384 of the kernel's
+// ~1100 bytes of LDS traffic per lane and tile in a kernel that is bound by LDS passes.  An MFMA whose B operand is
+// all ones in k slots 0..2 and whose A operand holds a row's scalar as three bf16 pieces (x = h + m + l, 24 significand bits) in
+// those slots delivers D[row][key] = x(row) for every key -- the scalar broadcast along the keys, in exactly the register
+// layout of the scores.  lse rides as a FIFTH k step of the score product itself (in units of 1 / sc2), gate and delta are one
+// product each per 32-row block: +6 MFMAs per tile (the pipe is 35 % busy) for 6 fragment reads instead of 24 broadcast reads.
+// Parity green (gpu_checks attention / dropout_exact), 240 VGPRs, no spill -- and measured 3-5 us SLOWER (210 against 206 us, without
+// dropout 169 against 163; three alternating same-box runs, profiles/r06/ab_attn_dkv_rsm.txt): a quarter of the kernel's LDS bytes
+// gone and six MFMAs added change nothing, i.e. the kernel is not bound by LDS bytes alone either.  Lab switch, OFF.
+#if !defined(WAVLM_EXPERIMENTAL)
+#undef FA_DKV_RSM
+#endif
+#ifndef FA_DKV_RSM
+#define FA_DKV_RSM 0
+#endif
+#define FA_RSM_STAGE 4096   // bytes per stage: [3 scalars][64 rows][8 bf16] fragments, then 1 KiB of row words / bit words
 template <bool DROP, bool BITS = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   static_assert(DROP || !BITS, "bit words are dropout decisions");
@@ -105,6 +122,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
   };
   auto rows_store = [&](const RowRegs& r, int st) {
     const int t = threadIdx.x;
+#if FA_DKV_RSM
+    static_assert(!FA_DKV_BIAS_IN_C, "the matrix-pipe form of the row scalars replaces the C-operand form");
+    unsigned char* rs = reinterpret_cast<unsigned char*>(rowv) + st * FA_RSM_STAGE;
+    if (t < 64) {
+      // x = h + m + l in bf16 pieces (round to nearest each: 24 significand bits together); rows past T: a finite -1e30 (the
+      // exponent becomes -inf-like: 2^x = 0) -- an infinity would make m = inf - inf
+      auto split3 = [](float x, unsigned char* dst) __attribute__((always_inline)) {
+        const bf16_t h = f2bf(x); const float r1 = x - bf2f(h);
+        const bf16_t m = f2bf(r1); const float r2 = r1 - bf2f(m);
+        const bf16_t l = f2bf(r2);
+        *reinterpret_cast<uint4*>(dst) = make_uint4((unsigned)h | ((unsigned)m << 16), (unsigned)l, 0u, 0u);
+      };
+      split3((r.ok ? p.log2sc - r.lse * FA_LOG2E : -1e30f) / p.sc2, rs + t * 16);            // rides in the score product: units of 1 / sc2
+      split3(p.gate ? r.gate * FA_LOG2E : 0.f, rs + 1024 + t * 16);
+      split3(r.delta * p.inv_sc, rs + 2048 + t * 16);
+      if constexpr (DROP && !BITS) reinterpret_cast<unsigned*>(rs + 3072)[t] = fa_row_word(p.s0, r.o);
+    }
+    if constexpr (BITS) reinterpret_cast<unsigned*>(rs + 3072)[t] = r.word;   // every wave its own 64 words
+    return;
+#endif
     if (t < 64) {
 #if FA_DKV_BIAS_IN_C
       // bias - lse enters as the C operand of the score MFMAs, in units of 1 / sc2 (P * sc = 2^(sc2 s))
@@ -141,6 +178,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
       FA_LOAD_QDO(iq0 + FA_BQ1, qbuf(cur ^ 1), dobuf(cur ^ 1));
     }
     const float* rv = rowv + cur * FA_ROWV;
+#if FA_DKV_RSM
+    const unsigned char* rsc = reinterpret_cast<const unsigned char*>(rowv) + cur * FA_RSM_STAGE;
+    const unsigned* rwords = reinterpret_cast<const unsigned*>(rsc + 3072) + (BITS ? 64 * wave_u : 0);
+    // B operand of the scalar products: ones in k slots 0..2 (held by the hi = 0 half-wave), zeros elsewhere -- both half-waves
+    // read the same fragment of their row, the hi = 1 copy meets zeros
+    U4 onesb; onesb.v = hi == 0 ? make_uint4(0x3f803f80u, 0x00003f80u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+#endif
     // S = Q K^T, dP = dO V^T  (rows = queries of the tile, col = this lane's key)
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -169,17 +213,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(qbuf(cur), 32 * f + kl, kk, hi), kf[kk].b, s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(dobuf(cur), 32 * f + kl, kk, hi), vf[kk].b, dp, 0, 0, 0);
       }
+#if FA_DKV_RSM
+      // the block's per-row scalars through the matrix pipe: lse / sc2 as a fifth k step of the scores; gate and delta as
+      // [32 rows] x [this lane's key] blocks in the scores' register layout
+      f32x16_t gblk, dblk;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { gblk[r] = 0.f; dblk[r] = 0.f; }
+      {
+        U4 a0, a1, a2;
+        a0.v = *reinterpret_cast<const uint4*>(rsc + (32 * f + kl) * 16);
+        a1.v = *reinterpret_cast<const uint4*>(rsc + 1024 + (32 * f + kl) * 16);
+        a2.v = *reinterpret_cast<const uint4*>(rsc + 2048 + (32 * f + kl) * 16);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.b, onesb.b, s, 0, 0, 0);
+        gblk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.b, onesb.b, gblk, 0, 0, 0);
+        dblk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.b, onesb.b, dblk, 0, 0, 0);
+      }
+#endif
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         // registers 4 q4 .. 4 q4 + 3 of a block are four consecutive query rows: per-row scalars come as 16-byte
         // LDS vectors; the Toeplitz entries rel[j - i] run downwards in i
         const int il0 = 32 * f + 8 * q4 + 4 * hi;
+#if FA_DKV_RSM
+        uint4 row4 = make_uint4(0, 0, 0, 0);
+        if constexpr (DROP) row4 = *reinterpret_cast<const uint4*>(rwords + il0);
+        const float delv[4] = {dblk[4 * q4], dblk[4 * q4 + 1], dblk[4 * q4 + 2], dblk[4 * q4 + 3]};
+        const unsigned roww[4] = {row4.x, row4.y, row4.z, row4.w};
+        const float gatv[4] = {gblk[4 * q4], gblk[4 * q4 + 1], gblk[4 * q4 + 2], gblk[4 * q4 + 3]};
+        const float* tq = tcol - (iq0 + il0);
+#else
         const float4 del4 = *reinterpret_cast<const float4*>(rv + 64 + il0);
         uint4 row4 = make_uint4(0, 0, 0, 0);
         if constexpr (DROP) row4 = *reinterpret_cast<const uint4*>(rv + 192 + (BITS ? 64 * wave_u : 0) + il0);
         const float delv[4] = {del4.x, del4.y, del4.z, del4.w};
         const unsigned roww[4] = {row4.x, row4.y, row4.z, row4.w};
-#if !FA_DKV_BIAS_IN_C
+#endif
+#if !FA_DKV_BIAS_IN_C && !FA_DKV_RSM
         const float4 lse4 = *reinterpret_cast<const float4*>(rv + il0);
         const float4 gat4 = *reinterpret_cast<const float4*>(rv + 128 + il0);
         const float lsev[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
@@ -191,7 +260,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(FaP p) {
         for (int e = 0; e < 4; ++e) {
           const int rr = 4 * q4 + e;
           // x - lse as two fmas (the -lse rides in the bias term)
-#if FA_DKV_BIAS_IN_C
+#if FA_DKV_RSM
+          const float pe = __builtin_amdgcn_exp2f(fmaf(s[rr], p.sc2, gatv[e] * tq[-e]));  // (s carries lse / sc2; rows past T: -1e30 -> 0)
+#elif FA_DKV_BIAS_IN_C
           const float pe = __builtin_amdgcn_exp2f(s[rr] * p.sc2);  // rows past T: -inf -> 0
 #else
           const float pe = __builtin_amdgcn_exp2f(fmaf(s[rr], p.sc2, fmaf(gatv[e], tq[-e], lsev[e])));  // rows past T: -inf -> 0
