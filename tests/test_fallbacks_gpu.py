@@ -25,6 +25,10 @@ wav = torch.randn(B, T, generator=g).cuda().to(torch.bfloat16)
 target = torch.randint(4, 504, (B, 150), generator=g).cuda()
 sample = {"id": torch.arange(B), "net_input": {"source": wav, "padding_mask": torch.zeros(B, T, dtype=torch.bool).cuda()},
           "target_list": [target]}
+import os
+if os.environ.get("WAVLM_TEST_DROPOUTS") == "1":   # the recipe's dropouts: the attention / LayerNorm dropout paths of every switch run
+    import test_model_gpu as TM
+    TM.BASE.update(dropout=0.1, attention_dropout=0.1, dropout_input=0.1, dropout_features=0.1)
 model, _sd, _cfg, crit = _base_models(2)
 model = model.cuda().to(torch.bfloat16).train()
 opt = FusedAdam(model.parameters(), model=model, lr=1e-4)
@@ -76,3 +80,23 @@ def test_round6_opt_in_variants_are_bit_identical_to_the_default():
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, tool + "\n" + out.stdout[-3000:] + out.stderr[-2000:]
         assert "DIFFERENT" not in out.stdout and ": False" not in out.stdout, out.stdout[-3000:]   # (the tools' own verdict words)
+
+
+@pytest.mark.gpu
+def test_switch_combinations_with_the_recipe_dropouts():
+    """every switch is tested alone; here four COMBINATIONS, with the recipe's dropouts on (dropout 0.1,
+    attention_dropout 0.1, dropout_input / dropout_features 0.1: same seeds -> same masks whatever the kernels), against the default
+    build's loss and gradient norm at bf16 rounding level: the switches compose."""
+    base = {"WAVLM_TEST_DROPOUTS": "1"}
+    ref = _run(base)
+    assert ref["loss"] > 0 and ref["gnorm"] > 0
+    combos = [
+        {"WAVLM_LAYER_FUSED": "0", "WAVLM_GEMM_W4": "1", "WAVLM_POSCONV_DIRECT": "0", "WAVLM_CONV0_BWD_MFMA": "0"},
+        {"WAVLM_ATTN_DBITS": "1", "WAVLM_ATTN_DKV64": "1", "WAVLM_WGRAD_FIXUP": "1", "WAVLM_FUSE_BIAS_COLSUM": "0", "WAVLM_CHAIN_CONSUMERS": "0"},
+        {"WAVLM_ATTN_STORE_P": "bits", "WAVLM_LAYER_FUSED": "0", "WAVLM_GEMM_W4": "2"},
+        {"WAVLM_ATTN_STORE_P": "1", "WAVLM_WGRAD_FIXUP": "1", "WAVLM_CONV0_FWD_MFMA": "0"},
+    ]
+    for c in combos:
+        got = _run(dict(base, **c))
+        assert abs(got["loss"] - ref["loss"]) <= 2e-3 * abs(ref["loss"]), (c, got, ref)
+        assert abs(got["gnorm"] - ref["gnorm"]) <= 2e-2 * abs(ref["gnorm"]), (c, got, ref)
