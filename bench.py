@@ -139,7 +139,9 @@ def cpu_baseline():
     return {"value": round(SECONDS / times[1], 2), "unit": "audio-s/s", "cores": best, "kind": "port",
             "sample": "oracle fwd+loss+bwd fp32, 12 layers, B=1 x 15 s, median of 3 after 1 warm-up; threads swept ON THE 15 s "
                       "SAMPLE ITSELF (seconds per run: %s; the largest count within 5 %% of the fastest is used; host has %d usable "
-                      "CPUs)" % ({c: round(t, 2) for c, t in sweep.items()}, ncpu)}
+                      "CPUs).  kind = port: the GPU box has no /root/reference; the reference's own WavLMModel + WavLMCriterion timed beside "
+                      "this oracle on one host (same threads, same 15 s sample, identical loss): 3.2-4.9 s against 3.8 s per run -- "
+                      "profiles/r06/ref_vs_oracle_cpu.txt" % ({c: round(t, 2) for c, t in sweep.items()}, ncpu)}
 
 
 def _pick_threads(run_once, ncpu):
